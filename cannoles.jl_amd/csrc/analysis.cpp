@@ -1,0 +1,783 @@
+// analysis.cpp — symbolic analysis: ordering, elimination tree, supernodes,
+// multifrontal index maps and the static LDS stack layout (see plan.h).
+//
+// Reference behaviour being replaced (not translated): LDLFactStruct's ctor,
+// /root/reference/src/solver_types.jl:61-65, which merges duplicate COO
+// entries (`sparse`), keeps one triangle (`triu`) and calls `ldl_analyze`
+// (AMD + etree + column counts in LDLFactorizations.jl).  Here the ordering
+// is constrained by the KKT block structure of src/CaNNOLeS.jl:282 —
+// residual nodes (pivot -1) first, multipliers (pivot -delta) last — so that
+// every x pivot is an entry of a Schur complement of H + rho I + J'J and
+// "factorisation completes" coincides with "inertia is (nvar, nequ+ncon, 0)".
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <unordered_map>
+
+namespace cnl {
+namespace {
+
+typedef std::vector<int32_t> ivec;
+
+inline int64_t tri(int64_t i) { return i * (i + 1) / 2; }
+
+struct Graph {  // symmetric adjacency, no diagonal, sorted neighbour lists
+  int32_t n = 0;
+  ivec ptr, idx;
+  int32_t deg(int32_t v) const { return ptr[v + 1] - ptr[v]; }
+};
+
+// ---------------------------------------------------------------------------
+// Minimum degree on an explicit elimination graph (exact external degree, no
+// quotient graph).  Used on ND leaves and, as one candidate, on the whole x
+// graph.  `nodes` are vertices of g; adjacency outside `nodes` is ignored.
+// A dense tail (remaining graph nearly complete) is emitted in natural order.
+void min_degree(const Graph& g, const ivec& nodes, ivec& out) {
+  const int32_t m = (int32_t)nodes.size();
+  if (m <= 2) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
+  std::unordered_map<int32_t, int32_t> loc;  // global -> local (small graphs only) or dense map
+  ivec locv;
+  bool dense_map = (int64_t)m * 4 > g.n;
+  if (dense_map) { locv.assign(g.n, -1); for (int32_t i = 0; i < m; i++) locv[nodes[i]] = i; }
+  else { loc.reserve(m * 2); for (int32_t i = 0; i < m; i++) loc[nodes[i]] = i; }
+  auto local = [&](int32_t v) -> int32_t {
+    if (dense_map) return locv[v];
+    auto it = loc.find(v);
+    return it == loc.end() ? -1 : it->second;
+  };
+  std::vector<ivec> adj(m);
+  for (int32_t i = 0; i < m; i++) {
+    int32_t v = nodes[i];
+    for (int32_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) { int32_t l = local(g.idx[p]); if (l >= 0) adj[i].push_back(l); }
+    std::sort(adj[i].begin(), adj[i].end());
+  }
+  // bucket lists by degree
+  ivec degv(m), next(m, -1), prev(m, -1), head(m + 1, -1);
+  std::vector<char> done(m, 0);
+  auto bucket_insert = [&](int32_t v) {
+    int32_t d = degv[v]; next[v] = head[d]; prev[v] = -1; if (head[d] >= 0) prev[head[d]] = v; head[d] = v;
+  };
+  auto bucket_remove = [&](int32_t v) {
+    int32_t d = degv[v];
+    if (prev[v] >= 0) next[prev[v]] = next[v]; else head[d] = next[v];
+    if (next[v] >= 0) prev[next[v]] = prev[v];
+  };
+  for (int32_t i = 0; i < m; i++) { degv[i] = (int32_t)adj[i].size(); }
+  for (int32_t i = m - 1; i >= 0; i--) bucket_insert(i);  // lower index at the head: deterministic ties
+  int32_t mind = 0, left = m;
+  ivec tmp;
+  while (left > 0) {
+    while (mind <= m && head[mind] < 0) mind++;
+    int32_t v = head[mind];
+    // dense tail: everything left is (almost) a clique
+    if (mind >= left - 1) {
+      for (int32_t i = 0; i < m; i++) if (!done[i]) { out.push_back(nodes[i]); }
+      return;
+    }
+    bucket_remove(v); done[v] = 1; left--; out.push_back(nodes[v]);
+    const ivec& nv = adj[v];
+    for (int32_t u : nv) {
+      // adj[u] = (adj[u] U nv) \ {u, v}
+      tmp.clear();
+      const ivec& au = adj[u];
+      size_t a = 0, b = 0;
+      while (a < au.size() || b < nv.size()) {
+        int32_t x;
+        if (b >= nv.size() || (a < au.size() && au[a] < nv[b])) x = au[a++];
+        else if (a >= au.size() || nv[b] < au[a]) x = nv[b++];
+        else { x = au[a]; a++; b++; }
+        if (x != u && x != v) tmp.push_back(x);
+      }
+      bucket_remove(u);
+      adj[u].swap(tmp);
+      degv[u] = (int32_t)adj[u].size();
+      bucket_insert(u);
+      if (degv[u] < mind) mind = degv[u];
+    }
+    ivec().swap(adj[v]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Nested dissection by BFS level structures (George's automatic ND) on the
+// subgraph induced by `nodes`.  Leaves are ordered by min_degree.
+struct NDWork {
+  const Graph* g;
+  ivec part;     // part id per vertex (-1 = not in play)
+  ivec level, queue;
+  int32_t leaf;
+  int32_t next_part = 1;
+};
+
+void bfs(NDWork& w, int32_t root, int32_t pid, ivec& order_out, int32_t& nlev) {
+  // BFS inside part pid; level[] filled; returns visited vertices in BFS order
+  order_out.clear();
+  w.level[root] = 0; order_out.push_back(root);
+  size_t h = 0; nlev = 1;
+  // mark visited by temporarily negating part: use a separate stamp via level>=0
+  while (h < order_out.size()) {
+    int32_t v = order_out[h++];
+    for (int32_t p = w.g->ptr[v]; p < w.g->ptr[v + 1]; p++) {
+      int32_t u = w.g->idx[p];
+      if (w.part[u] == pid && w.level[u] < 0) { w.level[u] = w.level[v] + 1; nlev = w.level[u] + 1; order_out.push_back(u); }
+    }
+  }
+}
+
+void nd_rec(NDWork& w, ivec nodes, ivec& out) {
+  // iterative on an explicit stack of tasks to avoid deep recursion
+  struct Task { ivec nodes; bool emit; };
+  std::vector<Task> st;
+  st.push_back({std::move(nodes), false});
+  ivec comp, comp2;
+  while (!st.empty()) {
+    Task t = std::move(st.back()); st.pop_back();
+    if (t.emit) { out.insert(out.end(), t.nodes.begin(), t.nodes.end()); continue; }
+    ivec& nd = t.nodes;
+    if ((int32_t)nd.size() <= w.leaf) { min_degree(*w.g, nd, out); continue; }
+    int32_t pid = w.next_part++;
+    for (int32_t v : nd) { w.part[v] = pid; w.level[v] = -1; }
+    // connected component of the first vertex
+    int32_t nlev;
+    bfs(w, nd[0], pid, comp, nlev);
+    if (comp.size() < nd.size()) {
+      // disconnected: order the component found, then the rest (independent)
+      ivec rest; rest.reserve(nd.size() - comp.size());
+      for (int32_t v : nd) if (w.level[v] < 0) rest.push_back(v);
+      for (int32_t v : nd) w.part[v] = -1;
+      st.push_back({std::move(rest), false});
+      st.push_back({comp, false});
+      continue;
+    }
+    // pseudo-peripheral root: repeat BFS from a min-degree vertex of the last level
+    for (int it = 0; it < 4; it++) {
+      int32_t last = comp.back(), best = last, bd = 1 << 30;
+      for (size_t k = comp.size(); k-- > 0 && w.level[comp[k]] == w.level[last];) {
+        int32_t d = w.g->deg(comp[k]); if (d < bd) { bd = d; best = comp[k]; }
+      }
+      for (int32_t v : nd) w.level[v] = -1;
+      int32_t nl2; bfs(w, best, pid, comp2, nl2);
+      bool better = nl2 > nlev;
+      comp.swap(comp2); nlev = nl2;
+      if (!better) break;
+    }
+    if (nlev < 3) { for (int32_t v : nd) w.part[v] = -1; min_degree(*w.g, nd, out); continue; }
+    // choose the separator level: among levels 1..nlev-2 the one minimising
+    // |S| * imbalance penalty around the median
+    ivec cnt(nlev, 0);
+    for (int32_t v : comp) cnt[w.level[v]]++;
+    int64_t total = (int64_t)comp.size(), acc = cnt[0];
+    int32_t bestl = 1; double bestscore = 1e300;
+    for (int32_t l = 1; l < nlev - 1; l++) {
+      int64_t a = acc, b = total - acc - cnt[l];
+      acc += cnt[l];
+      if (a == 0 || b == 0) continue;
+      double bal = (double)std::max(a, b) / (double)(a + b);  // 0.5 .. 1
+      if (bal > 0.75) continue;
+      double score = cnt[l] * (1.0 + 4.0 * (bal - 0.5));
+      if (score < bestscore) { bestscore = score; bestl = l; }
+    }
+    if (bestscore == 1e300) bestl = nlev / 2;
+    ivec A, B, S;
+    for (int32_t v : comp) {
+      int32_t l = w.level[v];
+      if (l < bestl) A.push_back(v); else if (l > bestl) B.push_back(v); else S.push_back(v);
+    }
+    // separator nodes with no neighbour in B move to A (thinner separator)
+    {
+      ivec S2;
+      for (int32_t v : S) {
+        bool touchB = false;
+        for (int32_t p = w.g->ptr[v]; p < w.g->ptr[v + 1] && !touchB; p++) {
+          int32_t u = w.g->idx[p];
+          if (w.part[u] == pid && w.level[u] == bestl + 1) touchB = true;
+        }
+        if (touchB) S2.push_back(v); else A.push_back(v);
+      }
+      S.swap(S2);
+    }
+    for (int32_t v : nd) w.part[v] = -1;
+    std::sort(S.begin(), S.end());
+    std::sort(A.begin(), A.end());
+    std::sort(B.begin(), B.end());
+    st.push_back({std::move(S), true});   // emitted last
+    st.push_back({std::move(B), false});
+    st.push_back({std::move(A), false});  // processed first
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct Symbolic {
+  ivec perm, iperm;            // postordered elimination order
+  ivec parent;                 // etree
+  std::vector<ivec> lstruct;   // strictly-below structure of every column of L (sorted ascending)
+  int64_t nnzL = 0;
+};
+
+// permuted adjacency split: lower neighbours (elim idx < j) for every j
+void perm_lower_adj(const Graph& g, const ivec& iperm, std::vector<ivec>& low, std::vector<ivec>* up) {
+  int32_t n = g.n;
+  low.assign(n, ivec());
+  if (up) up->assign(n, ivec());
+  for (int32_t v = 0; v < n; v++) {
+    int32_t a = iperm[v];
+    for (int32_t p = g.ptr[v]; p < g.ptr[v + 1]; p++) {
+      int32_t b = iperm[g.idx[p]];
+      if (b < a) low[a].push_back(b); else if (up) (*up)[a].push_back(b);
+    }
+  }
+}
+
+void etree(const std::vector<ivec>& low, ivec& parent) {
+  int32_t n = (int32_t)low.size();
+  parent.assign(n, -1);
+  ivec anc(n, -1);
+  for (int32_t j = 0; j < n; j++)
+    for (int32_t i0 : low[j]) {
+      int32_t i = i0;
+      while (i != -1 && i < j) {
+        int32_t nx = anc[i];
+        anc[i] = j;
+        if (nx == -1) parent[i] = j;
+        i = nx;
+      }
+    }
+}
+
+void postorder(const ivec& parent, ivec& post) {
+  int32_t n = (int32_t)parent.size();
+  ivec head(n, -1), next(n, -1);
+  for (int32_t j = n - 1; j >= 0; j--) if (parent[j] >= 0) { next[j] = head[parent[j]]; head[parent[j]] = j; }
+  post.clear(); post.reserve(n);
+  ivec stack;
+  for (int32_t r = 0; r < n; r++) {
+    if (parent[r] >= 0) continue;
+    stack.push_back(r);
+    while (!stack.empty()) {
+      int32_t v = stack.back();
+      int32_t c = head[v];
+      if (c >= 0) { head[v] = next[c]; stack.push_back(c); }
+      else { post.push_back(v); stack.pop_back(); }
+    }
+  }
+}
+
+// full symbolic factorisation for an elimination order (returned postordered)
+void symbolic(const Graph& g, const ivec& perm_in, Symbolic& S) {
+  int32_t n = g.n;
+  ivec iperm(n);
+  for (int32_t k = 0; k < n; k++) iperm[perm_in[k]] = k;
+  std::vector<ivec> low;
+  perm_lower_adj(g, iperm, low, nullptr);
+  ivec parent; etree(low, parent);
+  ivec post; postorder(parent, post);
+  S.perm.resize(n); S.iperm.resize(n);
+  for (int32_t k = 0; k < n; k++) { S.perm[k] = perm_in[post[k]]; S.iperm[S.perm[k]] = k; }
+  std::vector<ivec> up;
+  perm_lower_adj(g, S.iperm, low, &up);
+  etree(low, S.parent);
+  S.lstruct.assign(n, ivec());
+  std::vector<ivec> kids(n);
+  ivec mark(n, -1);
+  S.nnzL = 0;
+  for (int32_t j = 0; j < n; j++) {
+    ivec& L = S.lstruct[j];
+    mark[j] = j;
+    for (int32_t i : up[j]) if (mark[i] != j) { mark[i] = j; L.push_back(i); }
+    for (int32_t c : kids[j])
+      for (int32_t i : S.lstruct[c]) if (mark[i] != j) { mark[i] = j; L.push_back(i); }
+    std::sort(L.begin(), L.end());
+    if (!L.empty()) kids[L[0]].push_back(j);
+    S.nnzL += (int64_t)L.size();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernel cost model (wave-instructions, one 64-lane wave per problem)
+inline double chunks(int64_t n) { return (double)((n + 63) / 64); }
+double front_cost(int64_t npiv, int64_t nupd, int64_t indep = 0) {
+  int64_t f = 1 + nupd + npiv;
+  double c = 24.0 + 2.0 * chunks(tri(f)) + 3.0 * chunks(tri(f) - tri(1 + nupd)) + 3.0 * chunks(tri(1 + nupd));
+  c += (double)indep * (12.0 + 6.0 * chunks(tri(f - indep)));
+  for (int64_t i = f - indep - 1; i > nupd; i--) c += 12.0 + 6.0 * chunks(tri(i));
+  // backward solve: panel load + per pivot dot/reduce
+  c += 10.0 + 2.0 * chunks(tri(f) - tri(1 + nupd)) + 14.0 * (double)npiv;
+  return c;
+}
+double extend_cost(int64_t nupd_child) { return 6.0 + 5.0 * chunks(tri(1 + nupd_child)); }
+
+struct SNode {
+  ivec icols;       // leading mutually independent pivots (merged single-pivot leaves)
+  ivec cols;        // dependent pivot columns in elimination order (postordered labels)
+  int32_t nupd = 0; // update rows
+  int32_t parent = -1;
+  ivec kids;
+  bool alive = true;
+  int64_t np() const { return (int64_t)icols.size() + (int64_t)cols.size(); }
+};
+
+}  // namespace
+
+// ===========================================================================
+int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
+               int64_t nvar, int64_t nequ, int64_t ncon, const Options& opt_in, std::string& msg) {
+  Options opt = opt_in;
+  if (const char* e = getenv("CNL_ORDER")) opt.order_mode = atoi(e);
+  if (const char* e = getenv("CNL_ND_LEAF")) opt.nd_leaf = atoi(e);
+  if (const char* e = getenv("CNL_RELAX")) opt.relax = atoi(e);
+  if (N64 <= 0 || nvar < 0 || nequ < 0 || ncon < 0 || nvar + nequ + ncon != N64) { msg = "bad dimensions: N != nvar+nequ+ncon"; return 2; }
+  if (N64 + nnz >= (int64_t)1 << 30) { msg = "problem too large for 32-bit plan indices"; return 2; }
+  if (nnz < nvar) { msg = "nnz < nvar: the last nvar COO entries must be the rho slots"; return 2; }
+  const int32_t N = (int32_t)N64;
+  P = Plan();
+  P.N = N; P.nnz = nnz; P.nvar = nvar; P.nequ = nequ; P.ncon = ncon;
+  P.rho_begin = (int32_t)(nnz - nvar);
+
+  // ---- unique lower-triangular pattern + COO -> slot map -------------------
+  std::vector<int64_t> key(nnz);
+  for (int64_t k = 0; k < nnz; k++) {
+    int64_t i = rows1[k] - 1, j = cols1[k] - 1;
+    if (i < 0 || i >= N || j < 0 || j >= N) { msg = "COO index out of range at entry " + std::to_string(k); return 3; }
+    if (i < j) { msg = "COO entry " + std::to_string(k) + " is in the upper triangle (rows < cols); the KKT pattern must be lower triangular"; return 3; }
+    key[k] = j * (int64_t)N + i;
+  }
+  std::vector<int64_t> ukey(key);
+  std::sort(ukey.begin(), ukey.end());
+  ukey.erase(std::unique(ukey.begin(), ukey.end()), ukey.end());
+  const int64_t nK = (int64_t)ukey.size();
+  P.nnzK = nK;
+  ivec slot(nnz);
+  for (int64_t k = 0; k < nnz; k++) slot[k] = (int32_t)(std::lower_bound(ukey.begin(), ukey.end(), key[k]) - ukey.begin());
+  ivec Ki(nK), Kj(nK);
+  for (int64_t u = 0; u < nK; u++) { Kj[u] = (int32_t)(ukey[u] / N); Ki[u] = (int32_t)(ukey[u] % N); }
+
+  // ---- symmetric graph -----------------------------------------------------
+  Graph g; g.n = N; g.ptr.assign(N + 1, 0);
+  for (int64_t u = 0; u < nK; u++) if (Ki[u] != Kj[u]) { g.ptr[Ki[u] + 1]++; g.ptr[Kj[u] + 1]++; }
+  for (int32_t v = 0; v < N; v++) g.ptr[v + 1] += g.ptr[v];
+  g.idx.resize(g.ptr[N]);
+  {
+    ivec nx(g.ptr.begin(), g.ptr.end() - 1);
+    for (int64_t u = 0; u < nK; u++) if (Ki[u] != Kj[u]) { g.idx[nx[Ki[u]]++] = Kj[u]; g.idx[nx[Kj[u]]++] = Ki[u]; }
+    for (int32_t v = 0; v < N; v++) std::sort(g.idx.begin() + g.ptr[v], g.idx.begin() + g.ptr[v + 1]);
+  }
+
+  // ---- constrained ordering --------------------------------------------------
+  // stage A: residual nodes (pivot -1, mutually independent) first, except
+  //          "dense" rows (AMD-style threshold) which are postponed;
+  // stage B: x nodes, ordered on the Schur graph S = pattern(H + J'J);
+  // stage C: multipliers and postponed residual rows.
+  const int32_t nx_ = (int32_t)nvar, nr_ = (int32_t)nequ;
+  const int32_t dense_thr = std::max(16, (int32_t)(10.0 * std::sqrt((double)N)));
+  ivec stageA, stageC;
+  std::vector<char> firstR(N, 0);
+  for (int32_t r = nx_; r < nx_ + nr_; r++) {
+    bool only_x = true;
+    for (int32_t p = g.ptr[r]; p < g.ptr[r + 1]; p++) if (g.idx[p] >= nx_) { only_x = false; break; }
+    if (only_x && g.deg(r) <= dense_thr) { stageA.push_back(r); firstR[r] = 1; }
+    else stageC.push_back(r);
+  }
+  for (int32_t v = nx_ + nr_; v < N; v++) stageC.push_back(v);
+
+  // Schur graph on x
+  Graph sg; sg.n = nx_; sg.ptr.assign(nx_ + 1, 0);
+  {
+    // dedupe identical residual rows (e.g. a dense Jacobian): same neighbour list -> one clique
+    std::unordered_map<uint64_t, std::vector<int32_t>> buckets;
+    ivec rep;  // representative rows
+    for (int32_t r : stageA) {
+      uint64_t h = 1469598103934665603ull;
+      for (int32_t p = g.ptr[r]; p < g.ptr[r + 1]; p++) { h ^= (uint64_t)g.idx[p] + 0x9e3779b97f4a7c15ull; h *= 1099511628211ull; }
+      auto& b = buckets[h];
+      bool dup = false;
+      for (int32_t q : b) {
+        if (g.deg(q) == g.deg(r) && std::equal(g.idx.begin() + g.ptr[r], g.idx.begin() + g.ptr[r + 1], g.idx.begin() + g.ptr[q])) { dup = true; break; }
+      }
+      if (!dup) { b.push_back(r); rep.push_back(r); }
+    }
+    std::vector<ivec> rows_of_x(nx_);
+    for (int32_t r : rep) for (int32_t p = g.ptr[r]; p < g.ptr[r + 1]; p++) rows_of_x[g.idx[p]].push_back(r);
+    ivec mark(nx_, -1);
+    std::vector<ivec> adj(nx_);
+    for (int32_t j = 0; j < nx_; j++) {
+      mark[j] = j;
+      for (int32_t p = g.ptr[j]; p < g.ptr[j + 1]; p++) { int32_t u = g.idx[p]; if (u < nx_ && mark[u] != j) { mark[u] = j; adj[j].push_back(u); } }
+      for (int32_t r : rows_of_x[j])
+        for (int32_t p = g.ptr[r]; p < g.ptr[r + 1]; p++) { int32_t u = g.idx[p]; if (mark[u] != j) { mark[u] = j; adj[j].push_back(u); } }
+      std::sort(adj[j].begin(), adj[j].end());
+      sg.ptr[j + 1] = sg.ptr[j] + (int32_t)adj[j].size();
+    }
+    sg.idx.resize(sg.ptr[nx_]);
+    for (int32_t j = 0; j < nx_; j++) std::copy(adj[j].begin(), adj[j].end(), sg.idx.begin() + sg.ptr[j]);
+  }
+
+  // hubs of the x graph (degree far above the median) are ordered last among x
+  ivec xs_all(nx_);
+  std::iota(xs_all.begin(), xs_all.end(), 0);
+
+  auto assemble_perm = [&](const ivec& xorder) {
+    ivec perm; perm.reserve(N);
+    perm.insert(perm.end(), stageA.begin(), stageA.end());
+    perm.insert(perm.end(), xorder.begin(), xorder.end());
+    perm.insert(perm.end(), stageC.begin(), stageC.end());
+    return perm;
+  };
+
+  const int relax = opt.relax >= 0 ? opt.relax : 4;
+
+  // supernodes + amalgamation + cost for a candidate; returns the final
+  // supernode column lists (in final elimination order) through `sn_out`
+  struct Cand { std::string name; ivec perm; ivec sn_first, sn_indep; double cost = 0; int64_t nnzL = 0, nnzL_exact = 0; };
+  const int64_t merge_tri_cap = (int64_t)20000;  // do not grow LDS-sized fronts past this by relaxation
+  auto evaluate = [&](const ivec& perm0, Cand& c) {
+    Symbolic S; symbolic(g, perm0, S);
+    c.nnzL_exact = S.nnzL;
+    // maximal supernodes
+    std::vector<SNode> sn;
+    ivec sn_of(N);
+    for (int32_t j = 0; j < N; j++) {
+      bool join = j > 0 && S.parent[j - 1] == j && S.lstruct[j - 1].size() == S.lstruct[j].size() + 1;
+      if (!join) { sn.emplace_back(); }
+      sn.back().cols.push_back(j);
+      sn_of[j] = (int32_t)sn.size() - 1;
+    }
+    int32_t ns = (int32_t)sn.size();
+    for (int32_t s = 0; s < ns; s++) {
+      int32_t last = sn[s].cols.back();
+      sn[s].nupd = (int32_t)S.lstruct[last].size();
+      sn[s].parent = S.parent[last] >= 0 ? sn_of[S.parent[last]] : -1;
+      if (sn[s].parent >= 0) sn[sn[s].parent].kids.push_back(s);
+    }
+    auto cost_of = [&](const SNode& x) { return front_cost(x.np(), x.nupd, (int64_t)x.icols.size()); };
+    // relaxed amalgamation, children before parents (supernodes are in postorder)
+    for (int32_t p = 0; p < ns; p++) {
+      if (!sn[p].alive) continue;
+      // (1) single-pivot leaf children become leading independent pivots of p
+      {
+        ivec keep;
+        for (int32_t cidx : sn[p].kids) {
+          SNode& ch = sn[cidx];
+          bool leaf1 = ch.kids.empty() && ch.icols.empty() && ch.cols.size() == 1;
+          bool merged = false;
+          if (leaf1) {
+            int64_t fdep = 1 + sn[p].nupd + (int64_t)sn[p].cols.size();  // rows an independent pivot updates
+            double before = front_cost(1, ch.nupd) + extend_cost(ch.nupd) + cost_of(sn[p]);
+            SNode trial; trial.nupd = sn[p].nupd;
+            double after = front_cost(sn[p].np() + 1, sn[p].nupd, (int64_t)sn[p].icols.size() + 1);
+            bool fits = tri(1 + sn[p].nupd + sn[p].np() + 1) <= merge_tri_cap || (fdep - 1 - ch.nupd) * 4 <= fdep;
+            if (after <= before && fits) {
+              sn[p].icols.push_back(ch.cols[0]);
+              ch.alive = false; merged = true;
+            }
+          }
+          if (!merged) keep.push_back(cidx);
+        }
+        sn[p].kids.swap(keep);
+      }
+      // (2) dependent merges
+      bool changed = true;
+      while (changed) {
+        changed = false;
+        ivec ks = sn[p].kids;
+        std::sort(ks.begin(), ks.end(), [&](int32_t a, int32_t b) { return sn[a].nupd > sn[b].nupd; });
+        for (int32_t cidx : ks) {
+          SNode& ch = sn[cidx];
+          int64_t npc = ch.np(), npp = sn[p].np();
+          int64_t extra = (int64_t)sn[p].cols.size() + sn[p].nupd - ch.nupd;  // explicit zeros per child column
+          double before = cost_of(ch) + cost_of(sn[p]) + extend_cost(ch.nupd);
+          double after = front_cost(npc + npp, sn[p].nupd, (int64_t)(ch.icols.size() + sn[p].icols.size()));
+          bool ok = (extra <= relax && after <= before * 1.02) || after <= before * 0.9;
+          if (tri(1 + sn[p].nupd + npc + npp) > merge_tri_cap && extra > 0) ok = false;
+          if (!ok) continue;
+          // merge ch into p: ch's columns are eliminated right before p's
+          ivec nc; nc.reserve(ch.cols.size() + sn[p].cols.size());
+          nc.insert(nc.end(), ch.cols.begin(), ch.cols.end());
+          nc.insert(nc.end(), sn[p].cols.begin(), sn[p].cols.end());
+          sn[p].cols.swap(nc);
+          sn[p].icols.insert(sn[p].icols.begin(), ch.icols.begin(), ch.icols.end());
+          ivec nk;
+          for (int32_t k : sn[p].kids) if (k != cidx) nk.push_back(k);
+          for (int32_t k : ch.kids) { nk.push_back(k); sn[k].parent = p; }
+          sn[p].kids.swap(nk);
+          ch.alive = false; ch.kids.clear();
+          changed = true;
+          break;
+        }
+      }
+    }
+    // final order: DFS postorder over the merged tree; within a node: its columns
+    ivec order; order.reserve(N);
+    c.sn_first.clear(); c.sn_indep.clear();
+    {
+      // kids sorted so that the largest update matrix comes LAST
+      std::vector<int32_t> stack; ivec it(ns, 0);
+      for (int32_t s = 0; s < ns; s++) if (sn[s].alive)
+        std::sort(sn[s].kids.begin(), sn[s].kids.end(), [&](int32_t a, int32_t b) {
+          if (sn[a].nupd != sn[b].nupd) return sn[a].nupd < sn[b].nupd; return a < b; });
+      for (int32_t r = 0; r < ns; r++) {
+        if (!sn[r].alive || sn[r].parent >= 0) continue;
+        stack.push_back(r);
+        while (!stack.empty()) {
+          int32_t v = stack.back();
+          if (it[v] < (int32_t)sn[v].kids.size()) { stack.push_back(sn[v].kids[it[v]++]); }
+          else {
+            c.sn_first.push_back((int32_t)order.size());
+            c.sn_indep.push_back((int32_t)sn[v].icols.size());
+            for (int32_t col : sn[v].icols) order.push_back(S.perm[col]);
+            for (int32_t col : sn[v].cols) order.push_back(S.perm[col]);
+            stack.pop_back();
+          }
+        }
+      }
+      c.sn_first.push_back((int32_t)order.size());
+    }
+    c.perm.swap(order);
+    // cost + nnzL with explicit zeros
+    c.cost = 0; c.nnzL = 0;
+    for (int32_t s = 0; s < ns; s++) if (sn[s].alive) {
+      int64_t np = sn[s].np(), nu = sn[s].nupd;
+      c.cost += cost_of(sn[s]);
+      if (sn[s].parent >= 0) c.cost += extend_cost(nu);
+      c.nnzL += np * nu + np * (np - 1) / 2;
+    }
+  };
+
+  std::vector<Cand> cands;
+  auto add_cand = [&](const std::string& name, const ivec& xorder) {
+    Cand c; c.name = name;
+    evaluate(assemble_perm(xorder), c);
+    cands.push_back(std::move(c));
+  };
+  int mode = opt.order_mode;
+  if (mode == 0 || mode < 0) add_cand("canonical", xs_all);
+  double sdens = nx_ > 0 ? (double)sg.ptr[nx_] / ((double)nx_ * (double)std::max(1, nx_ - 1)) : 1.0;
+  bool sparse_enough = nx_ > 8 && sdens < 0.4;
+  if ((mode == 2 || mode < 0) && sparse_enough) {
+    ivec xo; min_degree(sg, xs_all, xo);
+    add_cand("md", xo);
+  }
+  if ((mode == 1 || mode < 0) && sparse_enough) {
+    // hubs: x nodes with degree > 8*median+16 are excluded from ND and go last among x
+    ivec dsort(nx_);
+    for (int32_t j = 0; j < nx_; j++) dsort[j] = sg.deg(j);
+    std::nth_element(dsort.begin(), dsort.begin() + nx_ / 2, dsort.end());
+    int32_t hub_thr = 8 * dsort[nx_ / 2] + 16;
+    ivec body, hubs;
+    for (int32_t j = 0; j < nx_; j++) (sg.deg(j) > hub_thr ? hubs : body).push_back(j);
+    Graph bg = sg;
+    if (!hubs.empty()) {  // drop hub edges from the working graph
+      std::vector<char> ish(nx_, 0); for (int32_t h : hubs) ish[h] = 1;
+      bg.ptr.assign(nx_ + 1, 0); bg.idx.clear();
+      for (int32_t j = 0; j < nx_; j++) {
+        if (!ish[j]) for (int32_t p = sg.ptr[j]; p < sg.ptr[j + 1]; p++) if (!ish[sg.idx[p]]) bg.idx.push_back(sg.idx[p]);
+        bg.ptr[j + 1] = (int32_t)bg.idx.size();
+      }
+    }
+    std::vector<int32_t> leaves;
+    if (opt.nd_leaf > 0) leaves.push_back(opt.nd_leaf);
+    else leaves = {32, 96, 256, 768, 2048};
+    for (int32_t leaf : leaves) {
+      if (leaf >= (int32_t)body.size() && leaves.size() > 1 && leaf != leaves.front()) break;
+      NDWork w; w.g = &bg; w.part.assign(nx_, -1); w.level.assign(nx_, -1); w.leaf = leaf;
+      ivec xo; xo.reserve(nx_);
+      nd_rec(w, body, xo);
+      xo.insert(xo.end(), hubs.begin(), hubs.end());
+      add_cand("nd" + std::to_string(leaf), xo);
+    }
+  }
+  if (cands.empty()) add_cand("canonical", xs_all);
+  size_t best = 0;
+  for (size_t i = 1; i < cands.size(); i++) if (cands[i].cost < cands[best].cost) best = i;
+  if (getenv("CNL_VERBOSE")) {
+    for (auto& c : cands)
+      fprintf(stderr, "[cnl] order %-10s cost %.3e nnzL %lld (exact %lld) fronts %zu\n", c.name.c_str(), c.cost,
+              (long long)c.nnzL, (long long)c.nnzL_exact, c.sn_first.size() - 1);
+    fprintf(stderr, "[cnl] chose %s\n", cands[best].name.c_str());
+  }
+  Cand& C = cands[best];
+  P.order_name = C.name; P.cost = C.cost; P.nnzL = C.nnzL; P.nnzL_exact = C.nnzL_exact;
+  P.perm = C.perm;
+  P.iperm.assign(N, 0);
+  for (int32_t k = 0; k < N; k++) P.iperm[P.perm[k]] = k;
+  const int32_t ns = (int32_t)C.sn_first.size() - 1;
+  P.nsuper = ns;
+
+  // ---- final structures on the chosen order -----------------------------------
+  // exact column structures in the final labelling (the order is already a
+  // postorder of its own etree up to sibling permutations; recompute directly)
+  std::vector<ivec> low, up;
+  perm_lower_adj(g, P.iperm, low, &up);
+  ivec sn_of(N);
+  for (int32_t s = 0; s < ns; s++) for (int32_t j = C.sn_first[s]; j < C.sn_first[s + 1]; j++) sn_of[j] = s;
+  // front rows: union of the below-front structure of all pivot columns, built bottom-up
+  std::vector<ivec> frows(ns);  // ascending elimination indices, all > last pivot
+  std::vector<ivec> skids(ns);
+  ivec sparent(ns, -1);
+  {
+    ivec mark(N, -1);
+    for (int32_t s = 0; s < ns; s++) {
+      int32_t lastp = C.sn_first[s + 1] - 1;
+      ivec& R = frows[s];
+      for (int32_t j = C.sn_first[s]; j <= lastp; j++)
+        for (int32_t i : up[j]) if (i > lastp && mark[i] != s) { mark[i] = s; R.push_back(i); }
+      for (int32_t c : skids[s])
+        for (int32_t i : frows[c]) if (i > lastp && mark[i] != s) { mark[i] = s; R.push_back(i); }
+      std::sort(R.begin(), R.end());
+      if (!R.empty()) { sparent[s] = sn_of[R[0]]; skids[sparent[s]].push_back(s); }
+    }
+    // consistency: children must precede parents and be contiguous subtrees
+    for (int32_t s = 0; s < ns; s++) if (sparent[s] >= 0 && sparent[s] <= s) { msg = "internal: supernode order is not a postorder"; return 9; }
+  }
+  // verify postorder contiguity (needed by the static stack layout): the
+  // children of s, in index order, must tile [first descendant, s)
+  {
+    ivec first_desc(ns);
+    for (int32_t s = 0; s < ns; s++) {
+      first_desc[s] = s;
+      int32_t expect = s;
+      for (size_t k = skids[s].size(); k-- > 0;) {
+        int32_t c = skids[s][k];
+        if (c != expect - 1) { msg = "internal: supernodal tree is not postordered"; return 9; }
+        expect = first_desc[c];
+      }
+      first_desc[s] = expect;
+    }
+  }
+
+  P.fronts.assign(ns, FrontHdr());
+  P.child_idx.clear(); P.rel_idx.clear();
+  int64_t lptr = 0; int32_t fmax = 0, panel_max = 0; double flops = 0;
+  for (int32_t s = 0; s < ns; s++) {
+    FrontHdr& F = P.fronts[s];
+    std::memset(&F, 0, sizeof(F));
+    F.npiv = C.sn_first[s + 1] - C.sn_first[s];
+    F.nupd = (int32_t)frows[s].size();
+    F.first_piv = C.sn_first[s];
+    F.parent = sparent[s];
+    int64_t f = 1 + (int64_t)F.nupd + F.npiv;
+    if (tri(f) >= ((int64_t)1 << 30)) { msg = "front too large"; return 2; }
+    fmax = std::max<int32_t>(fmax, (int32_t)f);
+    int64_t panel = tri(f) - tri(1 + F.nupd);
+    panel_max = (int32_t)std::max<int64_t>(panel_max, panel);
+    F.lptr_lo = (int32_t)(lptr & 0x7fffffff); F.lptr_hi = (int32_t)(lptr >> 31);
+    lptr += panel;
+    F.child_begin = (int32_t)P.child_idx.size();
+    for (int32_t c : skids[s]) P.child_idx.push_back(c);
+    F.child_end = (int32_t)P.child_idx.size();
+    F.indep = C.sn_indep[s];
+    flops += (double)F.indep * (double)tri(f - F.indep);
+    for (int64_t i = f - F.indep - 1; i > F.nupd; i--) flops += (double)tri(i);
+  }
+  P.lsize = lptr; P.fmax = fmax; P.panel_max = panel_max; P.flops = flops;
+
+  // local index of an elimination index inside front s
+  auto local_of = [&](int32_t s, int32_t e) -> int32_t {
+    const FrontHdr& F = P.fronts[s];
+    int32_t f = 1 + F.nupd + F.npiv;
+    if (e >= F.first_piv && e < F.first_piv + F.npiv) return f - 1 - (e - F.first_piv);
+    const ivec& R = frows[s];
+    auto it = std::lower_bound(R.begin(), R.end(), e);
+    if (it == R.end() || *it != e) return -1;
+    int32_t k = (int32_t)(it - R.begin());       // ascending position
+    return 1 + (F.nupd - 1 - k);                 // descending local order
+  };
+  // rel maps (child -> parent)
+  for (int32_t s = 0; s < ns; s++) {
+    FrontHdr& F = P.fronts[s];
+    F.rel_begin = (int32_t)P.rel_idx.size();
+    P.rel_idx.push_back(0);
+    if (F.parent >= 0) {
+      for (int32_t l = 1; l <= F.nupd; l++) {
+        int32_t e = frows[s][F.nupd - l];
+        int32_t q = local_of(F.parent, e);
+        if (q < 0) { msg = "internal: child row missing in parent front"; return 9; }
+        P.rel_idx.push_back(q);
+      }
+    } else {
+      for (int32_t l = 1; l <= F.nupd; l++) P.rel_idx.push_back(0);
+    }
+  }
+
+  // ---- assembly maps -------------------------------------------------------------
+  {
+    // rank of every COO entry among the entries of its slot, in COO order
+    ivec cnt(nK, 0), rank(nnz);
+    int32_t maxrank = 0;
+    for (int64_t k = 0; k < nnz; k++) { rank[k] = cnt[slot[k]]++; maxrank = std::max(maxrank, rank[k]); }
+    // (front, pos) of every slot
+    ivec sfront(nK), spos(nK);
+    for (int64_t u = 0; u < nK; u++) {
+      int32_t a = P.iperm[Ki[u]], b = P.iperm[Kj[u]];
+      int32_t lo = std::min(a, b), hi = std::max(a, b);
+      int32_t s = sn_of[lo];
+      int32_t li = local_of(s, lo), lj = local_of(s, hi);
+      if (li < 0 || lj < 0 || lj > li) { msg = "internal: assembly position"; return 9; }
+      sfront[u] = s; spos[u] = (int32_t)(tri(li) + lj);
+    }
+    // bucket entries by (front, rank)
+    struct E { int32_t front, rank, pos, src; };
+    std::vector<E> es; es.reserve(nnz + N);
+    for (int64_t k = 0; k < nnz; k++) es.push_back({sfront[slot[k]], rank[k], spos[slot[k]], (int32_t)k});
+    if (opt.with_rhs_row)
+      for (int32_t e = 0; e < N; e++) {
+        int32_t s = sn_of[e];
+        es.push_back({s, 0, (int32_t)tri(local_of(s, e)), (int32_t)(nnz + P.perm[e])});
+      }
+    std::sort(es.begin(), es.end(), [](const E& a, const E& b) {
+      if (a.front != b.front) return a.front < b.front;
+      if (a.rank != b.rank) return a.rank < b.rank;
+      return a.src < b.src;
+    });
+    P.seg_ptr.clear(); P.asm_pos.resize(es.size()); P.asm_src.resize(es.size());
+    size_t i = 0;
+    for (int32_t s = 0; s < ns; s++) {
+      P.fronts[s].seg_begin = (int32_t)P.seg_ptr.size();
+      while (i < es.size() && es[i].front == s) {
+        int32_t r = es[i].rank;
+        P.seg_ptr.push_back((int32_t)i);
+        while (i < es.size() && es[i].front == s && es[i].rank == r) { P.asm_pos[i] = es[i].pos; P.asm_src[i] = es[i].src; i++; }
+      }
+      P.fronts[s].seg_end = (int32_t)P.seg_ptr.size();
+    }
+    P.seg_ptr.push_back((int32_t)es.size());
+  }
+
+  // ---- static stack layout ----------------------------------------------------------
+  {
+    int64_t sp = 0, peak = 0;
+    for (int32_t s = 0; s < ns; s++) {
+      FrontHdr& F = P.fronts[s];
+      int64_t base = sp;
+      if (F.child_end > F.child_begin) base = P.fronts[P.child_idx[F.child_begin]].ubase;
+      int64_t f = 1 + (int64_t)F.nupd + F.npiv;
+      F.foff = (int32_t)sp;
+      peak = std::max(peak, sp + tri(f));
+      F.ubase = (int32_t)base;
+      sp = base + tri(1 + F.nupd);
+      if (peak >= ((int64_t)1 << 30)) { msg = "work stack too large"; return 2; }
+    }
+    P.fwd_peak = (int32_t)peak;
+    int64_t bpeak = 0;
+    for (int32_t s = ns - 1; s >= 0; s--) {
+      FrontHdr& F = P.fronts[s];
+      int64_t f = 1 + (int64_t)F.nupd + F.npiv;
+      if (F.parent < 0) F.xoff = 0;
+      else {
+        const FrontHdr& Pp = P.fronts[F.parent];
+        bool first_child = P.child_idx[Pp.child_begin] == s;
+        F.xoff = first_child ? Pp.xoff : Pp.xoff + (1 + Pp.nupd + Pp.npiv);
+      }
+      bpeak = std::max(bpeak, (int64_t)F.xoff + f);
+    }
+    P.bwd_peak = (int32_t)bpeak;
+  }
+  msg.clear();
+  return 0;
+}
+
+}  // namespace cnl

@@ -1,0 +1,421 @@
+// capi.cpp — the C ABI declared in include/cannoles_hip.h.
+//
+// Host-side driver: owns the symbolic plan, uploads it once, chooses the kernel
+// configuration for the front sizes at hand, stages host buffers for the
+// host-pointer entry points and launches the fused kernel (kernels.hip).
+// There is no CPU execution path: every numeric entry point needs the device.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cannoles_hip.h"
+#include "kernels.h"
+#include "plan.h"
+
+struct cnl_plan {
+  cnl::Plan P;
+};
+
+struct cnl_handle {
+  cnl_plan* plan = nullptr;
+  int device = 0;
+  int64_t batch = 1;
+  std::vector<void*> dev_allocs;
+  cnl::DevPlan dp{};
+  cnl::KernelConfig cfg{};
+  double* d_L = nullptr;
+  double* d_scratch = nullptr;
+  // staging for the host-pointer API
+  double *d_vals = nullptr, *d_rhs = nullptr, *d_d = nullptr, *d_rho_old = nullptr, *d_rho = nullptr;
+  int32_t *d_nfact = nullptr, *d_success = nullptr;
+  int64_t *d_npos = nullptr, *d_nzero = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing = false;
+  float last_ms = 0.f;
+  bool factorized = false;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& m) {
+  g_err = m;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail(CNL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+int upload(cnl_handle* h, const std::vector<T>& v, const T** out) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc(&p, bytes));
+  h->dev_allocs.push_back(p);
+  if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T*)p;
+  return CNL_OK;
+}
+
+template <class T>
+int dalloc(cnl_handle* h, T** out, size_t count) {
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+  h->dev_allocs.push_back(p);
+  *out = (T*)p;
+  return CNL_OK;
+}
+
+int choose_config(cnl_handle* h) {
+  const cnl::Plan& P = h->plan->P;
+  cnl::DevPlan& dp = h->dp;
+  int64_t pb_off = std::max<int64_t>(P.fwd_peak, P.bwd_peak);
+  pb_off = (pb_off + 1) & ~(int64_t)1;
+  int64_t wv_off = pb_off + ((P.panel_max + 1) & ~1);
+  int64_t work = wv_off + 2 * (int64_t)((P.fmax + 1) & ~1);
+  if (work >= ((int64_t)1 << 30)) return fail(CNL_ERR_DIM, "work area too large");
+  dp.pb_off = (int32_t)pb_off;
+  dp.wv_off = (int32_t)wv_off;
+  dp.work_doubles = (int32_t)work;
+  size_t maxlds = cnl::max_lds_bytes();
+  if (maxlds == 0) return fail(CNL_ERR_HIP, "cannot query LDS size (no HIP device?)");
+  maxlds = std::min<size_t>(maxlds, 160 * 1024);
+  cnl::KernelConfig& c = h->cfg;
+  const size_t hdr = 16 * sizeof(double);
+  const size_t per = (size_t)work * sizeof(double);
+  int tpp, ppb, ldsw;
+  if (hdr + per <= maxlds) {
+    ldsw = 1;
+    if (P.fmax <= 96) {
+      tpp = 64;
+      // problems per workgroup: leave room for two workgroups per CU when the work area
+      // allows it, and spread small batches over the 256 CUs
+      size_t fit = (maxlds - hdr) / per;
+      size_t fit2 = maxlds / 2 > hdr ? (maxlds / 2 - hdr) / per : 0;
+      size_t cap = fit2 >= 1 ? fit2 : fit;
+      size_t want = (size_t)std::min<int64_t>(16, std::max<int64_t>(1, h->batch / 256));
+      ppb = 1;
+      for (int cand : {16, 8, 4, 2, 1})
+        if ((size_t)cand <= cap && (size_t)cand <= want) { ppb = cand; break; }
+    } else {
+      tpp = P.fmax <= 400 ? 256 : 1024;
+      ppb = 1;
+    }
+  } else {
+    ldsw = 0;
+    tpp = P.fmax <= 96 ? 64 : (P.fmax <= 400 ? 256 : 1024);
+    ppb = tpp == 64 ? 4 : 1;
+  }
+  if (const char* e = getenv("CNL_TPP")) tpp = atoi(e);
+  if (const char* e = getenv("CNL_PPB")) ppb = atoi(e);
+  if (const char* e = getenv("CNL_LDS")) ldsw = atoi(e);
+  c.tpp = tpp; c.ppb = ppb; c.lds_work = ldsw;
+  c.lds_bytes = hdr + (ldsw ? (size_t)ppb * per : 0);
+  if (c.lds_bytes > maxlds) return fail(CNL_ERR_DIM, "kernel configuration exceeds LDS");
+  return CNL_OK;
+}
+
+int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
+  a.batch = (int)h->batch;
+  a.L = h->d_L;
+  a.scratch = h->d_scratch;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
+  hipError_t e = cnl::launch_newton(h->dp, h->cfg, a, stream);
+  if (e != hipSuccess)
+    return fail(CNL_ERR_HIP, std::string("kernel launch (tpp=") + std::to_string(h->cfg.tpp) + " ppb=" + std::to_string(h->cfg.ppb) +
+                                 " lds=" + std::to_string(h->cfg.lds_work) + "): " + hipGetErrorString(e));
+  if (h->timing) {
+    HIPCHK(hipEventRecord(h->ev1, stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  }
+  return CNL_OK;
+}
+
+int ensure_staging(cnl_handle* h) {
+  if (h->d_vals) return CNL_OK;
+  const cnl::Plan& P = h->plan->P;
+  int rc;
+  if ((rc = dalloc(h, &h->d_vals, (size_t)h->batch * P.nnz))) return rc;
+  if ((rc = dalloc(h, &h->d_rhs, (size_t)h->batch * P.N))) return rc;
+  if ((rc = dalloc(h, &h->d_d, (size_t)h->batch * P.N))) return rc;
+  if ((rc = dalloc(h, &h->d_rho_old, (size_t)h->batch))) return rc;
+  if ((rc = dalloc(h, &h->d_rho, (size_t)h->batch))) return rc;
+  if ((rc = dalloc(h, &h->d_nfact, (size_t)h->batch))) return rc;
+  if ((rc = dalloc(h, &h->d_success, (size_t)h->batch))) return rc;
+  if ((rc = dalloc(h, &h->d_npos, (size_t)h->batch))) return rc;
+  if ((rc = dalloc(h, &h->d_nzero, (size_t)h->batch))) return rc;
+  return CNL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cnl_last_error(void) { return g_err.c_str(); }
+int32_t cnl_version(void) { return 100; }
+
+void cnl_default_params(double p[9]) {
+  const double eps = 2.220446049250313e-16;  // eps(Float64); src/CaNNOLeS.jl:48-62
+  p[0] = eps;
+  p[1] = std::sqrt(eps);
+  p[2] = 1.0 / 3.0;
+  p[3] = 8.0;
+  p[4] = std::min(100.0, 8.0 * 16.0);
+  p[5] = std::cbrt(eps);
+  p[6] = std::pow(eps, -2.0);
+  p[7] = std::sqrt(eps);
+  p[8] = std::pow(eps, 0.25);
+}
+
+int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                    int64_t nequ, int64_t ncon) {
+  if (!plan || !rows1 || !cols1) return fail(CNL_ERR_ARG, "null argument");
+  cnl_plan* p = new cnl_plan();
+  std::string msg;
+  cnl::Options opt;
+  int rc = cnl::build_plan(p->P, N, nnz, rows1, cols1, nvar, nequ, ncon, opt, msg);
+  if (rc) {
+    delete p;
+    *plan = nullptr;
+    return fail(rc, msg);
+  }
+  *plan = p;
+  return CNL_OK;
+}
+
+void cnl_plan_destroy(cnl_plan* plan) { delete plan; }
+
+int cnl_plan_info(const cnl_plan* plan, int64_t info[16]) {
+  if (!plan || !info) return fail(CNL_ERR_ARG, "null argument");
+  const cnl::Plan& P = plan->P;
+  std::memset(info, 0, 16 * sizeof(int64_t));
+  info[0] = P.N; info[1] = P.nnz; info[2] = P.nnzK; info[3] = P.nsuper; info[4] = P.nnzL; info[5] = P.nnzL_exact;
+  info[6] = P.lsize; info[7] = P.fmax; info[8] = P.fwd_peak; info[9] = P.bwd_peak; info[10] = P.panel_max;
+  info[11] = (int64_t)P.flops; info[12] = (int64_t)P.asm_src.size();
+  return CNL_OK;
+}
+
+const char* cnl_plan_order_name(const cnl_plan* plan) { return plan ? plan->P.order_name.c_str() : ""; }
+
+int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* count) {
+  if (!plan || !name || !count) return fail(CNL_ERR_ARG, "null argument");
+  const cnl::Plan& P = plan->P;
+  const int32_t* src = nullptr;
+  int64_t n = 0;
+  std::string s(name);
+  if (s == "perm") { src = P.perm.data(); n = (int64_t)P.perm.size(); }
+  else if (s == "fronts") { src = reinterpret_cast<const int32_t*>(P.fronts.data()); n = (int64_t)P.fronts.size() * 16; }
+  else if (s == "seg_ptr") { src = P.seg_ptr.data(); n = (int64_t)P.seg_ptr.size(); }
+  else if (s == "asm_pos") { src = P.asm_pos.data(); n = (int64_t)P.asm_pos.size(); }
+  else if (s == "asm_src") { src = P.asm_src.data(); n = (int64_t)P.asm_src.size(); }
+  else if (s == "child_idx") { src = P.child_idx.data(); n = (int64_t)P.child_idx.size(); }
+  else if (s == "rel_idx") { src = P.rel_idx.data(); n = (int64_t)P.rel_idx.size(); }
+  else return fail(CNL_ERR_ARG, "unknown plan array: " + s);
+  if (out) {
+    if (*count < n) return fail(CNL_ERR_ARG, "buffer too small");
+    std::memcpy(out, src, (size_t)n * sizeof(int32_t));
+  }
+  *count = n;
+  return CNL_OK;
+}
+
+int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+               int64_t nequ, int64_t ncon, int64_t batch, int device) {
+  if (!hout) return fail(CNL_ERR_ARG, "null handle pointer");
+  *hout = nullptr;
+  if (batch < 1 || batch > (1 << 24)) return fail(CNL_ERR_ARG, "batch out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(CNL_ERR_HIP, "no HIP device available (this backend has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(CNL_ERR_ARG, "device index out of range");
+  cnl_plan* plan = nullptr;
+  int rc = cnl_plan_create(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon);
+  if (rc) return rc;
+  cnl_handle* h = new cnl_handle();
+  h->plan = plan; h->device = device; h->batch = batch;
+  auto bail = [&](int code) { cnl_destroy(h); return code; };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipSetDevice failed"));
+  const cnl::Plan& P = plan->P;
+  cnl::DevPlan& dp = h->dp;
+  if ((rc = upload(h, P.fronts, &dp.fronts))) return bail(rc);
+  if ((rc = upload(h, P.seg_ptr, &dp.seg_ptr))) return bail(rc);
+  if ((rc = upload(h, P.asm_pos, &dp.asm_pos))) return bail(rc);
+  if ((rc = upload(h, P.asm_src, &dp.asm_src))) return bail(rc);
+  if ((rc = upload(h, P.child_idx, &dp.child_idx))) return bail(rc);
+  if ((rc = upload(h, P.rel_idx, &dp.rel_idx))) return bail(rc);
+  if ((rc = upload(h, P.perm, &dp.perm))) return bail(rc);
+  dp.nsuper = P.nsuper; dp.N = (int32_t)P.N; dp.nnz = (int32_t)P.nnz; dp.rho_begin = P.rho_begin;
+  dp.nvar = (int32_t)P.nvar; dp.nequ = (int32_t)P.nequ; dp.ncon = (int32_t)P.ncon;
+  dp.fmax = (P.fmax + 1) & ~1; dp.lsize = P.lsize;
+  if ((rc = choose_config(h))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_L, (size_t)batch * (size_t)std::max<int64_t>(P.lsize, 1)))) return bail(rc);
+  if (!h->cfg.lds_work)
+    if ((rc = dalloc(h, &h->d_scratch, (size_t)batch * (size_t)dp.work_doubles))) return bail(rc);
+  if (hipStreamCreate(&h->stream) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipStreamCreate failed"));
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)
+    return bail(fail(CNL_ERR_HIP, "hipEventCreate failed"));
+  *hout = h;
+  return CNL_OK;
+}
+
+int cnl_destroy(cnl_handle* h) {
+  if (!h) return CNL_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->dev_allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  cnl_plan_destroy(h->plan);
+  delete h;
+  return CNL_OK;
+}
+
+const cnl_plan* cnl_get_plan(const cnl_handle* h) { return h ? h->plan : nullptr; }
+
+int cnl_set_timing(cnl_handle* h, int enable) {
+  if (!h) return fail(CNL_ERR_ARG, "null handle");
+  h->timing = enable != 0;
+  return CNL_OK;
+}
+
+int cnl_last_kernel_ms(cnl_handle* h, float* ms) {
+  if (!h || !ms) return fail(CNL_ERR_ARG, "null argument");
+  *ms = h->last_ms;
+  return CNL_OK;
+}
+
+int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
+  if (!h || !cfg) return fail(CNL_ERR_ARG, "null argument");
+  std::memset(cfg, 0, 8 * sizeof(int64_t));
+  cfg[0] = h->cfg.tpp; cfg[1] = h->cfg.ppb; cfg[2] = (int64_t)h->cfg.lds_bytes; cfg[3] = h->cfg.lds_work;
+  cfg[4] = (h->batch + h->cfg.ppb - 1) / h->cfg.ppb;
+  return CNL_OK;
+}
+
+// ---- device-pointer entry points -------------------------------------------------
+int cnl_factorize_dev(cnl_handle* h, const double* d_vals, double eig_tol, int32_t* d_success, void* stream) {
+  if (!h || !d_vals || !d_success) return fail(CNL_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  cnl::LaunchArgs a{};
+  a.mode = cnl::MODE_FACTOR;
+  a.vals = const_cast<double*>(d_vals);
+  a.success = d_success;
+  a.params[0] = eig_tol;
+  int rc = launch(h, a, (hipStream_t)stream);
+  if (rc == CNL_OK) h->factorized = true;
+  return rc;
+}
+
+int cnl_solve_dev(cnl_handle* h, const double* d_rhs, double* d_d, void* stream) {
+  if (!h || !d_rhs || !d_d) return fail(CNL_ERR_ARG, "null argument");
+  if (!h->factorized) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
+  HIPCHK(hipSetDevice(h->device));
+  cnl::LaunchArgs a{};
+  a.mode = cnl::MODE_SOLVE;
+  a.rhs = d_rhs;
+  a.d = d_d;
+  return launch(h, a, (hipStream_t)stream);
+}
+
+int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, double* d_d, double* d_rho_old, double* d_rho,
+                          int32_t* d_nfact, int32_t* d_success, const double params[9], void* stream) {
+  if (!h || !d_vals || !d_rhs || !d_d || !d_rho_old || !d_rho || !d_nfact || !d_success || !params)
+    return fail(CNL_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  cnl::LaunchArgs a{};
+  a.mode = cnl::MODE_NEWTON;
+  a.vals = d_vals; a.rhs = d_rhs; a.d = d_d; a.rho_old = d_rho_old; a.rho = d_rho; a.nfact = d_nfact; a.success = d_success;
+  std::memcpy(a.params, params, 9 * sizeof(double));
+  int rc = launch(h, a, (hipStream_t)stream);
+  if (rc == CNL_OK) h->factorized = true;
+  return rc;
+}
+
+// ---- host-pointer entry points (what the Julia glue ccalls) ------------------------
+int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* success, int64_t* npos, int64_t* nzero) {
+  if (!h || !vals || !success) return fail(CNL_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_staging(h);
+  if (rc) return rc;
+  const cnl::Plan& P = h->plan->P;
+  const size_t B = (size_t)h->batch;
+  HIPCHK(hipMemcpyAsync(h->d_vals, vals, B * P.nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  cnl::LaunchArgs a{};
+  a.mode = cnl::MODE_FACTOR;
+  a.vals = h->d_vals; a.success = h->d_success; a.npos = h->d_npos; a.nzero = h->d_nzero;
+  a.params[0] = eig_tol;
+  if ((rc = launch(h, a, h->stream))) return rc;
+  HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  if (npos) HIPCHK(hipMemcpyAsync(npos, h->d_npos, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  if (nzero) HIPCHK(hipMemcpyAsync(nzero, h->d_nzero, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->factorized = true;
+  return CNL_OK;
+}
+
+int cnl_solve(cnl_handle* h, const double* rhs, double* d) {
+  if (!h || !rhs || !d) return fail(CNL_ERR_ARG, "null argument");
+  if (!h->factorized) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_staging(h);
+  if (rc) return rc;
+  const cnl::Plan& P = h->plan->P;
+  const size_t B = (size_t)h->batch;
+  HIPCHK(hipMemcpyAsync(h->d_rhs, rhs, B * P.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  cnl::LaunchArgs a{};
+  a.mode = cnl::MODE_SOLVE;
+  a.rhs = h->d_rhs; a.d = h->d_d;
+  if ((rc = launch(h, a, h->stream))) return rc;
+  HIPCHK(hipMemcpyAsync(d, h->d_d, B * P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CNL_OK;
+}
+
+int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d, const double* rho_old, const double params[9],
+                      double* rho, double* rho_old_out, int32_t* nfact, int32_t* success) {
+  if (!h || !vals || !rhs || !d || !params || !rho || !rho_old_out || !nfact || !success) return fail(CNL_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_staging(h);
+  if (rc) return rc;
+  const cnl::Plan& P = h->plan->P;
+  const size_t B = (size_t)h->batch;
+  HIPCHK(hipMemcpyAsync(h->d_vals, vals, B * P.nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_rhs, rhs, B * P.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (rho_old) HIPCHK(hipMemcpyAsync(h->d_rho_old, rho_old, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  else HIPCHK(hipMemsetAsync(h->d_rho_old, 0, B * sizeof(double), h->stream));
+  // d is only written for problems that succeed; give the others zeros rather than stale data
+  HIPCHK(hipMemsetAsync(h->d_d, 0, B * P.N * sizeof(double), h->stream));
+  cnl::LaunchArgs a{};
+  a.mode = cnl::MODE_NEWTON;
+  a.vals = h->d_vals; a.rhs = h->d_rhs; a.d = h->d_d; a.rho_old = h->d_rho_old; a.rho = h->d_rho;
+  a.nfact = h->d_nfact; a.success = h->d_success;
+  std::memcpy(a.params, params, 9 * sizeof(double));
+  if ((rc = launch(h, a, h->stream))) return rc;
+  HIPCHK(hipMemcpyAsync(d, h->d_d, B * P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(rho, h->d_rho, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(rho_old_out, h->d_rho_old, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(nfact, h->d_nfact, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  // rho tail of vals (the reference mutates get_vals(LDLT)[end-nvar+1:end], src/CaNNOLeS.jl:1031,1038)
+  if (P.nvar > 0)
+    HIPCHK(hipMemcpy2DAsync(vals + P.rho_begin, (size_t)P.nnz * sizeof(double), h->d_vals + P.rho_begin,
+                            (size_t)P.nnz * sizeof(double), (size_t)P.nvar * sizeof(double), B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->factorized = true;
+  return CNL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// kernels.h — launch interface between the C ABI (capi.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "plan.h"
+
+namespace cnl {
+
+// device-resident copy of the plan (index data shared by every problem)
+struct DevPlan {
+  const FrontHdr* fronts;
+  const int32_t* seg_ptr;
+  const int32_t* asm_pos;
+  const int32_t* asm_src;
+  const int32_t* child_idx;
+  const int32_t* rel_idx;
+  const int32_t* perm;
+  int32_t nsuper, N, nnz, rho_begin, nvar, nequ, ncon;
+  int32_t fmax;
+  int32_t pb_off;        // offset (doubles) of the panel buffer inside a problem's work area
+  int32_t wv_off;        // offset of the two pivot-row staging vectors (2*fmax doubles)
+  int32_t work_doubles;  // work area per problem
+  int64_t lsize;         // factor storage per problem (doubles)
+};
+
+struct KernelConfig {
+  int tpp = 64;          // threads per problem (16, 32, 64, 256, 1024)
+  int ppb = 1;           // problems per workgroup
+  int lds_work = 1;      // work area in LDS (else global scratch)
+  size_t lds_bytes = 0;  // dynamic LDS per workgroup
+};
+
+enum { MODE_NEWTON = 0, MODE_FACTOR = 1, MODE_SOLVE = 2 };
+
+struct LaunchArgs {
+  int mode;
+  int batch;
+  double* vals;          // [batch][nnz]   (NEWTON: rho tail written back; FACTOR: read only)
+  const double* rhs;     // [batch][N]     (NEWTON, SOLVE)
+  double* d;             // [batch][N]     (NEWTON, SOLVE)
+  double* L;             // [batch][lsize] factor storage
+  double* scratch;       // [batch][work_doubles] when !lds_work
+  double* rho_old;       // [batch] in/out (NEWTON)
+  double* rho;           // [batch] out    (NEWTON)
+  int32_t* nfact;        // [batch] out    (NEWTON)
+  int32_t* success;      // [batch] out    (NEWTON: solve_success, FACTOR: success)
+  int64_t* npos;         // [batch] optional (FACTOR)
+  int64_t* nzero;        // [batch] optional (FACTOR)
+  double params[9];      // ParamCaNNOLeS; params[0] = eig_tol also for FACTOR
+};
+
+// returns hipSuccess or the launch error
+hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);
+// largest dynamic LDS a workgroup may use on the current device
+size_t max_lds_bytes();
+
+}  // namespace cnl

@@ -1,0 +1,81 @@
+// plan.h — host-side symbolic analysis of the CaNNOLeS Newton (KKT) system.
+//
+// Replaces what the reference gets from `ldl_analyze` (AMD ordering + etree +
+// column counts; /root/reference/src/solver_types.jl:61-65) with a static
+// multifrontal "plan" shared by every problem of a batch: elimination order,
+// supernodes (fronts), assembly / extend-add index maps and the LDS layout of
+// the update-matrix stack.  The plan is pure index data; the HIP kernels in
+// kernels.hip execute it.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace cnl {
+
+// One front (supernode), 16 x int32 = 64 bytes so a wave fetches it with
+// scalar loads.
+struct FrontHdr {
+  int32_t npiv;       // pivots eliminated in this front
+  int32_t nupd;       // update rows (excluding the rhs row)
+  int32_t foff;       // offset (doubles) of the packed front in the work stack
+  int32_t ubase;      // offset where the update matrix is left for the parent
+  int32_t seg_begin;  // assembly rounds [seg_begin, seg_end) into seg_ptr
+  int32_t seg_end;
+  int32_t child_begin;// children [child_begin, child_end) into child_idx
+  int32_t child_end;
+  int32_t rel_begin;  // rel map of THIS front into its parent: rel_idx[rel_begin + i], i in [0, 1+nupd)
+  int32_t first_piv;  // elimination index of the first pivot of the front
+  int32_t xoff;       // offset (doubles) of the front's solution vector in the backward stack
+  int32_t parent;     // parent front or -1
+  int32_t lptr_lo;    // offset (doubles) of the L panel in the per-problem factor storage
+  int32_t lptr_hi;    //   (lptr = lptr_lo | lptr_hi << 31)
+  int32_t indep;      // leading `indep` pivots (first eliminated) are mutually independent
+  int32_t pad;
+};
+
+struct Options {
+  int order_mode = -1;     // -1 auto, 0 canonical (r, x natural, lambda), 1 ND, 2 MD
+  int nd_leaf = 0;         // 0 = sweep
+  int relax = -1;          // relaxed-amalgamation budget (extra zeros per merged column); -1 = default
+  int lds_budget_doubles = 0; // 0 = default
+  int with_rhs_row = 1;
+};
+
+struct Plan {
+  int64_t N = 0, nnz = 0, nvar = 0, nequ = 0, ncon = 0;
+  int64_t nnzK = 0;          // unique lower-triangular entries
+  // ordering: perm[k] = original 0-based index eliminated k-th
+  std::vector<int32_t> perm, iperm;
+  // fronts in post-order
+  int32_t nsuper = 0;
+  std::vector<FrontHdr> fronts;
+  // assembly: front s owns rounds seg_begin..seg_end; round r = entries
+  // [seg_ptr[r], seg_ptr[r+1]) of (asm_pos, asm_src).  Within a round all
+  // positions are distinct; rounds are applied in order, which reproduces the
+  // COO-order summation of duplicates of set_vals! (solver_types.jl:53-59).
+  // asm_src < nnz: COO entry;  asm_src >= nnz: rhs[asm_src - nnz].
+  std::vector<int32_t> seg_ptr, asm_pos, asm_src;
+  std::vector<int32_t> child_idx;
+  std::vector<int32_t> rel_idx;
+  // universal triangular decode: tri_row[t] = i with i(i+1)/2 <= t < (i+1)(i+2)/2
+  int32_t fmax = 0;          // largest front order (1 + nupd + npiv)
+  int64_t lsize = 0;         // doubles of factor storage per problem
+  int64_t nnzL = 0;          // strictly-lower entries of L incl. explicit zeros of relaxed supernodes (no rhs row, no diagonal)
+  int64_t nnzL_exact = 0;    // fill of the ordering without relaxation
+  double flops = 0;          // FMAs of the numeric phase as executed (incl. rhs row)
+  int32_t fwd_peak = 0;      // doubles of work stack needed by the forward (factor) pass
+  int32_t bwd_peak = 0;      // doubles needed by the backward pass
+  int32_t panel_max = 0;     // largest L panel (doubles)
+  int32_t rho_begin = 0;     // COO entries >= rho_begin are the rho slots (nnz - nvar)
+  std::string order_name;
+  double cost = 0;           // model cost used to choose the ordering
+};
+
+// Builds the plan.  rows1/cols1: 1-based COO of the lower triangle, duplicates
+// allowed (summed).  Returns 0 or an error code (see cannoles_hip.h); msg gets
+// a description.
+int build_plan(Plan& P, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
+               int64_t nvar, int64_t nequ, int64_t ncon, const Options& opt, std::string& msg);
+
+}  // namespace cnl

@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference's linear-solver plugin surface, over the C ABI.
+
+The reference's extension point is `abstract type LinearSolverStruct`
+(/root/reference/src/solver_types.jl:1) with
+  * a constructor `Backend(N, rows, cols, vals)`        (src/CaNNOLeS.jl:323,327)
+  * `get_vals(LDLT)`                                      (src/solver_types.jl:25,67)
+  * `try_to_factorize(LDLT, vals, nvar, nequ, ncon, eig_tol)::Bool` (solver_types.jl:79-98)
+  * `solve_ldl!(rhs, LDLT.factor, d)::Bool`               (solver_types.jl:69-77)
+and the driver `newton_system!` (src/CaNNOLeS.jl:1008-1052).  The same names
+and argument meanings are kept here (`!` spelled `_`), so the parity tests read
+like the reference's own code.  All arithmetic happens in libcannoles_hip.so
+(HIP kernels); this module only marshals numpy / torch buffers through ctypes.
+Julia would bind the same symbols with `ccall`.
+
+There is no CPU fallback: if the shared library is missing, or no HIP device
+is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcannoles_hip.so")
+
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_lib = None
+
+# symbols declared in include/cannoles_hip.h (checked by the CPU test-suite)
+ABI_SYMBOLS = [
+    "cnl_last_error", "cnl_version", "cnl_default_params",
+    "cnl_plan_create", "cnl_plan_destroy", "cnl_plan_info", "cnl_plan_get", "cnl_plan_order_name",
+    "cnl_create", "cnl_destroy", "cnl_get_plan",
+    "cnl_factorize", "cnl_solve", "cnl_newton_system",
+    "cnl_factorize_dev", "cnl_solve_dev", "cnl_newton_system_dev",
+    "cnl_set_timing", "cnl_last_kernel_ms", "cnl_get_config",
+]
+
+
+class CnlError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"cannoles_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libcannoles_hip.so (built by __graft_entry__.build / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int32
+        L.cnl_last_error.restype = C.c_char_p
+        L.cnl_version.restype = i32
+        L.cnl_default_params.argtypes = [vp]
+        L.cnl_plan_create.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64]
+        L.cnl_plan_destroy.argtypes = [vp]
+        L.cnl_plan_destroy.restype = None
+        L.cnl_plan_info.argtypes = [vp, _i64p]
+        L.cnl_plan_get.argtypes = [vp, C.c_char_p, vp, C.POINTER(i64)]
+        L.cnl_plan_order_name.argtypes = [vp]
+        L.cnl_plan_order_name.restype = C.c_char_p
+        L.cnl_create.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64, i64, C.c_int]
+        L.cnl_destroy.argtypes = [vp]
+        L.cnl_get_plan.argtypes = [vp]
+        L.cnl_get_plan.restype = vp
+        L.cnl_factorize.argtypes = [vp, vp, dbl, vp, vp, vp]
+        L.cnl_solve.argtypes = [vp, vp, vp]
+        L.cnl_newton_system.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cnl_factorize_dev.argtypes = [vp, vp, dbl, vp, vp]
+        L.cnl_solve_dev.argtypes = [vp, vp, vp, vp]
+        L.cnl_newton_system_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cnl_set_timing.argtypes = [vp, C.c_int]
+        L.cnl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.cnl_get_config.argtypes = [vp, _i64p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise CnlError(rc, lib().cnl_last_error().decode())
+
+
+def default_params():
+    """ParamCaNNOLeS(Float64) (src/CaNNOLeS.jl:48-62) as
+    [eig_tol, dmin, kdec, kinc, klargeinc, rho0, rhomax, rhomin, gammaA]."""
+    p = np.zeros(9)
+    lib().cnl_default_params(p.ctypes.data)
+    return p
+
+
+def _i64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int64).ravel())
+
+
+_INFO_KEYS = ["N", "nnz", "nnzK", "nsuper", "nnzL", "nnzL_exact", "lsize", "fmax", "fwd_peak", "bwd_peak",
+              "panel_max", "flops", "nasm"]
+
+
+def _plan_info(p):
+    info = np.zeros(16, np.int64)
+    _check(lib().cnl_plan_info(p, info))
+    d = {k: int(info[i]) for i, k in enumerate(_INFO_KEYS)}
+    d["order"] = lib().cnl_plan_order_name(p).decode()
+    return d
+
+
+def _plan_array(p, name):
+    n = C.c_int64(0)
+    _check(lib().cnl_plan_get(p, name.encode(), None, C.byref(n)))
+    out = np.zeros(max(n.value, 1), np.int32)
+    cnt = C.c_int64(out.size)
+    _check(lib().cnl_plan_get(p, name.encode(), out.ctypes.data, C.byref(cnt)))
+    return out[:n.value]
+
+
+class Plan:
+    """Host-only symbolic analysis (what `ldl_analyze` is to the reference).
+    Needs no GPU; used by the CPU test-suite and for sizing."""
+
+    def __init__(self, N, rows, cols, nvar, nequ, ncon):
+        self.rows, self.cols = _i64(rows), _i64(cols)
+        p = C.c_void_p()
+        _check(lib().cnl_plan_create(C.byref(p), int(N), len(self.rows), self.rows, self.cols, int(nvar), int(nequ), int(ncon)))
+        self._p = p
+        self.info = _plan_info(p)
+
+    def array(self, name):
+        return _plan_array(self._p, name)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().cnl_plan_destroy(self._p)
+            self._p = None
+
+
+class _Factor:
+    """What `LDLT.factor` is to the reference: the object `solve_ldl!` dispatches on."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+
+class HIPLDLStruct:
+    """`struct HIPLDLStruct <: LinearSolverStruct` — drop-in for LDLFactStruct
+    (src/solver_types.jl:45-65).  `batch > 1` is the batched twin: one shared
+    pattern, problem-major values `vals[b, :]`."""
+
+    def __init__(self, N, rows, cols, vals, nvar=None, nequ=None, ncon=None, batch=1, device=0):
+        self.N = int(N)
+        self.rows, self.cols = _i64(rows), _i64(cols)
+        self.nnz = len(self.rows)
+        self.batch = int(batch)
+        if nvar is None:
+            raise ValueError("nvar/nequ/ncon are required (the Julia glue passes them from the solver)")
+        self.nvar, self.nequ, self.ncon = int(nvar), int(nequ), int(ncon)
+        # `vals` is aliased, not copied: the driver mutates the array returned by get_vals
+        self.vals = vals if vals is not None else np.ones((self.batch, self.nnz) if self.batch > 1 else self.nnz)
+        h = C.c_void_p()
+        _check(lib().cnl_create(C.byref(h), self.N, self.nnz, self.rows, self.cols, self.nvar, self.nequ, self.ncon,
+                                self.batch, int(device)))
+        self._h = h
+        self.factor = _Factor(self)
+        self.info = _plan_info(lib().cnl_get_plan(h))
+        cfg = np.zeros(8, np.int64)
+        _check(lib().cnl_get_config(h, cfg))
+        self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4])}
+
+    def plan_array(self, name):
+        return _plan_array(lib().cnl_get_plan(self._h), name)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cnl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timing(self, on=True):
+        _check(lib().cnl_set_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _check(lib().cnl_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+def get_vals(LDLT):
+    """get_vals(LDLT::LinearSolverStruct) = LDLT.vals (src/solver_types.jl:67)."""
+    return LDLT.vals
+
+
+def _f64c(a, shape=None):
+    a = np.asarray(a)
+    if a.dtype != np.float64 or not a.flags.c_contiguous:
+        raise TypeError("expected a C-contiguous float64 array (Float64 only; other element types stay on LDLFactStruct)")
+    return a
+
+
+def try_to_factorize(LDLT, vals, nvar, nequ, ncon, eig_tol, return_inertia=False):
+    """success = try_to_factorize(LDLT, vals, nvar, nequ, ncon, eig_tol) (src/solver_types.jl:79-98).
+    Batched handles return arrays."""
+    assert (nvar, nequ, ncon) == (LDLT.nvar, LDLT.nequ, LDLT.ncon)
+    vals = _f64c(vals)
+    assert vals.size == LDLT.batch * LDLT.nnz
+    B = LDLT.batch
+    succ = np.zeros(B, np.int32)
+    npos = np.zeros(B, np.int64)
+    nzer = np.zeros(B, np.int64)
+    _check(lib().cnl_factorize(LDLT._h, vals.ctypes.data, float(eig_tol), succ.ctypes.data, npos.ctypes.data, nzer.ctypes.data))
+    if B == 1:
+        return (bool(succ[0]), int(npos[0]), int(nzer[0])) if return_inertia else bool(succ[0])
+    return (succ.astype(bool), npos, nzer) if return_inertia else succ.astype(bool)
+
+
+def solve_ldl_(rhs, factor, d):
+    """solve_ldl!(rhs, factor, d): d = -(K^-1 rhs), returns true (src/solver_types.jl:69-77)."""
+    LDLT = factor._owner
+    rhs = _f64c(rhs)
+    d = _f64c(d)
+    assert rhs.size == LDLT.batch * LDLT.N and d.size == rhs.size
+    _check(lib().cnl_solve(LDLT._h, rhs.ctypes.data, d.ctypes.data))
+    return True
+
+
+def newton_system_(d, nvar, nequ, ncon, rhs, vals, LDLT, rho_old, params):
+    """d, solve_success, rho, rho_old, nfact = newton_system!(d, nvar, nequ, ncon, rhs, vals, LDLT, rho_old, params)
+    (src/CaNNOLeS.jl:1008-1052), fused on the device.  `vals` is mutated (rho slots).
+    Batched handles take/return arrays for rho_old / success / rho / nfact."""
+    assert (nvar, nequ, ncon) == (LDLT.nvar, LDLT.nequ, LDLT.ncon)
+    B = LDLT.batch
+    vals = _f64c(vals)
+    rhs = _f64c(rhs)
+    d = _f64c(d)
+    assert vals.size == B * LDLT.nnz and rhs.size == B * LDLT.N and d.size == B * LDLT.N
+    ro = np.ascontiguousarray(np.broadcast_to(np.asarray(rho_old, dtype=np.float64), (B,)))
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    rho = np.zeros(B)
+    ro_out = np.zeros(B)
+    nfact = np.zeros(B, np.int32)
+    succ = np.zeros(B, np.int32)
+    _check(lib().cnl_newton_system(LDLT._h, vals.ctypes.data, rhs.ctypes.data, d.ctypes.data, ro.ctypes.data,
+                                   params.ctypes.data, rho.ctypes.data, ro_out.ctypes.data, nfact.ctypes.data,
+                                   succ.ctypes.data))
+    if B == 1:
+        return d, bool(succ[0]), float(rho[0]), float(ro_out[0]), int(nfact[0])
+    return d, succ.astype(bool), rho, ro_out, nfact.astype(np.int64)
+
+
+def newton_system_dev(LDLT, vals_ptr, rhs_ptr, d_ptr, rho_old_ptr, rho_ptr, nfact_ptr, success_ptr, params, stream=0):
+    """Device-resident twin (cnl_newton_system_dev): all *_ptr are device addresses
+    (e.g. torch.Tensor.data_ptr()); asynchronous on `stream` (a hipStream_t value)."""
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    _check(lib().cnl_newton_system_dev(LDLT._h, vals_ptr, rhs_ptr, d_ptr, rho_old_ptr, rho_ptr, nfact_ptr, success_ptr,
+                                       params.ctypes.data, stream))

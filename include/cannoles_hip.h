@@ -1,0 +1,119 @@
+/*
+ * cannoles_hip.h — C ABI of the MI355X-native Newton-system backend for CaNNOLeS.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Every entry point cites the reference interface it replaces
+ * (paths under /root/reference).  The Julia binding a maintainer would add
+ * is shown in INTEGRATION.md and shipped in cannoles.jl_amd/julia/.
+ *
+ * Conventions
+ *   - Index arrays are int64, 1-based, exactly as Julia holds `rows`/`cols`
+ *     (src/CaNNOLeS.jl:276-315).  Values are double (Float64 only; other
+ *     element types must stay on the reference's LDLFactStruct).
+ *   - The COO pattern is the lower triangle of the KKT matrix in the
+ *     reference's 7-segment order [H_F | H_c | J_F | J_c | -I | -dI | rI];
+ *     duplicates are summed in COO order (src/solver_types.jl:53-59); the
+ *     LAST nvar entries are the rho slots (src/CaNNOLeS.jl:1027).
+ *   - A handle serves a batch of `batch` independent problems that share the
+ *     pattern (batch = 1 is the reference's one-solver-one-problem case).
+ *     Batched arrays are problem-major: vals[b*nnz + k], rhs[b*N + i].
+ *   - Host-pointer entry points copy in/out and keep no pointer afterwards.
+ *     `_dev` entry points take device pointers (HBM-resident data) and a
+ *     hipStream_t passed as void*; they are asynchronous on that stream.
+ *   - Return value: 0 = OK, otherwise one of CNL_ERR_*; cnl_last_error()
+ *     describes the last failure on the calling thread.  Numerical failure
+ *     (wrong inertia, zero pivot) is NOT an error: it is reported through
+ *     `success`, like the reference's Bool (src/solver_types.jl:96-97).
+ *   - There is no CPU fallback: without a usable HIP device every call that
+ *     needs one fails with CNL_ERR_HIP.
+ */
+#ifndef CANNOLES_HIP_H
+#define CANNOLES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNL_OK 0
+#define CNL_ERR_ARG 1      /* null pointer / bad handle / bad size              */
+#define CNL_ERR_DIM 2      /* inconsistent or unsupported dimensions            */
+#define CNL_ERR_PATTERN 3  /* malformed COO pattern (range, upper triangle)     */
+#define CNL_ERR_HIP 4      /* HIP runtime error or no device                    */
+#define CNL_ERR_STATE 5    /* call sequence error (solve before factorize)      */
+#define CNL_ERR_INTERNAL 9
+
+typedef struct cnl_plan cnl_plan;     /* host-only symbolic analysis            */
+typedef struct cnl_handle cnl_handle; /* plan + device state for one batch      */
+
+const char* cnl_last_error(void);
+/* library / ABI version: major*10000 + minor*100 + patch */
+int32_t cnl_version(void);
+
+/* ParamCaNNOLeS(Float64) defaults, src/CaNNOLeS.jl:48-62, in the order
+ * [eig_tol, delta_min, kappa_dec, kappa_inc, kappa_largeinc, rho0, rho_max, rho_min, gamma_A] */
+void cnl_default_params(double params[9]);
+
+/* ---- symbolic analysis (host only; replaces `ldl_analyze`, ------------------
+ *      src/solver_types.jl:61-65: sparse()+triu()+ldl_analyze) ---------------- */
+int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
+                    int64_t nvar, int64_t nequ, int64_t ncon);
+void cnl_plan_destroy(cnl_plan* plan);
+/* info[0]=N [1]=nnz [2]=unique nnz(K) [3]=nsuper [4]=nnz(L) stored (strictly lower, with relaxed zeros)
+ * [5]=nnz(L) of the ordering without relaxation [6]=factor storage doubles/problem [7]=largest front order
+ * [8]=forward work-stack doubles [9]=backward work-stack doubles [10]=largest panel doubles
+ * [11]=FMAs per factorisation [12]=assembly entries [13..15]=reserved */
+int cnl_plan_info(const cnl_plan* plan, int64_t info[16]);
+/* Copy a named int32 index array of the plan ("perm", "fronts", "seg_ptr", "asm_pos", "asm_src",
+ * "child_idx", "rel_idx").  With out == NULL only *count is set.  "fronts" is 16 int32 per front
+ * (struct FrontHdr, csrc/plan.h).  Used by the tests' plan simulator.                           */
+int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* count);
+const char* cnl_plan_order_name(const cnl_plan* plan);
+
+/* ---- solver object (replaces LDLFactStruct(N, rows, cols, vals), ---------------
+ *      src/solver_types.jl:45-51,61-65; called at src/CaNNOLeS.jl:327) --------- */
+int cnl_create(cnl_handle** h, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
+               int64_t nvar, int64_t nequ, int64_t ncon, int64_t batch, int device);
+int cnl_destroy(cnl_handle* h);
+const cnl_plan* cnl_get_plan(const cnl_handle* h);
+
+/* try_to_factorize(LDLT, vals, nvar, nequ, ncon, eig_tol) — src/solver_types.jl:79-98.
+ * vals: batch*nnz values (rho slots as given).  success[b] = 1 iff the factorisation completed
+ * with #{d > eig_tol} == nvar and #{|d| <= eig_tol} == 0.  npos/nzero (optional, batch each)
+ * return the two counts.                                                                      */
+int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* success, int64_t* npos, int64_t* nzero);
+
+/* solve_ldl!(rhs, factor, d) — src/solver_types.jl:69-77: d = -(K^-1 rhs); rhs untouched.
+ * Requires a preceding cnl_factorize.  Problems whose factorisation failed get NaN-free garbage
+ * (the reference never solves after a failure, src/CaNNOLeS.jl:1049).                          */
+int cnl_solve(cnl_handle* h, const double* rhs, double* d);
+
+/* newton_system!(d, nvar, nequ, ncon, rhs, vals, LDLT, rho_old, params) — src/CaNNOLeS.jl:1008-1052,
+ * fused on the device: factorise at rho=0, climb the rho ladder per problem on failure, solve.
+ * vals (batch*nnz) is mutated: the rho slots receive the last rho tried, as the reference leaves them.
+ * rho_old: batch inputs.  Outputs (batch each): rho, rho_old_out, nfact, success (= solve_success).  */
+int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d, const double* rho_old,
+                      const double params[9], double* rho, double* rho_old_out, int32_t* nfact, int32_t* success);
+
+/* Device-resident twins.  d_vals/d_rhs/d_d are device pointers with the layouts above.
+ * d_rho_old is read and updated in place (rho_old_out); d_rho, d_nfact, d_success are outputs. */
+int cnl_factorize_dev(cnl_handle* h, const double* d_vals, double eig_tol, int32_t* d_success, void* stream);
+int cnl_solve_dev(cnl_handle* h, const double* d_rhs, double* d_d, void* stream);
+int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, double* d_d, double* d_rho_old,
+                          double* d_rho, int32_t* d_nfact, int32_t* d_success, const double params[9], void* stream);
+
+/* Average device time of the last `_dev`/host call's kernels in milliseconds, measured with HIP
+ * events on the call's stream (0 if timing was not enabled with cnl_set_timing).               */
+int cnl_set_timing(cnl_handle* h, int enable);
+int cnl_last_kernel_ms(cnl_handle* h, float* ms);
+
+/* Kernel configuration actually chosen: cfg[0]=threads per problem, [1]=problems per workgroup,
+ * [2]=LDS bytes per workgroup, [3]=1 if the work stack lives in LDS else 0 (global scratch),
+ * [4]=grid size, [5..7] reserved.                                                              */
+int cnl_get_config(const cnl_handle* h, int64_t cfg[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CANNOLES_HIP_H */

@@ -1,0 +1,173 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  -m gpu.
+
+Tolerances (fp64, stated per SURVEY.md §7 "Hard parts"):
+  * forward:  max|d - d_oracle| / max|d_oracle| <= 1e-9 on the well-conditioned configs
+  * backward: max|K d + rhs| / (||K||_inf max|d| + max|rhs|) <= 1e-13
+  * (success, nfact, rho, rho_old) identical to the oracle's.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-9
+BWD_TOL = 1e-13
+
+
+def _mods():
+    import cannoles_jl_amd  # noqa: F401
+    from cannoles_jl_amd import hipldl, synthetic as syn
+    from oracle import oracle as O
+    return hipldl, syn, O
+
+
+def backward_error(s, vals, rhs, d):
+    import scipy.sparse as sp
+    rows, cols = s.kkt_pattern()
+    Kl = sp.coo_matrix((vals, (rows - 1, cols - 1)), shape=(s.N, s.N)).tocsr()
+    K = Kl + sp.tril(Kl, -1).T
+    res = K @ d + rhs
+    return np.abs(res).max() / (abs(K).sum(axis=1).max() * np.abs(d).max() + np.abs(rhs).max())
+
+
+def run_case(s, vals, rhs, rho_old=None, fwd_tol=FWD_TOL, check_fwd=True, env=None):
+    hipldl, syn, O = _mods()
+    B = vals.shape[0]
+    rows, cols = s.kkt_pattern()
+    p = hipldl.default_params()
+    ro = np.zeros(B) if rho_old is None else np.asarray(rho_old, float)
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    v = vals.copy()
+    d = np.zeros((B, s.N))
+    d, ok, rho, ro_out, nfact = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, LDLT, ro, p)
+    if B == 1:
+        ok, rho, ro_out, nfact = np.array([ok]), np.array([rho]), np.array([ro_out]), np.array([nfact])
+    perm = LDLT.plan_array("perm").astype(np.int64)
+    orc = O.Oracle(s.N, rows, cols, perm)
+    v0 = vals.copy()
+    d0, ok0, rho0, ro0, nf0 = O.newton_system_batch(orc, B, s.nvar, s.nequ, s.ncon, rhs, v0, ro, p)
+    assert np.array_equal(ok, ok0)
+    assert np.array_equal(nfact, nf0)
+    assert np.array_equal(rho, rho0)
+    assert np.array_equal(ro_out, ro0)
+    # the rho slots of vals are left as the reference leaves them
+    assert np.array_equal(v.reshape(B, -1)[:, -s.nvar:], v0[:, -s.nvar:])
+    d = d.reshape(B, s.N)
+    for b in range(B):
+        if not ok0[b]:
+            continue
+        vv = v0[b]
+        assert backward_error(s, vv, rhs[b], d[b]) <= BWD_TOL
+        if check_fwd:
+            assert np.abs(d[b] - d0[b]).max() / np.abs(d0[b]).max() <= fwd_tol
+    info, cfg = LDLT.info, LDLT.config
+    LDLT.close()
+    return info, cfg
+
+
+def test_fixture_mgh01con(built):
+    """F1: first Newton system of the reference's MGH01CON model (test/mgh01con.jl), exact answer known."""
+    hipldl, syn, O = _mods()
+    rows, cols, _ = O.kkt_pattern(2, 2, 1, hF=([1], [1]), hc=([1, 2, 2], [1, 1, 2]), jF=([1, 2, 2], [1, 1, 2]), jc=([1], [1]))
+    vals = np.array([88., -0., -0., -0., -1., 24., 10., 1., -1., -1., -0.1, 0., 0.])
+    rhs = np.array([0, -44, 0, 0, -1.2])
+    LDLT = hipldl.HIPLDLStruct(5, rows, cols, vals, 2, 2, 1)
+    assert hipldl.get_vals(LDLT) is vals
+    ok, npos, nzer = hipldl.try_to_factorize(LDLT, vals, 2, 2, 1, 2.220446049250313e-16, return_inertia=True)
+    assert ok and npos == 2 and nzer == 0
+    d = np.zeros(5)
+    assert hipldl.solve_ldl_(rhs, LDLT.factor, d) is True
+    exact = np.array([-52 / 55, 149 / 55, 52 / 55, 4.4, -236 / 11])
+    assert np.abs(d - exact).max() <= 1e-13 * np.abs(exact).max()
+    d2 = np.zeros(5)
+    d2, ok, rho, rho_old, nfact = hipldl.newton_system_(d2, 2, 2, 1, rhs, vals, LDLT, 0.0, hipldl.default_params())
+    assert ok and rho == 0.0 and rho_old == 0.0 and nfact == 1
+    assert np.abs(d2 - exact).max() <= 1e-13 * np.abs(exact).max()
+    LDLT.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_structures(built, seed):
+    hipldl, syn, O = _mods()
+    s = syn.random_structure(30 + 5 * seed, 40, 5 if seed % 2 else 0, 0.12, seed)
+    vals, rhs = syn.batch_values(s, 3, cfg=seed, gen=syn.random_values)
+    run_case(s, vals, rhs)
+
+
+def test_gauss_newton_no_hessian(built):
+    """method=:Newton_noFHess: empty H_F segment (hessian_approx.jl:5-9); underdetermined => rho > 0"""
+    hipldl, syn, O = _mods()
+    s = syn.random_structure(30, 20, 0, 0.15, 7, hess=False)
+    vals, rhs = syn.batch_values(s, 2, cfg=7, gen=syn.random_values)
+    run_case(s, vals, rhs, fwd_tol=1e-6)
+
+
+def test_cfg4_batch(built):
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(1000, 10)
+    vals, rhs = syn.batch_values(s, 64, cfg=4)
+    run_case(s, vals, rhs)
+
+
+def test_cfg5_rho_ladder(built):
+    """F3: failures at rho in {0, 6.06e-6, 6.06e-4, 6.06e-2, 6.06}, success at 605.5 => nfact = 6"""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(1000, 10)
+    vals, rhs = syn.batch_values(s, 8, cfg=5, stress="ladder")
+    # mix in healthy problems: the ladder is per problem
+    v2, r2 = syn.batch_values(s, 8, cfg=4)
+    vals[::2], rhs[::2] = v2[::2], r2[::2]
+    run_case(s, vals, rhs)
+    run_case(s, vals, rhs, rho_old=np.full(8, 10.0))
+
+
+def test_cfg5_illconditioned(built):
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(1000, 10)
+    vals, rhs = syn.batch_values(s, 4, cfg=5, stress="illcond")
+    run_case(s, vals, rhs, check_fwd=False)
+
+
+def test_cfg3_single(built):
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(10000, 50)
+    vals, rhs = syn.batch_values(s, 1, cfg=3)
+    run_case(s, vals, rhs)
+
+
+def test_cfg2_dense_small(built):
+    hipldl, syn, O = _mods()
+    s = syn.dense_structure(60, 120)
+    vals, rhs = syn.batch_values(s, 2, cfg=2, gen=syn.dense_values)
+    run_case(s, vals, rhs)
+
+
+def test_factorize_then_solve_batch(built):
+    """the two-call plugin path (try_to_factorize; solve_ldl!) on a batch, several right-hand sides"""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(400, 8)
+    B = 5
+    vals, rhs = syn.batch_values(s, B, cfg=4)
+    rows, cols = s.kkt_pattern()
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, vals, s.nvar, s.nequ, s.ncon, batch=B)
+    ok = hipldl.try_to_factorize(LDLT, vals, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16)
+    assert ok.all()
+    for k in range(2):
+        r = rhs * (k + 1)
+        d = np.zeros((B, s.N))
+        hipldl.solve_ldl_(r, LDLT.factor, d)
+        for b in range(B):
+            assert backward_error(s, vals[b], r[b], d[b]) <= BWD_TOL
+    LDLT.close()
+
+
+def test_errors(built):
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(50, 2)
+    rows, cols = s.kkt_pattern()
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon)
+    with pytest.raises(hipldl.CnlError):
+        hipldl.solve_ldl_(np.zeros(s.N), LDLT.factor, np.zeros(s.N))  # solve before factorize
+    LDLT.close()
+    with pytest.raises(hipldl.CnlError):
+        hipldl.HIPLDLStruct(s.N, cols, rows, None, s.nvar, s.nequ, s.ncon)  # upper triangle
