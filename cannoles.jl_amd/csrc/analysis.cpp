@@ -776,6 +776,93 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     }
     P.bwd_peak = (int32_t)bpeak;
   }
+
+  // ---- v2 streams (register-front kernel) ---------------------------------------------
+  P.v2_ok = opt.with_rhs_row && P.fmax <= 64;
+  if (const char* e = getenv("CNL_NO_V2")) if (atoi(e)) P.v2_ok = false;
+  if (P.v2_ok) {
+    const int64_t ubig_thr = tri(17);  // update matrices above this size live in global scratch
+    ivec uoff2(ns, 0), uglob(ns, 0), fsglob(ns, 0), fsoff2(ns, 0), cls(ns, 16);
+    int64_t spL = 0, spG = 0, peakL = 0, peakG = 0, fsmax = 0;
+    for (int32_t s = 0; s < ns; s++) {
+      const FrontHdr& F = P.fronts[s];
+      int64_t f = 1 + (int64_t)F.nupd + F.npiv;
+      cls[s] = f <= 16 ? 16 : (f <= 32 ? 32 : 64);
+      P.ncls[cls[s] == 16 ? 0 : (cls[s] == 32 ? 1 : 2)]++;
+      int64_t baseL = spL, baseG = spG;
+      bool seenL = false, seenG = false;
+      for (int32_t ci = F.child_begin; ci < F.child_end; ci++) {
+        int32_t c = P.child_idx[ci];
+        if (uglob[c]) { if (!seenG) { baseG = uoff2[c]; seenG = true; } }
+        else { if (!seenL) { baseL = uoff2[c]; seenL = true; } }
+      }
+      fsglob[s] = cls[s] == 64;
+      int64_t tu = tri(1 + F.nupd);
+      uglob[s] = tu > ubig_thr;
+      if (fsglob[s]) {
+        // the staging triangle must not overlap the slot its own update matrix is written to
+        // (rows >= 32 of the update matrix are stored while rows < 32 are still read from staging)
+        int64_t fo = uglob[s] ? std::max(spG, baseG + tu) : spG;
+        fsoff2[s] = (int32_t)fo;
+        peakG = std::max(peakG, fo + tri(f));
+      } else fsmax = std::max(fsmax, tri(f));
+      if (uglob[s]) { uoff2[s] = (int32_t)baseG; spG = baseG + tu; spL = baseL; peakG = std::max(peakG, spG); }
+      else { uoff2[s] = (int32_t)baseL; spL = baseL + tu; spG = baseG; peakL = std::max(peakL, spL); }
+    }
+    P.u2_peak = (int32_t)((peakL + 1) & ~(int64_t)1);
+    P.fs2_max = (int32_t)((fsmax + 1) & ~(int64_t)1);
+    P.gs_doubles = (peakG + 1) & ~(int64_t)1;
+    // forward records
+    P.rec.clear(); P.rec_maxlen = 0;
+    for (int32_t s = 0; s < ns; s++) {
+      const FrontHdr& F = P.fronts[s];
+      size_t r0 = P.rec.size();
+      P.rec.resize(r0 + R_HDR, 0);
+      // assembly entries, every round padded to a multiple of 16 (dummy: src -1 -> value 0 added to slot 0)
+      ivec asrc, apos;
+      for (int32_t r = F.seg_begin; r < F.seg_end; r++) {
+        for (int32_t e = P.seg_ptr[r]; e < P.seg_ptr[r + 1]; e++) { asrc.push_back(P.asm_src[e]); apos.push_back(P.asm_pos[e]); }
+        while (asrc.size() % 16) { asrc.push_back(-1); apos.push_back(0); }
+      }
+      int32_t asm_off = (int32_t)(P.rec.size() - r0);
+      P.rec.insert(P.rec.end(), asrc.begin(), asrc.end());
+      P.rec.insert(P.rec.end(), apos.begin(), apos.end());
+      int32_t child_off = (int32_t)(P.rec.size() - r0);
+      for (int32_t ci = F.child_begin; ci < F.child_end; ci++) {
+        int32_t c = P.child_idx[ci];
+        const FrontHdr& C = P.fronts[c];
+        int32_t tuc = (int32_t)tri(1 + C.nupd);
+        P.rec.push_back(uoff2[c]); P.rec.push_back(tuc); P.rec.push_back(uglob[c] ? 1 : 0); P.rec.push_back(0);
+        const int32_t* rel = P.rel_idx.data() + C.rel_begin;
+        for (int32_t a = 0; a <= C.nupd; a++)
+          for (int32_t b = 0; b <= a; b++) P.rec.push_back((int32_t)(tri(rel[a]) + rel[b]));
+        while ((P.rec.size() - r0) % 4) P.rec.push_back(0);
+      }
+      while ((P.rec.size() - r0) % 4) P.rec.push_back(0);
+      int32_t* H = P.rec.data() + r0;
+      H[R_NPIV] = F.npiv; H[R_NUPD] = F.nupd; H[R_RECLEN] = (int32_t)(P.rec.size() - r0); H[R_NASM] = (int32_t)asrc.size();
+      H[R_NCHILD] = F.child_end - F.child_begin; H[R_UOFF] = uoff2[s];
+      H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0); H[R_FSOFF] = fsoff2[s];
+      H[R_LPTR_LO] = F.lptr_lo; H[R_LPTR_HI] = F.lptr_hi; H[R_CLS] = cls[s]; H[R_ASM_OFF] = asm_off; H[R_CHILD_OFF] = child_off;
+      P.rec_maxlen = std::max(P.rec_maxlen, H[R_RECLEN]);
+    }
+    // backward records, reverse post-order
+    P.brec.clear(); P.brec_maxlen = 0;
+    for (int32_t s = ns - 1; s >= 0; s--) {
+      const FrontHdr& F = P.fronts[s];
+      size_t r0 = P.brec.size();
+      P.brec.resize(r0 + B_HDR, 0);
+      for (int32_t l = 0; l <= F.nupd; l++) P.brec.push_back(P.rel_idx[F.rel_begin + l]);
+      const int32_t f = 1 + F.nupd + F.npiv;
+      for (int32_t i = F.nupd + 1; i < f; i++) P.brec.push_back(P.perm[F.first_piv + (f - 1 - i)]);
+      while ((P.brec.size() - r0) % 4) P.brec.push_back(0);
+      int32_t* H = P.brec.data() + r0;
+      H[B_NPIV] = F.npiv; H[B_NUPD] = F.nupd; H[B_RECLEN] = (int32_t)(P.brec.size() - r0); H[B_XOFF] = F.xoff;
+      H[B_PXOFF] = F.parent >= 0 ? P.fronts[F.parent].xoff : -1;
+      H[B_LPTR_LO] = F.lptr_lo; H[B_LPTR_HI] = F.lptr_hi; H[B_CLS] = cls[s];
+      P.brec_maxlen = std::max(P.brec_maxlen, H[B_RECLEN]);
+    }
+  }
   msg.clear();
   return 0;
 }

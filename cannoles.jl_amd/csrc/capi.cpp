@@ -29,6 +29,12 @@ struct cnl_handle {
   std::vector<void*> dev_allocs;
   cnl::DevPlan dp{};
   cnl::KernelConfig cfg{};
+  // v2 (register-front kernel): used for newton_system / factorize when every front has order <= 64
+  bool use_v2 = false;
+  cnl::DevPlan2 dp2{};
+  int wpb2 = 1;
+  size_t lds2 = 0;
+  double* d_gs = nullptr;
   double* d_L = nullptr;
   double* d_scratch = nullptr;
   // staging for the host-pointer API
@@ -126,12 +132,52 @@ int choose_config(cnl_handle* h) {
   return CNL_OK;
 }
 
+int setup_v2(cnl_handle* h) {
+  const cnl::Plan& P = h->plan->P;
+  h->use_v2 = false;
+  if (!P.v2_ok) return CNL_OK;
+  if (const char* e = getenv("CNL_FORCE_V1")) if (atoi(e)) return CNL_OK;
+  cnl::DevPlan2& d = h->dp2;
+  // streams are over-read by the prefetcher: pad with zeros
+  std::vector<int32_t> rec(P.rec), brec(P.brec);
+  rec.resize(rec.size() + 2048, 0);
+  brec.resize(brec.size() + 2048, 0);
+  int rc;
+  if ((rc = upload(h, rec, &d.rec))) return rc;
+  if ((rc = upload(h, brec, &d.brec))) return rc;
+  d.nsuper = P.nsuper; d.N = (int32_t)P.N; d.nnz = (int32_t)P.nnz; d.rho_begin = P.rho_begin; d.nvar = (int32_t)P.nvar;
+  d.reccap = (std::max(P.rec_maxlen, P.brec_maxlen) + 3) & ~3;
+  d.u2_peak = P.u2_peak;
+  int64_t prob = std::max<int64_t>((int64_t)P.u2_peak + P.fs2_max + 16, P.bwd_peak + 2);
+  d.prob_doubles = (int32_t)((prob + 1) & ~(int64_t)1);
+  d.gs_doubles = P.gs_doubles + 64;
+  d.lsize = P.lsize;
+  const size_t wave_bytes = ((size_t)d.reccap + 4 * (size_t)d.prob_doubles + 8) * sizeof(double);
+  size_t maxlds = std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024);
+  if (wave_bytes + 512 > maxlds) return CNL_OK;  // does not fit: stay on v1
+  // waves per workgroup: small workgroups give the dispatcher freedom; 2 keeps the launch grid moderate
+  int wpb = 1;
+  if (const char* e = getenv("CNL_WPB")) wpb = std::max(1, std::min(4, atoi(e)));
+  while (wpb > 1 && wpb * wave_bytes + 512 > maxlds) wpb--;
+  h->wpb2 = wpb;
+  h->lds2 = wpb * wave_bytes + 512;
+  if ((rc = dalloc(h, &h->d_gs, (size_t)h->batch * (size_t)d.gs_doubles))) return rc;
+  h->use_v2 = true;
+  return CNL_OK;
+}
+
 int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch;
   a.L = h->d_L;
   a.scratch = h->d_scratch;
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
-  hipError_t e = cnl::launch_newton(h->dp, h->cfg, a, stream);
+  hipError_t e;
+  if (h->use_v2 && a.mode != cnl::MODE_SOLVE) {
+    a.scratch = h->d_gs;
+    e = cnl::launch_newton2(h->dp2, h->wpb2, h->lds2, a, stream);
+  } else {
+    e = cnl::launch_newton(h->dp, h->cfg, a, stream);
+  }
   if (e != hipSuccess)
     return fail(CNL_ERR_HIP, std::string("kernel launch (tpp=") + std::to_string(h->cfg.tpp) + " ppb=" + std::to_string(h->cfg.ppb) +
                                  " lds=" + std::to_string(h->cfg.lds_work) + "): " + hipGetErrorString(e));
@@ -204,6 +250,9 @@ int cnl_plan_info(const cnl_plan* plan, int64_t info[16]) {
   info[0] = P.N; info[1] = P.nnz; info[2] = P.nnzK; info[3] = P.nsuper; info[4] = P.nnzL; info[5] = P.nnzL_exact;
   info[6] = P.lsize; info[7] = P.fmax; info[8] = P.fwd_peak; info[9] = P.bwd_peak; info[10] = P.panel_max;
   info[11] = (int64_t)P.flops; info[12] = (int64_t)P.asm_src.size();
+  info[13] = P.v2_ok ? ((int64_t)P.ncls[0] | ((int64_t)P.ncls[1] << 20) | ((int64_t)P.ncls[2] << 40)) : -1;
+  info[14] = P.v2_ok ? ((int64_t)P.u2_peak | ((int64_t)P.fs2_max << 20) | ((int64_t)std::max(P.rec_maxlen, P.brec_maxlen) << 40)) : -1;
+  info[15] = P.gs_doubles;
   return CNL_OK;
 }
 
@@ -260,6 +309,7 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   dp.nvar = (int32_t)P.nvar; dp.nequ = (int32_t)P.nequ; dp.ncon = (int32_t)P.ncon;
   dp.fmax = (P.fmax + 1) & ~1; dp.lsize = P.lsize;
   if ((rc = choose_config(h))) return bail(rc);
+  if ((rc = setup_v2(h))) return bail(rc);
   if ((rc = dalloc(h, &h->d_L, (size_t)batch * (size_t)std::max<int64_t>(P.lsize, 1)))) return bail(rc);
   if (!h->cfg.lds_work)
     if ((rc = dalloc(h, &h->d_scratch, (size_t)batch * (size_t)dp.work_doubles))) return bail(rc);
@@ -302,6 +352,9 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   std::memset(cfg, 0, 8 * sizeof(int64_t));
   cfg[0] = h->cfg.tpp; cfg[1] = h->cfg.ppb; cfg[2] = (int64_t)h->cfg.lds_bytes; cfg[3] = h->cfg.lds_work;
   cfg[4] = (h->batch + h->cfg.ppb - 1) / h->cfg.ppb;
+  cfg[5] = h->use_v2 ? 2 : 1;
+  cfg[6] = h->wpb2;
+  cfg[7] = (int64_t)h->lds2;
   return CNL_OK;
 }
 

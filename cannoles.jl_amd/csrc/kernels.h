@@ -32,6 +32,18 @@ struct KernelConfig {
   size_t lds_bytes = 0;  // dynamic LDS per workgroup
 };
 
+// device-resident v2 plan (record streams, see plan.h / kernels2.hip)
+struct DevPlan2 {
+  const int32_t* rec;
+  const int32_t* brec;
+  int32_t nsuper, N, nnz, rho_begin, nvar;
+  int32_t reccap;        // words per record buffer (two buffers per wave)
+  int32_t u2_peak;       // doubles: per-problem LDS update stack; the staging triangle follows it
+  int32_t prob_doubles;  // doubles of LDS per problem
+  int64_t gs_doubles;    // doubles of global scratch per problem
+  int64_t lsize;
+};
+
 enum { MODE_NEWTON = 0, MODE_FACTOR = 1, MODE_SOLVE = 2 };
 
 struct LaunchArgs {
@@ -53,6 +65,7 @@ struct LaunchArgs {
 
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);
+hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream);
 // largest dynamic LDS a workgroup may use on the current device
 size_t max_lds_bytes();
 

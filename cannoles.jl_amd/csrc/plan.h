@@ -70,7 +70,28 @@ struct Plan {
   int32_t rho_begin = 0;     // COO entries >= rho_begin are the rho slots (nnz - nvar)
   std::string order_name;
   double cost = 0;           // model cost used to choose the ordering
+
+  // ---- v2 ("register front") streams: valid when every front has order <= 64 ----
+  // Forward records (post-order) and backward records (reverse post-order) are
+  // self-describing word streams read sequentially by a wavefront; layouts in
+  // kernels2.hip (R_* / B_* constants).
+  bool v2_ok = false;
+  std::vector<int32_t> rec, brec;
+  int32_t rec_maxlen = 0, brec_maxlen = 0;  // words
+  int32_t u2_peak = 0;       // doubles of LDS update-matrix stack per problem
+  int32_t fs2_max = 0;       // doubles of LDS front staging per problem (fronts of order <= 32)
+  int64_t gs_doubles = 0;    // doubles of global scratch per problem (large fronts / update matrices)
+  int32_t ncls[3] = {0, 0, 0};  // fronts per class (order <=16, <=32, <=64)
 };
+
+// record layouts shared by analysis.cpp (writer) and kernels2.hip (reader)
+enum {
+  R_NPIV = 0, R_NUPD, R_RECLEN, R_NASM, R_NCHILD, R_UOFF, R_FLAGS, R_FSOFF, R_LPTR_LO, R_LPTR_HI, R_CLS,
+  R_ASM_OFF, R_CHILD_OFF, R_PAD13, R_PAD14, R_PAD15, R_HDR = 16
+};
+enum { RF_U_GLOBAL = 1, RF_FS_GLOBAL = 2 };
+enum { C_UOFF = 0, C_TUC, C_FLAGS, C_PAD, C_HDR = 4 };
+enum { B_NPIV = 0, B_NUPD, B_RECLEN, B_XOFF, B_PXOFF, B_LPTR_LO, B_LPTR_HI, B_CLS, B_HDR = 8 };
 
 // Builds the plan.  rows1/cols1: 1-based COO of the lower triangle, duplicates
 // allowed (summed).  Returns 0 or an error code (see cannoles_hip.h); msg gets

@@ -98,7 +98,7 @@ def _i64(a):
 
 
 _INFO_KEYS = ["N", "nnz", "nnzK", "nsuper", "nnzL", "nnzL_exact", "lsize", "fmax", "fwd_peak", "bwd_peak",
-              "panel_max", "flops", "nasm"]
+              "panel_max", "flops", "nasm", "v2_classes", "v2_lds", "v2_gs"]
 
 
 def _plan_info(p):
@@ -106,6 +106,13 @@ def _plan_info(p):
     _check(lib().cnl_plan_info(p, info))
     d = {k: int(info[i]) for i, k in enumerate(_INFO_KEYS)}
     d["order"] = lib().cnl_plan_order_name(p).decode()
+    c, l = d.pop("v2_classes"), d.pop("v2_lds")
+    if c >= 0:
+        d["v2"] = {"fronts16": c & 0xfffff, "fronts32": (c >> 20) & 0xfffff, "fronts64": c >> 40,
+                   "ustack": l & 0xfffff, "staging": (l >> 20) & 0xfffff, "reclen": l >> 40, "gscratch": d.pop("v2_gs")}
+    else:
+        d["v2"] = None
+        d.pop("v2_gs")
     return d
 
 
@@ -168,7 +175,8 @@ class HIPLDLStruct:
         self.info = _plan_info(lib().cnl_get_plan(h))
         cfg = np.zeros(8, np.int64)
         _check(lib().cnl_get_config(h, cfg))
-        self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4])}
+        self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4]),
+                       "kernel": "v2" if cfg[5] == 2 else "v1", "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7])}
 
     def plan_array(self, name):
         return _plan_array(lib().cnl_get_plan(self._h), name)
