@@ -311,6 +311,21 @@ double front_cost(int64_t npiv, int64_t nupd, int64_t indep = 0) {
 }
 double extend_cost(int64_t nupd_child) { return 6.0 + 5.0 * chunks(tri(1 + nupd_child)); }
 
+// ---- cost model of the register-front kernel (kernels2.hip), in cycles per wavefront (= 4 problems) ----
+inline int64_t ceil4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+double front_cost2(int64_t npiv, int64_t nupd, int64_t /*indep*/ = 0) {
+  const int64_t f = 1 + nupd + npiv;
+  const int64_t TE = f <= 16 ? 16 : (f <= 32 ? 32 : 64);
+  const double passes = (double)(TE / 16);
+  double c = 1500.0 + 12.0 * (double)((tri(f) + 15) / 16) * (TE == 64 ? 4.0 : 1.0) + 50.0 * (double)((7 * npiv + 15) / 16);
+  double el = (double)TE * 10.0 + (double)(nupd + 1) * 14.0;
+  for (int64_t i = f - 1; i > nupd; i--) el += 260.0 + 35.0 * (double)ceil4(std::min<int64_t>(i - 1, TE - 1));
+  c += passes * el * (TE == 64 ? 1.5 : 1.0);
+  c += passes * (350.0 + 220.0 * (double)npiv + 4.0 * (double)TE);
+  return c;
+}
+double extend_cost2(int64_t nupd_child) { return 120.0 + 35.0 * (double)((tri(1 + nupd_child) + 15) / 16); }
+
 struct SNode {
   ivec icols;       // leading mutually independent pivots (merged single-pivot leaves)
   ivec cols;        // dependent pivot columns in elimination order (postordered labels)
@@ -453,7 +468,14 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       sn[s].parent = S.parent[last] >= 0 ? sn_of[S.parent[last]] : -1;
       if (sn[s].parent >= 0) sn[sn[s].parent].kids.push_back(s);
     }
-    auto cost_of = [&](const SNode& x) { return front_cost(x.np(), x.nupd, (int64_t)x.icols.size()); };
+    // kernel selection: the register-front kernel needs every front of order <= 64
+    int64_t fund_fmax = 0;
+    for (int32_t s = 0; s < ns; s++) fund_fmax = std::max<int64_t>(fund_fmax, 1 + sn[s].nupd + sn[s].np());
+    const bool m2 = fund_fmax <= 64 && !getenv("CNL_NO_V2");
+    const int64_t fcap = m2 ? 64 : ((int64_t)1 << 40);
+    auto fcost = [&](int64_t np_, int64_t nu_, int64_t ind_) { return m2 ? front_cost2(np_, nu_, ind_) : front_cost(np_, nu_, ind_); };
+    auto ecost = [&](int64_t nu_) { return m2 ? extend_cost2(nu_) : extend_cost(nu_); };
+    auto cost_of = [&](const SNode& x) { return fcost(x.np(), x.nupd, (int64_t)x.icols.size()); };
     // relaxed amalgamation, children before parents (supernodes are in postorder)
     for (int32_t p = 0; p < ns; p++) {
       if (!sn[p].alive) continue;
@@ -466,10 +488,10 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
           bool merged = false;
           if (leaf1) {
             int64_t fdep = 1 + sn[p].nupd + (int64_t)sn[p].cols.size();  // rows an independent pivot updates
-            double before = front_cost(1, ch.nupd) + extend_cost(ch.nupd) + cost_of(sn[p]);
-            SNode trial; trial.nupd = sn[p].nupd;
-            double after = front_cost(sn[p].np() + 1, sn[p].nupd, (int64_t)sn[p].icols.size() + 1);
-            bool fits = tri(1 + sn[p].nupd + sn[p].np() + 1) <= merge_tri_cap || (fdep - 1 - ch.nupd) * 4 <= fdep;
+            double before = fcost(1, ch.nupd, 0) + ecost(ch.nupd) + cost_of(sn[p]);
+            double after = fcost(sn[p].np() + 1, sn[p].nupd, (int64_t)sn[p].icols.size() + 1);
+            bool fits = (tri(1 + sn[p].nupd + sn[p].np() + 1) <= merge_tri_cap || (fdep - 1 - ch.nupd) * 4 <= fdep) &&
+                        1 + sn[p].nupd + sn[p].np() + 1 <= fcap;
             if (after <= before && fits) {
               sn[p].icols.push_back(ch.cols[0]);
               ch.alive = false; merged = true;
@@ -489,10 +511,11 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
           SNode& ch = sn[cidx];
           int64_t npc = ch.np(), npp = sn[p].np();
           int64_t extra = (int64_t)sn[p].cols.size() + sn[p].nupd - ch.nupd;  // explicit zeros per child column
-          double before = cost_of(ch) + cost_of(sn[p]) + extend_cost(ch.nupd);
-          double after = front_cost(npc + npp, sn[p].nupd, (int64_t)(ch.icols.size() + sn[p].icols.size()));
-          bool ok = (extra <= relax && after <= before * 1.02) || after <= before * 0.9;
+          double before = cost_of(ch) + cost_of(sn[p]) + ecost(ch.nupd);
+          double after = fcost(npc + npp, sn[p].nupd, (int64_t)(ch.icols.size() + sn[p].icols.size()));
+          bool ok = m2 ? after <= before : ((extra <= relax && after <= before * 1.02) || after <= before * 0.9);
           if (tri(1 + sn[p].nupd + npc + npp) > merge_tri_cap && extra > 0) ok = false;
+          if (1 + sn[p].nupd + npc + npp > fcap) ok = false;
           if (!ok) continue;
           // merge ch into p: ch's columns are eliminated right before p's
           ivec nc; nc.reserve(ch.cols.size() + sn[p].cols.size());
@@ -542,7 +565,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     for (int32_t s = 0; s < ns; s++) if (sn[s].alive) {
       int64_t np = sn[s].np(), nu = sn[s].nupd;
       c.cost += cost_of(sn[s]);
-      if (sn[s].parent >= 0) c.cost += extend_cost(nu);
+      if (sn[s].parent >= 0) c.cost += ecost(nu);
       c.nnzL += np * nu + np * (np - 1) / 2;
     }
   };
@@ -782,6 +805,8 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
   if (const char* e = getenv("CNL_NO_V2")) if (atoi(e)) P.v2_ok = false;
   if (P.v2_ok) {
     const int64_t ubig_thr = tri(17);  // update matrices above this size live in global scratch
+    int32_t wait_thr = 2;
+    if (const char* e = getenv("CNL_WAIT_THR")) wait_thr = atoi(e);
     ivec uoff2(ns, 0), uglob(ns, 0), fsglob(ns, 0), fsoff2(ns, 0), cls(ns, 16);
     int64_t spL = 0, spG = 0, peakL = 0, peakG = 0, fsmax = 0;
     for (int32_t s = 0; s < ns; s++) {
@@ -789,6 +814,13 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       int64_t f = 1 + (int64_t)F.nupd + F.npiv;
       cls[s] = f <= 16 ? 16 : (f <= 32 ? 32 : 64);
       P.ncls[cls[s] == 16 ? 0 : (cls[s] == 32 ? 1 : 2)]++;
+    }
+    // fronts of order 17..32 are staged in LDS only when they are common; a few of them would
+    // otherwise set the LDS footprint of every problem
+    const bool fs32_lds = (int64_t)P.ncls[1] * 20 > ns;
+    for (int32_t s = 0; s < ns; s++) {
+      const FrontHdr& F = P.fronts[s];
+      int64_t f = 1 + (int64_t)F.nupd + F.npiv;
       int64_t baseL = spL, baseG = spG;
       bool seenL = false, seenG = false;
       for (int32_t ci = F.child_begin; ci < F.child_end; ci++) {
@@ -796,9 +828,12 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
         if (uglob[c]) { if (!seenG) { baseG = uoff2[c]; seenG = true; } }
         else { if (!seenL) { baseL = uoff2[c]; seenL = true; } }
       }
-      fsglob[s] = cls[s] == 64;
+      fsglob[s] = cls[s] == 64 || (cls[s] == 32 && !fs32_lds);
       int64_t tu = tri(1 + F.nupd);
-      uglob[s] = tu > ubig_thr;
+      // update matrices that wait long for their parent (left siblings of big subtrees) would pin LDS:
+      // they go to the global scratch; only the ones consumed within the next few fronts stay in LDS
+      const int32_t wait = F.parent >= 0 ? F.parent - s - 1 : 0;
+      uglob[s] = tu > ubig_thr || wait > wait_thr;
       if (fsglob[s]) {
         // the staging triangle must not overlap the slot its own update matrix is written to
         // (rows >= 32 of the update matrix are stored while rows < 32 are still read from staging)
@@ -844,7 +879,8 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       H[R_NCHILD] = F.child_end - F.child_begin; H[R_UOFF] = uoff2[s];
       H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0); H[R_FSOFF] = fsoff2[s];
       H[R_LPTR_LO] = F.lptr_lo; H[R_LPTR_HI] = F.lptr_hi; H[R_CLS] = cls[s]; H[R_ASM_OFF] = asm_off; H[R_CHILD_OFF] = child_off;
-      P.rec_maxlen = std::max(P.rec_maxlen, H[R_RECLEN]);
+      // globally staged fronts read their lists from the stream itself: only the header must fit the LDS buffer
+      P.rec_maxlen = std::max(P.rec_maxlen, fsglob[s] ? (int32_t)R_HDR : H[R_RECLEN]);
     }
     // backward records, reverse post-order
     P.brec.clear(); P.brec_maxlen = 0;

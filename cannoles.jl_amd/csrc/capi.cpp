@@ -15,11 +15,15 @@
 #include <vector>
 
 #include "../../include/cannoles_hip.h"
+#include "condense.h"
 #include "kernels.h"
 #include "plan.h"
 
 struct cnl_plan {
-  cnl::Plan P;
+  cnl::Cond C;   // static condensation of the residual block (outer -> condensed system)
+  cnl::Plan P;   // multifrontal plan of the (condensed) system
+  int64_t N = 0, nnz = 0, nvar = 0, nequ = 0, ncon = 0;  // outer dimensions, as the reference sees them
+  std::vector<int32_t> perm_outer;
 };
 
 struct cnl_handle {
@@ -35,6 +39,12 @@ struct cnl_handle {
   int wpb2 = 1;
   size_t lds2 = 0;
   double* d_gs = nullptr;
+  // condensation state
+  cnl::DevCond dc{};
+  double* d_cbuf = nullptr;   // [batch][cstride]
+  double* d_d2 = nullptr;     // [batch][N2]
+  int *d_xpos = nullptr, *d_xzer = nullptr;
+  const double* last_vals = nullptr;  // device vals of the last factorisation (needed to condense later right-hand sides)
   double* d_L = nullptr;
   double* d_scratch = nullptr;
   // staging for the host-pointer API
@@ -152,6 +162,7 @@ int setup_v2(cnl_handle* h) {
   d.prob_doubles = (int32_t)((prob + 1) & ~(int64_t)1);
   d.gs_doubles = P.gs_doubles + 64;
   d.lsize = P.lsize;
+  d.vstride = h->dp.vstride; d.rstride = h->dp.rstride; d.dstride = h->dp.dstride;
   const size_t wave_bytes = ((size_t)d.reccap + 4 * (size_t)d.prob_doubles + 8) * sizeof(double);
   size_t maxlds = std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024);
   if (wave_bytes + 512 > maxlds) return CNL_OK;  // does not fit: stay on v1
@@ -170,7 +181,6 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch;
   a.L = h->d_L;
   a.scratch = h->d_scratch;
-  if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
   hipError_t e;
   if (h->use_v2 && a.mode != cnl::MODE_SOLVE) {
     a.scratch = h->d_gs;
@@ -181,6 +191,48 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   if (e != hipSuccess)
     return fail(CNL_ERR_HIP, std::string("kernel launch (tpp=") + std::to_string(h->cfg.tpp) + " ppb=" + std::to_string(h->cfg.ppb) +
                                  " lds=" + std::to_string(h->cfg.lds_work) + "): " + hipGetErrorString(e));
+  return CNL_OK;
+}
+
+// One call of the path on device-resident data: [condense ->] multifrontal kernel [-> expand].
+int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, double* d_d, hipStream_t stream) {
+  const cnl::Cond& C = h->plan->C;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
+  int rc = CNL_OK;
+  if (!C.active) {
+    a.vals = d_vals; a.rhs = d_rhs; a.d = d_d;
+    rc = launch(h, a, stream);
+  } else {
+    const int B = (int)h->batch;
+    const int s_mat = (int)(C.ncs + C.nvar), s_all = (int)C.cstride;
+    double* crhs = h->d_cbuf + s_mat;
+    hipError_t e = hipSuccess;
+    if (a.mode == cnl::MODE_NEWTON) {
+      e = cnl::launch_condense(h->dc, d_vals, d_rhs, h->d_cbuf, 0, s_all, B, stream);
+      if (e == hipSuccess) e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
+      a.vals = h->d_cbuf; a.rhs = crhs; a.d = h->d_d2; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
+      if ((rc = launch(h, a, stream))) return rc;
+      e = cnl::launch_expand(h->dc, d_vals, d_rhs, h->d_d2, h->d_cbuf, d_d, a.success, 1, B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
+    } else if (a.mode == cnl::MODE_FACTOR) {
+      e = cnl::launch_condense(h->dc, d_vals, nullptr, h->d_cbuf, 0, s_mat, B, stream);
+      if (e == hipSuccess) e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
+      a.vals = h->d_cbuf; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
+      if ((rc = launch(h, a, stream))) return rc;
+      h->last_vals = d_vals;
+    } else {
+      if (!h->last_vals) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
+      e = cnl::launch_condense(h->dc, h->last_vals, d_rhs, h->d_cbuf, s_mat, s_all, B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
+      a.rhs = crhs; a.d = h->d_d2;
+      if ((rc = launch(h, a, stream))) return rc;
+      e = cnl::launch_expand(h->dc, const_cast<double*>(h->last_vals), d_rhs, h->d_d2, h->d_cbuf, d_d, nullptr, 0, B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
+    }
+  }
+  if (rc) return rc;
   if (h->timing) {
     HIPCHK(hipEventRecord(h->ev1, stream));
     HIPCHK(hipEventSynchronize(h->ev1));
@@ -191,7 +243,7 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 
 int ensure_staging(cnl_handle* h) {
   if (h->d_vals) return CNL_OK;
-  const cnl::Plan& P = h->plan->P;
+  const cnl_plan& P = *h->plan;
   int rc;
   if ((rc = dalloc(h, &h->d_vals, (size_t)h->batch * P.nnz))) return rc;
   if ((rc = dalloc(h, &h->d_rhs, (size_t)h->batch * P.N))) return rc;
@@ -229,13 +281,29 @@ int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows
                     int64_t nequ, int64_t ncon) {
   if (!plan || !rows1 || !cols1) return fail(CNL_ERR_ARG, "null argument");
   cnl_plan* p = new cnl_plan();
+  p->N = N; p->nnz = nnz; p->nvar = nvar; p->nequ = nequ; p->ncon = ncon;
   std::string msg;
   cnl::Options opt;
-  int rc = cnl::build_plan(p->P, N, nnz, rows1, cols1, nvar, nequ, ncon, opt, msg);
+  int rc = cnl::build_condensation(p->C, N, nnz, rows1, cols1, nvar, nequ, ncon, msg);
+  if (!rc) {
+    if (p->C.active)
+      rc = cnl::build_plan(p->P, p->C.N2, p->C.ncs + nvar, p->C.rows2.data(), p->C.cols2.data(), nvar, p->C.nequ2, ncon, opt, msg);
+    else
+      rc = cnl::build_plan(p->P, N, nnz, rows1, cols1, nvar, nequ, ncon, opt, msg);
+  }
   if (rc) {
     delete p;
     *plan = nullptr;
     return fail(rc, msg);
+  }
+  // elimination order in the reference's numbering: condensed residual nodes first
+  if (p->C.active) {
+    p->perm_outer.assign(p->C.r_orig.begin(), p->C.r_orig.end());
+    for (int32_t e : p->P.perm) p->perm_outer.push_back(p->C.orig_of[e]);
+    std::vector<int64_t>().swap(p->C.rows2);
+    std::vector<int64_t>().swap(p->C.cols2);
+  } else {
+    p->perm_outer = p->P.perm;
   }
   *plan = p;
   return CNL_OK;
@@ -247,12 +315,16 @@ int cnl_plan_info(const cnl_plan* plan, int64_t info[16]) {
   if (!plan || !info) return fail(CNL_ERR_ARG, "null argument");
   const cnl::Plan& P = plan->P;
   std::memset(info, 0, 16 * sizeof(int64_t));
-  info[0] = P.N; info[1] = P.nnz; info[2] = P.nnzK; info[3] = P.nsuper; info[4] = P.nnzL; info[5] = P.nnzL_exact;
+  info[0] = plan->N; info[1] = plan->nnz; info[2] = P.nnzK; info[3] = P.nsuper; info[4] = P.nnzL; info[5] = P.nnzL_exact;
+  if (plan->C.active) {  // the L rows of the condensed residual pivots (J_r / d_r) belong to the factor too
+    info[4] += (int64_t)plan->C.r_jsrc.size();
+    info[5] += (int64_t)plan->C.r_jsrc.size();
+  }
   info[6] = P.lsize; info[7] = P.fmax; info[8] = P.fwd_peak; info[9] = P.bwd_peak; info[10] = P.panel_max;
   info[11] = (int64_t)P.flops; info[12] = (int64_t)P.asm_src.size();
   info[13] = P.v2_ok ? ((int64_t)P.ncls[0] | ((int64_t)P.ncls[1] << 20) | ((int64_t)P.ncls[2] << 40)) : -1;
   info[14] = P.v2_ok ? ((int64_t)P.u2_peak | ((int64_t)P.fs2_max << 20) | ((int64_t)std::max(P.rec_maxlen, P.brec_maxlen) << 40)) : -1;
-  info[15] = P.gs_doubles;
+  info[15] = plan->C.active ? (int64_t)plan->C.r_orig.size() : 0;  // condensed residual nodes
   return CNL_OK;
 }
 
@@ -264,7 +336,19 @@ int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* 
   const int32_t* src = nullptr;
   int64_t n = 0;
   std::string s(name);
-  if (s == "perm") { src = P.perm.data(); n = (int64_t)P.perm.size(); }
+  const cnl::Cond& C = plan->C;
+  if (s == "perm") { src = plan->perm_outer.data(); n = (int64_t)plan->perm_outer.size(); }
+  else if (s == "inner_perm") { src = P.perm.data(); n = (int64_t)P.perm.size(); }
+  else if (s == "c_ptr") { src = C.c_ptr.data(); n = (int64_t)C.c_ptr.size(); }
+  else if (s == "c_a") { src = C.c_a.data(); n = (int64_t)C.c_a.size(); }
+  else if (s == "c_b") { src = C.c_b.data(); n = (int64_t)C.c_b.size(); }
+  else if (s == "c_d") { src = C.c_d.data(); n = (int64_t)C.c_d.size(); }
+  else if (s == "orig_of") { src = C.orig_of.data(); n = (int64_t)C.orig_of.size(); }
+  else if (s == "r_orig") { src = C.r_orig.data(); n = (int64_t)C.r_orig.size(); }
+  else if (s == "r_dsrc") { src = C.r_dsrc.data(); n = (int64_t)C.r_dsrc.size(); }
+  else if (s == "r_ptr") { src = C.r_ptr.data(); n = (int64_t)C.r_ptr.size(); }
+  else if (s == "r_jsrc") { src = C.r_jsrc.data(); n = (int64_t)C.r_jsrc.size(); }
+  else if (s == "r_jx") { src = C.r_jx.data(); n = (int64_t)C.r_jx.size(); }
   else if (s == "fronts") { src = reinterpret_cast<const int32_t*>(P.fronts.data()); n = (int64_t)P.fronts.size() * 16; }
   else if (s == "seg_ptr") { src = P.seg_ptr.data(); n = (int64_t)P.seg_ptr.size(); }
   else if (s == "asm_pos") { src = P.asm_pos.data(); n = (int64_t)P.asm_pos.size(); }
@@ -308,6 +392,31 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   dp.nsuper = P.nsuper; dp.N = (int32_t)P.N; dp.nnz = (int32_t)P.nnz; dp.rho_begin = P.rho_begin;
   dp.nvar = (int32_t)P.nvar; dp.nequ = (int32_t)P.nequ; dp.ncon = (int32_t)P.ncon;
   dp.fmax = (P.fmax + 1) & ~1; dp.lsize = P.lsize;
+  const cnl::Cond& C = plan->C;
+  dp.vstride = C.active ? C.cstride : (int64_t)nnz;
+  dp.rstride = C.active ? C.cstride : N;
+  dp.dstride = C.active ? C.N2 : N;
+  if (C.active) {
+    cnl::DevCond& dc = h->dc;
+    std::vector<int32_t> cidx(N, -1);
+    for (size_t q = 0; q < C.r_orig.size(); q++) cidx[C.r_orig[q]] = (int32_t)q;
+    if ((rc = upload(h, C.c_ptr, &dc.c_ptr))) return bail(rc);
+    if ((rc = upload(h, C.c_a, &dc.c_a))) return bail(rc);
+    if ((rc = upload(h, C.c_b, &dc.c_b))) return bail(rc);
+    if ((rc = upload(h, C.c_d, &dc.c_d))) return bail(rc);
+    if ((rc = upload(h, C.r_dsrc, &dc.r_dsrc))) return bail(rc);
+    if ((rc = upload(h, C.r_ptr, &dc.r_ptr))) return bail(rc);
+    if ((rc = upload(h, C.r_jsrc, &dc.r_jsrc))) return bail(rc);
+    if ((rc = upload(h, C.r_jx, &dc.r_jx))) return bail(rc);
+    if ((rc = upload(h, C.red_of, &dc.red_of))) return bail(rc);
+    if ((rc = upload(h, cidx, &dc.cidx_of))) return bail(rc);
+    dc.N = (int32_t)N; dc.nnz = (int32_t)nnz; dc.nvar = (int32_t)nvar; dc.N2 = (int32_t)C.N2; dc.ncs = (int32_t)C.ncs;
+    dc.ncond = (int32_t)C.r_orig.size(); dc.cstride = C.cstride;
+    if ((rc = dalloc(h, &h->d_cbuf, (size_t)batch * (size_t)C.cstride))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_d2, (size_t)batch * (size_t)C.N2))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_xpos, (size_t)batch))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_xzer, (size_t)batch))) return bail(rc);
+  }
   if ((rc = choose_config(h))) return bail(rc);
   if ((rc = setup_v2(h))) return bail(rc);
   if ((rc = dalloc(h, &h->d_L, (size_t)batch * (size_t)std::max<int64_t>(P.lsize, 1)))) return bail(rc);
@@ -364,11 +473,10 @@ int cnl_factorize_dev(cnl_handle* h, const double* d_vals, double eig_tol, int32
   HIPCHK(hipSetDevice(h->device));
   cnl::LaunchArgs a{};
   a.mode = cnl::MODE_FACTOR;
-  a.vals = const_cast<double*>(d_vals);
   a.success = d_success;
   a.params[0] = eig_tol;
-  int rc = launch(h, a, (hipStream_t)stream);
-  if (rc == CNL_OK) h->factorized = true;
+  int rc = run(h, a, const_cast<double*>(d_vals), nullptr, nullptr, (hipStream_t)stream);
+  if (rc == CNL_OK) { h->factorized = true; h->last_vals = d_vals; }
   return rc;
 }
 
@@ -378,9 +486,7 @@ int cnl_solve_dev(cnl_handle* h, const double* d_rhs, double* d_d, void* stream)
   HIPCHK(hipSetDevice(h->device));
   cnl::LaunchArgs a{};
   a.mode = cnl::MODE_SOLVE;
-  a.rhs = d_rhs;
-  a.d = d_d;
-  return launch(h, a, (hipStream_t)stream);
+  return run(h, a, nullptr, d_rhs, d_d, (hipStream_t)stream);
 }
 
 int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, double* d_d, double* d_rho_old, double* d_rho,
@@ -390,10 +496,10 @@ int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, do
   HIPCHK(hipSetDevice(h->device));
   cnl::LaunchArgs a{};
   a.mode = cnl::MODE_NEWTON;
-  a.vals = d_vals; a.rhs = d_rhs; a.d = d_d; a.rho_old = d_rho_old; a.rho = d_rho; a.nfact = d_nfact; a.success = d_success;
+  a.rho_old = d_rho_old; a.rho = d_rho; a.nfact = d_nfact; a.success = d_success;
   std::memcpy(a.params, params, 9 * sizeof(double));
-  int rc = launch(h, a, (hipStream_t)stream);
-  if (rc == CNL_OK) h->factorized = true;
+  int rc = run(h, a, d_vals, d_rhs, d_d, (hipStream_t)stream);
+  if (rc == CNL_OK) { h->factorized = true; h->last_vals = d_vals; }
   return rc;
 }
 
@@ -403,14 +509,15 @@ int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* su
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_staging(h);
   if (rc) return rc;
-  const cnl::Plan& P = h->plan->P;
+  const cnl_plan& P = *h->plan;
   const size_t B = (size_t)h->batch;
   HIPCHK(hipMemcpyAsync(h->d_vals, vals, B * P.nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
   cnl::LaunchArgs a{};
   a.mode = cnl::MODE_FACTOR;
-  a.vals = h->d_vals; a.success = h->d_success; a.npos = h->d_npos; a.nzero = h->d_nzero;
+  a.success = h->d_success; a.npos = h->d_npos; a.nzero = h->d_nzero;
   a.params[0] = eig_tol;
-  if ((rc = launch(h, a, h->stream))) return rc;
+  if ((rc = run(h, a, h->d_vals, nullptr, nullptr, h->stream))) return rc;
+  h->last_vals = h->d_vals;
   HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   if (npos) HIPCHK(hipMemcpyAsync(npos, h->d_npos, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   if (nzero) HIPCHK(hipMemcpyAsync(nzero, h->d_nzero, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
@@ -425,13 +532,12 @@ int cnl_solve(cnl_handle* h, const double* rhs, double* d) {
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_staging(h);
   if (rc) return rc;
-  const cnl::Plan& P = h->plan->P;
+  const cnl_plan& P = *h->plan;
   const size_t B = (size_t)h->batch;
   HIPCHK(hipMemcpyAsync(h->d_rhs, rhs, B * P.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   cnl::LaunchArgs a{};
   a.mode = cnl::MODE_SOLVE;
-  a.rhs = h->d_rhs; a.d = h->d_d;
-  if ((rc = launch(h, a, h->stream))) return rc;
+  if ((rc = run(h, a, nullptr, h->d_rhs, h->d_d, h->stream))) return rc;
   HIPCHK(hipMemcpyAsync(d, h->d_d, B * P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return CNL_OK;
@@ -443,7 +549,7 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_staging(h);
   if (rc) return rc;
-  const cnl::Plan& P = h->plan->P;
+  const cnl_plan& P = *h->plan;
   const size_t B = (size_t)h->batch;
   HIPCHK(hipMemcpyAsync(h->d_vals, vals, B * P.nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_rhs, rhs, B * P.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -453,10 +559,11 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   HIPCHK(hipMemsetAsync(h->d_d, 0, B * P.N * sizeof(double), h->stream));
   cnl::LaunchArgs a{};
   a.mode = cnl::MODE_NEWTON;
-  a.vals = h->d_vals; a.rhs = h->d_rhs; a.d = h->d_d; a.rho_old = h->d_rho_old; a.rho = h->d_rho;
+  a.rho_old = h->d_rho_old; a.rho = h->d_rho;
   a.nfact = h->d_nfact; a.success = h->d_success;
   std::memcpy(a.params, params, 9 * sizeof(double));
-  if ((rc = launch(h, a, h->stream))) return rc;
+  if ((rc = run(h, a, h->d_vals, h->d_rhs, h->d_d, h->stream))) return rc;
+  h->last_vals = h->d_vals;
   HIPCHK(hipMemcpyAsync(d, h->d_d, B * P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(rho, h->d_rho, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(rho_old_out, h->d_rho_old, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -464,7 +571,7 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   // rho tail of vals (the reference mutates get_vals(LDLT)[end-nvar+1:end], src/CaNNOLeS.jl:1031,1038)
   if (P.nvar > 0)
-    HIPCHK(hipMemcpy2DAsync(vals + P.rho_begin, (size_t)P.nnz * sizeof(double), h->d_vals + P.rho_begin,
+    HIPCHK(hipMemcpy2DAsync(vals + (P.nnz - P.nvar), (size_t)P.nnz * sizeof(double), h->d_vals + (P.nnz - P.nvar),
                             (size_t)P.nnz * sizeof(double), (size_t)P.nvar * sizeof(double), B, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->factorized = true;

@@ -1,0 +1,134 @@
+// condense.cpp — builds the static condensation of the residual (-I) block (see condense.h).
+#include "condense.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <numeric>
+
+namespace cnl {
+
+int build_condensation(Cond& C, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                       int64_t nequ, int64_t ncon, std::string& msg) {
+  C = Cond();
+  C.N = N; C.nnz = nnz; C.nvar = nvar; C.nequ = nequ; C.ncon = ncon;
+  if (getenv("CNL_NO_CONDENSE") && atoi(getenv("CNL_NO_CONDENSE"))) return 0;
+  if (N <= 0 || nvar < 0 || nequ < 0 || ncon < 0 || nvar + nequ + ncon != N || nnz < nvar) return 0;  // build_plan reports it
+  if (nequ == 0) return 0;
+  if (N + nnz >= ((int64_t)1 << 29)) return 0;
+  // the last nvar entries must be the rho slots (i, i), i = 1..nvar (src/CaNNOLeS.jl:313-315)
+  for (int64_t k = 0; k < nvar; k++)
+    if (rows1[nnz - nvar + k] != k + 1 || cols1[nnz - nvar + k] != k + 1) return 0;
+  const int64_t nbody = nnz - nvar;
+  // duplicates per slot
+  std::vector<int64_t> key(nnz);
+  for (int64_t k = 0; k < nnz; k++) {
+    int64_t i = rows1[k] - 1, j = cols1[k] - 1;
+    if (i < 0 || i >= N || j < 0 || j >= N || i < j) return 0;  // malformed: let build_plan produce the error
+    key[k] = j * N + i;
+  }
+  std::vector<int64_t> order(nnz);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
+  std::vector<char> dup(nnz, 0);
+  for (int64_t t = 1; t < nnz; t++)
+    if (key[order[t]] == key[order[t - 1]]) dup[order[t]] = dup[order[t - 1]] = 1;
+  // rows of the residual nodes
+  const int32_t dense_thr = std::max(16, (int32_t)(10.0 * std::sqrt((double)N)));
+  std::vector<std::vector<int32_t>> rowent(nequ);  // COO entries of row r (J entries)
+  std::vector<int32_t> diag(nequ, -1);
+  std::vector<char> bad(nequ, 0);
+  for (int64_t k = 0; k < nbody; k++) {
+    int64_t i = rows1[k] - 1, j = cols1[k] - 1;
+    if (i >= nvar && i < nvar + nequ) {
+      int64_t r = i - nvar;
+      if (j == i) { if (diag[r] >= 0 || dup[k]) bad[r] = 1; diag[r] = (int32_t)k; }
+      else if (j < nvar) { if (dup[k]) bad[r] = 1; rowent[r].push_back((int32_t)k); }
+      else bad[r] = 1;
+    }
+    if (j >= nvar && j < nvar + nequ && i != j) bad[j - nvar] = 1;  // something below the diagonal in column r
+  }
+  C.red_of.assign(N, -1);
+  int64_t ncond = 0;
+  for (int64_t r = 0; r < nequ; r++) {
+    if (diag[r] < 0 || (int32_t)rowent[r].size() > dense_thr) bad[r] = 1;
+    if (!bad[r]) ncond++;
+  }
+  if (ncond == 0) return 0;
+  // reduced numbering: x, kept residual nodes, multipliers
+  int64_t nxt = 0;
+  for (int64_t v = 0; v < nvar; v++) C.red_of[v] = (int32_t)nxt++;
+  for (int64_t r = 0; r < nequ; r++) if (bad[r]) C.red_of[nvar + r] = (int32_t)nxt++;
+  C.nequ2 = nxt - nvar;
+  for (int64_t v = nvar + nequ; v < N; v++) C.red_of[v] = (int32_t)nxt++;
+  C.N2 = nxt;
+  C.orig_of.assign(C.N2, -1);
+  for (int64_t v = 0; v < N; v++) if (C.red_of[v] >= 0) C.orig_of[C.red_of[v]] = (int32_t)v;
+  // contributions to the slots of K2
+  struct Ct { int64_t key; int64_t ord; int32_t a, b, d; };
+  std::vector<Ct> cts;
+  cts.reserve(nbody + ncond * 16);
+  for (int64_t k = 0; k < nbody; k++) {
+    int64_t i = rows1[k] - 1, j = cols1[k] - 1;
+    int32_t i2 = C.red_of[i], j2 = C.red_of[j];
+    if (i2 < 0 || j2 < 0) continue;  // belongs to a condensed row
+    cts.push_back({(int64_t)j2 * C.N2 + i2, k, (int32_t)k, -1, -1});
+  }
+  int64_t pord = nnz;
+  for (int64_t r = 0; r < nequ; r++) {
+    if (bad[r]) continue;
+    C.r_orig.push_back((int32_t)(nvar + r));
+    C.r_dsrc.push_back(diag[r]);
+    C.r_ptr.push_back((int32_t)C.r_jsrc.size());
+    const auto& re = rowent[r];
+    for (int32_t k : re) { C.r_jsrc.push_back(k); C.r_jx.push_back((int32_t)(cols1[k] - 1)); }
+    for (size_t p = 0; p < re.size(); p++)
+      for (size_t q = p; q < re.size(); q++) {
+        int64_t xa = cols1[re[p]] - 1, xb = cols1[re[q]] - 1;
+        int64_t hi = std::max(xa, xb), lo = std::min(xa, xb);
+        cts.push_back({lo * C.N2 + hi, pord++, re[p], re[q], diag[r]});
+      }
+  }
+  C.r_ptr.push_back((int32_t)C.r_jsrc.size());
+  std::sort(cts.begin(), cts.end(), [](const Ct& a, const Ct& b) { return a.key < b.key || (a.key == b.key && a.ord < b.ord); });
+  C.c_ptr.clear(); C.c_a.clear(); C.c_b.clear(); C.c_d.clear();
+  C.rows2.clear(); C.cols2.clear();
+  for (size_t t = 0; t < cts.size(); t++) {
+    if (t == 0 || cts[t].key != cts[t - 1].key) {
+      C.c_ptr.push_back((int32_t)C.c_a.size());
+      C.rows2.push_back(cts[t].key % C.N2 + 1);
+      C.cols2.push_back(cts[t].key / C.N2 + 1);
+    }
+    C.c_a.push_back(cts[t].a); C.c_b.push_back(cts[t].b); C.c_d.push_back(cts[t].d);
+  }
+  C.ncs = (int64_t)C.rows2.size();
+  // rho slots
+  for (int64_t k = 0; k < nvar; k++) {
+    C.c_ptr.push_back((int32_t)C.c_a.size());
+    C.c_a.push_back((int32_t)(nnz - nvar + k)); C.c_b.push_back(-1); C.c_d.push_back(-1);
+    C.rows2.push_back(k + 1); C.cols2.push_back(k + 1);
+  }
+  // right-hand side of the condensed system: rhs_v - sum_r J_rv rhs_r / d_r
+  std::vector<std::vector<int32_t>> xr(nvar);  // per x: indices into r_jsrc
+  for (size_t q = 0; q < C.r_jsrc.size(); q++) xr[C.r_jx[q]].push_back((int32_t)q);
+  std::vector<int32_t> rowof(C.r_jsrc.size());
+  for (size_t rr = 0; rr + 1 < C.r_ptr.size(); rr++)
+    for (int32_t q = C.r_ptr[rr]; q < C.r_ptr[rr + 1]; q++) rowof[q] = (int32_t)rr;
+  for (int64_t v = 0; v < C.N2; v++) {
+    C.c_ptr.push_back((int32_t)C.c_a.size());
+    int32_t o = C.orig_of[v];
+    C.c_a.push_back((int32_t)(nnz + o)); C.c_b.push_back(-1); C.c_d.push_back(-1);
+    if (o < nvar)
+      for (int32_t q : xr[o]) {
+        int32_t rr = rowof[q];
+        C.c_a.push_back(C.r_jsrc[q]); C.c_b.push_back((int32_t)(nnz + C.r_orig[rr])); C.c_d.push_back(C.r_dsrc[rr]);
+      }
+  }
+  C.c_ptr.push_back((int32_t)C.c_a.size());
+  C.cstride = C.ncs + nvar + C.N2;
+  C.active = true;
+  msg.clear();
+  return 0;
+}
+
+}  // namespace cnl

@@ -23,6 +23,7 @@ struct DevPlan {
   int32_t wv_off;        // offset of the two pivot-row staging vectors (2*fmax doubles)
   int32_t work_doubles;  // work area per problem
   int64_t lsize;         // factor storage per problem (doubles)
+  int64_t vstride, rstride, dstride;  // per-problem strides (doubles) of vals / rhs / d
 };
 
 struct KernelConfig {
@@ -42,6 +43,16 @@ struct DevPlan2 {
   int32_t prob_doubles;  // doubles of LDS per problem
   int64_t gs_doubles;    // doubles of global scratch per problem
   int64_t lsize;
+  int64_t vstride, rstride, dstride;  // per-problem strides (doubles) of vals / rhs / d
+};
+
+// device-resident condensation lists (condense.h)
+struct DevCond {
+  const int32_t *c_ptr, *c_a, *c_b, *c_d;
+  const int32_t *r_dsrc, *r_ptr, *r_jsrc, *r_jx;
+  const int32_t *red_of, *cidx_of;
+  int32_t N, nnz, nvar, N2, ncs, ncond;
+  int64_t cstride;
 };
 
 enum { MODE_NEWTON = 0, MODE_FACTOR = 1, MODE_SOLVE = 2 };
@@ -61,11 +72,19 @@ struct LaunchArgs {
   int64_t* npos;         // [batch] optional (FACTOR)
   int64_t* nzero;        // [batch] optional (FACTOR)
   double params[9];      // ParamCaNNOLeS; params[0] = eig_tol also for FACTOR
+  const int* extra_pos;  // [batch] optional: inertia counts of pivots eliminated outside the kernel (condensed r nodes)
+  const int* extra_zer;
 };
 
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream);
+hipError_t launch_condense(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int slot_begin, int slot_end,
+                           int batch, hipStream_t stream);
+hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_pos, int* extra_zer, double eig_tol, int batch,
+                               hipStream_t stream);
+hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, const double* d2, const double* cbuf, double* dout,
+                         const int* success, int copy_rho_tail, int batch, hipStream_t stream);
 // largest dynamic LDS a workgroup may use on the current device
 size_t max_lds_bytes();
 

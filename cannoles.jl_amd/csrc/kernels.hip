@@ -250,8 +250,8 @@ __device__ __forceinline__ void front_backward(const DevPlan& P, const FrontHdr&
 
 template <int TPP, bool LDSW>
 __device__ __forceinline__ bool factor_attempt(const DevPlan& P, const ProblemCtx& c, int tid, bool rho_override, double rho,
-                                               double eig_tol, int& npos_out, int& nzer_out) {
-  int npos = 0, nzer = 0;
+                                               double eig_tol, int& npos_out, int& nzer_out, int xpos, int xzer) {
+  int npos = xpos, nzer = xzer;
   for (int s = 0; s < P.nsuper; s++) front_forward<TPP, LDSW, true>(P, P.fronts[s], c, tid, rho_override, rho, eig_tol, npos, nzer);
   npos_out = npos; nzer_out = nzer;
   return npos == P.nvar && nzer == 0;  // src/solver_types.jl:96
@@ -265,14 +265,15 @@ __global__ void __launch_bounds__(TPP* PPB) newton_kernel(const DevPlan P, const
   const int b = blockIdx.x * PPB + gl;
   if (b >= A.batch) return;             // whole owner group exits together (no block barrier when PPB > 1)
   ProblemCtx c;
-  c.vals = A.vals ? A.vals + (long long)b * P.nnz : nullptr;
-  c.rhs = A.rhs ? A.rhs + (long long)b * P.N : nullptr;
+  c.vals = A.vals ? A.vals + (long long)b * P.vstride : nullptr;
+  c.rhs = A.rhs ? A.rhs + (long long)b * P.rstride : nullptr;
   c.L = A.L + (long long)b * P.lsize;
   double* redbase = smem;               // 16 doubles for cross-wave sums (TPP > 64)
   c.red = redbase;
   c.W = LDSW ? (smem + 16 + (long long)gl * P.work_doubles) : (A.scratch + (long long)b * P.work_doubles);
-  double* dout = A.d ? A.d + (long long)b * P.N : nullptr;
+  double* dout = A.d ? A.d + (long long)b * P.dstride : nullptr;
   const double eig_tol = A.params[0];
+  const int xpos = A.extra_pos ? A.extra_pos[b] : 0, xzer = A.extra_zer ? A.extra_zer[b] : 0;
 
   if (A.mode == MODE_SOLVE) {
     int np = 0, nz = 0;
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(TPP* PPB) newton_kernel(const DevPlan P, const
   if (A.mode == MODE_FACTOR) {
     int np, nz;
     ProblemCtx cf = c; cf.rhs = nullptr;
-    const bool ok = factor_attempt<TPP, LDSW>(P, cf, tid, false, 0.0, eig_tol, np, nz);
+    const bool ok = factor_attempt<TPP, LDSW>(P, cf, tid, false, 0.0, eig_tol, np, nz, xpos, xzer);
     if (tid == 0) {
       A.success[b] = ok ? 1 : 0;
       if (A.npos) A.npos[b] = np;
@@ -298,24 +299,24 @@ __global__ void __launch_bounds__(TPP* PPB) newton_kernel(const DevPlan P, const
   double rho_old = A.rho_old[b];
   double rho = 0.0, wrote = 0.0;
   int nfact = 0, np, nz;
-  bool success = factor_attempt<TPP, LDSW>(P, c, tid, false, 0.0, eig_tol, np, nz);
+  bool success = factor_attempt<TPP, LDSW>(P, c, tid, false, 0.0, eig_tol, np, nz, xpos, xzer);
   nfact++;
   if (!success) {
     rho = rho_old == 0.0 ? rho0 : fmax(rhomin, kdec * rho_old);
     wrote = rho;
-    success = factor_attempt<TPP, LDSW>(P, c, tid, true, rho, eig_tol, np, nz);
+    success = factor_attempt<TPP, LDSW>(P, c, tid, true, rho, eig_tol, np, nz, xpos, xzer);
     nfact++;
     while (!success && rho <= rhomax) {
       rho = rho_old == 0.0 ? klarge * rho : kinc * rho;
       if (rho <= rhomax) {
         wrote = rho;
-        success = factor_attempt<TPP, LDSW>(P, c, tid, true, rho, eig_tol, np, nz);
+        success = factor_attempt<TPP, LDSW>(P, c, tid, true, rho, eig_tol, np, nz, xpos, xzer);
         nfact++;
       }
     }
     if (rho <= rhomax) rho_old = rho;
     // the reference leaves the last rho tried in the rho slots of vals
-    double* vt = A.vals + (long long)b * P.nnz + P.rho_begin;
+    double* vt = A.vals + (long long)b * P.vstride + P.rho_begin;
     for (int i = tid; i < P.nvar; i += TPP) vt[i] = wrote;
   }
   phase_fence<TPP>();

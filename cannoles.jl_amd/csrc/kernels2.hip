@@ -60,6 +60,13 @@ __device__ __forceinline__ double bcast(double v, int a, int grp4) {
   }
 }
 
+// value of the lane whose byte address (4 * lane) is `addr4`
+__device__ __forceinline__ double bcast_addr(double v, int addr4) {
+  int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(v));
+  int hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
@@ -89,156 +96,75 @@ struct Ctx2 {
 };
 
 // ------------------------------------------------------------------------------------------
-// register elimination of one front for the problems of pass `pass` (class TE)
-template <int TE, bool GFS, bool GU>
-__device__ __forceinline__ void eliminate(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, int f, int nupd,
-                                          long long lptr, int uoff, int fsoff, double* pbase0, int* cnt, double eig_tol) {
-  constexpr int PPW = 64 / TE;                      // problems per pass
-  const int gp = pass * PPW + (TE == 64 ? 0 : lane / TE);  // problem slot 0..3 handled by this lane
-  const int b = lane % TE;                          // my column
-  const int grp4 = (lane - b) * 4;
-  const int prob = prob0 + gp;
-  const bool valid = prob < c.batch;
-  const long long pclamp = valid ? prob : prob0;
-  double* pb = pbase0 + gp * P.prob_doubles;
-  const double* Fs = GFS ? (c.gs + pclamp * P.gs_doubles + fsoff) : (pb + P.u2_peak);
-  double* Lp = c.L + pclamp * P.lsize + lptr;
-  const int tu = tri2(1 + nupd);
+// Register elimination of one front for the problems of pass `pass` (class TE lanes per problem).
+// Lane b holds column b.  Register r<k> holds row (top - k) where `top` is the highest live row,
+// so the pivot row is always r0; the rank-1 update writes row (top-k) into r<k-1>, which shifts
+// the triangle up by one as a side effect (no moves, no dynamic register index):
+//     r<k-1> = fma(-l[top-k], w, r<k>),   l = w / d broadcast with ds_bpermute.
+// The rows are spelled as individual scalars through the X-macro lists of elim_lists.inc.
+#include "elim_lists.inc"
 
-  double acc[TE];
-#pragma unroll
-  for (int a = 0; a < TE; a++) {
-    // lanes b > a read past the row: harmless garbage in the unused upper triangle (staging is padded).
-    // (no separate zero fill either: it would be merged into a memset and defeat scalar promotion)
-    double v0 = 0.0;
-    if (a < f) v0 = Fs[tri2(a) + b];
-    acc[a] = v0;
-  }
-  int npos = 0, nzer = 0;
-#pragma unroll
-  for (int i = TE - 1; i >= 1; i--) {
-    if (i < f && i > nupd) {
-      const double dpiv = bcast<TE>(acc[i], i, grp4);
-      npos += dpiv > eig_tol;
-      nzer += fabs(dpiv) <= eig_tol;
-      const double w = acc[i];
-      const double lv = w / dpiv;
-      if (valid && b <= i) Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;
-#pragma unroll
-      for (int a = 1; a < i; a++) {
-        const double la = bcast<TE>(lv, a, grp4);
-        acc[a] = fma(-la, w, acc[a]);
-      }
-    }
-  }
-  if (b == 0) { cnt[gp * 2] += npos; cnt[gp * 2 + 1] += nzer; }
-  // update matrix (packed prefix) to its stack slot
-  double* U = GU ? (c.gs + pclamp * P.gs_doubles + uoff) : (pb + uoff);
-#pragma unroll
-  for (int a = 0; a < TE; a++) {
-    if (a <= nupd) {
-      if (b <= a && (!GU || valid)) U[tri2(a) + b] = acc[a];
-    }
-  }
-}
+#define CNL_DECL(k) double r##k;
+// lanes b > row read past the row: harmless garbage in the unused upper triangle (staging is padded)
+#define CNL_LOAD(k) { const int a_ = top - k > 0 ? top - k : 0; r##k = Fs[tri2(a_) + b]; }  /* rows below 0: unused copies of row 0 */
+#define CNL_STEP(km1, k) r##km1 = fma(-bcast_addr(lv, base + (TE_ - 1 - k) * 4), w, r##k);
+#define CNL_CHK(k) if (k >= i) goto rows_done;  /* rows i-k >= 1 only (row 0 is the unused rhs-row diagonal) */
+#define CNL_USTG(k) { const int a_ = nupd - k; if (a_ >= 0) { if (b <= a_ && valid) Ug[tri2(a_) + b] = r##k; } }
+#define CNL_USTL(k) { const int a_ = nupd - k; if (a_ >= 0) { if (b <= a_) Ul[tri2(a_) + b] = r##k; } }
 
-// Order 33..64: one problem per pass, 64 lanes = 64 columns.  To stay within the register
-// budget of the small-front path the rows are processed in two halves: rows 32..63 first
-// (their pivots update only themselves), then rows 0..31 receive the deferred updates of
-// those pivots (pivot rows re-read from the stored panel / the staging triangle), then the
-// remaining pivots.  The arithmetic and its order are those of the one-piece elimination.
-template <bool GU>
-__device__ __forceinline__ void eliminate64(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, int f, int nupd,
-                                            long long lptr, int uoff, int fsoff, double* pbase0, int* cnt, double eig_tol) {
-  const int gp = pass;
-  const int b = lane;
-  const int prob = prob0 + gp;  // caller guarantees prob < batch
-  double* pb = pbase0 + gp * P.prob_doubles;
-  double* Fs = c.gs + (long long)prob * P.gs_doubles + fsoff;
-  double* Lp = c.L + (long long)prob * P.lsize + lptr;
-  double* U = GU ? (c.gs + (long long)prob * P.gs_doubles + uoff) : (pb + uoff);
-  const int tu = tri2(1 + nupd);
-  int npos = 0, nzer = 0;
-  {
-    double hi[32];
-#pragma unroll
-    for (int a = 32; a < 64; a++) {
-      double v0 = 0.0;
-      if (a < f) v0 = Fs[tri2(a) + b];
-      hi[a - 32] = v0;
-    }
-#pragma unroll
-    for (int i = 63; i >= 32; i--) {
-      if (i < f && i > nupd) {
-        const double dpiv = bcast<64>(hi[i - 32], i, 0);
-        npos += dpiv > eig_tol;
-        nzer += fabs(dpiv) <= eig_tol;
-        const double w = hi[i - 32];
-        const double lv = w / dpiv;
-        if (b <= i) {
-          Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;
-          Fs[tri2(i) + b] = w;  // keep the un-scaled pivot row for the deferred update
-        }
-#pragma unroll
-        for (int a = 32; a < i; a++) {
-          const double la = bcast<64>(lv, a, 0);
-          hi[a - 32] = fma(-la, w, hi[a - 32]);
-        }
-      }
-    }
-#pragma unroll
-    for (int a = 32; a < 64; a++) {
-      if (a <= nupd) {
-        if (b <= a) U[tri2(a) + b] = hi[a - 32];
-      }
-    }
+#define CNL_DEFINE_ELIM(NAME, INL, TEV, GFS, ALL, STEPS)                                                               \
+  __device__ INL void NAME(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, int f,        \
+                                       int nupd, long long lptr, int uoff, int fsoff, bool uglob, double* pbase0,     \
+                                       int* cnt, double eig_tol) {                                                     \
+    constexpr int TE_ = TEV;                                                                                           \
+    constexpr int PPW = 64 / TE_;                                                                                      \
+    const int gp = pass * PPW + (TE_ == 64 ? 0 : lane / TE_);                                                          \
+    const int b = lane % TE_;                                                                                          \
+    const int grp4 = (lane - b) * 4;                                                                                   \
+    const int prob = prob0 + gp;                                                                                       \
+    const bool valid = prob < c.batch;                                                                                 \
+    const long long pclamp = valid ? prob : prob0;                                                                     \
+    double* pb = pbase0 + gp * P.prob_doubles;                                                                         \
+    const double* Fs = GFS ? (c.gs + pclamp * P.gs_doubles + fsoff) : (pb + P.u2_peak);                                \
+    double* Lp = c.L + pclamp * P.lsize + lptr;                                                                        \
+    const int tu = tri2(1 + nupd);                                                                                     \
+    const int top = f - 1;                                                                                             \
+    ALL(CNL_DECL)                                                                                                      \
+    ALL(CNL_LOAD)                                                                                                      \
+    int npos = 0, nzer = 0;                                                                                            \
+    int base = grp4 + (top - (TE_ - 1)) * 4;                                                                           \
+    for (int i = top; i > nupd; i--) {                                                                                 \
+      const double w = r0;                                                                                             \
+      const double dpiv = bcast_addr(w, base + (TE_ - 1) * 4);                                                         \
+      npos += dpiv > eig_tol;                                                                                          \
+      nzer += fabs(dpiv) <= eig_tol;                                                                                   \
+      const double lv = w / dpiv;                                                                                      \
+      if (valid && b <= i) Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;                                                \
+      STEPS(CNL_STEP, CNL_CHK)                                                                                         \
+    rows_done:                                                                                                         \
+      base -= 4;                                                                                                       \
+    }                                                                                                                  \
+    if (b == 0) { cnt[gp * 2] += npos; cnt[gp * 2 + 1] += nzer; }                                                      \
+    if (uglob) {                                                                                                       \
+      double* Ug = c.gs + pclamp * P.gs_doubles + uoff;                                                                \
+      ALL(CNL_USTG)                                                                                                    \
+    } else {                                                                                                           \
+      double* Ul = pb + uoff;                                                                                          \
+      ALL(CNL_USTL)                                                                                                    \
+    }                                                                                                                  \
   }
-  gsync();
-  double lo[32];
-#pragma unroll
-  for (int a = 0; a < 32; a++) {
-    double v0 = 0.0;
-    if (a < f) v0 = Fs[tri2(a) + b];
-    lo[a] = v0;
-  }
-  {
-    const int ihi = f - 1, ilo = nupd + 1 > 32 ? nupd + 1 : 32;
-    for (int i = ihi; i >= ilo; i--) {
-      double lrow = 0.0, w = 0.0;
-      if (b < i) { lrow = Lp[tri2(i) - tu + b]; w = Fs[tri2(i) + b]; }
-#pragma unroll
-      for (int a = 1; a < 32; a++) {
-        const double la = bcast<64>(lrow, a, 0);
-        lo[a] = fma(-la, w, lo[a]);
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 31; i >= 1; i--) {
-    if (i < f && i > nupd) {
-      const double dpiv = bcast<64>(lo[i], i, 0);
-      npos += dpiv > eig_tol;
-      nzer += fabs(dpiv) <= eig_tol;
-      const double w = lo[i];
-      const double lv = w / dpiv;
-      if (b <= i) Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;
-#pragma unroll
-      for (int a = 1; a < i; a++) {
-        const double la = bcast<64>(lv, a, 0);
-        lo[a] = fma(-la, w, lo[a]);
-      }
-    }
-  }
-  if (b == 0) { cnt[gp * 2] += npos; cnt[gp * 2 + 1] += nzer; }
-#pragma unroll
-  for (int a = 0; a < 32; a++) {
-    if (a <= nupd) {
-      if (b <= a) U[tri2(a) + b] = lo[a];
-    }
-  }
-}
+
+// the rare large classes are real calls so that their register needs do not leak into the hot path
+CNL_DEFINE_ELIM(eliminate16, __forceinline__, 16, false, CNL_ALL16, CNL_STEPS16)
+CNL_DEFINE_ELIM(eliminate32, __attribute__((noinline)), 32, false, CNL_ALL32, CNL_STEPS32)
+CNL_DEFINE_ELIM(eliminate32g, __attribute__((noinline)), 32, true, CNL_ALL32, CNL_STEPS32)
+CNL_DEFINE_ELIM(eliminate64, __attribute__((noinline)), 64, true, CNL_ALL64, CNL_STEPS64)
 
 // backward substitution of one front for the problems of a pass
+template <int TE>
+__device__ __attribute__((noinline)) void back_front_call(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, const int* rec, int f,
+                                                     int nupd, int npiv, long long lptr, int xoff, int pxoff, double* pbase0, const int* okflag);
+
 template <int TE>
 __device__ __forceinline__ void back_front(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, const int* rec, int f,
                                            int nupd, int npiv, long long lptr, int xoff, int pxoff, double* pbase0, const int* okflag) {
@@ -277,12 +203,18 @@ __device__ __forceinline__ void back_front(const DevPlan2& P, const Ctx2& c, int
         const double xi = z - s;
         if (b == i) {
           xb = xi;
-          if (valid) c.dout[pclamp * P.N + rec[B_HDR + 1 + nupd + k0 + k]] = -xi;
+          if (valid) c.dout[pclamp * P.dstride + rec[B_HDR + 1 + nupd + k0 + k]] = -xi;
         }
       }
     }
   }
   if (b >= 1 && b < f) xs[xoff + b] = xb;
+}
+
+template <int TE>
+__device__ __attribute__((noinline)) void back_front_call(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, const int* rec, int f,
+                                                     int nupd, int npiv, long long lptr, int xoff, int pxoff, double* pbase0, const int* okflag) {
+  back_front<TE>(P, c, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);
 }
 
 }  // namespace
@@ -310,10 +242,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
 
   Ctx2 c;
   c.vals = A.vals; c.rhs = A.rhs; c.L = A.L; c.gs = A.scratch; c.dout = A.d; c.batch = A.batch;
-  const double* myvals = A.vals + pclamp * P.nnz;
-  const double* myrhs = (A.mode == MODE_FACTOR || !A.rhs) ? nullptr : A.rhs + pclamp * P.N;
+  const double* myvals = A.vals + pclamp * P.vstride;
+  const double* myrhs = (A.mode == MODE_FACTOR || !A.rhs) ? nullptr : A.rhs + pclamp * P.rstride;
   double* mygs = A.scratch + pclamp * P.gs_doubles;
   const double eig_tol = A.params[0];
+  const int xpos = A.extra_pos ? A.extra_pos[pclamp] : 0, xzer = A.extra_zer ? A.extra_zer[pclamp] : 0;
 
   // per-problem ladder state, replicated over the 16 lanes of the group
   double rho = 0.0, wrote = 0.0;
@@ -325,18 +258,19 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
 
   while (true) {
     // ---------------- forward pass over the record stream ----------------
-    if (l == 0) { cnt[g * 2] = 0; cnt[g * 2 + 1] = 0; }
+    if (l == 0) { cnt[g * 2] = xpos; cnt[g * 2 + 1] = xzer; }
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
     // prologue: record 0 -> buffer 0 (synchronous), then prefetch record 1 and the values of front 0
     int roff = 0;  // word offset of the current record
     {
-      const int len0 = P.rec[R_RECLEN];
+      int len0 = P.rec[R_RECLEN];
+      if (len0 > P.reccap) len0 = P.reccap;
       for (int w4 = lane; w4 * 4 < len0; w4 += 64) reinterpret_cast<int4*>(recbuf)[w4] = rstream[w4];
       wsync();
     }
     int4 R[RN];
     double pv[PVN];
-    int nxt_off = roff + rfl(recbuf[R_RECLEN]);  // offset of record 1
+    int nxt_off = roff + P.rec[R_RECLEN];  // offset of record 1
     {
 #pragma unroll
       for (int k = 0; k < RN; k++) R[k] = rstream[(nxt_off >> 2) + lane + 64 * k];  // stream is padded: over-read is safe
@@ -346,16 +280,17 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
         double v0 = 0.0;
         const int e = j * 16 + l;
         if (e < nasm0) {
-          const int src = recbuf[aoff0 + e];
+          const int src = P.rec[aoff0 + e];
           if (src >= P.nnz) v0 = myrhs ? myrhs[src - P.nnz] : 0.0;
           else if (src >= 0) v0 = (ovr && src >= P.rho_begin) ? rho : myvals[src];
         }
         pv[j] = v0;
       }
     }
+    int cur_next = 0;
     for (int s = 0; s < P.nsuper; s++) {
       const int* rec = recbuf + (s & 1) * P.reccap;
-      const int npiv = rfl(rec[R_NPIV]), nupd = rfl(rec[R_NUPD]), reclen = rfl(rec[R_RECLEN]), nasm = rfl(rec[R_NASM]);
+      const int npiv = rfl(rec[R_NPIV]), nupd = rfl(rec[R_NUPD]), nasm = rfl(rec[R_NASM]);
       const int nchild = rfl(rec[R_NCHILD]), uoff = rfl(rec[R_UOFF]), flags = rfl(rec[R_FLAGS]), fsoff = rfl(rec[R_FSOFF]);
       const int cls = rfl(rec[R_CLS]), aoff = rfl(rec[R_ASM_OFF]), coff = rfl(rec[R_CHILD_OFF]);
       const long long lptr = (long long)rfl(rec[R_LPTR_LO]) | ((long long)rfl(rec[R_LPTR_HI]) << 31);
@@ -385,11 +320,12 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
         }
       } else {
         double* Fg = mygs + fsoff;
+        const int* grec = P.rec + roff;  // lists of a globally staged front are read from the stream itself
         for (int t = l; t < tf; t += 16) Fg[t] = 0.0;
         gsync();
         for (int e0 = 0; e0 < nasm; e0 += 16) {
           const int e = e0 + l;
-          const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
+          const int src = grec[aoff + e], pos = grec[aoff + nasm + e];
           double v = 0.0;
           if (e0 < PVN * 16) {
             // prefetched slot j = e0/16 (static index needed): fall through the unrolled select below
@@ -407,11 +343,12 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
       int* nrec = recbuf + ((s + 1) & 1) * P.reccap;
       if (s + 1 < P.nsuper) {
         const int nlen = __builtin_amdgcn_readlane(R[0].z, 0);  // word R_RECLEN of the prefetched header
+        const int clen = nlen < P.reccap ? nlen : P.reccap;     // globally staged fronts keep only their head in LDS
 #pragma unroll
         for (int k = 0; k < RN; k++)
-          if ((lane + 64 * k) * 4 < nlen) reinterpret_cast<int4*>(nrec)[lane + 64 * k] = R[k];
+          if ((lane + 64 * k) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 64 * k] = R[k];
         wsync();
-        for (int w4 = RN * 64 + lane; w4 * 4 < nlen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = rstream[(nxt_off >> 2) + w4];
+        for (int w4 = RN * 64 + lane; w4 * 4 < clen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = rstream[(nxt_off >> 2) + w4];
         wsync();
         const int nn_off = nxt_off + nlen;
         if (s + 2 < P.nsuper) {
@@ -419,64 +356,78 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
           for (int k = 0; k < RN; k++) R[k] = rstream[(nn_off >> 2) + lane + 64 * k];
         }
         const int nasm1 = rfl(nrec[R_NASM]), aoff1 = rfl(nrec[R_ASM_OFF]);
+        const bool ngfs = rfl(nrec[R_FLAGS]) & RF_FS_GLOBAL;
+        const int* gnrec = P.rec + nxt_off;
 #pragma unroll
         for (int j = 0; j < PVN; j++) {
           double v0 = 0.0;
           const int e = j * 16 + l;
           if (j * 16 < nasm1) {
             if (e < nasm1) {
-              const int src = nrec[aoff1 + e];
+              const int src = ngfs ? gnrec[aoff1 + e] : nrec[aoff1 + e];
               if (src >= P.nnz) v0 = myrhs ? myrhs[src - P.nnz] : 0.0;
               else if (src >= 0) v0 = (ovr && src >= P.rho_begin) ? rho : myvals[src];
             }
           }
           pv[j] = v0;
         }
-        roff = nxt_off;
+        cur_next = nxt_off;
         nxt_off = nn_off;
       }
       // (4) extend-add the children's update matrices
       {
         int co = coff;
         for (int ci = 0; ci < nchild; ci++) {
-          const int cu = rfl(rec[co + C_UOFF]), tuc = rfl(rec[co + C_TUC]), cfl = rfl(rec[co + C_FLAGS]);
-          const int* dest = rec + co + C_HDR;
+          int cu, tuc, cfl;
+          if (gfs) {
+            const int* crec = P.rec + roff + co;
+            cu = rfl(crec[C_UOFF]); tuc = rfl(crec[C_TUC]); cfl = rfl(crec[C_FLAGS]);
+          } else {
+            cu = rfl(rec[co + C_UOFF]); tuc = rfl(rec[co + C_TUC]); cfl = rfl(rec[co + C_FLAGS]);
+          }
           if (!gfs && !cfl) {
+            const int* dest = rec + co + C_HDR;
             const double* U = myU + cu;
             for (int t = l; t < tuc; t += 16)
               __hip_atomic_fetch_add(&myFs[dest[t]], U[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          } else if (!gfs) {
+            const int* dest = rec + co + C_HDR;
+            const double* Ug = mygs + cu;
+            for (int t = l; t < tuc; t += 16)
+              __hip_atomic_fetch_add(&myFs[dest[t]], Ug[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           } else {
+            const int* dest = P.rec + roff + co + C_HDR;
             const double* Ul = myU + cu;
             const double* Ug = mygs + cu;
             double* Fg = mygs + fsoff;
             for (int t = l; t < tuc; t += 16) {
               const double u = cfl ? Ug[t] : Ul[t];
-              if (gfs) { if (valid) Fg[dest[t]] += u; }
-              else __hip_atomic_fetch_add(&myFs[dest[t]], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              if (valid) Fg[dest[t]] += u;
             }
-            if (gfs) gsync();
+            gsync();
           }
           co += C_HDR + ((tuc + 3) & ~3);
         }
       }
       if (gfs) gsync(); else wsync();
       // (5) eliminate in registers, store L rows and the update matrix
+      const bool uglob = flags & RF_U_GLOBAL;
       if (cls == 16) {
-        eliminate<16, false, false>(P, c, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, pbase0, cnt, eig_tol);
+        eliminate16(P, c, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
       } else if (cls == 32) {
         for (int pass = 0; pass < 2; pass++) {
           if (prob0 + pass * 2 >= A.batch) break;
-          if (flags & RF_U_GLOBAL) eliminate<32, false, true>(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, pbase0, cnt, eig_tol);
-          else eliminate<32, false, false>(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, pbase0, cnt, eig_tol);
+          if (gfs) eliminate32g(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
+          else eliminate32(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
         }
       } else {
         for (int pass = 0; pass < 4; pass++) {
           if (prob0 + pass >= A.batch) break;
-          if (flags & RF_U_GLOBAL) eliminate64<true>(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, pbase0, cnt, eig_tol);
-          else eliminate64<false>(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, pbase0, cnt, eig_tol);
+          eliminate64(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
         }
       }
       if (flags & (RF_U_GLOBAL | RF_FS_GLOBAL)) gsync(); else wsync();
+      roff = cur_next;
     }
     // ---------------- inertia test and rho ladder (src/solver_types.jl:90-97, src/CaNNOLeS.jl:1023-1047) ----
     wsync();
@@ -506,7 +457,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
   if (nfact > 1) {
     if (rho <= rhomax) rho_old = rho;
     if (valid) {
-      double* vt = A.vals + pclamp * P.nnz + P.rho_begin;
+      double* vt = A.vals + pclamp * P.vstride + P.rho_begin;
       for (int i = l; i < P.nvar; i += 16) vt[i] = wrote;
     }
   }
@@ -548,12 +499,12 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
       } else if (cls == 32) {
         for (int pass = 0; pass < 2; pass++) {
           if (prob0 + pass * 2 >= A.batch) break;
-          back_front<32>(P, cb, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, cnt + 8);
+          back_front_call<32>(P, cb, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, cnt + 8);
         }
       } else {
         for (int pass = 0; pass < 4; pass++) {
           if (prob0 + pass >= A.batch) break;
-          back_front<64>(P, cb, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, cnt + 8);
+          back_front_call<64>(P, cb, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, cnt + 8);
         }
       }
       wsync();

@@ -1,0 +1,104 @@
+// kernels_aux.hip — thread-parallel pre/post passes around the multifrontal kernels (see condense.h):
+//   condense_kernel : vals/rhs -> condensed slots [K2 entries | rho tail | condensed rhs]
+//   cond_inertia    : inertia contribution of the condensed residual pivots d_r
+//   expand_kernel   : solution of the condensed system -> d of the full system, r components recovered
+// They stream over independent (problem, entry) pairs at full occupancy; no dependency chains.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace cnl {
+
+__global__ void __launch_bounds__(256) condense_kernel(const DevCond C, const double* __restrict__ vals,
+                                                       const double* __restrict__ rhs, double* __restrict__ cbuf,
+                                                       int slot_begin, int slot_end, int batch) {
+  const int s = slot_begin + blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (s >= slot_end || b >= batch) return;
+  const double* v = vals + (long long)b * C.nnz;
+  const double* r = rhs ? rhs + (long long)b * C.N : nullptr;
+  auto X = [&](int i) -> double { return i < C.nnz ? v[i] : (r ? r[i - C.nnz] : 0.0); };
+  double acc = 0.0;
+  const int c0 = C.c_ptr[s], c1 = C.c_ptr[s + 1];
+  for (int c = c0; c < c1; c++) {
+    const int a = C.c_a[c], bb = C.c_b[c];
+    if (bb < 0) acc += X(a);
+    else acc += -(X(a) * X(bb)) / X(C.c_d[c]);
+  }
+  cbuf[(long long)b * C.cstride + s] = acc;
+}
+
+// pos_r = #{d_r > eig_tol}, zer_r = #{|d_r| <= eig_tol} over the condensed pivots (src/solver_types.jl:90-95)
+__global__ void __launch_bounds__(256) cond_inertia_kernel(const DevCond C, const double* __restrict__ vals, int* extra_pos,
+                                                           int* extra_zer, double eig_tol, int batch) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (b >= batch) return;
+  int pos = 0, zer = 0;
+  if (q < C.ncond) {
+    const double d = vals[(long long)b * C.nnz + C.r_dsrc[q]];
+    pos = d > eig_tol;
+    zer = fabs(d) <= eig_tol;
+  }
+  // wave reduction, then one atomic per wave (only when non-zero: the common case adds nothing)
+  const unsigned long long mp = __ballot(pos), mz = __ballot(zer);
+  if ((threadIdx.x & 63) == 0) {
+    if (mp) atomicAdd(&extra_pos[b], __popcll(mp));
+    if (mz) atomicAdd(&extra_zer[b], __popcll(mz));
+  }
+}
+
+// d_full from the condensed solution d2 (= -K2^-1 crhs): kept nodes copy; condensed r:
+//   sol_r = (rhs_r - sum_k J_rk sol_xk) / d_r,  d_r_out = -sol_r = -(rhs_r + sum_k J_rk d2_xk) / d_r
+__global__ void __launch_bounds__(256) expand_kernel(const DevCond C, double* __restrict__ vals, const double* __restrict__ rhs,
+                                                     const double* __restrict__ d2, const double* __restrict__ cbuf,
+                                                     double* __restrict__ dout, const int* __restrict__ success,
+                                                     int copy_rho_tail, int batch) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (b >= batch) return;
+  if (copy_rho_tail && i < C.nvar)
+    vals[(long long)b * C.nnz + (C.nnz - C.nvar) + i] = cbuf[(long long)b * C.cstride + C.ncs + i];
+  if (i >= C.N) return;
+  if (success && !success[b]) return;
+  const double* x2 = d2 + (long long)b * C.N2;
+  const int red = C.red_of[i];
+  double out;
+  if (red >= 0) out = x2[red];
+  else {
+    const int q = C.cidx_of[i];
+    const double* v = vals + (long long)b * C.nnz;
+    double s = rhs[(long long)b * C.N + i];
+    for (int k = C.r_ptr[q]; k < C.r_ptr[q + 1]; k++) s += v[C.r_jsrc[k]] * x2[C.r_jx[k]];
+    out = -s / v[C.r_dsrc[q]];
+  }
+  dout[(long long)b * C.N + i] = out;
+}
+
+hipError_t launch_condense(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int slot_begin, int slot_end,
+                           int batch, hipStream_t stream) {
+  const int n = slot_end - slot_begin;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(condense_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, C, vals, rhs, cbuf, slot_begin, slot_end, batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_pos, int* extra_zer, double eig_tol, int batch,
+                               hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(extra_pos, 0, sizeof(int) * batch, stream);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(extra_zer, 0, sizeof(int) * batch, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cond_inertia_kernel, dim3((C.ncond + 255) / 256, batch), dim3(256), 0, stream, C, vals, extra_pos, extra_zer, eig_tol, batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, const double* d2, const double* cbuf, double* dout,
+                         const int* success, int copy_rho_tail, int batch, hipStream_t stream) {
+  const int n = (int)C.N;
+  hipLaunchKernelGGL(expand_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, C, vals, rhs, d2, cbuf, dout, success,
+                     copy_rho_tail, batch);
+  return hipGetLastError();
+}
+
+}  // namespace cnl

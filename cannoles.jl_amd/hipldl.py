@@ -98,7 +98,7 @@ def _i64(a):
 
 
 _INFO_KEYS = ["N", "nnz", "nnzK", "nsuper", "nnzL", "nnzL_exact", "lsize", "fmax", "fwd_peak", "bwd_peak",
-              "panel_max", "flops", "nasm", "v2_classes", "v2_lds", "v2_gs"]
+              "panel_max", "flops", "nasm", "v2_classes", "v2_lds", "ncond"]
 
 
 def _plan_info(p):
@@ -109,10 +109,9 @@ def _plan_info(p):
     c, l = d.pop("v2_classes"), d.pop("v2_lds")
     if c >= 0:
         d["v2"] = {"fronts16": c & 0xfffff, "fronts32": (c >> 20) & 0xfffff, "fronts64": c >> 40,
-                   "ustack": l & 0xfffff, "staging": (l >> 20) & 0xfffff, "reclen": l >> 40, "gscratch": d.pop("v2_gs")}
+                   "ustack": l & 0xfffff, "staging": (l >> 20) & 0xfffff, "reclen": l >> 40}
     else:
         d["v2"] = None
-        d.pop("v2_gs")
     return d
 
 

@@ -18,8 +18,24 @@ def tri(i):
 
 
 class PlanSim:
+    """Executes the plan of `plan` (a hipldl.Plan).  When the plan condenses the residual block
+    (csrc/condense.h) the pre/post passes are emulated with numpy as well."""
+
     def __init__(self, plan):
         self.info = plan.info
+        self.ncond = plan.info.get("ncond", 0)
+        self.Nout, self.nnzout = plan.info["N"], plan.info["nnz"]
+        if self.ncond:
+            self.c_ptr = plan.array("c_ptr").astype(np.int64)
+            self.c_a = plan.array("c_a").astype(np.int64)
+            self.c_b = plan.array("c_b").astype(np.int64)
+            self.c_d = plan.array("c_d").astype(np.int64)
+            self.orig_of = plan.array("orig_of").astype(np.int64)
+            self.r_orig = plan.array("r_orig").astype(np.int64)
+            self.r_dsrc = plan.array("r_dsrc").astype(np.int64)
+            self.r_ptr = plan.array("r_ptr").astype(np.int64)
+            self.r_jsrc = plan.array("r_jsrc").astype(np.int64)
+            self.r_jx = plan.array("r_jx").astype(np.int64)
         fr = plan.array("fronts").reshape(-1, 16)
         self.fr = {k: fr[:, i].astype(np.int64) for i, k in enumerate(HDR)}
         self.ns = fr.shape[0]
@@ -28,8 +44,10 @@ class PlanSim:
         self.asm_src = plan.array("asm_src").astype(np.int64)
         self.child_idx = plan.array("child_idx").astype(np.int64)
         self.rel_idx = plan.array("rel_idx").astype(np.int64)
-        self.perm = plan.array("perm").astype(np.int64)
-        self.N, self.nnz = self.info["N"], self.info["nnz"]
+        self.perm = plan.array("inner_perm").astype(np.int64)
+        self.N = len(self.perm)                       # order of the (condensed) system the fronts work on
+        # inner "nnz": rhs entries of the assembly lists are encoded as nnz_inner + index
+        self.nnz = self.info["nnz"] if not self.ncond else int(self.c_ptr.size - 1 - self.N)
         fmax = self.info["fmax"]
         self.ti, self.tj = np.tril_indices(fmax)
         self.lptr = self.fr["lptr_lo"] | (self.fr["lptr_hi"] << 31)
@@ -115,24 +133,57 @@ class PlanSim:
                 d[self.perm[f["first_piv"][s] + (fs - 1 - i)]] = -xi
         return d
 
+    def condense(self, vals, rhs):
+        """numpy twin of condense_kernel: [K2 slots | rho tail | condensed rhs]"""
+        x = np.concatenate([np.asarray(vals, float), np.asarray(rhs, float)])
+        out = np.zeros(len(self.c_ptr) - 1)
+        plain = self.c_b < 0
+        with np.errstate(all="ignore"):
+            contrib = np.where(plain, x[self.c_a], -(x[self.c_a] * x[np.maximum(self.c_b, 0)]) / x[np.maximum(self.c_d, 0)])
+        slot = np.repeat(np.arange(len(out)), np.diff(self.c_ptr))
+        np.add.at(out, slot, contrib)
+        return out
+
+    def expand(self, vals, rhs, d2):
+        d = np.zeros(self.Nout)
+        d[self.orig_of] = d2
+        for q in range(len(self.r_orig)):
+            k = slice(self.r_ptr[q], self.r_ptr[q + 1])
+            s_ = rhs[self.r_orig[q]] + np.dot(vals[self.r_jsrc[k]], d2[self.r_jx[k]])
+            d[self.r_orig[q]] = -s_ / vals[self.r_dsrc[q]]
+        return d
+
     def newton_system(self, vals, rhs, nvar, nequ, ncon, rho_old, params):
+        if self.ncond:
+            cb = self.condense(vals, rhs)
+            nmat = len(cb) - self.N
+            dr = np.asarray(vals)[self.r_dsrc]
+            xpos, xzer = int((dr > params[0]).sum()), int((np.abs(dr) <= params[0]).sum())
+            d2, ok, rho, rho_old, nfact = self._newton_inner(cb[:nmat].copy(), cb[nmat:], nvar, rho_old, params, xpos, xzer)
+            return (self.expand(np.asarray(vals), np.asarray(rhs), d2) if ok else np.zeros(self.Nout)), ok, rho, rho_old, nfact
+        return self._newton_inner(vals, rhs, nvar, rho_old, params, 0, 0)
+
+    def _newton_inner(self, vals, rhs, nvar, rho_old, params, xpos, xzer):
         """same ladder as the kernel / src/CaNNOLeS.jl:1019-1051"""
+        nvar_ = nvar
+        def inert(npos, nzer):
+            return npos + xpos == nvar_ and nzer + xzer == 0
         eig_tol, kdec, kinc, klarge, rho0, rhomax, rhomin = params[0], params[2], params[3], params[4], params[5], params[6], params[7]
         rho, nfact = 0.0, 0
         L, npos, nzer = self.factor(vals, rhs, nvar, eig_tol)
         nfact += 1
-        ok = npos == nvar and nzer == 0
+        ok = inert(npos, nzer)
         if not ok:
             rho = rho0 if rho_old == 0 else max(rhomin, kdec * rho_old)
             L, npos, nzer = self.factor(vals, rhs, nvar, eig_tol, rho)
             nfact += 1
-            ok = npos == nvar and nzer == 0
+            ok = inert(npos, nzer)
             while not ok and rho <= rhomax:
                 rho = klarge * rho if rho_old == 0 else kinc * rho
                 if rho <= rhomax:
                     L, npos, nzer = self.factor(vals, rhs, nvar, eig_tol, rho)
                     nfact += 1
-                    ok = npos == nvar and nzer == 0
+                    ok = inert(npos, nzer)
             if rho <= rhomax:
                 rho_old = rho
         d = self.backward(L) if ok else np.zeros(self.N)
