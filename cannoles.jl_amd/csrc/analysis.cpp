@@ -847,6 +847,15 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     P.u2_peak = (int32_t)((peakL + 1) & ~(int64_t)1);
     P.fs2_max = (int32_t)((fsmax + 1) & ~(int64_t)1);
     P.gs_doubles = (peakG + 1) & ~(int64_t)1;
+    // fast fronts (order <= 16, LDS staging) use a strided image: (a, b) -> a*16 + b instead of a(a+1)/2 + b
+    auto stride_pos = [&](int32_t packed) -> int32_t {
+      int32_t a = (int32_t)((std::sqrt(8.0 * packed + 1.0) - 1.0) * 0.5);
+      while (tri(a + 1) <= packed) a++;
+      while (tri(a) > packed) a--;
+      return a * 16 + (packed - (int32_t)tri(a));
+    };
+    for (int32_t s = 0; s < ns; s++) if (cls[s] == 16 && !fsglob[s]) fsmax = std::max<int64_t>(fsmax, 16 * 16);
+    P.fs2_max = (int32_t)((fsmax + 1) & ~(int64_t)1);
     // forward records
     P.rec.clear(); P.rec_maxlen = 0;
     for (int32_t s = 0; s < ns; s++) {
@@ -855,9 +864,13 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       P.rec.resize(r0 + R_HDR, 0);
       // assembly entries, every round padded to a multiple of 16 (dummy: src -1 -> value 0 added to slot 0)
       ivec asrc, apos;
+      const bool strided = cls[s] == 16 && !fsglob[s];
       for (int32_t r = F.seg_begin; r < F.seg_end; r++) {
-        for (int32_t e = P.seg_ptr[r]; e < P.seg_ptr[r + 1]; e++) { asrc.push_back(P.asm_src[e]); apos.push_back(P.asm_pos[e]); }
-        while (asrc.size() % 16) { asrc.push_back(-1); apos.push_back(0); }
+        for (int32_t e = P.seg_ptr[r]; e < P.seg_ptr[r + 1]; e++) {
+          asrc.push_back(P.asm_src[e]);
+          apos.push_back(strided ? stride_pos(P.asm_pos[e]) : P.asm_pos[e]);
+        }
+        while (asrc.size() % 16) { asrc.push_back(0); apos.push_back(0); }  // dummy: some value added to the unused slot 0
       }
       int32_t asm_off = (int32_t)(P.rec.size() - r0);
       P.rec.insert(P.rec.end(), asrc.begin(), asrc.end());
@@ -870,7 +883,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
         P.rec.push_back(uoff2[c]); P.rec.push_back(tuc); P.rec.push_back(uglob[c] ? 1 : 0); P.rec.push_back(0);
         const int32_t* rel = P.rel_idx.data() + C.rel_begin;
         for (int32_t a = 0; a <= C.nupd; a++)
-          for (int32_t b = 0; b <= a; b++) P.rec.push_back((int32_t)(tri(rel[a]) + rel[b]));
+          for (int32_t b = 0; b <= a; b++) P.rec.push_back(strided ? rel[a] * 16 + rel[b] : (int32_t)(tri(rel[a]) + rel[b]));
         while ((P.rec.size() - r0) % 4) P.rec.push_back(0);
       }
       while ((P.rec.size() - r0) % 4) P.rec.push_back(0);

@@ -158,7 +158,7 @@ int setup_v2(cnl_handle* h) {
   d.nsuper = P.nsuper; d.N = (int32_t)P.N; d.nnz = (int32_t)P.nnz; d.rho_begin = P.rho_begin; d.nvar = (int32_t)P.nvar;
   d.reccap = (std::max(P.rec_maxlen, P.brec_maxlen) + 3) & ~3;
   d.u2_peak = P.u2_peak;
-  int64_t prob = std::max<int64_t>((int64_t)P.u2_peak + P.fs2_max + 16, P.bwd_peak + 2);
+  int64_t prob = std::max<int64_t>((int64_t)P.u2_peak + std::max<int64_t>(P.fs2_max, 64) + 16, P.bwd_peak + 2);
   d.prob_doubles = (int32_t)((prob + 1) & ~(int64_t)1);
   d.gs_doubles = P.gs_doubles + 64;
   d.lsize = P.lsize;
@@ -252,7 +252,7 @@ int ensure_staging(cnl_handle* h) {
   if ((rc = dalloc(h, &h->d_rho, (size_t)h->batch))) return rc;
   if ((rc = dalloc(h, &h->d_nfact, (size_t)h->batch))) return rc;
   if ((rc = dalloc(h, &h->d_success, (size_t)h->batch))) return rc;
-  if ((rc = dalloc(h, &h->d_npos, (size_t)h->batch))) return rc;
+  if ((rc = dalloc(h, &h->d_npos, (size_t)h->batch * 2 + 64))) return rc;
   if ((rc = dalloc(h, &h->d_nzero, (size_t)h->batch))) return rc;
   return CNL_OK;
 }
@@ -404,6 +404,7 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
     if ((rc = upload(h, C.c_a, &dc.c_a))) return bail(rc);
     if ((rc = upload(h, C.c_b, &dc.c_b))) return bail(rc);
     if ((rc = upload(h, C.c_d, &dc.c_d))) return bail(rc);
+    if ((rc = upload(h, C.c_order, &dc.c_order))) return bail(rc);
     if ((rc = upload(h, C.r_dsrc, &dc.r_dsrc))) return bail(rc);
     if ((rc = upload(h, C.r_ptr, &dc.r_ptr))) return bail(rc);
     if ((rc = upload(h, C.r_jsrc, &dc.r_jsrc))) return bail(rc);
@@ -466,6 +467,14 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   cfg[7] = (int64_t)h->lds2;
   return CNL_OK;
 }
+
+#ifdef CNL_STAMPS
+int cnl_debug_stamps(cnl_handle* h, int64_t* out, int64_t n) {
+  if (!h || !h->d_npos) return fail(CNL_ERR_ARG, "no stamps");
+  HIPCHK(hipMemcpy(out, h->d_npos, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return CNL_OK;
+}
+#endif
 
 // ---- device-pointer entry points -------------------------------------------------
 int cnl_factorize_dev(cnl_handle* h, const double* d_vals, double eig_tol, int32_t* d_success, void* stream) {
@@ -561,6 +570,9 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   a.mode = cnl::MODE_NEWTON;
   a.rho_old = h->d_rho_old; a.rho = h->d_rho;
   a.nfact = h->d_nfact; a.success = h->d_success;
+#ifdef CNL_STAMPS
+  a.npos = h->d_npos;  // diagnostic build: per-wave phase stamps land here (cnl_debug_stamps)
+#endif
   std::memcpy(a.params, params, 9 * sizeof(double));
   if ((rc = run(h, a, h->d_vals, h->d_rhs, h->d_d, h->stream))) return rc;
   h->last_vals = h->d_vals;

@@ -33,6 +33,8 @@ struct Cond {
   //   else    : -x(c_a) * x(c_b) / x(c_d)  product
   // where x(i) = vals[i] for i < nnz and rhs[i - nnz] otherwise.
   std::vector<int32_t> c_ptr, c_a, c_b, c_d;
+  // processing order of the slots (identity: the natural column-major order coalesces best)
+  std::vector<int32_t> c_order;
   // condensed residual nodes: diag source, original index, Jacobian row (sources / reduced x indices)
   std::vector<int32_t> r_orig, r_dsrc, r_ptr, r_jsrc, r_jx;
   // original index -> reduced index (-1 for condensed nodes) and back

@@ -48,7 +48,7 @@ struct DevPlan2 {
 
 // device-resident condensation lists (condense.h)
 struct DevCond {
-  const int32_t *c_ptr, *c_a, *c_b, *c_d;
+  const int32_t *c_ptr, *c_a, *c_b, *c_d, *c_order;
   const int32_t *r_dsrc, *r_ptr, *r_jsrc, *r_jx;
   const int32_t *red_of, *cidx_of;
   int32_t N, nnz, nvar, N2, ncs, ncond;

@@ -257,8 +257,22 @@ __device__ __forceinline__ bool factor_attempt(const DevPlan& P, const ProblemCt
   return npos == P.nvar && nzer == 0;  // src/solver_types.jl:96
 }
 
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {  // struct members are generic pointers to the compiler: mark them global
+  return (T*)(__attribute__((address_space(1))) T*)p;
+}
+
 template <int TPP, int PPB, bool LDSW>
-__global__ void __launch_bounds__(TPP* PPB) newton_kernel(const DevPlan P, const LaunchArgs A) {
+__global__ void __launch_bounds__(TPP* PPB) newton_kernel(const DevPlan Pin, const LaunchArgs Ain) {
+  DevPlan P = Pin;
+  P.fronts = as_global(Pin.fronts); P.seg_ptr = as_global(Pin.seg_ptr); P.asm_pos = as_global(Pin.asm_pos);
+  P.asm_src = as_global(Pin.asm_src); P.child_idx = as_global(Pin.child_idx); P.rel_idx = as_global(Pin.rel_idx);
+  P.perm = as_global(Pin.perm);
+  LaunchArgs A = Ain;
+  A.vals = as_global(Ain.vals); A.rhs = as_global(Ain.rhs); A.d = as_global(Ain.d); A.L = as_global(Ain.L);
+  A.scratch = as_global(Ain.scratch); A.rho_old = as_global(Ain.rho_old); A.rho = as_global(Ain.rho);
+  A.nfact = as_global(Ain.nfact); A.success = as_global(Ain.success); A.npos = as_global(Ain.npos); A.nzero = as_global(Ain.nzero);
+  A.extra_pos = as_global(Ain.extra_pos); A.extra_zer = as_global(Ain.extra_zer);
   extern __shared__ double smem[];
   const int gl = threadIdx.x / TPP;     // problem slot inside the workgroup
   const int tid = threadIdx.x % TPP;

@@ -46,6 +46,14 @@ __device__ __forceinline__ void gsync() {
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Pointers that arrive inside by-value structs are generic ("flat") to the compiler.  Flat accesses
+// count on lgkmcnt as well as vmcnt, so every LDS wait would also wait for outstanding global
+// prefetches.  Round-tripping through address space 1 tells the compiler they are global.
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+  return (T*)(__attribute__((address_space(1))) T*)p;
+}
+
 // broadcast lane (group base + a) of a TE-lane group
 template <int TE>
 __device__ __forceinline__ double bcast(double v, int a, int grp4) {
@@ -67,6 +75,19 @@ __device__ __forceinline__ double bcast_addr(double v, int addr4) {
   return __hiloint2double(hi, lo);
 }
 
+// w / d through a refined reciprocal: shorter dependent chain than the IEEE expansion (no scaling /
+// fix-up steps; a zero or non-finite pivot still yields inf/NaN, which fails the inertia test anyway)
+__device__ __forceinline__ double fast_div(double w, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  double q = w * r;
+  const double res = fma(-d, q, w);
+  return fma(res, r, q);
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
@@ -85,6 +106,17 @@ __device__ __forceinline__ double gsum(double v) {
   if (TE >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
+
+// optional in-kernel stamps (diagnostic build only: -DCNL_STAMPS); sums of s_memtime deltas per phase
+#ifdef CNL_STAMPS
+#define STAMP_DECL unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_BEGIN { __builtin_amdgcn_sched_barrier(0); st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN
+#define STAMP(k)
+#endif
 
 struct Ctx2 {
   const double* vals;   // batch base
@@ -107,15 +139,45 @@ struct Ctx2 {
 #define CNL_DECL(k) double r##k;
 // lanes b > row read past the row: harmless garbage in the unused upper triangle (staging is padded)
 #define CNL_LOAD(k) { const int a_ = top - k > 0 ? top - k : 0; r##k = Fs[tri2(a_) + b]; }  /* rows below 0: unused copies of row 0 */
-#define CNL_STEP(km1, k) r##km1 = fma(-bcast_addr(lv, base + (TE_ - 1 - k) * 4), w, r##k);
+// multipliers l_a of the current pivot are published once per pivot in LDS (lane b -> lb[i - b]) and read
+// back two rows at a time with one broadcast 16-byte read: a third of the LDS instructions of a
+// ds_bpermute-per-row scheme (the LDS pipe is shared by all waves of the CU and was the bottleneck)
+#define CNL_STEPA(km1, k)                                                          \
+  r##km1 = fma(-lb[1], w, r##k);                                                   \
+  wn = r##km1;                                                                     \
+  dn = bcast_addr(wn, base + (TE_ - 2) * 4);                                       \
+  lvn = fast_div(wn, dn);
+#define CNL_STEPP(km1, k, kp1)                                                     \
+  {                                                                                \
+    const double2 l2_ = *reinterpret_cast<const double2*>(lb + k);                 \
+    r##km1 = fma(-l2_.x, w, r##k);                                                 \
+    r##k = fma(-l2_.y, w, r##kp1);                                                 \
+  }
 #define CNL_CHK(k) if (k >= i) goto rows_done;  /* rows i-k >= 1 only (row 0 is the unused rhs-row diagonal) */
-#define CNL_USTG(k) { const int a_ = nupd - k; if (a_ >= 0) { if (b <= a_ && valid) Ug[tri2(a_) + b] = r##k; } }
-#define CNL_USTL(k) { const int a_ = nupd - k; if (a_ >= 0) { if (b <= a_) Ul[tri2(a_) + b] = r##k; } }
+// Update-matrix rows are stored in ASCENDING row order with all lanes active: the lanes b > a of row a
+// land on entries of later rows (or just past the matrix, in free stack space) and are overwritten by
+// the stores that follow in program order, so no per-row lane predicate is needed.
+#define CNL_USTG(k) { const int a_ = nupd - k; if (a_ >= 0) Ug[tri2(a_) + b] = r##k; }
+#define CNL_USTL(k) { const int a_ = nupd - k; if (a_ >= 0) Ul[tri2(a_) + b] = r##k; }
 
-#define CNL_DEFINE_ELIM(NAME, INL, TEV, GFS, ALL, STEPS)                                                               \
-  __device__ INL void NAME(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, int f,        \
-                                       int nupd, long long lptr, int uoff, int fsoff, bool uglob, double* pbase0,     \
-                                       int* cnt, double eig_tol) {                                                     \
+// fast fronts (order <= 16, LDS staging) use a strided staging image: row a at a*16, so the 16 row
+// loads are one base address plus immediate offsets (rows below 0 read unused garbage)
+#define CNL_LOADS(k) r##k = Fss[(15 - k) * 16];
+#ifdef CNL_STAMPS
+#define ESTAMP0 unsigned long long et0_ = 0; if (st_) { __builtin_amdgcn_sched_barrier(0); et0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define ESTAMP(k) if (st_) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[k] += t_ - et0_; et0_ = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ESTAMP0
+#define ESTAMP(k)
+#endif
+#define CNL_DEFINE_ELIM(NAME, INL, TEV, GFS, ALL, REV, STEPS, LOADM)                                                   \
+  __device__ INL void NAME(int P_prob_doubles, int P_u2_peak, long long P_gs_doubles, long long P_lsize, double* cL_,   \
+                           double* cgs_, int cbatch, int lane, int prob0, int pass,                                   \
+                           int f, int nupd, long long lptr, int uoff, int fsoff, bool uglob, double* pbase0,          \
+                           int* cnt, double eig_tol, unsigned long long* st_ = nullptr) {                              \
+    Ctx2 c;                                                                                                            \
+    ESTAMP0                                                                                                            \
+    c.L = as_global(cL_); c.gs = as_global(cgs_); c.batch = cbatch;                                                    \
     constexpr int TE_ = TEV;                                                                                           \
     constexpr int PPW = 64 / TE_;                                                                                      \
     const int gp = pass * PPW + (TE_ == 64 ? 0 : lane / TE_);                                                          \
@@ -124,58 +186,80 @@ struct Ctx2 {
     const int prob = prob0 + gp;                                                                                       \
     const bool valid = prob < c.batch;                                                                                 \
     const long long pclamp = valid ? prob : prob0;                                                                     \
-    double* pb = pbase0 + gp * P.prob_doubles;                                                                         \
-    const double* Fs = GFS ? (c.gs + pclamp * P.gs_doubles + fsoff) : (pb + P.u2_peak);                                \
-    double* Lp = c.L + pclamp * P.lsize + lptr;                                                                        \
+    double* pb = pbase0 + gp * P_prob_doubles;                                                                         \
+    const double* Fs = GFS ? (c.gs + pclamp * P_gs_doubles + fsoff) : (pb + P_u2_peak);                                \
+    double* Lp = c.L + pclamp * P_lsize + lptr;                                                                        \
     const int tu = tri2(1 + nupd);                                                                                     \
     const int top = f - 1;                                                                                             \
+    const double* Fss = Fs + (top - 15) * 16 + b;                                                                      \
+    double* lb = pb + P_u2_peak; /* the LDS staging area is dead once the rows are in registers */                     \
+    (void)Fss;                                                                                                         \
     ALL(CNL_DECL)                                                                                                      \
-    ALL(CNL_LOAD)                                                                                                      \
+    ALL(LOADM)                                                                                                         \
+    ESTAMP(7)                                                                                                          \
     int npos = 0, nzer = 0;                                                                                            \
     int base = grp4 + (top - (TE_ - 1)) * 4;                                                                           \
+    /* software look-ahead: the pivot value, its broadcast and the division of the NEXT pivot row are     */          \
+    /* started as soon as that row has been updated, and overlap the remaining row updates of this pivot */          \
+    double w = r0;                                                                                                     \
+    double dpiv = bcast_addr(w, base + (TE_ - 1) * 4);                                                                 \
+    double lv = fast_div(w, dpiv);                                                                                     \
     for (int i = top; i > nupd; i--) {                                                                                 \
-      const double w = r0;                                                                                             \
-      const double dpiv = bcast_addr(w, base + (TE_ - 1) * 4);                                                         \
       npos += dpiv > eig_tol;                                                                                          \
       nzer += fabs(dpiv) <= eig_tol;                                                                                   \
-      const double lv = w / dpiv;                                                                                      \
       if (valid && b <= i) Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;                                                \
-      STEPS(CNL_STEP, CNL_CHK)                                                                                         \
+      double wn = 0.0, dn = 1.0, lvn = 0.0;                                                                            \
+      {                                                                                                                \
+        int li_ = i - b;                                                                                               \
+        li_ = li_ > 0 ? li_ : 0; /* lanes b >= i park their value in the unused slot 0 */                              \
+        lb[li_] = lv;                                                                                                  \
+      }                                                                                                                \
+      if (1 >= i) goto rows_done;                                                                                      \
+      STEPS(CNL_STEPP, CNL_CHK, CNL_STEPA)                                                                             \
     rows_done:                                                                                                         \
       base -= 4;                                                                                                       \
+      w = wn; dpiv = dn; lv = lvn;                                                                                     \
     }                                                                                                                  \
+    ESTAMP(5)                                                                                                          \
     if (b == 0) { cnt[gp * 2] += npos; cnt[gp * 2 + 1] += nzer; }                                                      \
     if (uglob) {                                                                                                       \
-      double* Ug = c.gs + pclamp * P.gs_doubles + uoff;                                                                \
-      ALL(CNL_USTG)                                                                                                    \
+      if (valid) {                                                                                                     \
+        double* Ug = c.gs + pclamp * P_gs_doubles + uoff;                                                              \
+        REV(CNL_USTG)                                                                                                  \
+      }                                                                                                                \
     } else {                                                                                                           \
       double* Ul = pb + uoff;                                                                                          \
-      ALL(CNL_USTL)                                                                                                    \
+      REV(CNL_USTL)                                                                                                    \
     }                                                                                                                  \
   }
 
 // the rare large classes are real calls so that their register needs do not leak into the hot path
-CNL_DEFINE_ELIM(eliminate16, __forceinline__, 16, false, CNL_ALL16, CNL_STEPS16)
-CNL_DEFINE_ELIM(eliminate32, __attribute__((noinline)), 32, false, CNL_ALL32, CNL_STEPS32)
-CNL_DEFINE_ELIM(eliminate32g, __attribute__((noinline)), 32, true, CNL_ALL32, CNL_STEPS32)
-CNL_DEFINE_ELIM(eliminate64, __attribute__((noinline)), 64, true, CNL_ALL64, CNL_STEPS64)
+CNL_DEFINE_ELIM(eliminate16, __forceinline__, 16, false, CNL_ALL16, CNL_REV16, CNL_STEPS16, CNL_LOADS)
+CNL_DEFINE_ELIM(eliminate16g, __attribute__((noinline)), 16, true, CNL_ALL16, CNL_REV16, CNL_STEPS16, CNL_LOAD)
+CNL_DEFINE_ELIM(eliminate32, __attribute__((noinline)), 32, false, CNL_ALL32, CNL_REV32, CNL_STEPS32, CNL_LOAD)
+CNL_DEFINE_ELIM(eliminate32g, __attribute__((noinline)), 32, true, CNL_ALL32, CNL_REV32, CNL_STEPS32, CNL_LOAD)
+CNL_DEFINE_ELIM(eliminate64, __attribute__((noinline)), 64, true, CNL_ALL64, CNL_REV64, CNL_STEPS64, CNL_LOAD)
 
 // backward substitution of one front for the problems of a pass
 template <int TE>
-__device__ __attribute__((noinline)) void back_front_call(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, const int* rec, int f,
-                                                     int nupd, int npiv, long long lptr, int xoff, int pxoff, double* pbase0, const int* okflag);
+__device__ __attribute__((noinline)) void back_front_call(int P_prob_doubles, long long P_lsize, long long P_dstride, double* cL_, double* cdout_,
+                                                     int cbatch, int lane, int prob0, int pass, const int* rec, int f, int nupd, int npiv,
+                                                     long long lptr, int xoff, int pxoff, double* pbase0, const int* okflag);
 
 template <int TE>
-__device__ __forceinline__ void back_front(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, const int* rec, int f,
-                                           int nupd, int npiv, long long lptr, int xoff, int pxoff, double* pbase0, const int* okflag) {
+__device__ __forceinline__ void back_front(int P_prob_doubles, long long P_lsize, long long P_dstride, double* cL_, double* cdout_,
+                                           int cbatch, int lane, int prob0, int pass, const int* rec, int f, int nupd, int npiv,
+                                           long long lptr, int xoff, int pxoff, double* pbase0, const int* okflag) {
+  Ctx2 c;
+  c.L = as_global(cL_); c.dout = as_global(cdout_); c.batch = cbatch;
   constexpr int PPW = 64 / TE;
   const int gp = pass * PPW + (TE == 64 ? 0 : lane / TE);
   const int b = lane % TE;
   const int prob = prob0 + gp;
   const bool valid = prob < c.batch && okflag[gp] != 0;
   const long long pclamp = prob < c.batch ? prob : prob0;
-  double* xs = pbase0 + gp * P.prob_doubles;
-  const double* Lp = c.L + pclamp * P.lsize + lptr;
+  double* xs = pbase0 + gp * P_prob_doubles;
+  const double* Lp = c.L + pclamp * P_lsize + lptr;
   const int tu = tri2(1 + nupd);
   double xb = 0.0;
   if (pxoff >= 0 && b >= 1 && b <= nupd) xb = xs[pxoff + rec[B_HDR + b]];
@@ -203,7 +287,7 @@ __device__ __forceinline__ void back_front(const DevPlan2& P, const Ctx2& c, int
         const double xi = z - s;
         if (b == i) {
           xb = xi;
-          if (valid) c.dout[pclamp * P.dstride + rec[B_HDR + 1 + nupd + k0 + k]] = -xi;
+          if (valid) c.dout[pclamp * P_dstride + rec[B_HDR + 1 + nupd + k0 + k]] = -xi;
         }
       }
     }
@@ -212,15 +296,123 @@ __device__ __forceinline__ void back_front(const DevPlan2& P, const Ctx2& c, int
 }
 
 template <int TE>
-__device__ __attribute__((noinline)) void back_front_call(const DevPlan2& P, const Ctx2& c, int lane, int prob0, int pass, const int* rec, int f,
-                                                     int nupd, int npiv, long long lptr, int xoff, int pxoff, double* pbase0, const int* okflag) {
-  back_front<TE>(P, c, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);
+__device__ __attribute__((noinline)) void back_front_call(int P_prob_doubles, long long P_lsize, long long P_dstride, double* cL_, double* cdout_,
+                                                     int cbatch, int lane, int prob0, int pass, const int* rec, int f, int nupd, int npiv,
+                                                     long long lptr, int xoff, int pxoff, double* pbase0, const int* okflag) {
+  back_front<TE>(P_prob_doubles, P_lsize, P_dstride, cL_, cdout_, cbatch, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);
+}
+
+// Out-of-line handling of the rare fronts (order > 16, or staged in the global scratch): staging,
+// extend-add and elimination without the register prefetch of the hot path.  Lists are read from
+// the record stream in global memory.
+struct SlowArgs {  // the few plan scalars the out-of-line path needs (passed by value: no plan struct in scratch)
+  int prob_doubles, u2_peak, nnz, rho_begin;
+  long long gs_doubles, lsize, vstride, rstride;
+  const int* rec;
+};
+__device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_prob_doubles, int P_u2_peak, int P_nnz, int P_rho_begin,
+                                                     long long P_gs_doubles, long long P_lsize, long long P_vstride, long long P_rstride,
+                                                     const double* vals_, const double* rhs_, double* L_,
+                                                     double* gs_, int batch, int lane, int prob0, const int* rec, int roff,
+                                                     double* pbase0, int* cnt, double eig_tol, double rho, bool ovr) {
+  SlowArgs P;
+  P.prob_doubles = P_prob_doubles; P.u2_peak = P_u2_peak; P.nnz = P_nnz; P.rho_begin = P_rho_begin;
+  P.gs_doubles = P_gs_doubles; P.lsize = P_lsize; P.vstride = P_vstride; P.rstride = P_rstride; P.rec = prec_;
+  const double* vals = as_global(vals_);
+  const double* rhsb = as_global(rhs_);
+  double* Lb = as_global(L_);
+  double* gsb = as_global(gs_);
+  const int* grec = as_global(P.rec) + roff;
+  const int g = lane >> 4, l = lane & 15;
+  const int prob = prob0 + g;
+  const bool valid = prob < batch;
+  const long long pclamp = valid ? prob : prob0;
+  const double* myvals = vals + pclamp * P.vstride;
+  const double* myrhs = rhs_ ? rhsb + pclamp * P.rstride : nullptr;
+  double* mygs = gsb + pclamp * P.gs_doubles;
+  double* myU = pbase0 + g * P.prob_doubles;
+  double* myFs = myU + P.u2_peak;
+  const int npiv = rfl(rec[R_NPIV]), nupd = rfl(rec[R_NUPD]), nasm = rfl(rec[R_NASM]);
+  const int nchild = rfl(rec[R_NCHILD]), uoff = rfl(rec[R_UOFF]), flags = rfl(rec[R_FLAGS]), fsoff = rfl(rec[R_FSOFF]);
+  const int cls = rfl(rec[R_CLS]), aoff = rfl(rec[R_ASM_OFF]), coff = rfl(rec[R_CHILD_OFF]);
+  const long long lptr = (long long)rfl(rec[R_LPTR_LO]) | ((long long)rfl(rec[R_LPTR_HI]) << 31);
+  const int f = 1 + nupd + npiv;
+  const int tf = tri2(f);
+  const bool gfs = flags & RF_FS_GLOBAL;
+  const bool uglob = flags & RF_U_GLOBAL;
+  if (!gfs) {
+    for (int t = l; t < tf; t += 16) myFs[t] = 0.0;
+    wsync();
+    for (int e = l; e < nasm; e += 16) {
+      const int src = grec[aoff + e], pos = grec[aoff + nasm + e];
+      double v = 0.0;
+      if (src >= P.nnz) v = myrhs ? myrhs[src - P.nnz] : 0.0;
+      else v = (ovr && src >= P.rho_begin) ? rho : myvals[src];
+      __hip_atomic_fetch_add(&myFs[pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  } else {
+    double* Fg = mygs + fsoff;
+    for (int t = l; t < tf; t += 16) Fg[t] = 0.0;
+    gsync();
+    for (int e0 = 0; e0 < nasm; e0 += 16) {  // one round of 16 entries at a time: duplicates of a slot sit in different rounds
+      const int e = e0 + l;
+      const int src = grec[aoff + e], pos = grec[aoff + nasm + e];
+      double v = 0.0;
+      if (src >= P.nnz) v = myrhs ? myrhs[src - P.nnz] : 0.0;
+      else v = (ovr && src >= P.rho_begin) ? rho : myvals[src];
+      if (valid) Fg[pos] += v;
+      gsync();
+    }
+  }
+  int co = coff;
+  for (int ci = 0; ci < nchild; ci++) {
+    const int cu = rfl(grec[co + C_UOFF]), tuc = rfl(grec[co + C_TUC]), cfl = rfl(grec[co + C_FLAGS]);
+    const int* dest = grec + co + C_HDR;
+    const double* Ul = myU + cu;
+    const double* Ug = mygs + cu;
+    if (!gfs) {
+      for (int t = l; t < tuc; t += 16) {
+        const double u = cfl ? Ug[t] : Ul[t];
+        __hip_atomic_fetch_add(&myFs[dest[t]], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    } else {
+      double* Fg = mygs + fsoff;
+      for (int t = l; t < tuc; t += 16) {
+        const double u = cfl ? Ug[t] : Ul[t];
+        if (valid) Fg[dest[t]] += u;
+      }
+      gsync();
+    }
+    co += C_HDR + ((tuc + 3) & ~3);
+  }
+  if (gfs) gsync(); else wsync();
+  if (cls == 16) {
+    eliminate16g(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, Lb, gsb, batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
+  } else if (cls == 32) {
+    for (int pass = 0; pass < 2; pass++) {
+      if (prob0 + pass * 2 >= batch) break;
+      if (gfs) eliminate32g(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, Lb, gsb, batch, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
+      else eliminate32(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, Lb, gsb, batch, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
+    }
+  } else {
+    for (int pass = 0; pass < 4; pass++) {
+      if (prob0 + pass >= batch) break;
+      eliminate64(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, Lb, gsb, batch, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
+    }
+  }
 }
 
 }  // namespace
 
 // ==========================================================================================
-__global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const LaunchArgs A) {
+__global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, const LaunchArgs Ain) {
+  DevPlan2 P = Pin;
+  P.rec = as_global(Pin.rec); P.brec = as_global(Pin.brec);
+  LaunchArgs A = Ain;
+  A.vals = as_global(Ain.vals); A.rhs = as_global(Ain.rhs); A.d = as_global(Ain.d); A.L = as_global(Ain.L);
+  A.scratch = as_global(Ain.scratch); A.rho_old = as_global(Ain.rho_old); A.rho = as_global(Ain.rho);
+  A.nfact = as_global(Ain.nfact); A.success = as_global(Ain.success); A.npos = as_global(Ain.npos); A.nzero = as_global(Ain.nzero);
+  A.extra_pos = as_global(Ain.extra_pos); A.extra_zer = as_global(Ain.extra_zer);
   const int WPB = blockDim.x >> 6;
   extern __shared__ double smem[];
   const int lane = threadIdx.x & 63;
@@ -256,178 +448,145 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
   const double kdec = A.params[2], kinc = A.params[3], klarge = A.params[4], rho0 = A.params[5], rhomax = A.params[6],
                rhomin = A.params[7];
 
+  STAMP_DECL
   while (true) {
+    STAMP_BEGIN
     // ---------------- forward pass over the record stream ----------------
     if (l == 0) { cnt[g * 2] = xpos; cnt[g * 2 + 1] = xzer; }
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
-    // prologue: record 0 -> buffer 0 (synchronous), then prefetch record 1 and the values of front 0
-    int roff = 0;  // word offset of the current record
-    {
-      int len0 = P.rec[R_RECLEN];
-      if (len0 > P.reccap) len0 = P.reccap;
-      for (int w4 = lane; w4 * 4 < len0; w4 += 64) reinterpret_cast<int4*>(recbuf)[w4] = rstream[w4];
-      wsync();
-    }
-    int4 R[RN];
+    const double* rhs_or_vals = myrhs ? myrhs - P.nnz : myvals - P.nnz;  // base for entries src >= nnz (dummy when no rhs)
+    int4 R0, R1;      // record prefetch registers (two named values: an array would be kept in scratch)
     double pv[PVN];
-    int nxt_off = roff + P.rec[R_RECLEN];  // offset of record 1
-    {
+    int roff = 0;     // word offset of the current record
+    int nxt_off = 0;  // word offset of the next record
+    int s = 0;
+    bool primed = false;
+    while (s < P.nsuper) {
+      int* recw = recbuf + (s & 1) * P.reccap;
+      if (!primed) {
+        // (re)start the pipeline at front s: record s synchronously, then prefetch record s+1 and the values of s
+        int len = P.rec[roff + R_RECLEN];
+        nxt_off = roff + len;
+        if (len > P.reccap) len = P.reccap;
+        for (int w4 = lane; w4 * 4 < len; w4 += 64) reinterpret_cast<int4*>(recw)[w4] = rstream[(roff >> 2) + w4];
+        wsync();
+        R0 = rstream[(nxt_off >> 2) + lane];  // stream is padded: over-read is safe
+        R1 = rstream[(nxt_off >> 2) + lane + 64];
+        const int nasm0 = rfl(recw[R_NASM]), aoff0 = rfl(recw[R_ASM_OFF]);
+        const bool fast0 = rfl(recw[R_CLS]) == 16 && !(rfl(recw[R_FLAGS]) & RF_FS_GLOBAL);
 #pragma unroll
-      for (int k = 0; k < RN; k++) R[k] = rstream[(nxt_off >> 2) + lane + 64 * k];  // stream is padded: over-read is safe
-      const int nasm0 = rfl(recbuf[R_NASM]), aoff0 = rfl(recbuf[R_ASM_OFF]);
-#pragma unroll
-      for (int j = 0; j < PVN; j++) {
-        double v0 = 0.0;
-        const int e = j * 16 + l;
-        if (e < nasm0) {
-          const int src = P.rec[aoff0 + e];
-          if (src >= P.nnz) v0 = myrhs ? myrhs[src - P.nnz] : 0.0;
-          else if (src >= 0) v0 = (ovr && src >= P.rho_begin) ? rho : myvals[src];
+        for (int j = 0; j < PVN; j++) {
+          int e = j * 16 + l;
+          e = e < nasm0 ? e : (nasm0 > 0 ? nasm0 - 1 : 0);
+          const int src = (fast0 && nasm0 > 0) ? recw[aoff0 + e] : 0;
+          const double* ptr = src >= P.nnz ? rhs_or_vals + src : myvals + src;
+          pv[j] = *ptr;  // unconditional load: no wait is needed before the next one is issued
         }
-        pv[j] = v0;
+        primed = true;
       }
-    }
-    int cur_next = 0;
-    for (int s = 0; s < P.nsuper; s++) {
-      const int* rec = recbuf + (s & 1) * P.reccap;
+      const int* rec = recw;
       const int npiv = rfl(rec[R_NPIV]), nupd = rfl(rec[R_NUPD]), nasm = rfl(rec[R_NASM]);
       const int nchild = rfl(rec[R_NCHILD]), uoff = rfl(rec[R_UOFF]), flags = rfl(rec[R_FLAGS]), fsoff = rfl(rec[R_FSOFF]);
       const int cls = rfl(rec[R_CLS]), aoff = rfl(rec[R_ASM_OFF]), coff = rfl(rec[R_CHILD_OFF]);
       const long long lptr = (long long)rfl(rec[R_LPTR_LO]) | ((long long)rfl(rec[R_LPTR_HI]) << 31);
       const int f = 1 + nupd + npiv;
-      const int tf = tri2(f);
       const bool gfs = flags & RF_FS_GLOBAL;
-      // (1) zero the staging triangle, (2) assemble (prefetched values first)
-      if (!gfs) {
-        for (int t = l; t < tf; t += 16) myFs[t] = 0.0;
-        wsync();
-#pragma unroll
-        for (int j = 0; j < PVN; j++) {
-          const int e = j * 16 + l;
-          if (j * 16 < nasm) {
-            if (e < nasm) {
-              const int pos = rec[aoff + nasm + e];
-              __hip_atomic_fetch_add(&myFs[pos], pv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-          }
-        }
-        for (int e = PVN * 16 + l; e < nasm; e += 16) {
-          const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
-          double v = 0.0;
-          if (src >= P.nnz) v = myrhs ? myrhs[src - P.nnz] : 0.0;
-          else if (src >= 0) v = (ovr && src >= P.rho_begin) ? rho : myvals[src];
-          __hip_atomic_fetch_add(&myFs[pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-      } else {
-        double* Fg = mygs + fsoff;
-        const int* grec = P.rec + roff;  // lists of a globally staged front are read from the stream itself
-        for (int t = l; t < tf; t += 16) Fg[t] = 0.0;
+      const bool fast = cls == 16 && !gfs;
+      const bool uglob = flags & RF_U_GLOBAL;
+      if (!fast) {
+        // rare: large or globally staged front, handled out of line; the prefetch pipeline restarts after it
+        slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, myrhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, rec, roff, pbase0, cnt, eig_tol, rho, ovr);
         gsync();
-        for (int e0 = 0; e0 < nasm; e0 += 16) {
-          const int e = e0 + l;
-          const int src = grec[aoff + e], pos = grec[aoff + nasm + e];
-          double v = 0.0;
-          if (e0 < PVN * 16) {
-            // prefetched slot j = e0/16 (static index needed): fall through the unrolled select below
+        roff = nxt_off;
+        s++;
+        primed = false;
+        continue;
+      }
+      // (1) zero the strided staging image (f rows of 16), (2) assemble the prefetched values (then any overflow)
+      {
+        double2* z2 = reinterpret_cast<double2*>(myFs);
+        for (int t = l; t < f * 8; t += 16) z2[t] = make_double2(0.0, 0.0);
+      }
+      wsync();
 #pragma unroll
-            for (int j = 0; j < PVN; j++) if (j * 16 == e0) v = pv[j];
-          } else {
-            if (src >= P.nnz) v = myrhs ? myrhs[src - P.nnz] : 0.0;
-            else if (src >= 0) v = (ovr && src >= P.rho_begin) ? rho : myvals[src];
+      for (int j = 0; j < PVN; j++) {
+        const int e = j * 16 + l;
+        if (j * 16 < nasm) {
+          if (e < nasm) {
+            const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
+            double v = pv[j];
+            if (src >= P.nnz) { if (!myrhs) v = 0.0; }
+            else if (ovr && src >= P.rho_begin) v = rho;
+            __hip_atomic_fetch_add(&myFs[pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           }
-          if (src != -1 && valid) Fg[pos] += v;
-          gsync();
         }
       }
+      for (int e = PVN * 16 + l; e < nasm; e += 16) {
+        const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
+        double v = 0.0;
+        if (src >= P.nnz) v = myrhs ? myrhs[src - P.nnz] : 0.0;
+        else v = (ovr && src >= P.rho_begin) ? rho : myvals[src];
+        __hip_atomic_fetch_add(&myFs[pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      STAMP(0)
       // (3) next record into the other buffer; prefetch the one after and the next front's values
-      int* nrec = recbuf + ((s + 1) & 1) * P.reccap;
+      int nroff = nxt_off;
       if (s + 1 < P.nsuper) {
-        const int nlen = __builtin_amdgcn_readlane(R[0].z, 0);  // word R_RECLEN of the prefetched header
-        const int clen = nlen < P.reccap ? nlen : P.reccap;     // globally staged fronts keep only their head in LDS
-#pragma unroll
-        for (int k = 0; k < RN; k++)
-          if ((lane + 64 * k) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 64 * k] = R[k];
+        int* nrec = recbuf + ((s + 1) & 1) * P.reccap;
+        const int nlen = __builtin_amdgcn_readlane(R0.z, 0);  // word R_RECLEN of the prefetched header
+        const int clen = nlen < P.reccap ? nlen : P.reccap;   // globally staged fronts keep only their head in LDS
+        if (lane * 4 < clen) reinterpret_cast<int4*>(nrec)[lane] = R0;
+        if ((lane + 64) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 64] = R1;
         wsync();
         for (int w4 = RN * 64 + lane; w4 * 4 < clen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = rstream[(nxt_off >> 2) + w4];
         wsync();
         const int nn_off = nxt_off + nlen;
-        if (s + 2 < P.nsuper) {
-#pragma unroll
-          for (int k = 0; k < RN; k++) R[k] = rstream[(nn_off >> 2) + lane + 64 * k];
-        }
+        R0 = rstream[(nn_off >> 2) + lane];
+        R1 = rstream[(nn_off >> 2) + lane + 64];
         const int nasm1 = rfl(nrec[R_NASM]), aoff1 = rfl(nrec[R_ASM_OFF]);
-        const bool ngfs = rfl(nrec[R_FLAGS]) & RF_FS_GLOBAL;
-        const int* gnrec = P.rec + nxt_off;
+        const bool nfast = rfl(nrec[R_CLS]) == 16 && !(rfl(nrec[R_FLAGS]) & RF_FS_GLOBAL);
 #pragma unroll
         for (int j = 0; j < PVN; j++) {
-          double v0 = 0.0;
-          const int e = j * 16 + l;
-          if (j * 16 < nasm1) {
-            if (e < nasm1) {
-              const int src = ngfs ? gnrec[aoff1 + e] : nrec[aoff1 + e];
-              if (src >= P.nnz) v0 = myrhs ? myrhs[src - P.nnz] : 0.0;
-              else if (src >= 0) v0 = (ovr && src >= P.rho_begin) ? rho : myvals[src];
-            }
-          }
-          pv[j] = v0;
+          int e = j * 16 + l;
+          e = e < nasm1 ? e : (nasm1 > 0 ? nasm1 - 1 : 0);
+          const int src = (nfast && nasm1 > 0) ? nrec[aoff1 + e] : 0;
+          const double* ptr = src >= P.nnz ? rhs_or_vals + src : myvals + src;
+          pv[j] = *ptr;
         }
-        cur_next = nxt_off;
         nxt_off = nn_off;
       }
+      STAMP(1)
       // (4) extend-add the children's update matrices
       {
         int co = coff;
         for (int ci = 0; ci < nchild; ci++) {
-          int cu, tuc, cfl;
-          if (gfs) {
-            const int* crec = P.rec + roff + co;
-            cu = rfl(crec[C_UOFF]); tuc = rfl(crec[C_TUC]); cfl = rfl(crec[C_FLAGS]);
-          } else {
-            cu = rfl(rec[co + C_UOFF]); tuc = rfl(rec[co + C_TUC]); cfl = rfl(rec[co + C_FLAGS]);
-          }
-          if (!gfs && !cfl) {
-            const int* dest = rec + co + C_HDR;
+          const int cu = rfl(rec[co + C_UOFF]), tuc = rfl(rec[co + C_TUC]), cfl = rfl(rec[co + C_FLAGS]);
+          const int* dest = rec + co + C_HDR;
+          if (!cfl) {
             const double* U = myU + cu;
             for (int t = l; t < tuc; t += 16)
               __hip_atomic_fetch_add(&myFs[dest[t]], U[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          } else if (!gfs) {
-            const int* dest = rec + co + C_HDR;
+          } else {
             const double* Ug = mygs + cu;
             for (int t = l; t < tuc; t += 16)
               __hip_atomic_fetch_add(&myFs[dest[t]], Ug[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          } else {
-            const int* dest = P.rec + roff + co + C_HDR;
-            const double* Ul = myU + cu;
-            const double* Ug = mygs + cu;
-            double* Fg = mygs + fsoff;
-            for (int t = l; t < tuc; t += 16) {
-              const double u = cfl ? Ug[t] : Ul[t];
-              if (valid) Fg[dest[t]] += u;
-            }
-            gsync();
           }
           co += C_HDR + ((tuc + 3) & ~3);
         }
       }
-      if (gfs) gsync(); else wsync();
+      wsync();
+      STAMP(2)
       // (5) eliminate in registers, store L rows and the update matrix
-      const bool uglob = flags & RF_U_GLOBAL;
-      if (cls == 16) {
-        eliminate16(P, c, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
-      } else if (cls == 32) {
-        for (int pass = 0; pass < 2; pass++) {
-          if (prob0 + pass * 2 >= A.batch) break;
-          if (gfs) eliminate32g(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
-          else eliminate32(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
-        }
-      } else {
-        for (int pass = 0; pass < 4; pass++) {
-          if (prob0 + pass >= A.batch) break;
-          eliminate64(P, c, lane, prob0, pass, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
-        }
-      }
-      if (flags & (RF_U_GLOBAL | RF_FS_GLOBAL)) gsync(); else wsync();
-      roff = cur_next;
+#ifdef CNL_STAMPS
+      eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol, st_acc);
+#else
+      eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
+#endif
+      STAMP(3)
+      if (uglob) gsync(); else wsync();
+      roff = nroff;
+      s++;
+      STAMP(4)
     }
     // ---------------- inertia test and rho ladder (src/solver_types.jl:90-97, src/CaNNOLeS.jl:1023-1047) ----
     wsync();
@@ -463,53 +622,136 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 P, const
   }
   if (l == 0) cnt[8 + g] = (success && valid) ? 1 : 0;
   gsync();
+  STAMP(5)
   // ---------------- backward pass (d = -K^-1 rhs), only where the factorisation succeeded -----------
   // (problems that failed still walk the stream with the wave; their output is not stored)
   if (__any(success)) {
-    Ctx2 cb = c;
-    cb.batch = A.batch;
     const int4* bstream = reinterpret_cast<const int4*>(P.brec);
-    int boff = 0;
-    {
-      const int len0 = P.brec[B_RECLEN];
-      for (int w4 = lane; w4 * 4 < len0; w4 += 64) reinterpret_cast<int4*>(recbuf)[w4] = bstream[w4];
-      wsync();
-    }
-    int nxt = rfl(recbuf[B_RECLEN]);
-    int4 Rb = bstream[(nxt >> 2) + lane];  // padded stream
-    for (int s = 0; s < P.nsuper; s++) {
-      const int* rec = recbuf + (s & 1) * P.reccap;
+    const int* okflag = cnt + 8;
+    const bool okme = valid && okflag[g] != 0;
+    const double* myL = A.L + pclamp * P.lsize;
+    double* mydout = A.d + pclamp * P.dstride;
+    double* xs = myU;  // the x stack reuses the per-problem LDS area
+    constexpr int KB = 8;
+    int boff = 0, nxt = 0;
+    int4 Rb;
+    double lr[KB];     // panel rows of the CURRENT front (first KB pivots), prefetched one front ahead
+    bool primed = false;
+    int s = 0;
+    while (s < P.nsuper) {
+      int* recw = recbuf + (s & 1) * P.reccap;
+      if (!primed) {
+        const int len = P.brec[boff + B_RECLEN];
+        nxt = boff + len;
+        for (int w4 = lane; w4 * 4 < len; w4 += 64) reinterpret_cast<int4*>(recw)[w4] = bstream[(boff >> 2) + w4];
+        wsync();
+        Rb = bstream[(nxt >> 2) + lane];  // padded stream
+        const int nupd0 = rfl(recw[B_NUPD]), npiv0 = rfl(recw[B_NPIV]);
+        const long long lp0 = (long long)rfl(recw[B_LPTR_LO]) | ((long long)rfl(recw[B_LPTR_HI]) << 31);
+        const int tu0 = tri2(1 + nupd0);
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          int i = nupd0 + 1 + k;
+          i = i < nupd0 + npiv0 ? i : nupd0 + npiv0;  // clamp to the last pivot row: loads stay inside the panel
+          const int bb = l < i ? l : i;
+          lr[k] = myL[lp0 + tri2(i) - tu0 + bb];
+        }
+        primed = true;
+      }
+      const int* rec = recw;
       const int npiv = rfl(rec[B_NPIV]), nupd = rfl(rec[B_NUPD]), xoff = rfl(rec[B_XOFF]), pxoff = rfl(rec[B_PXOFF]);
       const int cls = rfl(rec[B_CLS]);
       const long long lptr = (long long)rfl(rec[B_LPTR_LO]) | ((long long)rfl(rec[B_LPTR_HI]) << 31);
       const int f = 1 + nupd + npiv;
-      // next record
-      int* nrec = recbuf + ((s + 1) & 1) * P.reccap;
+      if (cls != 16) {
+        // rare large front: out of line, then restart the pipeline
+        if (cls == 32) {
+          for (int pass = 0; pass < 2; pass++) {
+            if (prob0 + pass * 2 >= A.batch) break;
+            back_front_call<32>(P.prob_doubles, P.lsize, P.dstride, A.L, A.d, A.batch, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);
+          }
+        } else {
+          for (int pass = 0; pass < 4; pass++) {
+            if (prob0 + pass >= A.batch) break;
+            back_front_call<64>(P.prob_doubles, P.lsize, P.dstride, A.L, A.d, A.batch, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);
+          }
+        }
+        wsync();
+        boff = nxt;
+        s++;
+        primed = false;
+        continue;
+      }
+      // next record into the other buffer, then prefetch the record after it and the next front's panel rows
+      double lrn[KB];
+      int nboff = nxt;
       if (s + 1 < P.nsuper) {
+        int* nrec = recbuf + ((s + 1) & 1) * P.reccap;
         const int nlen = __builtin_amdgcn_readlane(Rb.z, 0);  // word B_RECLEN
         if (lane * 4 < nlen) reinterpret_cast<int4*>(nrec)[lane] = Rb;
         wsync();
         for (int w4 = 64 + lane; w4 * 4 < nlen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = bstream[(nxt >> 2) + w4];
+        wsync();
         const int nn = nxt + nlen;
-        if (s + 2 < P.nsuper) Rb = bstream[(nn >> 2) + lane];
+        Rb = bstream[(nn >> 2) + lane];
         nxt = nn;
-      }
-      if (cls == 16) {
-        back_front<16>(P, cb, lane, prob0, 0, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, cnt + 8);
-      } else if (cls == 32) {
-        for (int pass = 0; pass < 2; pass++) {
-          if (prob0 + pass * 2 >= A.batch) break;
-          back_front_call<32>(P, cb, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, cnt + 8);
+        const int nupd1 = rfl(nrec[B_NUPD]), npiv1 = rfl(nrec[B_NPIV]);
+        const long long lp1 = (long long)rfl(nrec[B_LPTR_LO]) | ((long long)rfl(nrec[B_LPTR_HI]) << 31);
+        const int tu1 = tri2(1 + nupd1);
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          int i = nupd1 + 1 + k;
+          i = i < nupd1 + npiv1 ? i : nupd1 + npiv1;
+          const int bb = l < i ? l : i;
+          lrn[k] = myL[lp1 + tri2(i) - tu1 + bb];
         }
       } else {
-        for (int pass = 0; pass < 4; pass++) {
-          if (prob0 + pass >= A.batch) break;
-          back_front_call<64>(P, cb, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, cnt + 8);
+#pragma unroll
+        for (int k = 0; k < KB; k++) lrn[k] = lr[k];
+      }
+      // x of the update rows from the parent's vector (in place when this front reuses the parent's slot)
+      const int tu = tri2(1 + nupd);
+      double xb = 0.0;
+      if (pxoff >= 0 && l >= 1 && l <= nupd) xb = xs[pxoff + rec[B_HDR + l]];
+      wsync();
+#pragma unroll
+      for (int k = 0; k < KB; k++) {
+        if (k < npiv) {
+          const int i = nupd + 1 + k;
+          const double t = (l >= 1 && l < i) ? lr[k] * xb : 0.0;
+          const double sum = gsum<16>(t);
+          const double z = bcast<16>(lr[k], 0, (lane - l) * 4);
+          const double xi = z - sum;
+          if (l == i) {
+            xb = xi;
+            if (okme) mydout[rec[B_HDR + 1 + nupd + k]] = -xi;
+          }
         }
       }
+      for (int k0 = KB; k0 < npiv; k0++) {  // fronts with more than KB pivots: remaining rows loaded on demand
+        const int i = nupd + 1 + k0;
+        const double lv = l < i ? myL[lptr + tri2(i) - tu + l] : 0.0;
+        const double t = (l >= 1 && l < i) ? lv * xb : 0.0;
+        const double sum = gsum<16>(t);
+        const double z = bcast<16>(lv, 0, (lane - l) * 4);
+        const double xi = z - sum;
+        if (l == i) {
+          xb = xi;
+          if (okme) mydout[rec[B_HDR + 1 + nupd + k0]] = -xi;
+        }
+      }
+      if (l >= 1 && l < f) xs[xoff + l] = xb;
       wsync();
+#pragma unroll
+      for (int k = 0; k < KB; k++) lr[k] = lrn[k];
+      boff = nboff;
+      s++;
     }
   }
+#ifdef CNL_STAMPS
+  STAMP(6)
+  if (lane == 0 && A.npos) for (int k = 0; k < 8; k++) A.npos[(blockIdx.x * WPB + wave) * 8 + k] = (long long)st_acc[k];
+#endif
   if (valid && l == 0) {
     A.rho[prob] = rho;
     A.rho_old[prob] = rho_old;

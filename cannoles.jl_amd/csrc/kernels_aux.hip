@@ -9,28 +9,78 @@
 
 namespace cnl {
 
-__global__ void __launch_bounds__(256) condense_kernel(const DevCond C, const double* __restrict__ vals,
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) { return (T*)(__attribute__((address_space(1))) T*)p; }
+__device__ __forceinline__ DevCond globalize(const DevCond& Cin) {
+  DevCond C = Cin;
+  C.c_order = as_global(Cin.c_order);
+  C.c_ptr = as_global(Cin.c_ptr); C.c_a = as_global(Cin.c_a); C.c_b = as_global(Cin.c_b); C.c_d = as_global(Cin.c_d);
+  C.r_dsrc = as_global(Cin.r_dsrc); C.r_ptr = as_global(Cin.r_ptr); C.r_jsrc = as_global(Cin.r_jsrc); C.r_jx = as_global(Cin.r_jx);
+  C.red_of = as_global(Cin.red_of); C.cidx_of = as_global(Cin.cidx_of);
+  return C;
+}
+
+// refined reciprocal division (same as the multifrontal kernel's): shorter than the IEEE expansion
+__device__ __forceinline__ double fast_div_aux(double w, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  const double q = w * r;
+  return fma(fma(-d, q, w), r, q);
+}
+
+// One thread forms one slot for CPB problems: the contribution indices are read once and reused for
+// every problem, and the CPB independent gathers per index give the memory system some parallelism.
+constexpr int CPB = 4;
+__global__ void __launch_bounds__(256) condense_kernel(const DevCond Cin, const double* __restrict__ vals,
                                                        const double* __restrict__ rhs, double* __restrict__ cbuf,
                                                        int slot_begin, int slot_end, int batch) {
-  const int s = slot_begin + blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y;
-  if (s >= slot_end || b >= batch) return;
-  const double* v = vals + (long long)b * C.nnz;
-  const double* r = rhs ? rhs + (long long)b * C.N : nullptr;
-  auto X = [&](int i) -> double { return i < C.nnz ? v[i] : (r ? r[i - C.nnz] : 0.0); };
-  double acc = 0.0;
+  const DevCond C = globalize(Cin);
+  const int t = slot_begin + blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * CPB;
+  if (t >= slot_end || b0 >= batch) return;
+  const int s = C.c_order[t];  // slots of equal contribution count sit together: no divergence inside a wavefront
+  const double* v[CPB];
+  const double* r[CPB];
+#pragma unroll
+  for (int q = 0; q < CPB; q++) {
+    const int b = b0 + q < batch ? b0 + q : batch - 1;
+    v[q] = vals + (long long)b * C.nnz;
+    r[q] = rhs ? rhs + (long long)b * C.N - C.nnz : v[q];  // entries >= nnz address the right-hand side
+  }
+  double acc[CPB];
+#pragma unroll
+  for (int q = 0; q < CPB; q++) acc[q] = 0.0;
   const int c0 = C.c_ptr[s], c1 = C.c_ptr[s + 1];
   for (int c = c0; c < c1; c++) {
     const int a = C.c_a[c], bb = C.c_b[c];
-    if (bb < 0) acc += X(a);
-    else acc += -(X(a) * X(bb)) / X(C.c_d[c]);
+    if (bb < 0) {
+#pragma unroll
+      for (int q = 0; q < CPB; q++) {
+        const double xa = a < C.nnz ? v[q][a] : (rhs ? r[q][a] : 0.0);
+        acc[q] += xa;
+      }
+    } else {
+      const int dd = C.c_d[c];
+#pragma unroll
+      for (int q = 0; q < CPB; q++) {
+        const double xa = v[q][a];
+        const double xb = bb < C.nnz ? v[q][bb] : (rhs ? r[q][bb] : 0.0);
+        acc[q] -= fast_div_aux(xa * xb, v[q][dd]);
+      }
+    }
   }
-  cbuf[(long long)b * C.cstride + s] = acc;
+#pragma unroll
+  for (int q = 0; q < CPB; q++)
+    if (b0 + q < batch) cbuf[(long long)(b0 + q) * C.cstride + s] = acc[q];
 }
 
 // pos_r = #{d_r > eig_tol}, zer_r = #{|d_r| <= eig_tol} over the condensed pivots (src/solver_types.jl:90-95)
-__global__ void __launch_bounds__(256) cond_inertia_kernel(const DevCond C, const double* __restrict__ vals, int* extra_pos,
+__global__ void __launch_bounds__(256) cond_inertia_kernel(const DevCond Cin, const double* __restrict__ vals, int* extra_pos,
                                                            int* extra_zer, double eig_tol, int batch) {
+  const DevCond C = globalize(Cin);
   const int q = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (b >= batch) return;
@@ -50,10 +100,11 @@ __global__ void __launch_bounds__(256) cond_inertia_kernel(const DevCond C, cons
 
 // d_full from the condensed solution d2 (= -K2^-1 crhs): kept nodes copy; condensed r:
 //   sol_r = (rhs_r - sum_k J_rk sol_xk) / d_r,  d_r_out = -sol_r = -(rhs_r + sum_k J_rk d2_xk) / d_r
-__global__ void __launch_bounds__(256) expand_kernel(const DevCond C, double* __restrict__ vals, const double* __restrict__ rhs,
+__global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* __restrict__ vals, const double* __restrict__ rhs,
                                                      const double* __restrict__ d2, const double* __restrict__ cbuf,
                                                      double* __restrict__ dout, const int* __restrict__ success,
                                                      int copy_rho_tail, int batch) {
+  const DevCond C = globalize(Cin);
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (b >= batch) return;
@@ -79,7 +130,7 @@ hipError_t launch_condense(const DevCond& C, const double* vals, const double* r
                            int batch, hipStream_t stream) {
   const int n = slot_end - slot_begin;
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(condense_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, C, vals, rhs, cbuf, slot_begin, slot_end, batch);
+  hipLaunchKernelGGL(condense_kernel, dim3((n + 255) / 256, (batch + CPB - 1) / CPB), dim3(256), 0, stream, C, vals, rhs, cbuf, slot_begin, slot_end, batch);
   return hipGetLastError();
 }
 

@@ -1,0 +1,38 @@
+"""Diagnostic: build the library with -DCNL_STAMPS and print the per-phase cycle shares of the
+register-front kernel (not part of the test-suite; run on the GPU box)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "cannoles.jl_amd", "csrc")
+subprocess.check_call(["make", "-s", "-C", csrc, "-B", "CXXFLAGS=-O3 -std=c++17 -fPIC -DCNL_STAMPS"])
+import cannoles_jl_amd  # noqa
+from cannoles_jl_amd import hipldl, synthetic as syn
+
+n, p, B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000, int(sys.argv[2]) if len(sys.argv) > 2 else 50, int(sys.argv[3]) if len(sys.argv) > 3 else 256
+s = syn.band_structure(n, p)
+rows, cols = s.kkt_pattern()
+vals, rhs = syn.batch_values(s, 8, cfg=3)
+vals = np.tile(vals, (B // 8, 1)); rhs = np.tile(rhs, (B // 8, 1))
+L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+d = np.zeros((B, s.N))
+prm = hipldl.default_params()
+for it in range(2):
+    hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, np.zeros(B), prm)
+lib = hipldl.lib()
+nw = B // 4
+out = np.zeros(nw * 8, np.int64)
+lib.cnl_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+assert lib.cnl_debug_stamps(L._h, out.ctypes.data, out.size) == 0
+st = out.reshape(nw, 8).astype(float)
+names = ["zero+asm", "rec+prefetch", "extend-add", "eliminate(all)", "sync", "el:pivots(+ladder)", "backward", "el:loads"]
+tot = st.sum(axis=1).mean()
+print(L.info)
+print("cycles per wave (s_memtime ticks): total %.3e" % tot)
+for k, nm in enumerate(names):
+    print("  %-14s %10.3e  %5.1f%%  per front %8.0f" % (nm, st[:, k].mean(), 100 * st[:, k].mean() / tot, st[:, k].mean() / L.info["nsuper"]))
