@@ -171,3 +171,53 @@ def test_errors(built):
     LDLT.close()
     with pytest.raises(hipldl.CnlError):
         hipldl.HIPLDLStruct(s.N, cols, rows, None, s.nvar, s.nequ, s.ncon)  # upper triangle
+
+
+def test_reference_problems_through_outer_loop(built):
+    """the reference's end-to-end known answers (test/runtests.jl:56-100) with the HIP path as linsolve"""
+    hipldl, syn, O = _mods()
+    from tests.support.outer_loop import SymNLS, solve
+    from tests.test_oracle_pinning import CONSTRAINED, UNCONSTRAINED
+
+    def hip_solver(N, rows, cols, vals, nvar, nequ, ncon):
+        return hipldl.HIPLDLStruct(N, rows, cols, vals, nvar, nequ, ncon)
+
+    def hip_newton(LDLT, nvar, nequ, ncon, rhs, vals, rho_old, params):
+        d = np.zeros(LDLT.N)
+        return hipldl.newton_system_(d, nvar, nequ, ncon, np.ascontiguousarray(rhs), vals, LDLT, rho_old, params)
+
+    p = hipldl.default_params()
+    for F, x0, xf in UNCONSTRAINED[:4]:
+        out = solve(SymNLS(F, x0), hip_solver, hip_newton, p)
+        assert np.allclose(out["solution"], xf, atol=1e-4)
+    for F, c, x0, xf in CONSTRAINED:
+        out = solve(SymNLS(F, x0, c), hip_solver, hip_newton, p)
+        assert np.allclose(out["solution"], xf, atol=1e-4)
+
+
+def test_cfg3_batch_properties_full_size(built):
+    """BASELINE config 3 at full size, batch of 32: size-independent properties —
+    backward error of every system and linearity of the solve in the right-hand side."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(10000, 50)
+    B = 32
+    vals, rhs = syn.batch_values(s, B, cfg=3)
+    rows, cols = s.kkt_pattern()
+    p = hipldl.default_params()
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    d1 = np.zeros((B, s.N))
+    d1, ok, rho, ro, nf = hipldl.newton_system_(d1, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), LDLT, np.zeros(B), p)
+    assert ok.all() and (nf == 1).all() and (rho == 0).all()
+    for b in range(B):
+        assert backward_error(s, vals[b], rhs[b], d1[b]) <= BWD_TOL
+    d2 = np.zeros((B, s.N))
+    d2, ok2, *_ = hipldl.newton_system_(d2, s.nvar, s.nequ, s.ncon, -2.0 * rhs, vals.copy(), LDLT, np.zeros(B), p)
+    assert ok2.all()
+    assert np.abs(d2 + 2.0 * d1).max() <= 1e-12 * np.abs(d1).max()
+    # the two-call path gives the same solution as the fused one
+    okf = hipldl.try_to_factorize(LDLT, vals, s.nvar, s.nequ, s.ncon, p[0])
+    assert okf.all()
+    d3 = np.zeros((B, s.N))
+    hipldl.solve_ldl_(rhs, LDLT.factor, d3)
+    assert np.abs(d3 - d1).max() <= 1e-10 * np.abs(d1).max()
+    LDLT.close()

@@ -1,0 +1,94 @@
+"""Pins the oracle against the reference's own known answers (CPU, no GPU).
+
+The reference asserts final solutions of `cannoles(nls, linsolve = :ldlfactorizations)` at atol = 1e-4
+(/root/reference/test/runtests.jl:56-100, 116-171).  Here the restated outer loop
+(tests/support/outer_loop.py) drives the ORACLE's newton_system! on the same problems and must reach
+the same solutions; this is the only way the reference's tests constrain the linear-solver boundary.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.support.outer_loop import SymNLS, solve
+
+
+def oracle_solver(N, rows, cols, vals, nvar, nequ, ncon):
+    return O.Oracle(N, rows, cols, O.canonical_perm(nvar, nequ, ncon))
+
+
+def oracle_newton(LDLT, nvar, nequ, ncon, rhs, vals, rho_old, params):
+    return O.newton_system(LDLT, nvar, nequ, ncon, rhs, vals, rho_old, params)
+
+
+F_linear = lambda x: [x[0] - 2, x[1] - 3]
+F_Rosen = lambda x: [x[0] - 1, 10 * (x[1] - x[0] ** 2)]
+
+
+def F_larger(n):
+    return lambda x: [10 * (x[i + 1] - x[i] ** 2) for i in range(n - 1)] + [x[i] - 1 for i in range(n - 1)]
+
+
+def F_under(n):
+    return lambda x: [x[0] - x[i] for i in range(1, n)]
+
+
+c_linear = lambda x: [sum(x) - 1]
+
+
+def c_quad(x):
+    prod = 1
+    for xi in x:
+        prod = prod * xi
+    return [sum(xi ** 2 for xi in x) - 5, prod - 2]
+
+
+UNCONSTRAINED = [  # test/runtests.jl:63-78
+    (F_linear, [-1.0, -1.0], [2.0, 3.0]),
+    (F_Rosen, [-1.2, 1.0], [1.0, 1.0]),
+    (F_larger(10), [0.9] * 10, [1.0] * 10),
+] + [(F_under(10), [float(i)] * 10, [float(i)] * 10) for i in range(1, 6)]
+
+CONSTRAINED = [  # test/runtests.jl:82-99
+    (F_linear, c_linear, [-1.0, -1.0], [0.0, 1.0]),
+    (F_Rosen, c_linear, [-1.2, 1.0], [0.6188, 0.3812]),
+    (F_under(10), c_linear, [j / 10 for j in range(1, 11)], [0.1] * 10),
+    (F_linear, c_quad, [0.9, 1.9], [1.0, 2.0]),
+    (F_Rosen, c_quad, [0.9, 1.9], [1.0, 2.0]),
+    (F_larger(3), c_quad, [0.5, 1.0, 1.5], [1.0647, 1.215, 1.546]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(UNCONSTRAINED)))
+def test_unconstrained_known_answers(params, case):
+    F, x0, xf = UNCONSTRAINED[case]
+    nls = SymNLS(F, x0)
+    out = solve(nls, oracle_solver, oracle_newton, params)
+    assert out["status"] in ("first_order", "small_residual")
+    assert np.allclose(out["solution"], xf, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", range(len(CONSTRAINED)))
+def test_constrained_known_answers(params, case):
+    F, c, x0, xf = CONSTRAINED[case]
+    nls = SymNLS(F, x0, c)
+    out = solve(nls, oracle_solver, oracle_newton, params)
+    assert out["status"] in ("first_order", "small_residual")
+    assert np.allclose(out["solution"], xf, atol=1e-4)
+
+
+def test_hs6_resolve_and_small_residual(params):
+    """test/runtests.jl:116-171: HS6 from two starting points, and the small-residual stop"""
+    F = lambda x: [x[0] - 1]
+    c = lambda x: [10 * (x[1] - x[0] ** 2)]
+    for x0 in ([-1.2, 1.0], [10.0, 10.0]):
+        out = solve(SymNLS(F, x0, c), oracle_solver, oracle_newton, params)
+        assert out["status"] == "first_order"
+        assert np.allclose(out["solution"], [1.0, 1.0], atol=1e-6)
+    out = solve(SymNLS(F, [-1.2, 1.0], c), oracle_solver, oracle_newton, params, atol=1e-15, rtol=0.0, Fatol=1e-6, Frtol=0.0)
+    assert out["status"] == "small_residual" and abs(out["objective"]) < 1e-6
+
+
+def test_gauss_newton_variant(params):
+    """method = :Newton_noFHess (test/runtests.jl:205-214): empty H_F segment, still reaches [1, 1]"""
+    out = solve(SymNLS(F_Rosen, [-1.2, 1.0]), oracle_solver, oracle_newton, params, method="Newton_noFHess")
+    assert np.allclose(out["solution"], [1.0, 1.0], atol=1e-6)

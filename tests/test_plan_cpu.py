@@ -1,0 +1,132 @@
+"""Host-side analysis and C-ABI surface, no GPU: the plan is executed by the numpy interpreter
+(tests/support/plan_sim.py) and compared with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cannoles_jl_amd  # noqa: F401
+from cannoles_jl_amd import hipldl, synthetic as syn
+from oracle import oracle as O
+from tests.support.plan_sim import PlanSim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def check_structure(s, vals, rhs, params, rho_old=0.0, fwd_tol=1e-9, expect=None):
+    rows, cols = s.kkt_pattern()
+    pl = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon)
+    perm = pl.array("perm").astype(np.int64)
+    assert sorted(perm.tolist()) == list(range(s.N))
+    sim = PlanSim(pl)
+    sim.check_layout()
+    d, ok, rho, ro, nf = sim.newton_system(vals.copy(), rhs, s.nvar, s.nequ, s.ncon, rho_old, params)
+    orc = O.Oracle(s.N, rows, cols, perm)
+    d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), rho_old, params)
+    assert (ok, rho, ro, nf) == (ok0, rho0, ro0, nf0)
+    if expect is not None:
+        assert (ok, nf) == expect
+    if ok:
+        assert np.abs(d - d0).max() <= fwd_tol * np.abs(d0).max()
+    return pl
+
+
+def test_abi_exports_every_declared_symbol(built):
+    """every function declared in include/cannoles_hip.h is exported by the shared library"""
+    hdr = open(os.path.join(ROOT, "include", "cannoles_hip.h")).read()
+    declared = set(re.findall(r"\b(cnl_[a-z0-9_]+)\s*\(", hdr))
+    lib = C.CDLL(hipldl.LIB_PATH)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in cannoles_hip.h but not exported"
+    assert declared >= set(hipldl.ABI_SYMBOLS)
+    assert hipldl.lib().cnl_version() >= 100
+
+
+def test_default_params_match_reference(built, params):
+    assert np.array_equal(hipldl.default_params(), params)
+
+
+def test_no_device_is_a_loud_error(built):
+    """there is no CPU fallback: creating a solver without a HIP device must fail"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    s = syn.band_structure(20, 2)
+    rows, cols = s.kkt_pattern()
+    with pytest.raises(hipldl.CnlError) as e:
+        hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon)
+    assert e.value.code == 4 and "no CPU fallback" in str(e.value)
+
+
+def test_pattern_errors(built):
+    s = syn.band_structure(20, 2)
+    rows, cols = s.kkt_pattern()
+    with pytest.raises(hipldl.CnlError) as e:
+        hipldl.Plan(s.N, cols, rows, s.nvar, s.nequ, s.ncon)  # upper triangle
+    assert e.value.code == 3
+    with pytest.raises(hipldl.CnlError) as e:
+        hipldl.Plan(s.N + 1, rows, cols, s.nvar, s.nequ, s.ncon)  # N != nvar + nequ + ncon
+    assert e.value.code == 2
+    bad = rows.copy()
+    bad[0] = s.N + 5
+    with pytest.raises(hipldl.CnlError) as e:
+        hipldl.Plan(s.N, bad, cols, s.nvar, s.nequ, s.ncon)
+    assert e.value.code == 3
+
+
+def test_fixture_mgh01con(built, params):
+    import json
+    f = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))["F1"]
+    pl = hipldl.Plan(5, f["rows"], f["cols"], 2, 2, 1)
+    d, ok, rho, ro, nf = PlanSim(pl).newton_system(np.array(f["vals"]), np.array(f["rhs"]), 2, 2, 1, 0.0, params)
+    assert ok and nf == 1 and rho == 0.0
+    assert np.allclose(d, f["d"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_structures(built, params, seed):
+    s = syn.random_structure(25 + 6 * seed, 35, 4 if seed % 2 else 0, 0.12, seed)
+    vals, rhs = syn.random_values(s, seed)
+    check_structure(s, vals, rhs, params)
+
+
+def test_band_cfg4_and_ladder(built, params):
+    s = syn.band_structure(1000, 10)
+    vals, rhs = syn.band_values(s, 4000)
+    pl = check_structure(s, vals, rhs, params, expect=(True, 1))
+    assert pl.info["ncond"] == 1000 and pl.info["v2"] is not None
+    vals, rhs = syn.band_values(s, 5000, stress="ladder")
+    check_structure(s, vals, rhs, params, expect=(True, 6))
+    check_structure(s, vals, rhs, params, rho_old=10.0)
+
+
+def test_gauss_newton_and_dense(built, params):
+    s = syn.random_structure(30, 20, 0, 0.15, 7, hess=False)   # underdetermined: needs rho > 0
+    vals, rhs = syn.random_values(s, 7)
+    check_structure(s, vals, rhs, params, fwd_tol=1e-6)
+    s = syn.dense_structure(40, 80)
+    vals, rhs = syn.dense_values(s, 2000)
+    check_structure(s, vals, rhs, params)
+
+
+def test_without_condensation_and_v1_only(built, params, monkeypatch):
+    """the residual-block condensation and the register-front streams are optional layers: the plain plan agrees"""
+    s = syn.band_structure(300, 6)
+    vals, rhs = syn.band_values(s, 4001)
+    monkeypatch.setenv("CNL_NO_CONDENSE", "1")
+    pl = check_structure(s, vals, rhs, params)
+    assert pl.info["ncond"] == 0
+    monkeypatch.setenv("CNL_NO_V2", "1")
+    pl = check_structure(s, vals, rhs, params)
+    assert pl.info["v2"] is None
+
+
+def test_cfg3_plan_quality(built):
+    """the headline pattern: fill below the canonical r/x/lambda order of SURVEY.md §8 and small fronts"""
+    s = syn.band_structure(10000, 50)
+    rows, cols = s.kkt_pattern()
+    pl = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon)
+    assert pl.info["nnzL_exact"] < 346209
+    assert pl.info["v2"]["fronts16"] > 0.95 * pl.info["nsuper"]
