@@ -181,6 +181,7 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch;
   a.L = h->d_L;
   a.scratch = h->d_scratch;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));  // events bracket the multifrontal kernel only
   hipError_t e;
   if (h->use_v2 && a.mode != cnl::MODE_SOLVE) {
     a.scratch = h->d_gs;
@@ -191,13 +192,13 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   if (e != hipSuccess)
     return fail(CNL_ERR_HIP, std::string("kernel launch (tpp=") + std::to_string(h->cfg.tpp) + " ppb=" + std::to_string(h->cfg.ppb) +
                                  " lds=" + std::to_string(h->cfg.lds_work) + "): " + hipGetErrorString(e));
+  if (h->timing) HIPCHK(hipEventRecord(h->ev1, stream));
   return CNL_OK;
 }
 
 // One call of the path on device-resident data: [condense ->] multifrontal kernel [-> expand].
 int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, double* d_d, hipStream_t stream) {
   const cnl::Cond& C = h->plan->C;
-  if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
   int rc = CNL_OK;
   if (!C.active) {
     a.vals = d_vals; a.rhs = d_rhs; a.d = d_d;
@@ -234,7 +235,6 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
   }
   if (rc) return rc;
   if (h->timing) {
-    HIPCHK(hipEventRecord(h->ev1, stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   }

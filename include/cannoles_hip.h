@@ -63,11 +63,17 @@ void cnl_plan_destroy(cnl_plan* plan);
 /* info[0]=N [1]=nnz [2]=unique nnz(K) [3]=nsuper [4]=nnz(L) stored (strictly lower, with relaxed zeros)
  * [5]=nnz(L) of the ordering without relaxation [6]=factor storage doubles/problem [7]=largest front order
  * [8]=forward work-stack doubles [9]=backward work-stack doubles [10]=largest panel doubles
- * [11]=FMAs per factorisation [12]=assembly entries [13..15]=reserved */
+ * [11]=FMAs per factorisation [12]=assembly entries
+ * [13]=fronts per class of the register-front kernel, packed (order<=16 | <=32 << 20 | <=64 << 40), -1 if unused
+ * [14]=its LDS need, packed (update stack doubles | staging doubles << 20 | record words << 40), -1 if unused
+ * [15]=residual nodes eliminated by static condensation (csrc/condense.h).  [4],[5] include their L rows. */
 int cnl_plan_info(const cnl_plan* plan, int64_t info[16]);
-/* Copy a named int32 index array of the plan ("perm", "fronts", "seg_ptr", "asm_pos", "asm_src",
- * "child_idx", "rel_idx").  With out == NULL only *count is set.  "fronts" is 16 int32 per front
- * (struct FrontHdr, csrc/plan.h).  Used by the tests' plan simulator.                           */
+/* Copy a named int32 index array of the plan.  "perm": elimination order in the reference's numbering
+ * (0-based; condensed residual nodes first).  Multifrontal plan of the (condensed) system: "inner_perm",
+ * "fronts" (16 int32 per front, struct FrontHdr in csrc/plan.h), "seg_ptr", "asm_pos", "asm_src",
+ * "child_idx", "rel_idx".  Condensation lists (csrc/condense.h): "c_ptr", "c_a", "c_b", "c_d", "orig_of",
+ * "r_orig", "r_dsrc", "r_ptr", "r_jsrc", "r_jx".  With out == NULL only *count is set.
+ * Used by the tests' plan simulator and to hand the ordering to the oracle.                          */
 int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* count);
 const char* cnl_plan_order_name(const cnl_plan* plan);
 
@@ -103,14 +109,17 @@ int cnl_solve_dev(cnl_handle* h, const double* d_rhs, double* d_d, void* stream)
 int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, double* d_d, double* d_rho_old,
                           double* d_rho, int32_t* d_nfact, int32_t* d_success, const double params[9], void* stream);
 
-/* Average device time of the last `_dev`/host call's kernels in milliseconds, measured with HIP
- * events on the call's stream (0 if timing was not enabled with cnl_set_timing).               */
+/* Device time, in milliseconds, of the multifrontal kernel (the dominant kernel) of the last call,
+ * measured with HIP events on the call's stream.  Enabling timing makes every call synchronise on
+ * its stream, so it is meant for measurement loops, not for production (0 if not enabled).      */
 int cnl_set_timing(cnl_handle* h, int enable);
 int cnl_last_kernel_ms(cnl_handle* h, float* ms);
 
 /* Kernel configuration actually chosen: cfg[0]=threads per problem, [1]=problems per workgroup,
  * [2]=LDS bytes per workgroup, [3]=1 if the work stack lives in LDS else 0 (global scratch),
- * [4]=grid size, [5..7] reserved.                                                              */
+ * [4]=grid size (those five describe the general kernel, kernels.hip), [5]=2 if the register-front
+ * kernel (kernels2.hip) serves newton_system/factorize else 1, [6]=its wavefronts per workgroup,
+ * [7]=its LDS bytes per workgroup.                                                              */
 int cnl_get_config(const cnl_handle* h, int64_t cfg[8]);
 
 #ifdef __cplusplus
