@@ -134,6 +134,71 @@ int build_condensation(Cond& C, int64_t N, int64_t nnz, const int64_t* rows1, co
     // wavefront) is 2x SLOWER than the natural column-major order, whose gathers and stores coalesce
     (void)n_mat;
   }
+  // ---- chunks and source ranges for the LDS-staged kernel ----
+  {
+    const int32_t CS = 256, TMAX = 1024, GAP = 2;
+    const int32_t bounds[4] = {0, (int32_t)C.ncs, (int32_t)(C.ncs + nvar), (int32_t)C.cstride};
+    C.c_la.assign(C.c_a.size(), 0); C.c_lb.assign(C.c_a.size(), -1); C.c_ld.assign(C.c_a.size(), -1);
+    C.ch_slot.clear(); C.ch_rng.clear(); C.ch_tile.clear(); C.rng_start.clear(); C.rng_len.clear();
+    C.ch_tptr.clear(); C.tile_src.clear();
+    std::vector<int32_t> src;
+    for (int reg = 0; reg < 3; reg++) {
+      C.ch_region[reg] = (int32_t)C.ch_slot.size();
+      int32_t s0 = bounds[reg];
+      while (s0 < bounds[reg + 1]) {
+        int32_t cs = std::min(CS, bounds[reg + 1] - s0);
+        std::vector<int32_t> rs, rl;
+        int32_t tile = 0;
+        while (true) {  // shrink the chunk until its tile fits
+          src.clear();
+          for (int32_t c = C.c_ptr[s0]; c < C.c_ptr[s0 + cs]; c++) {
+            src.push_back(C.c_a[c]);
+            if (C.c_b[c] >= 0) { src.push_back(C.c_b[c]); src.push_back(C.c_d[c]); }
+          }
+          std::sort(src.begin(), src.end());
+          src.erase(std::unique(src.begin(), src.end()), src.end());
+          rs.clear(); rl.clear(); tile = 0;
+          for (size_t i = 0; i < src.size();) {
+            size_t j = i;
+            // extend while the gap is small and the range does not straddle the vals / rhs boundary
+            while (j + 1 < src.size() && src[j + 1] - src[j] <= GAP && ((src[j + 1] < nnz) == (src[i] < nnz))) j++;
+            rs.push_back(src[i]); rl.push_back(src[j] - src[i] + 1);
+            tile += src[j] - src[i] + 1;
+            i = j + 1;
+          }
+          if (tile <= TMAX || cs == 1) break;
+          cs = std::max(1, cs / 2);
+        }
+        if (tile > 32768) { C.active = false; return 0; }  // a single slot with a huge fan-in: give up condensation
+        // local offsets
+        std::vector<int32_t> roff(rs.size());
+        int32_t o = 0;
+        for (size_t i = 0; i < rs.size(); i++) { roff[i] = o; o += rl[i]; }
+        auto local = [&](int32_t g) {
+          size_t i = std::upper_bound(rs.begin(), rs.end(), g) - rs.begin() - 1;
+          return roff[i] + (g - rs[i]);
+        };
+        for (int32_t c = C.c_ptr[s0]; c < C.c_ptr[s0 + cs]; c++) {
+          C.c_la[c] = local(C.c_a[c]);
+          if (C.c_b[c] >= 0) { C.c_lb[c] = local(C.c_b[c]); C.c_ld[c] = local(C.c_d[c]); }
+        }
+        C.ch_tptr.push_back((int32_t)C.tile_src.size());
+        for (size_t i = 0; i < rs.size(); i++)
+          for (int32_t k = 0; k < rl[i]; k++) C.tile_src.push_back(rs[i] + k);
+        C.ch_slot.push_back(s0);
+        C.ch_rng.push_back((int32_t)C.rng_start.size());
+        C.ch_tile.push_back(tile);
+        C.tile_max = std::max(C.tile_max, tile);
+        C.rng_start.insert(C.rng_start.end(), rs.begin(), rs.end());
+        C.rng_len.insert(C.rng_len.end(), rl.begin(), rl.end());
+        s0 += cs;
+      }
+    }
+    C.ch_region[3] = (int32_t)C.ch_slot.size();
+    C.ch_slot.push_back((int32_t)C.cstride);
+    C.ch_rng.push_back((int32_t)C.rng_start.size());
+    C.ch_tptr.push_back((int32_t)C.tile_src.size());
+  }
   C.active = true;
   msg.clear();
   return 0;

@@ -35,6 +35,16 @@ struct Cond {
   std::vector<int32_t> c_ptr, c_a, c_b, c_d;
   // processing order of the slots (identity: the natural column-major order coalesces best)
   std::vector<int32_t> c_order;
+  // Tiling for the LDS-staged condense kernel: consecutive slots are grouped in chunks; the sources a chunk
+  // reads form a few contiguous ranges of [vals | rhs], which the kernel stages in LDS with coalesced loads.
+  // chunk k: slots [ch_slot[k], ch_slot[k+1]), ranges [ch_rng[k], ch_rng[k+1]) of (rng_start, rng_len) in the
+  // unified source space (index >= nnz = rhs), tile doubles per problem ch_tile[k]; c_la/c_lb/c_ld are the
+  // contribution sources as offsets into that tile.  ch_region[r] = first chunk of region r
+  // (0: matrix slots, 1: rho slots, 2: right-hand-side slots, 3: end).
+  std::vector<int32_t> ch_slot, ch_rng, ch_tile, rng_start, rng_len, c_la, c_lb, c_ld;
+  std::vector<int32_t> ch_tptr, tile_src;  // flattened staging list: tile position -> source index (chunk k: [ch_tptr[k], ch_tptr[k+1]))
+  int32_t ch_region[4] = {0, 0, 0, 0};
+  int32_t tile_max = 0;
   // condensed residual nodes: diag source, original index, Jacobian row (sources / reduced x indices)
   std::vector<int32_t> r_orig, r_dsrc, r_ptr, r_jsrc, r_jx;
   // original index -> reduced index (-1 for condensed nodes) and back

@@ -14,6 +14,10 @@ __device__ __forceinline__ T* as_global(T* p) { return (T*)(__attribute__((addre
 __device__ __forceinline__ DevCond globalize(const DevCond& Cin) {
   DevCond C = Cin;
   C.c_order = as_global(Cin.c_order);
+  C.ch_slot = as_global(Cin.ch_slot); C.ch_rng = as_global(Cin.ch_rng); C.ch_tile = as_global(Cin.ch_tile);
+  C.rng_start = as_global(Cin.rng_start); C.rng_len = as_global(Cin.rng_len);
+  C.c_la = as_global(Cin.c_la); C.c_lb = as_global(Cin.c_lb); C.c_ld = as_global(Cin.c_ld);
+  C.ch_tptr = as_global(Cin.ch_tptr); C.tile_src = as_global(Cin.tile_src);
   C.c_ptr = as_global(Cin.c_ptr); C.c_a = as_global(Cin.c_a); C.c_b = as_global(Cin.c_b); C.c_d = as_global(Cin.c_d);
   C.r_dsrc = as_global(Cin.r_dsrc); C.r_ptr = as_global(Cin.r_ptr); C.r_jsrc = as_global(Cin.r_jsrc); C.r_jx = as_global(Cin.r_jx);
   C.red_of = as_global(Cin.red_of); C.cidx_of = as_global(Cin.cidx_of);
@@ -77,6 +81,59 @@ __global__ void __launch_bounds__(256) condense_kernel(const DevCond Cin, const 
     if (b0 + q < batch) cbuf[(long long)(b0 + q) * C.cstride + s] = acc[q];
 }
 
+// LDS-tiled condense: a workgroup forms the slots of one chunk for TPB problems.  The sources the chunk
+// needs are a few contiguous ranges of [vals | rhs]; they are staged in LDS with fully coalesced loads
+// (each 64-byte line of vals is fetched once per workgroup), then every thread forms one slot for the
+// TPB problems from LDS (contribution indices are read once per slot and reused for every problem).
+constexpr int TPB = 4;
+__global__ void __launch_bounds__(256) condense_tiled_kernel(const DevCond Cin, const double* __restrict__ vals,
+                                                             const double* __restrict__ rhs, double* __restrict__ cbuf,
+                                                             int chunk_begin, int batch) {
+  extern __shared__ double tile[];
+  const DevCond C = globalize(Cin);
+  const int ch = chunk_begin + blockIdx.x;
+  const int b0 = blockIdx.y * TPB;
+  const int s0 = C.ch_slot[ch], s1 = C.ch_slot[ch + 1];
+  const int T = C.ch_tile[ch];
+  const int tid = threadIdx.x;
+  // stage the tile: position t of the tile holds source tile_src[t] (runs of consecutive indices: coalesced)
+  {
+    const int* tsrc = C.tile_src + C.ch_tptr[ch];
+    for (int t = tid; t < T; t += 256) {
+      const int gsrc = tsrc[t];
+#pragma unroll
+      for (int q = 0; q < TPB; q++) {
+        const int b = b0 + q < batch ? b0 + q : batch - 1;
+        double v;
+        if (gsrc < C.nnz) v = vals[(long long)b * C.nnz + gsrc];
+        else v = rhs ? rhs[(long long)b * C.N + (gsrc - C.nnz)] : 0.0;
+        tile[q * T + t] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const int s = s0 + tid;
+  if (s >= s1) return;
+  double acc[TPB];
+#pragma unroll
+  for (int q = 0; q < TPB; q++) acc[q] = 0.0;
+  const int c0 = C.c_ptr[s], c1 = C.c_ptr[s + 1];
+  for (int c = c0; c < c1; c++) {
+    const int la = C.c_la[c], lb = C.c_lb[c];
+    if (lb < 0) {
+#pragma unroll
+      for (int q = 0; q < TPB; q++) acc[q] += tile[q * T + la];
+    } else {
+      const int ld = C.c_ld[c];
+#pragma unroll
+      for (int q = 0; q < TPB; q++) acc[q] -= fast_div_aux(tile[q * T + la] * tile[q * T + lb], tile[q * T + ld]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < TPB; q++)
+    if (b0 + q < batch) cbuf[(long long)(b0 + q) * C.cstride + s] = acc[q];
+}
+
 // pos_r = #{d_r > eig_tol}, zer_r = #{|d_r| <= eig_tol} over the condensed pivots (src/solver_types.jl:90-95)
 __global__ void __launch_bounds__(256) cond_inertia_kernel(const DevCond Cin, const double* __restrict__ vals, int* extra_pos,
                                                            int* extra_zer, double eig_tol, int batch) {
@@ -131,6 +188,21 @@ hipError_t launch_condense(const DevCond& C, const double* vals, const double* r
   const int n = slot_end - slot_begin;
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(condense_kernel, dim3((n + 255) / 256, (batch + CPB - 1) / CPB), dim3(256), 0, stream, C, vals, rhs, cbuf, slot_begin, slot_end, batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int chunk_begin,
+                                 int chunk_end, int batch, hipStream_t stream) {
+  const int n = chunk_end - chunk_begin;
+  if (n <= 0) return hipSuccess;
+  const size_t lds = (size_t)TPB * (size_t)C.tile_max * sizeof(double);
+  static size_t attr_set = 0;
+  if (lds > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(condense_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = lds;
+  }
+  hipLaunchKernelGGL(condense_tiled_kernel, dim3(n, (batch + TPB - 1) / TPB), dim3(256), lds, stream, C, vals, rhs, cbuf, chunk_begin, batch);
   return hipGetLastError();
 }
 
