@@ -804,7 +804,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
   P.v2_ok = opt.with_rhs_row && P.fmax <= 64;
   if (const char* e = getenv("CNL_NO_V2")) if (atoi(e)) P.v2_ok = false;
   if (P.v2_ok) {
-    const int64_t ubig_thr = tri(17);  // update matrices above this size live in global scratch
+    const int64_t ubig_thr = getenv("CNL_UBIG") ? tri(atoi(getenv("CNL_UBIG"))) : tri(17);  // update matrices above this size live in global scratch
     int32_t wait_thr = 2;
     if (const char* e = getenv("CNL_WAIT_THR")) wait_thr = atoi(e);
     ivec uoff2(ns, 0), uglob(ns, 0), fsglob(ns, 0), fsoff2(ns, 0), cls(ns, 16);

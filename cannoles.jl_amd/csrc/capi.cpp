@@ -431,7 +431,12 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   }
   if ((rc = choose_config(h))) return bail(rc);
   if ((rc = setup_v2(h))) return bail(rc);
-  if ((rc = dalloc(h, &h->d_L, (size_t)batch * (size_t)std::max<int64_t>(P.lsize, 1)))) return bail(rc);
+  {
+    // factor storage, zero-filled and padded: the row prefetch of the backward pass reads (never uses) a little past a panel
+    const size_t ldoubles = (size_t)batch * (size_t)std::max<int64_t>(P.lsize, 1) + 4096;
+    if ((rc = dalloc(h, &h->d_L, ldoubles))) return bail(rc);
+    if (hipMemset(h->d_L, 0, ldoubles * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
+  }
   if (!h->cfg.lds_work)
     if ((rc = dalloc(h, &h->d_scratch, (size_t)batch * (size_t)dp.work_doubles))) return bail(rc);
   if (hipStreamCreate(&h->stream) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipStreamCreate failed"));

@@ -45,6 +45,8 @@ __device__ __forceinline__ void gsync() {
 }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// word k of a record header that lane (k & 15) read into `hv` with ONE LDS read per wave
+#define HDRW(hv, k) __builtin_amdgcn_readlane(hv, k)
 
 // Pointers that arrive inside by-value structs are generic ("flat") to the compiler.  Flat accesses
 // count on lgkmcnt as well as vmcnt, so every LDS wait would also wait for outstanding global
@@ -404,6 +406,38 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
 
 }  // namespace
 
+// Gathers of the first PVN*16 assembly values of a front (lists are padded to multiples of 16, so
+// every lane of an issued round has a valid entry).  Loads sit in wave-uniform branches and their
+// results are first used one front later: nothing waits between consecutive loads.
+// First KB rows of a front's L panel, lane l takes entry l of each row (row k of the panel starts
+// k(k+1)/2 + k*(nupd+1) doubles after the panel start).  No clamps: lanes past the end of a row and
+// rows past the last pivot read finite data that is never used (the factor storage is zero-padded).
+#define PREFETCH_ROWS(DST, LPTR, NUPD)                                                 \
+  {                                                                                    \
+    const double* rp_ = myL + (LPTR) + l;                                              \
+    int ro_ = 0;                                                                       \
+    _Pragma("unroll") for (int k = 0; k < KB; k++) {                                   \
+      DST[k] = rp_[ro_];                                                               \
+      ro_ += (NUPD) + 2 + k;                                                           \
+    }                                                                                  \
+  }
+
+#define PREFETCH_VALUES(RECP, AOFF, NASM)                                              \
+  {                                                                                    \
+    const int na_ = (NASM);                                                            \
+    const int* sp_ = (RECP) + (AOFF) + l;                                              \
+    if (unified) {                                                                     \
+      _Pragma("unroll") for (int j = 0; j < PVN; j++)                                  \
+        if (j * 16 < na_) pv[j] = myvals[sp_[j * 16]];                                 \
+    } else {                                                                           \
+      _Pragma("unroll") for (int j = 0; j < PVN; j++)                                  \
+        if (j * 16 < na_) {                                                            \
+          const int src_ = sp_[j * 16];                                                \
+          pv[j] = *(src_ >= P.nnz ? rhs_or_vals + src_ : myvals + src_);               \
+        }                                                                              \
+    }                                                                                  \
+  }
+
 // ==========================================================================================
 __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, const LaunchArgs Ain) {
   DevPlan2 P = Pin;
@@ -455,8 +489,12 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     if (l == 0) { cnt[g * 2] = xpos; cnt[g * 2 + 1] = xzer; }
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
     const double* rhs_or_vals = myrhs ? myrhs - P.nnz : myvals - P.nnz;  // base for entries src >= nnz (dummy when no rhs)
+    // condensed systems keep [slots | rho | rhs] in ONE buffer: every source is myvals[src], no pointer select
+    const bool unified = A.rhs == A.vals + P.nnz && P.rstride == P.vstride;
     int4 R0, R1;      // record prefetch registers (two named values: an array would be kept in scratch)
     double pv[PVN];
+#pragma unroll
+    for (int j = 0; j < PVN; j++) pv[j] = 0.0;
     int roff = 0;     // word offset of the current record
     int nxt_off = 0;  // word offset of the next record
     int s = 0;
@@ -472,23 +510,18 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         wsync();
         R0 = rstream[(nxt_off >> 2) + lane];  // stream is padded: over-read is safe
         R1 = rstream[(nxt_off >> 2) + lane + 64];
-        const int nasm0 = rfl(recw[R_NASM]), aoff0 = rfl(recw[R_ASM_OFF]);
-        const bool fast0 = rfl(recw[R_CLS]) == 16 && !(rfl(recw[R_FLAGS]) & RF_FS_GLOBAL);
-#pragma unroll
-        for (int j = 0; j < PVN; j++) {
-          int e = j * 16 + l;
-          e = e < nasm0 ? e : (nasm0 > 0 ? nasm0 - 1 : 0);
-          const int src = (fast0 && nasm0 > 0) ? recw[aoff0 + e] : 0;
-          const double* ptr = src >= P.nnz ? rhs_or_vals + src : myvals + src;
-          pv[j] = *ptr;  // unconditional load: no wait is needed before the next one is issued
-        }
+        const int hv0 = recw[lane & 15];
+        const int nasm0 = HDRW(hv0, R_NASM), aoff0 = HDRW(hv0, R_ASM_OFF);
+        const bool fast0 = HDRW(hv0, R_CLS) == 16 && !(HDRW(hv0, R_FLAGS) & RF_FS_GLOBAL);
+        PREFETCH_VALUES(recw, aoff0, fast0 ? nasm0 : 0)
         primed = true;
       }
       const int* rec = recw;
-      const int npiv = rfl(rec[R_NPIV]), nupd = rfl(rec[R_NUPD]), nasm = rfl(rec[R_NASM]);
-      const int nchild = rfl(rec[R_NCHILD]), uoff = rfl(rec[R_UOFF]), flags = rfl(rec[R_FLAGS]), fsoff = rfl(rec[R_FSOFF]);
-      const int cls = rfl(rec[R_CLS]), aoff = rfl(rec[R_ASM_OFF]), coff = rfl(rec[R_CHILD_OFF]);
-      const long long lptr = (long long)rfl(rec[R_LPTR_LO]) | ((long long)rfl(rec[R_LPTR_HI]) << 31);
+      const int hv = rec[lane & 15];
+      const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM);
+      const int nchild = HDRW(hv, R_NCHILD), uoff = HDRW(hv, R_UOFF), flags = HDRW(hv, R_FLAGS), fsoff = HDRW(hv, R_FSOFF);
+      const int cls = HDRW(hv, R_CLS), aoff = HDRW(hv, R_ASM_OFF), coff = HDRW(hv, R_CHILD_OFF);
+      const long long lptr = (long long)HDRW(hv, R_LPTR_LO) | ((long long)HDRW(hv, R_LPTR_HI) << 31);
       const int f = 1 + nupd + npiv;
       const bool gfs = flags & RF_FS_GLOBAL;
       const bool fast = cls == 16 && !gfs;
@@ -533,7 +566,13 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       int nroff = nxt_off;
       if (s + 1 < P.nsuper) {
         int* nrec = recbuf + ((s + 1) & 1) * P.reccap;
-        const int nlen = __builtin_amdgcn_readlane(R0.z, 0);  // word R_RECLEN of the prefetched header
+        // header words of the next record straight from the prefetch registers: lane q holds words 4q .. 4q+3
+        const int nlen = __builtin_amdgcn_readlane(R0.z, 0);          // R_RECLEN = 2
+        const int nasm1 = __builtin_amdgcn_readlane(R0.w, 0);         // R_NASM = 3
+        const int nflags1 = __builtin_amdgcn_readlane(R0.z, 1);       // R_FLAGS = 6
+        const int ncls1 = __builtin_amdgcn_readlane(R0.z, 2);         // R_CLS = 10
+        const int aoff1 = __builtin_amdgcn_readlane(R0.w, 2);         // R_ASM_OFF = 11
+        static_assert(R_RECLEN == 2 && R_NASM == 3 && R_FLAGS == 6 && R_CLS == 10 && R_ASM_OFF == 11, "record header layout");
         const int clen = nlen < P.reccap ? nlen : P.reccap;   // globally staged fronts keep only their head in LDS
         if (lane * 4 < clen) reinterpret_cast<int4*>(nrec)[lane] = R0;
         if ((lane + 64) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 64] = R1;
@@ -543,16 +582,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         const int nn_off = nxt_off + nlen;
         R0 = rstream[(nn_off >> 2) + lane];
         R1 = rstream[(nn_off >> 2) + lane + 64];
-        const int nasm1 = rfl(nrec[R_NASM]), aoff1 = rfl(nrec[R_ASM_OFF]);
-        const bool nfast = rfl(nrec[R_CLS]) == 16 && !(rfl(nrec[R_FLAGS]) & RF_FS_GLOBAL);
-#pragma unroll
-        for (int j = 0; j < PVN; j++) {
-          int e = j * 16 + l;
-          e = e < nasm1 ? e : (nasm1 > 0 ? nasm1 - 1 : 0);
-          const int src = (nfast && nasm1 > 0) ? nrec[aoff1 + e] : 0;
-          const double* ptr = src >= P.nnz ? rhs_or_vals + src : myvals + src;
-          pv[j] = *ptr;
-        }
+        const bool nfast = ncls1 == 16 && !(nflags1 & RF_FS_GLOBAL);
+        PREFETCH_VALUES(nrec, aoff1, nfast ? nasm1 : 0)
         nxt_off = nn_off;
       }
       STAMP(1)
@@ -560,7 +591,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       {
         int co = coff;
         for (int ci = 0; ci < nchild; ci++) {
-          const int cu = rfl(rec[co + C_UOFF]), tuc = rfl(rec[co + C_TUC]), cfl = rfl(rec[co + C_FLAGS]);
+          const int cv = rec[co + (lane & 3)];
+          const int cu = HDRW(cv, C_UOFF), tuc = HDRW(cv, C_TUC), cfl = HDRW(cv, C_FLAGS);
           const int* dest = rec + co + C_HDR;
           if (!cfl) {
             const double* U = myU + cu;
@@ -646,22 +678,18 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         for (int w4 = lane; w4 * 4 < len; w4 += 64) reinterpret_cast<int4*>(recw)[w4] = bstream[(boff >> 2) + w4];
         wsync();
         Rb = bstream[(nxt >> 2) + lane];  // padded stream
-        const int nupd0 = rfl(recw[B_NUPD]), npiv0 = rfl(recw[B_NPIV]);
-        const long long lp0 = (long long)rfl(recw[B_LPTR_LO]) | ((long long)rfl(recw[B_LPTR_HI]) << 31);
-        const int tu0 = tri2(1 + nupd0);
-#pragma unroll
-        for (int k = 0; k < KB; k++) {
-          int i = nupd0 + 1 + k;
-          i = i < nupd0 + npiv0 ? i : nupd0 + npiv0;  // clamp to the last pivot row: loads stay inside the panel
-          const int bb = l < i ? l : i;
-          lr[k] = myL[lp0 + tri2(i) - tu0 + bb];
-        }
+        const int hb0 = recw[lane & 7];
+        const int nupd0 = HDRW(hb0, B_NUPD), npiv0 = HDRW(hb0, B_NPIV);
+        const long long lp0 = (long long)HDRW(hb0, B_LPTR_LO) | ((long long)HDRW(hb0, B_LPTR_HI) << 31);
+        (void)npiv0;
+        PREFETCH_ROWS(lr, lp0, nupd0)
         primed = true;
       }
       const int* rec = recw;
-      const int npiv = rfl(rec[B_NPIV]), nupd = rfl(rec[B_NUPD]), xoff = rfl(rec[B_XOFF]), pxoff = rfl(rec[B_PXOFF]);
-      const int cls = rfl(rec[B_CLS]);
-      const long long lptr = (long long)rfl(rec[B_LPTR_LO]) | ((long long)rfl(rec[B_LPTR_HI]) << 31);
+      const int hb = rec[lane & 7];
+      const int npiv = HDRW(hb, B_NPIV), nupd = HDRW(hb, B_NUPD), xoff = HDRW(hb, B_XOFF), pxoff = HDRW(hb, B_PXOFF);
+      const int cls = HDRW(hb, B_CLS);
+      const long long lptr = (long long)HDRW(hb, B_LPTR_LO) | ((long long)HDRW(hb, B_LPTR_HI) << 31);
       const int f = 1 + nupd + npiv;
       if (cls != 16) {
         // rare large front: out of line, then restart the pipeline
@@ -687,7 +715,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       int nboff = nxt;
       if (s + 1 < P.nsuper) {
         int* nrec = recbuf + ((s + 1) & 1) * P.reccap;
-        const int nlen = __builtin_amdgcn_readlane(Rb.z, 0);  // word B_RECLEN
+        // next header words straight from the prefetch registers (lane 0: words 0..3, lane 1: words 4..7)
+        const int nlen = __builtin_amdgcn_readlane(Rb.z, 0);   // B_RECLEN = 2
+        const int npiv1 = __builtin_amdgcn_readlane(Rb.x, 0), nupd1 = __builtin_amdgcn_readlane(Rb.y, 0);
+        const long long lp1 = (long long)__builtin_amdgcn_readlane(Rb.y, 1) | ((long long)__builtin_amdgcn_readlane(Rb.z, 1) << 31);
+        static_assert(B_NPIV == 0 && B_NUPD == 1 && B_RECLEN == 2 && B_LPTR_LO == 5 && B_LPTR_HI == 6, "backward header layout");
         if (lane * 4 < nlen) reinterpret_cast<int4*>(nrec)[lane] = Rb;
         wsync();
         for (int w4 = 64 + lane; w4 * 4 < nlen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = bstream[(nxt >> 2) + w4];
@@ -695,21 +727,15 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         const int nn = nxt + nlen;
         Rb = bstream[(nn >> 2) + lane];
         nxt = nn;
-        const int nupd1 = rfl(nrec[B_NUPD]), npiv1 = rfl(nrec[B_NPIV]);
-        const long long lp1 = (long long)rfl(nrec[B_LPTR_LO]) | ((long long)rfl(nrec[B_LPTR_HI]) << 31);
-        const int tu1 = tri2(1 + nupd1);
-#pragma unroll
-        for (int k = 0; k < KB; k++) {
-          int i = nupd1 + 1 + k;
-          i = i < nupd1 + npiv1 ? i : nupd1 + npiv1;
-          const int bb = l < i ? l : i;
-          lrn[k] = myL[lp1 + tri2(i) - tu1 + bb];
-        }
+        (void)npiv1;
+        PREFETCH_ROWS(lrn, lp1, nupd1)
       } else {
 #pragma unroll
         for (int k = 0; k < KB; k++) lrn[k] = lr[k];
       }
-      // x of the update rows from the parent's vector (in place when this front reuses the parent's slot)
+      // x of the update rows from the parent's vector (in place when this front reuses the parent's slot).
+      // Lane l keeps x of local row l; rows not known yet (and the rhs slot, lane 0) hold 0, so the dot product of
+      // a pivot row needs no lane predicate: entries beyond the row multiply zeros.
       const int tu = tri2(1 + nupd);
       double xb = 0.0;
       if (pxoff >= 0 && l >= 1 && l <= nupd) xb = xs[pxoff + rec[B_HDR + l]];
@@ -717,29 +743,20 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
 #pragma unroll
       for (int k = 0; k < KB; k++) {
         if (k < npiv) {
-          const int i = nupd + 1 + k;
-          const double t = (l >= 1 && l < i) ? lr[k] * xb : 0.0;
-          const double sum = gsum<16>(t);
+          const double sum = gsum<16>(lr[k] * xb);
           const double z = bcast<16>(lr[k], 0, (lane - l) * 4);
-          const double xi = z - sum;
-          if (l == i) {
-            xb = xi;
-            if (okme) mydout[rec[B_HDR + 1 + nupd + k]] = -xi;
-          }
+          if (l == nupd + 1 + k) xb = z - sum;
         }
       }
       for (int k0 = KB; k0 < npiv; k0++) {  // fronts with more than KB pivots: remaining rows loaded on demand
         const int i = nupd + 1 + k0;
-        const double lv = l < i ? myL[lptr + tri2(i) - tu + l] : 0.0;
-        const double t = (l >= 1 && l < i) ? lv * xb : 0.0;
-        const double sum = gsum<16>(t);
+        const double lv = myL[lptr + tri2(i) - tu + l];
+        const double sum = gsum<16>(lv * xb);
         const double z = bcast<16>(lv, 0, (lane - l) * 4);
-        const double xi = z - sum;
-        if (l == i) {
-          xb = xi;
-          if (okme) mydout[rec[B_HDR + 1 + nupd + k0]] = -xi;
-        }
+        if (l == i) xb = z - sum;
       }
+      // d = -x of the pivots: one scattered store per front (rec holds the original index of every pivot)
+      if (okme && l > nupd && l < f) mydout[rec[B_HDR + l]] = -xb;
       if (l >= 1 && l < f) xs[xoff + l] = xb;
       wsync();
 #pragma unroll
