@@ -870,7 +870,12 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
           asrc.push_back(P.asm_src[e]);
           apos.push_back(strided ? stride_pos(P.asm_pos[e]) : P.asm_pos[e]);
         }
-        while (asrc.size() % 16) { asrc.push_back(0); apos.push_back(0); }  // dummy: some value added to the unused slot 0
+        {
+          // padding entries add some value to an UNUSED slot; in the strided image the upper part of row 0
+          // (positions 1..15) is free, and distinct positions avoid same-address LDS atomics
+          int32_t dk = 0;
+          while (asrc.size() % 16) { asrc.push_back(0); apos.push_back(strided ? 1 + (dk++ % 15) : 0); }
+        }
       }
       int32_t asm_off = (int32_t)(P.rec.size() - r0);
       P.rec.insert(P.rec.end(), asrc.begin(), asrc.end());

@@ -209,7 +209,8 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
     double* crhs = h->d_cbuf + s_mat;
     hipError_t e = hipSuccess;
     if (a.mode == cnl::MODE_NEWTON) {
-      e = cnl::launch_condense_tiled(h->dc, d_vals, d_rhs, h->d_cbuf, C.ch_region[0], C.ch_region[3], B, stream);
+      e = C.tiled_ok ? cnl::launch_condense_tiled(h->dc, d_vals, d_rhs, h->d_cbuf, 7, C.ch_region[3], B, stream)
+                     : cnl::launch_condense(h->dc, d_vals, d_rhs, h->d_cbuf, 0, s_all, B, stream);
       if (e == hipSuccess) e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
       if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
       a.vals = h->d_cbuf; a.rhs = crhs; a.d = h->d_d2; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
@@ -217,7 +218,8 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
       e = cnl::launch_expand(h->dc, d_vals, d_rhs, h->d_d2, h->d_cbuf, d_d, a.success, 1, B, stream);
       if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
     } else if (a.mode == cnl::MODE_FACTOR) {
-      e = cnl::launch_condense_tiled(h->dc, d_vals, nullptr, h->d_cbuf, C.ch_region[0], C.ch_region[2], B, stream);
+      e = C.tiled_ok ? cnl::launch_condense_tiled(h->dc, d_vals, nullptr, h->d_cbuf, 3, C.ch_region[3], B, stream)
+                     : cnl::launch_condense(h->dc, d_vals, nullptr, h->d_cbuf, 0, s_mat, B, stream);
       if (e == hipSuccess) e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
       if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
       a.vals = h->d_cbuf; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
@@ -225,7 +227,8 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
       h->last_vals = d_vals;
     } else {
       if (!h->last_vals) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
-      e = cnl::launch_condense_tiled(h->dc, h->last_vals, d_rhs, h->d_cbuf, C.ch_region[2], C.ch_region[3], B, stream);
+      e = C.tiled_ok ? cnl::launch_condense_tiled(h->dc, h->last_vals, d_rhs, h->d_cbuf, 4, C.ch_region[3], B, stream)
+                     : cnl::launch_condense(h->dc, h->last_vals, d_rhs, h->d_cbuf, s_mat, s_all, B, stream);
       if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
       a.rhs = crhs; a.d = h->d_d2;
       if ((rc = launch(h, a, stream))) return rc;
@@ -415,7 +418,8 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
     if ((rc = upload(h, C.c_ld, &dc.c_ld))) return bail(rc);
     if ((rc = upload(h, C.ch_tptr, &dc.ch_tptr))) return bail(rc);
     if ((rc = upload(h, C.tile_src, &dc.tile_src))) return bail(rc);
-    dc.tile_max = C.tile_max;
+    if ((rc = upload(h, C.c_pack, &dc.c_pack))) return bail(rc);
+    dc.tile_max = C.tile_max; dc.chunk_ncon_max = C.chunk_ncon_max; dc.chunk_nslot_max = C.chunk_nslot_max; dc.tiled_ok = C.tiled_ok ? 1 : 0;
     if ((rc = upload(h, C.r_dsrc, &dc.r_dsrc))) return bail(rc);
     if ((rc = upload(h, C.r_ptr, &dc.r_ptr))) return bail(rc);
     if ((rc = upload(h, C.r_jsrc, &dc.r_jsrc))) return bail(rc);

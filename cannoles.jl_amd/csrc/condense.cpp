@@ -134,70 +134,101 @@ int build_condensation(Cond& C, int64_t N, int64_t nnz, const int64_t* rows1, co
     // wavefront) is 2x SLOWER than the natural column-major order, whose gathers and stores coalesce
     (void)n_mat;
   }
-  // ---- chunks and source ranges for the LDS-staged kernel ----
+  // ---- chunks for the LDS-staged kernel: a chunk is a COLUMN RANGE [c0, c1) of the condensed system and
+  // owns three contiguous slot ranges: the matrix slots of those columns, their rho slots and their
+  // right-hand-side slots.  They share most sources (the Jacobian rows of the residuals touching the
+  // columns), so one staged tile serves all three.
   {
-    const int32_t CS = 256, TMAX = 1024, GAP = 2;
-    const int32_t bounds[4] = {0, (int32_t)C.ncs, (int32_t)(C.ncs + nvar), (int32_t)C.cstride};
+    const int32_t SLOTS_MAX = 256, TMAX = 896, GAP = 2;  // measured best on MI355X (448/1536: 8.4 ms, 256/896: 5.9 ms, 128/512: 6.9 ms at B = 8192)
+    // first matrix slot of every column (slots are column-major; rows2/cols2 still hold the pattern)
+    std::vector<int32_t> colstart(C.N2 + 1, 0);
+    {
+      std::vector<int32_t> cnt(C.N2 + 1, 0);
+      for (int64_t s_ = 0; s_ < C.ncs; s_++) cnt[C.cols2[s_] - 1]++;
+      colstart[0] = 0;
+      for (int64_t j = 0; j < C.N2; j++) colstart[j + 1] = colstart[j] + cnt[j];
+    }
     C.c_la.assign(C.c_a.size(), 0); C.c_lb.assign(C.c_a.size(), -1); C.c_ld.assign(C.c_a.size(), -1);
     C.ch_slot.clear(); C.ch_rng.clear(); C.ch_tile.clear(); C.rng_start.clear(); C.rng_len.clear();
     C.ch_tptr.clear(); C.tile_src.clear();
     std::vector<int32_t> src;
-    for (int reg = 0; reg < 3; reg++) {
-      C.ch_region[reg] = (int32_t)C.ch_slot.size();
-      int32_t s0 = bounds[reg];
-      while (s0 < bounds[reg + 1]) {
-        int32_t cs = std::min(CS, bounds[reg + 1] - s0);
-        std::vector<int32_t> rs, rl;
-        int32_t tile = 0;
-        while (true) {  // shrink the chunk until its tile fits
-          src.clear();
-          for (int32_t c = C.c_ptr[s0]; c < C.c_ptr[s0 + cs]; c++) {
-            src.push_back(C.c_a[c]);
-            if (C.c_b[c] >= 0) { src.push_back(C.c_b[c]); src.push_back(C.c_d[c]); }
-          }
-          std::sort(src.begin(), src.end());
-          src.erase(std::unique(src.begin(), src.end()), src.end());
-          rs.clear(); rl.clear(); tile = 0;
-          for (size_t i = 0; i < src.size();) {
-            size_t j = i;
-            // extend while the gap is small and the range does not straddle the vals / rhs boundary
-            while (j + 1 < src.size() && src[j + 1] - src[j] <= GAP && ((src[j + 1] < nnz) == (src[i] < nnz))) j++;
-            rs.push_back(src[i]); rl.push_back(src[j] - src[i] + 1);
-            tile += src[j] - src[i] + 1;
-            i = j + 1;
-          }
-          if (tile <= TMAX || cs == 1) break;
-          cs = std::max(1, cs / 2);
-        }
-        if (tile > 32768) { C.active = false; return 0; }  // a single slot with a huge fan-in: give up condensation
-        // local offsets
-        std::vector<int32_t> roff(rs.size());
-        int32_t o = 0;
-        for (size_t i = 0; i < rs.size(); i++) { roff[i] = o; o += rl[i]; }
-        auto local = [&](int32_t g) {
-          size_t i = std::upper_bound(rs.begin(), rs.end(), g) - rs.begin() - 1;
-          return roff[i] + (g - rs[i]);
-        };
-        for (int32_t c = C.c_ptr[s0]; c < C.c_ptr[s0 + cs]; c++) {
-          C.c_la[c] = local(C.c_a[c]);
-          if (C.c_b[c] >= 0) { C.c_lb[c] = local(C.c_b[c]); C.c_ld[c] = local(C.c_d[c]); }
-        }
-        C.ch_tptr.push_back((int32_t)C.tile_src.size());
-        for (size_t i = 0; i < rs.size(); i++)
-          for (int32_t k = 0; k < rl[i]; k++) C.tile_src.push_back(rs[i] + k);
-        C.ch_slot.push_back(s0);
-        C.ch_rng.push_back((int32_t)C.rng_start.size());
-        C.ch_tile.push_back(tile);
-        C.tile_max = std::max(C.tile_max, tile);
-        C.rng_start.insert(C.rng_start.end(), rs.begin(), rs.end());
-        C.rng_len.insert(C.rng_len.end(), rl.begin(), rl.end());
-        s0 += cs;
+    auto ranges_of = [&](int32_t c0, int32_t c1, int32_t rg[6]) {
+      rg[0] = colstart[c0]; rg[1] = colstart[c1] - colstart[c0];                       // matrix slots
+      int32_t x0 = std::min<int32_t>(c0, (int32_t)nvar), x1 = std::min<int32_t>(c1, (int32_t)nvar);
+      rg[2] = (int32_t)C.ncs + x0; rg[3] = x1 - x0;                                     // rho slots
+      rg[4] = (int32_t)(C.ncs + nvar) + c0; rg[5] = c1 - c0;                            // rhs slots
+    };
+    int32_t c0 = 0;
+    while (c0 < C.N2) {
+      int32_t c1 = c0 + 1, rg[6];
+      while (c1 < C.N2) {  // grow while the slot count stays within the workgroup's reach
+        ranges_of(c0, c1 + 1, rg);
+        if (rg[1] + rg[3] + rg[5] > SLOTS_MAX) break;
+        c1++;
       }
+      std::vector<int32_t> rs, rl;
+      int32_t tile = 0;
+      while (true) {  // shrink until the staged tile fits
+        ranges_of(c0, c1, rg);
+        src.clear();
+        for (int q = 0; q < 3; q++)
+          for (int32_t s_ = rg[2 * q]; s_ < rg[2 * q] + rg[2 * q + 1]; s_++)
+            for (int32_t c = C.c_ptr[s_]; c < C.c_ptr[s_ + 1]; c++) {
+              src.push_back(C.c_a[c]);
+              if (C.c_b[c] >= 0) { src.push_back(C.c_b[c]); src.push_back(C.c_d[c]); }
+            }
+        std::sort(src.begin(), src.end());
+        src.erase(std::unique(src.begin(), src.end()), src.end());
+        rs.clear(); rl.clear(); tile = 0;
+        for (size_t i = 0; i < src.size();) {
+          size_t j = i;
+          while (j + 1 < src.size() && src[j + 1] - src[j] <= GAP && ((src[j + 1] < nnz) == (src[i] < nnz))) j++;
+          rs.push_back(src[i]); rl.push_back(src[j] - src[i] + 1);
+          tile += src[j] - src[i] + 1;
+          i = j + 1;
+        }
+        if (tile <= TMAX || c1 == c0 + 1) break;
+        c1 = c0 + std::max(1, (c1 - c0) / 2);
+      }
+      // (a column with a huge fan-in makes the tile too large for LDS: the plain slot kernel is used then)
+      std::vector<int32_t> roff(rs.size());
+      int32_t o = 0;
+      for (size_t i = 0; i < rs.size(); i++) { roff[i] = o; o += rl[i]; }
+      auto local = [&](int32_t g) {
+        size_t i = std::upper_bound(rs.begin(), rs.end(), g) - rs.begin() - 1;
+        return roff[i] + (g - rs[i]);
+      };
+      for (int q = 0; q < 3; q++)
+        for (int32_t s_ = rg[2 * q]; s_ < rg[2 * q] + rg[2 * q + 1]; s_++)
+          for (int32_t c = C.c_ptr[s_]; c < C.c_ptr[s_ + 1]; c++) {
+            C.c_la[c] = local(C.c_a[c]);
+            if (C.c_b[c] >= 0) { C.c_lb[c] = local(C.c_b[c]); C.c_ld[c] = local(C.c_d[c]); }
+          }
+      C.ch_tptr.push_back((int32_t)C.tile_src.size());
+      for (size_t i = 0; i < rs.size(); i++)
+        for (int32_t k = 0; k < rl[i]; k++) C.tile_src.push_back(rs[i] + k);
+      for (int q = 0; q < 6; q++) C.ch_slot.push_back(rg[q]);  // six words per chunk: (start, len) x 3
+      C.ch_tile.push_back(tile);
+      C.tile_max = std::max(C.tile_max, tile);
+      c0 = c1;
     }
-    C.ch_region[3] = (int32_t)C.ch_slot.size();
-    C.ch_slot.push_back((int32_t)C.cstride);
-    C.ch_rng.push_back((int32_t)C.rng_start.size());
     C.ch_tptr.push_back((int32_t)C.tile_src.size());
+    C.tiled_ok = C.tile_max <= 4608;
+    C.c_pack.assign(C.c_a.size(), 0);
+    if (C.tiled_ok)
+      for (size_t c = 0; c < C.c_a.size(); c++)
+        C.c_pack[c] = (uint64_t)C.c_la[c] | ((uint64_t)(C.c_lb[c] + 1) << 16) | ((uint64_t)(C.c_ld[c] + 1) << 32);
+    for (size_t k = 0; k < C.ch_tile.size(); k++) {
+      int32_t ncon_ = 0, nsl = 0;
+      for (int q = 0; q < 3; q++) {
+        int32_t s0_ = C.ch_slot[6 * k + 2 * q], len_ = C.ch_slot[6 * k + 2 * q + 1];
+        ncon_ += C.c_ptr[s0_ + len_] - C.c_ptr[s0_];
+        nsl += len_;
+      }
+      C.chunk_ncon_max = std::max(C.chunk_ncon_max, ncon_);
+      C.chunk_nslot_max = std::max(C.chunk_nslot_max, nsl);
+    }
+    C.ch_region[0] = 0; C.ch_region[1] = C.ch_region[2] = C.ch_region[3] = (int32_t)C.ch_tile.size();
   }
   C.active = true;
   msg.clear();

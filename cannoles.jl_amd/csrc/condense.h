@@ -35,16 +35,18 @@ struct Cond {
   std::vector<int32_t> c_ptr, c_a, c_b, c_d;
   // processing order of the slots (identity: the natural column-major order coalesces best)
   std::vector<int32_t> c_order;
-  // Tiling for the LDS-staged condense kernel: consecutive slots are grouped in chunks; the sources a chunk
-  // reads form a few contiguous ranges of [vals | rhs], which the kernel stages in LDS with coalesced loads.
-  // chunk k: slots [ch_slot[k], ch_slot[k+1]), ranges [ch_rng[k], ch_rng[k+1]) of (rng_start, rng_len) in the
-  // unified source space (index >= nnz = rhs), tile doubles per problem ch_tile[k]; c_la/c_lb/c_ld are the
-  // contribution sources as offsets into that tile.  ch_region[r] = first chunk of region r
-  // (0: matrix slots, 1: rho slots, 2: right-hand-side slots, 3: end).
+  // Tiling for the LDS-staged condense kernel: chunk k is a column range of the condensed system and owns three
+  // contiguous slot ranges, ch_slot[6k..6k+5] = (start, len) of its matrix, rho and right-hand-side slots.  The
+  // sources it reads ([vals | rhs], index >= nnz = rhs) are staged in LDS: tile position t holds source
+  // tile_src[ch_tptr[k] + t], ch_tile[k] positions per problem; c_la/c_lb/c_ld are the contribution sources as
+  // tile offsets.  ch_region[3] = number of chunks.
   std::vector<int32_t> ch_slot, ch_rng, ch_tile, rng_start, rng_len, c_la, c_lb, c_ld;
   std::vector<int32_t> ch_tptr, tile_src;  // flattened staging list: tile position -> source index (chunk k: [ch_tptr[k], ch_tptr[k+1]))
   int32_t ch_region[4] = {0, 0, 0, 0};
   int32_t tile_max = 0;
+  int32_t chunk_ncon_max = 0, chunk_nslot_max = 0;  // largest contribution / slot count of a chunk
+  bool tiled_ok = false;                            // the tile fits the LDS budget of the tiled kernel
+  std::vector<uint64_t> c_pack;                     // per contribution: la | (lb+1) << 16 | (ld+1) << 32  (tile offsets)
   // condensed residual nodes: diag source, original index, Jacobian row (sources / reduced x indices)
   std::vector<int32_t> r_orig, r_dsrc, r_ptr, r_jsrc, r_jx;
   // original index -> reduced index (-1 for condensed nodes) and back

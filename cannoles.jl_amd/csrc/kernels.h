@@ -50,7 +50,8 @@ struct DevPlan2 {
 struct DevCond {
   const int32_t *c_ptr, *c_a, *c_b, *c_d, *c_order;
   const int32_t *ch_slot, *ch_rng, *ch_tile, *rng_start, *rng_len, *c_la, *c_lb, *c_ld, *ch_tptr, *tile_src;  // LDS-tiled condense (condense.h)
-  int32_t tile_max;
+  const uint64_t* c_pack;
+  int32_t tile_max, chunk_ncon_max, chunk_nslot_max, tiled_ok;
   const int32_t *r_dsrc, *r_ptr, *r_jsrc, *r_jx;
   const int32_t *red_of, *cidx_of;
   int32_t N, nnz, nvar, N2, ncs, ncond;
@@ -83,9 +84,9 @@ hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const Launch
 hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_condense(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int slot_begin, int slot_end,
                            int batch, hipStream_t stream);
-// LDS-tiled variant over whole chunks [chunk_begin, chunk_end)
-hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int chunk_begin,
-                                 int chunk_end, int batch, hipStream_t stream);
+// LDS-tiled variant over all chunks; mask: 1 matrix slots, 2 rho slots, 4 right-hand-side slots
+hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int mask, int nchunks,
+                                 int batch, hipStream_t stream);
 hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_pos, int* extra_zer, double eig_tol, int batch,
                                hipStream_t stream);
 hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, const double* d2, const double* cbuf, double* dout,

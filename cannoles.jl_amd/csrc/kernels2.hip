@@ -491,6 +491,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     const double* rhs_or_vals = myrhs ? myrhs - P.nnz : myvals - P.nnz;  // base for entries src >= nnz (dummy when no rhs)
     // condensed systems keep [slots | rho | rhs] in ONE buffer: every source is myvals[src], no pointer select
     const bool unified = A.rhs == A.vals + P.nnz && P.rstride == P.vstride;
+    const bool needs_fix = __any(ovr) || !myrhs;  // wave-uniform: some value must be replaced at assembly time
     int4 R0, R1;      // record prefetch registers (two named values: an array would be kept in scratch)
     double pv[PVN];
 #pragma unroll
@@ -541,11 +542,19 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         for (int t = l; t < f * 8; t += 16) z2[t] = make_double2(0.0, 0.0);
       }
       wsync();
+      if (!needs_fix) {
+        // common case (no rho override in this wave, rhs present): the prefetched values go in as they are
 #pragma unroll
-      for (int j = 0; j < PVN; j++) {
-        const int e = j * 16 + l;
-        if (j * 16 < nasm) {
-          if (e < nasm) {
+        for (int j = 0; j < PVN; j++)
+          if (j * 16 < nasm) {
+            const int pos = rec[aoff + nasm + j * 16 + l];
+            __hip_atomic_fetch_add(&myFs[pos], pv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < PVN; j++) {
+          const int e = j * 16 + l;
+          if (j * 16 < nasm) {
             const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
             double v = pv[j];
             if (src >= P.nnz) { if (!myrhs) v = 0.0; }

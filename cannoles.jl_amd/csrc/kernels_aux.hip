@@ -17,7 +17,7 @@ __device__ __forceinline__ DevCond globalize(const DevCond& Cin) {
   C.ch_slot = as_global(Cin.ch_slot); C.ch_rng = as_global(Cin.ch_rng); C.ch_tile = as_global(Cin.ch_tile);
   C.rng_start = as_global(Cin.rng_start); C.rng_len = as_global(Cin.rng_len);
   C.c_la = as_global(Cin.c_la); C.c_lb = as_global(Cin.c_lb); C.c_ld = as_global(Cin.c_ld);
-  C.ch_tptr = as_global(Cin.ch_tptr); C.tile_src = as_global(Cin.tile_src);
+  C.ch_tptr = as_global(Cin.ch_tptr); C.tile_src = as_global(Cin.tile_src); C.c_pack = as_global(Cin.c_pack);
   C.c_ptr = as_global(Cin.c_ptr); C.c_a = as_global(Cin.c_a); C.c_b = as_global(Cin.c_b); C.c_d = as_global(Cin.c_d);
   C.r_dsrc = as_global(Cin.r_dsrc); C.r_ptr = as_global(Cin.r_ptr); C.r_jsrc = as_global(Cin.r_jsrc); C.r_jx = as_global(Cin.r_jx);
   C.red_of = as_global(Cin.red_of); C.cidx_of = as_global(Cin.cidx_of);
@@ -81,22 +81,21 @@ __global__ void __launch_bounds__(256) condense_kernel(const DevCond Cin, const 
     if (b0 + q < batch) cbuf[(long long)(b0 + q) * C.cstride + s] = acc[q];
 }
 
-// LDS-tiled condense: a workgroup forms the slots of one chunk for TPB problems.  The sources the chunk
-// needs are a few contiguous ranges of [vals | rhs]; they are staged in LDS with fully coalesced loads
-// (each 64-byte line of vals is fetched once per workgroup), then every thread forms one slot for the
-// TPB problems from LDS (contribution indices are read once per slot and reused for every problem).
+// LDS-tiled condense: a workgroup forms the slots of one chunk (a column range: its matrix, rho and rhs
+// slots) for TPB problems.  The sources the chunk needs are staged in LDS with coalesced loads (a line of
+// vals is fetched about once per problem), then every thread forms slots for the TPB problems from LDS
+// (contribution indices are read once per slot and reused for every problem).  `mask` selects the slot
+// ranges to produce: 1 matrix, 2 rho, 4 right-hand side.
 constexpr int TPB = 4;
 __global__ void __launch_bounds__(256) condense_tiled_kernel(const DevCond Cin, const double* __restrict__ vals,
                                                              const double* __restrict__ rhs, double* __restrict__ cbuf,
-                                                             int chunk_begin, int batch) {
+                                                             int mask, int batch) {
   extern __shared__ double tile[];
   const DevCond C = globalize(Cin);
-  const int ch = chunk_begin + blockIdx.x;
+  const int ch = blockIdx.x;
   const int b0 = blockIdx.y * TPB;
-  const int s0 = C.ch_slot[ch], s1 = C.ch_slot[ch + 1];
   const int T = C.ch_tile[ch];
   const int tid = threadIdx.x;
-  // stage the tile: position t of the tile holds source tile_src[t] (runs of consecutive indices: coalesced)
   {
     const int* tsrc = C.tile_src + C.ch_tptr[ch];
     for (int t = tid; t < T; t += 256) {
@@ -111,27 +110,48 @@ __global__ void __launch_bounds__(256) condense_tiled_kernel(const DevCond Cin, 
       }
     }
   }
-  __syncthreads();
-  const int s = s0 + tid;
-  if (s >= s1) return;
-  double acc[TPB];
-#pragma unroll
-  for (int q = 0; q < TPB; q++) acc[q] = 0.0;
-  const int c0 = C.c_ptr[s], c1 = C.c_ptr[s + 1];
-  for (int c = c0; c < c1; c++) {
-    const int la = C.c_la[c], lb = C.c_lb[c];
-    if (lb < 0) {
-#pragma unroll
-      for (int q = 0; q < TPB; q++) acc[q] += tile[q * T + la];
-    } else {
-      const int ld = C.c_ld[c];
-#pragma unroll
-      for (int q = 0; q < TPB; q++) acc[q] -= fast_div_aux(tile[q * T + la] * tile[q * T + lb], tile[q * T + ld]);
-    }
+  // stage the contribution lists of the chunk too: the compute phase then touches global memory only to store
+  unsigned long long* cpk = reinterpret_cast<unsigned long long*>(tile + TPB * C.tile_max);
+  int* cpl = reinterpret_cast<int*>(cpk + C.chunk_ncon_max);  // local contribution pointer of every slot of the chunk (+1 per range)
+  const int* rg = C.ch_slot + 6 * ch;
+  int coff = 0, soff = 0;
+  for (int r = 0; r < 3; r++) {
+    const int s0 = rg[2 * r], len = rg[2 * r + 1];
+    const int cb = C.c_ptr[s0], ce = C.c_ptr[s0 + len];
+    for (int i = tid; i < ce - cb; i += 256) cpk[coff + i] = C.c_pack[cb + i];
+    for (int i = tid; i <= len; i += 256) cpl[soff + i] = C.c_ptr[s0 + i] - cb + coff;
+    coff += ce - cb;
+    soff += len + 1;
   }
+  __syncthreads();
+  soff = 0;
+  for (int r = 0; r < 3; r++) {
+    const int s0 = rg[2 * r], len = rg[2 * r + 1];
+    if (mask & (1 << r)) {
+      for (int t = tid; t < len; t += 256) {
+        double acc[TPB];
 #pragma unroll
-  for (int q = 0; q < TPB; q++)
-    if (b0 + q < batch) cbuf[(long long)(b0 + q) * C.cstride + s] = acc[q];
+        for (int q = 0; q < TPB; q++) acc[q] = 0.0;
+        const int c0 = cpl[soff + t], c1 = cpl[soff + t + 1];
+        for (int c = c0; c < c1; c++) {
+          const unsigned long long pk = cpk[c];
+          const int la = (int)(pk & 0xffff), lb = (int)((pk >> 16) & 0xffff) - 1;
+          if (lb < 0) {
+#pragma unroll
+            for (int q = 0; q < TPB; q++) acc[q] += tile[q * T + la];
+          } else {
+            const int ld = (int)((pk >> 32) & 0xffff) - 1;
+#pragma unroll
+            for (int q = 0; q < TPB; q++) acc[q] -= fast_div_aux(tile[q * T + la] * tile[q * T + lb], tile[q * T + ld]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < TPB; q++)
+          if (b0 + q < batch) cbuf[(long long)(b0 + q) * C.cstride + s0 + t] = acc[q];
+      }
+    }
+    soff += len + 1;
+  }
 }
 
 // pos_r = #{d_r > eig_tol}, zer_r = #{|d_r| <= eig_tol} over the condensed pivots (src/solver_types.jl:90-95)
@@ -191,18 +211,17 @@ hipError_t launch_condense(const DevCond& C, const double* vals, const double* r
   return hipGetLastError();
 }
 
-hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int chunk_begin,
-                                 int chunk_end, int batch, hipStream_t stream) {
-  const int n = chunk_end - chunk_begin;
-  if (n <= 0) return hipSuccess;
-  const size_t lds = (size_t)TPB * (size_t)C.tile_max * sizeof(double);
+hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int mask, int nchunks,
+                                 int batch, hipStream_t stream) {
+  if (nchunks <= 0) return hipSuccess;
+  const size_t lds = (size_t)TPB * (size_t)C.tile_max * sizeof(double) + (size_t)C.chunk_ncon_max * 8 + ((size_t)C.chunk_nslot_max + 8) * 4;
   static size_t attr_set = 0;
   if (lds > attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(condense_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = lds;
   }
-  hipLaunchKernelGGL(condense_tiled_kernel, dim3(n, (batch + TPB - 1) / TPB), dim3(256), lds, stream, C, vals, rhs, cbuf, chunk_begin, batch);
+  hipLaunchKernelGGL(condense_tiled_kernel, dim3(nchunks, (batch + TPB - 1) / TPB), dim3(256), lds, stream, C, vals, rhs, cbuf, mask, batch);
   return hipGetLastError();
 }
 
