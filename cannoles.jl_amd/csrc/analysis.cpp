@@ -847,59 +847,10 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     P.u2_peak = (int32_t)((peakL + 1) & ~(int64_t)1);
     P.fs2_max = (int32_t)((fsmax + 1) & ~(int64_t)1);
     P.gs_doubles = (peakG + 1) & ~(int64_t)1;
-    // fast fronts (order <= 16, LDS staging) use a strided image: (a, b) -> a*16 + b instead of a(a+1)/2 + b
-    auto stride_pos = [&](int32_t packed) -> int32_t {
-      int32_t a = (int32_t)((std::sqrt(8.0 * packed + 1.0) - 1.0) * 0.5);
-      while (tri(a + 1) <= packed) a++;
-      while (tri(a) > packed) a--;
-      return a * 16 + (packed - (int32_t)tri(a));
-    };
+    P.v2_cls = cls; P.v2_fsglob = fsglob; P.v2_uglob = uglob; P.v2_uoff = uoff2; P.v2_fsoff = fsoff2;
     for (int32_t s = 0; s < ns; s++) if (cls[s] == 16 && !fsglob[s]) fsmax = std::max<int64_t>(fsmax, 16 * 16);
     P.fs2_max = (int32_t)((fsmax + 1) & ~(int64_t)1);
-    // forward records
-    P.rec.clear(); P.rec_maxlen = 0;
-    for (int32_t s = 0; s < ns; s++) {
-      const FrontHdr& F = P.fronts[s];
-      size_t r0 = P.rec.size();
-      P.rec.resize(r0 + R_HDR, 0);
-      // assembly entries, every round padded to a multiple of 16 (dummy: src -1 -> value 0 added to slot 0)
-      ivec asrc, apos;
-      const bool strided = cls[s] == 16 && !fsglob[s];
-      for (int32_t r = F.seg_begin; r < F.seg_end; r++) {
-        for (int32_t e = P.seg_ptr[r]; e < P.seg_ptr[r + 1]; e++) {
-          asrc.push_back(P.asm_src[e]);
-          apos.push_back(strided ? stride_pos(P.asm_pos[e]) : P.asm_pos[e]);
-        }
-        {
-          // padding entries add some value to an UNUSED slot; in the strided image the upper part of row 0
-          // (positions 1..15) is free, and distinct positions avoid same-address LDS atomics
-          int32_t dk = 0;
-          while (asrc.size() % 16) { asrc.push_back(0); apos.push_back(strided ? 1 + (dk++ % 15) : 0); }
-        }
-      }
-      int32_t asm_off = (int32_t)(P.rec.size() - r0);
-      P.rec.insert(P.rec.end(), asrc.begin(), asrc.end());
-      P.rec.insert(P.rec.end(), apos.begin(), apos.end());
-      int32_t child_off = (int32_t)(P.rec.size() - r0);
-      for (int32_t ci = F.child_begin; ci < F.child_end; ci++) {
-        int32_t c = P.child_idx[ci];
-        const FrontHdr& C = P.fronts[c];
-        int32_t tuc = (int32_t)tri(1 + C.nupd);
-        P.rec.push_back(uoff2[c]); P.rec.push_back(tuc); P.rec.push_back(uglob[c] ? 1 : 0); P.rec.push_back(0);
-        const int32_t* rel = P.rel_idx.data() + C.rel_begin;
-        for (int32_t a = 0; a <= C.nupd; a++)
-          for (int32_t b = 0; b <= a; b++) P.rec.push_back(strided ? rel[a] * 16 + rel[b] : (int32_t)(tri(rel[a]) + rel[b]));
-        while ((P.rec.size() - r0) % 4) P.rec.push_back(0);
-      }
-      while ((P.rec.size() - r0) % 4) P.rec.push_back(0);
-      int32_t* H = P.rec.data() + r0;
-      H[R_NPIV] = F.npiv; H[R_NUPD] = F.nupd; H[R_RECLEN] = (int32_t)(P.rec.size() - r0); H[R_NASM] = (int32_t)asrc.size();
-      H[R_NCHILD] = F.child_end - F.child_begin; H[R_UOFF] = uoff2[s];
-      H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0); H[R_FSOFF] = fsoff2[s];
-      H[R_LPTR_LO] = F.lptr_lo; H[R_LPTR_HI] = F.lptr_hi; H[R_CLS] = cls[s]; H[R_ASM_OFF] = asm_off; H[R_CHILD_OFF] = child_off;
-      // globally staged fronts read their lists from the stream itself: only the header must fit the LDS buffer
-      P.rec_maxlen = std::max(P.rec_maxlen, fsglob[s] ? (int32_t)R_HDR : H[R_RECLEN]);
-    }
+    write_forward_records(P, nullptr);
     // backward records, reverse post-order
     P.brec.clear(); P.brec_maxlen = 0;
     for (int32_t s = ns - 1; s >= 0; s--) {
@@ -918,6 +869,134 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     }
   }
   msg.clear();
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+int write_forward_records(Plan& P, const DirectLists* D) {
+  const int32_t ns = P.nsuper;
+  const ivec &cls = P.v2_cls, &fsglob = P.v2_fsglob, &uglob = P.v2_uglob, &uoff2 = P.v2_uoff, &fsoff2 = P.v2_fsoff;
+  // fast fronts (order <= 16, LDS staging) use a strided image: (a, b) -> a*16 + b instead of a(a+1)/2 + b
+  auto stride_pos = [&](int32_t packed) -> int32_t {
+    int32_t a = (int32_t)((std::sqrt(8.0 * packed + 1.0) - 1.0) * 0.5);
+    while (tri(a + 1) <= packed) a++;
+    while (tri(a) > packed) a--;
+    return a * 16 + (packed - (int32_t)tri(a));
+  };
+  std::vector<int32_t> rec;
+  int32_t rec_maxlen = 0;
+  int64_t st_raw = 0, st_prod = 0, st_asm = 0, st_rawmax = 0, st_prodmax = 0, st_asmmax = 0;
+  for (int32_t s = 0; s < ns; s++) {
+    const FrontHdr& F = P.fronts[s];
+    size_t r0 = rec.size();
+    rec.resize(r0 + R_HDR, 0);
+    const bool strided = cls[s] == 16 && !fsglob[s];
+    // plain entries (pos, src) grouped in rounds: all positions of a round are distinct, rounds are applied in
+    // order (COO-order sums of duplicates); every round is padded to a multiple of 16 with entries that add
+    // some value to an UNUSED slot (strided image: the free upper part of row 0, distinct positions)
+    struct PE { int32_t round, src, pos; };
+    std::vector<PE> pes;
+    struct PR { int32_t pos, a, b, d; };
+    std::vector<PR> prs;
+    {
+      std::unordered_map<int32_t, int32_t> occ;  // position -> plain entries so far
+      for (int32_t r = F.seg_begin; r < F.seg_end; r++)
+        for (int32_t e = P.seg_ptr[r]; e < P.seg_ptr[r + 1]; e++) {
+          const int32_t pos = strided ? stride_pos(P.asm_pos[e]) : P.asm_pos[e];
+          const int32_t src = P.asm_src[e];
+          if (!D) { pes.push_back({occ[pos]++, src, pos}); continue; }
+          for (int32_t c = D->c_ptr[src]; c < D->c_ptr[src + 1]; c++) {
+            if (D->c_b[c] < 0) pes.push_back({occ[pos]++, D->c_a[c], pos});
+            else prs.push_back({pos, D->c_a[c], D->c_b[c], D->c_d[c]});
+          }
+        }
+    }
+    std::stable_sort(pes.begin(), pes.end(), [](const PE& x, const PE& y) { return x.round < y.round || (x.round == y.round && x.src < y.src); });
+    ivec asrc, apos;
+    for (size_t i = 0; i < pes.size(); i++) {
+      if (i > 0 && pes[i].round != pes[i - 1].round) {
+        int32_t dk = 0;
+        while (asrc.size() % 16) { asrc.push_back(0); apos.push_back(strided ? 1 + (dk++ % 15) : 0); }
+      }
+      asrc.push_back(pes[i].src); apos.push_back(pes[i].pos);
+    }
+    { int32_t dk = 0; while (asrc.size() % 16) { asrc.push_back(0); apos.push_back(strided ? 1 + (dk++ % 15) : 0); } }
+    // products of one position go to different rounds of 16 (same-address LDS atomics of one instruction serialise):
+    // order by (occurrence of the position, position)
+    {
+      std::unordered_map<int32_t, int32_t> occ;
+      std::vector<std::pair<int64_t, size_t>> key(prs.size());
+      for (size_t i = 0; i < prs.size(); i++) key[i] = {((int64_t)occ[prs[i].pos]++ << 32) | (uint32_t)prs[i].pos, i};
+      std::sort(key.begin(), key.end());
+      std::vector<PR> q(prs.size());
+      for (size_t i = 0; i < prs.size(); i++) q[i] = prs[key[i].second];
+      prs.swap(q);
+    }
+    // raw sources of the products: pivots d first, then the other operands
+    ivec raw; int32_t nrd = 0;
+    std::unordered_map<int32_t, int32_t> rawidx;
+    for (auto& p_ : prs) if (!rawidx.count(p_.d)) { rawidx[p_.d] = (int32_t)raw.size(); raw.push_back(p_.d); }
+    nrd = (int32_t)raw.size();
+    for (auto& p_ : prs) {
+      if (!rawidx.count(p_.a)) { rawidx[p_.a] = (int32_t)raw.size(); raw.push_back(p_.a); }
+      if (!rawidx.count(p_.b)) { rawidx[p_.b] = (int32_t)raw.size(); raw.push_back(p_.b); }
+    }
+    auto why = [&](const char* w) { if (getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] direct records: front %d (order %d): %s (raw %zu, products %zu)\n", s, 1 + F.nupd + F.npiv, w, raw.size(), prs.size()); return 1; };
+    if (raw.size() > 1023) return why("more than 1023 raw values");       // descriptor fields are 10 bits
+    if (strided && raw.size() > 128) return why("fast front with more than 128 raw values");  // 7-bit fields, LDS area of 128
+    for (auto& p_ : prs) if (rawidx[p_.a] < nrd || rawidx[p_.b] < nrd) return why("a pivot is also an operand");
+    while (raw.size() % 16) raw.push_back(raw.empty() ? 0 : raw[0]);
+    ivec prod;
+    {
+      int32_t dk = 0;
+      if (strided) {  // one word per product: pos | ia << 8 | ib << 15 | id << 22
+        for (auto& p_ : prs) prod.push_back(p_.pos | (rawidx[p_.a] << 8) | (rawidx[p_.b] << 15) | (rawidx[p_.d] << 22));
+        while (prod.size() % 16) prod.push_back(1 + (dk++ % 15));
+      } else {        // two words: pos, ia | ib << 10 | id << 20
+        for (auto& p_ : prs) { prod.push_back(p_.pos); prod.push_back(rawidx[p_.a] | (rawidx[p_.b] << 10) | (rawidx[p_.d] << 20)); }
+        while ((prod.size() / 2) % 16) { prod.push_back(0); prod.push_back(0); }
+      }
+      if (prs.empty()) prod.clear();
+    }
+    if (prs.empty()) raw.clear();
+    int32_t asm_off = (int32_t)(rec.size() - r0);
+    rec.insert(rec.end(), asrc.begin(), asrc.end());
+    rec.insert(rec.end(), apos.begin(), apos.end());
+    rec.insert(rec.end(), raw.begin(), raw.end());
+    rec.insert(rec.end(), prod.begin(), prod.end());
+    int32_t child_off = (int32_t)(rec.size() - r0);
+    for (int32_t ci = F.child_begin; ci < F.child_end; ci++) {
+      int32_t c = P.child_idx[ci];
+      const FrontHdr& C = P.fronts[c];
+      int32_t tuc = (int32_t)tri(1 + C.nupd);
+      rec.push_back(uoff2[c]); rec.push_back(tuc); rec.push_back(uglob[c] ? 1 : 0); rec.push_back(0);
+      const int32_t* rel = P.rel_idx.data() + C.rel_begin;
+      for (int32_t a = 0; a <= C.nupd; a++)
+        for (int32_t b = 0; b <= a; b++) rec.push_back(strided ? rel[a] * 16 + rel[b] : (int32_t)(tri(rel[a]) + rel[b]));
+      while ((rec.size() - r0) % 4) rec.push_back(0);
+    }
+    while ((rec.size() - r0) % 4) rec.push_back(0);
+    int32_t* H = rec.data() + r0;
+    H[R_NPIV] = F.npiv; H[R_NUPD] = F.nupd; H[R_RECLEN] = (int32_t)(rec.size() - r0); H[R_NASM] = (int32_t)asrc.size();
+    H[R_NCHILD] = F.child_end - F.child_begin; H[R_UOFF] = uoff2[s];
+    H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0); H[R_FSOFF] = fsoff2[s];
+    H[R_LPTR_LO] = F.lptr_lo; H[R_LPTR_HI] = F.lptr_hi; H[R_CLS] = cls[s]; H[R_ASM_OFF] = asm_off; H[R_CHILD_OFF] = child_off;
+    H[R_NPROD] = (int32_t)(strided ? prod.size() : prod.size() / 2); H[R_NRAW] = (int32_t)raw.size(); H[R_NRD] = nrd;
+    st_raw += H[R_NRAW]; st_prod += H[R_NPROD]; st_asm += H[R_NASM];
+    st_rawmax = std::max<int64_t>(st_rawmax, H[R_NRAW]); st_prodmax = std::max<int64_t>(st_prodmax, H[R_NPROD]);
+    st_asmmax = std::max<int64_t>(st_asmmax, H[R_NASM]);
+    // globally staged fronts read their lists from the stream itself: only the header must fit the LDS buffer
+    rec_maxlen = std::max(rec_maxlen, fsglob[s] ? (int32_t)R_HDR : H[R_RECLEN]);
+  }
+  if (getenv("CNL_VERBOSE"))
+    fprintf(stderr, "[cnl] records%s: fronts %d, plain %lld (max %lld), raw %lld (max %lld), products %lld (max %lld), words %zu\n",
+            D ? " (direct)" : "", ns, (long long)st_asm, (long long)st_asmmax, (long long)st_raw, (long long)st_rawmax,
+            (long long)st_prod, (long long)st_prodmax, rec.size());
+  P.rec.swap(rec);
+  P.rec_maxlen = rec_maxlen;
+  P.rec_direct = D != nullptr;
+  if (D) { P.nnz_outer = D->nnz_outer; P.n_outer = D->n_outer; }
   return 0;
 }
 

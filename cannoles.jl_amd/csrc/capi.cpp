@@ -156,14 +156,21 @@ int setup_v2(cnl_handle* h) {
   if ((rc = upload(h, rec, &d.rec))) return rc;
   if ((rc = upload(h, brec, &d.brec))) return rc;
   d.nsuper = P.nsuper; d.N = (int32_t)P.N; d.nnz = (int32_t)P.nnz; d.rho_begin = P.rho_begin; d.nvar = (int32_t)P.nvar;
-  d.reccap = (std::max(P.rec_maxlen, P.brec_maxlen) + 3) & ~3;
+  d.reccap = (P.rec_maxlen + 64 + 3) & ~3;  // + slack: the product loop reads up to 48 words past a list
+  d.breccap = (P.brec_maxlen + 3) & ~3;
+  d.recwords = std::max(d.reccap, 2 * d.breccap);
   d.u2_peak = P.u2_peak;
-  int64_t prob = std::max<int64_t>((int64_t)P.u2_peak + std::max<int64_t>(P.fs2_max, 64) + 16, P.bwd_peak + 2);
+  d.jraw_off = (int32_t)((P.u2_peak + std::max<int64_t>(P.fs2_max, 64) + 16 + 1) & ~(int64_t)1);
+  int64_t prob = std::max<int64_t>((int64_t)d.jraw_off + (P.rec_direct ? 128 : 0), P.bwd_peak + 2);
   d.prob_doubles = (int32_t)((prob + 1) & ~(int64_t)1);
   d.gs_doubles = P.gs_doubles + 64;
   d.lsize = P.lsize;
   d.vstride = h->dp.vstride; d.rstride = h->dp.rstride; d.dstride = h->dp.dstride;
-  const size_t wave_bytes = ((size_t)d.reccap + 4 * (size_t)d.prob_doubles + 8) * sizeof(double);
+  if (P.rec_direct) {  // the assembly lists address the caller's arrays
+    d.nnz = P.nnz_outer; d.rho_begin = P.nnz_outer - (int32_t)P.nvar;
+    d.vstride = P.nnz_outer; d.rstride = P.n_outer;
+  }
+  const size_t wave_bytes = ((size_t)(d.recwords >> 1) + 4 * (size_t)d.prob_doubles + 8) * sizeof(double);
   size_t maxlds = std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024);
   if (wave_bytes + 512 > maxlds) return CNL_OK;  // does not fit: stay on v1
   // waves per workgroup: small workgroups give the dispatcher freedom; 2 keeps the launch grid moderate
@@ -208,7 +215,21 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
     const int s_mat = (int)(C.ncs + C.nvar), s_all = (int)C.cstride;
     double* crhs = h->d_cbuf + s_mat;
     hipError_t e = hipSuccess;
-    if (a.mode == cnl::MODE_NEWTON) {
+    const bool direct = h->use_v2 && h->plan->P.rec_direct;  // the register-front kernel condenses on the fly
+    if (direct && a.mode == cnl::MODE_NEWTON) {
+      e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
+      a.vals = d_vals; a.rhs = d_rhs; a.d = h->d_d2; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
+      if ((rc = launch(h, a, stream))) return rc;
+      e = cnl::launch_expand(h->dc, d_vals, d_rhs, h->d_d2, h->d_cbuf, d_d, a.success, 0, B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
+    } else if (direct && a.mode == cnl::MODE_FACTOR) {
+      e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
+      a.vals = d_vals; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
+      if ((rc = launch(h, a, stream))) return rc;
+      h->last_vals = d_vals;
+    } else if (a.mode == cnl::MODE_NEWTON) {
       e = C.tiled_ok ? cnl::launch_condense_tiled(h->dc, d_vals, d_rhs, h->d_cbuf, 7, C.ch_region[3], B, stream)
                      : cnl::launch_condense(h->dc, d_vals, d_rhs, h->d_cbuf, 0, s_all, B, stream);
       if (e == hipSuccess) e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
@@ -298,6 +319,17 @@ int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows
     delete p;
     *plan = nullptr;
     return fail(rc, msg);
+  }
+  // register-front kernel on a condensed system: rewrite the assembly lists against the ORIGINAL arrays, so
+  // that the kernel condenses on the fly and the separate condense pass disappears (CNL_NO_DIRECT=1 keeps it)
+  if (p->C.active && p->P.v2_ok && !(getenv("CNL_NO_DIRECT") && atoi(getenv("CNL_NO_DIRECT")))) {
+    cnl::DirectLists D{p->C.c_ptr.data(), p->C.c_a.data(), p->C.c_b.data(), p->C.c_d.data(), (int32_t)nnz, (int32_t)N};
+    const int32_t old_len = p->P.rec_maxlen;
+    const size_t old_words = p->P.rec.size();
+    int drc = cnl::write_forward_records(p->P, &D);
+    if (getenv("CNL_VERBOSE"))
+      fprintf(stderr, "[cnl] direct records: %s, rec words %zu -> %zu, longest %d -> %d\n", drc ? "not possible" : "ok", old_words,
+              p->P.rec.size(), old_len, p->P.rec_maxlen);
   }
   // elimination order in the reference's numbering: condensed residual nodes first
   if (p->C.active) {

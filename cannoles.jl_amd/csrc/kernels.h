@@ -38,9 +38,12 @@ struct DevPlan2 {
   const int32_t* rec;
   const int32_t* brec;
   int32_t nsuper, N, nnz, rho_begin, nvar;
-  int32_t reccap;        // words per record buffer (two buffers per wave)
+  int32_t reccap;        // words of the forward record buffer (one per wave)
+  int32_t breccap;       // words per backward record buffer (two per wave, same LDS area)
+  int32_t recwords;      // words of that area = max(reccap, 2 * breccap)
   int32_t u2_peak;       // doubles: per-problem LDS update stack; the staging triangle follows it
   int32_t prob_doubles;  // doubles of LDS per problem
+  int32_t jraw_off;      // doubles: offset of the raw-value area of the on-the-fly condensation inside the per-problem LDS
   int64_t gs_doubles;    // doubles of global scratch per problem
   int64_t lsize;
   int64_t vstride, rstride, dstride;  // per-problem strides (doubles) of vals / rhs / d

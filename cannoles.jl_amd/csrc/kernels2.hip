@@ -29,7 +29,8 @@ namespace cnl {
 
 namespace {
 
-constexpr int RN = 2;    // record prefetch: RN x dwordx4 per lane = RN*256 words
+constexpr int RN = 3;    // record prefetch: RN x dwordx4 per lane = RN*256 words
+constexpr int PVR = 7;   // raw-value prefetch of the on-the-fly condensation: PVR*16 values per problem
 constexpr int PVN = 8;   // value prefetch: PVN doubles per lane = PVN*16 entries per problem
 
 __device__ __forceinline__ int tri2(int i) { return (i * (i + 1)) >> 1; }
@@ -366,6 +367,25 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
       gsync();
     }
   }
+  // on-the-fly condensation, out-of-line form: two words per product (pos, ia | ib<<10 | id<<20), raw values gathered directly
+  const int nprod = rfl(rec[R_NPROD]), nraw = rfl(rec[R_NRAW]);
+  if (nprod > 0) {
+    const int raw_off = aoff + 2 * nasm, prod_off = raw_off + nraw;
+    if (gfs) gsync(); else wsync();
+    for (int e = l; e < nprod; e += 16) {
+      const int pos = grec[prod_off + 2 * e], w = grec[prod_off + 2 * e + 1];
+      double x[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int src = grec[raw_off + ((w >> (10 * q)) & 1023)];
+        x[q] = src >= P.nnz ? (myrhs ? myrhs[src - P.nnz] : 0.0) : myvals[src];
+      }
+      const double v = fast_div(-(x[0] * x[1]), x[2]);
+      if (!gfs) __hip_atomic_fetch_add(&myFs[pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      else if (valid) __hip_atomic_fetch_add(&mygs[fsoff + pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (gfs) gsync();
+  }
   int co = coff;
   for (int ci = 0; ci < nchild; ci++) {
     const int cu = rfl(grec[co + C_UOFF]), tuc = rfl(grec[co + C_TUC]), cfl = rfl(grec[co + C_FLAGS]);
@@ -438,6 +458,19 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     }                                                                                  \
   }
 
+// Raw values (Jacobian entries, residual pivots, residual right-hand sides) of the products a front's
+// condensed slots are made of: same scheme as PREFETCH_VALUES.
+#define PREFETCH_RAW(RECP, ROFF, NRAW)                                                 \
+  {                                                                                    \
+    const int nr_ = (NRAW);                                                            \
+    const int* sp_ = (RECP) + (ROFF) + l;                                              \
+    _Pragma("unroll") for (int j = 0; j < PVR; j++)                                    \
+      if (j * 16 < nr_) {                                                              \
+        const int src_ = sp_[j * 16];                                                  \
+        pvr[j] = *(src_ >= P.nnz ? rhs_or_vals + src_ : myvals + src_);                \
+      }                                                                                \
+  }
+
 // ==========================================================================================
 __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, const LaunchArgs Ain) {
   DevPlan2 P = Pin;
@@ -458,13 +491,14 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   const bool valid = prob < A.batch;
   const long long pclamp = valid ? prob : prob0;
 
-  const int wave_doubles = P.reccap + 4 * P.prob_doubles + 8;
+  const int wave_doubles = (P.recwords >> 1) + 4 * P.prob_doubles + 8;
   double* wbase = smem + wave * wave_doubles;
-  int* recbuf = reinterpret_cast<int*>(wbase);  // two buffers of reccap words
-  double* pbase0 = wbase + P.reccap;
+  int* recbuf = reinterpret_cast<int*>(wbase);  // forward: one record of up to reccap words; backward: two of breccap
+  double* pbase0 = wbase + (P.recwords >> 1);
   int* cnt = reinterpret_cast<int*>(pbase0 + 4 * P.prob_doubles);
   double* myU = pbase0 + g * P.prob_doubles;
   double* myFs = myU + P.u2_peak;
+  double* jraw = myU + P.jraw_off;  // raw values of the current front's products (reciprocal pivots first)
 
   Ctx2 c;
   c.vals = A.vals; c.rhs = A.rhs; c.L = A.L; c.gs = A.scratch; c.dout = A.d; c.batch = A.batch;
@@ -492,16 +526,18 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     // condensed systems keep [slots | rho | rhs] in ONE buffer: every source is myvals[src], no pointer select
     const bool unified = A.rhs == A.vals + P.nnz && P.rstride == P.vstride;
     const bool needs_fix = __any(ovr) || !myrhs;  // wave-uniform: some value must be replaced at assembly time
-    int4 R0, R1;      // record prefetch registers (two named values: an array would be kept in scratch)
-    double pv[PVN];
+    int4 R0, R1, R2;  // record prefetch registers (named values: an array would be kept in scratch)
+    double pv[PVN], pvr[PVR];
 #pragma unroll
     for (int j = 0; j < PVN; j++) pv[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < PVR; j++) pvr[j] = 0.0;
     int roff = 0;     // word offset of the current record
     int nxt_off = 0;  // word offset of the next record
     int s = 0;
     bool primed = false;
     while (s < P.nsuper) {
-      int* recw = recbuf + (s & 1) * P.reccap;
+      int* recw = recbuf;
       if (!primed) {
         // (re)start the pipeline at front s: record s synchronously, then prefetch record s+1 and the values of s
         int len = P.rec[roff + R_RECLEN];
@@ -511,10 +547,12 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         wsync();
         R0 = rstream[(nxt_off >> 2) + lane];  // stream is padded: over-read is safe
         R1 = rstream[(nxt_off >> 2) + lane + 64];
+        R2 = rstream[(nxt_off >> 2) + lane + 128];
         const int hv0 = recw[lane & 15];
         const int nasm0 = HDRW(hv0, R_NASM), aoff0 = HDRW(hv0, R_ASM_OFF);
         const bool fast0 = HDRW(hv0, R_CLS) == 16 && !(HDRW(hv0, R_FLAGS) & RF_FS_GLOBAL);
         PREFETCH_VALUES(recw, aoff0, fast0 ? nasm0 : 0)
+        PREFETCH_RAW(recw, aoff0 + 2 * nasm0, fast0 ? HDRW(hv0, R_NRAW) : 0)
         primed = true;
       }
       const int* rec = recw;
@@ -522,6 +560,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM);
       const int nchild = HDRW(hv, R_NCHILD), uoff = HDRW(hv, R_UOFF), flags = HDRW(hv, R_FLAGS), fsoff = HDRW(hv, R_FSOFF);
       const int cls = HDRW(hv, R_CLS), aoff = HDRW(hv, R_ASM_OFF), coff = HDRW(hv, R_CHILD_OFF);
+      const int nprod = HDRW(hv, R_NPROD), nraw = HDRW(hv, R_NRAW), nrd = HDRW(hv, R_NRD);
       const long long lptr = (long long)HDRW(hv, R_LPTR_LO) | ((long long)HDRW(hv, R_LPTR_HI) << 31);
       const int f = 1 + nupd + npiv;
       const bool gfs = flags & RF_FS_GLOBAL;
@@ -540,6 +579,26 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       {
         double2* z2 = reinterpret_cast<double2*>(myFs);
         for (int t = l; t < f * 8; t += 16) z2[t] = make_double2(0.0, 0.0);
+      }
+      const int raw_off = aoff + 2 * nasm;
+      if (nraw > 0) {
+        // on-the-fly condensation: raw values to LDS (a missing right-hand side reads as zero)
+#pragma unroll
+        for (int j = 0; j < PVR; j++)
+          if (j * 16 < nraw) {
+            double v = pvr[j];
+            if (!myrhs) { if (rec[raw_off + j * 16 + l] >= P.nnz) v = 0.0; }
+            if (j * 16 < nrd) {  // the first nrd raw values are residual pivots d_r: keep -1/d_r
+              const double r = fast_div(-1.0, v);
+              v = j * 16 + l < nrd ? r : v;
+            }
+            jraw[j * 16 + l] = v;
+          }
+        for (int e = PVR * 16 + l; e < nraw; e += 16) {
+          const int src = rec[raw_off + e];
+          const double v = src >= P.nnz ? (myrhs ? myrhs[src - P.nnz] : 0.0) : myvals[src];
+          jraw[e] = e < nrd ? fast_div(-1.0, v) : v;
+        }
       }
       wsync();
       if (!needs_fix) {
@@ -570,33 +629,25 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         else v = (ovr && src >= P.rho_begin) ? rho : myvals[src];
         __hip_atomic_fetch_add(&myFs[pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
-      STAMP(0)
-      // (3) next record into the other buffer; prefetch the one after and the next front's values
-      int nroff = nxt_off;
-      if (s + 1 < P.nsuper) {
-        int* nrec = recbuf + ((s + 1) & 1) * P.reccap;
-        // header words of the next record straight from the prefetch registers: lane q holds words 4q .. 4q+3
-        const int nlen = __builtin_amdgcn_readlane(R0.z, 0);          // R_RECLEN = 2
-        const int nasm1 = __builtin_amdgcn_readlane(R0.w, 0);         // R_NASM = 3
-        const int nflags1 = __builtin_amdgcn_readlane(R0.z, 1);       // R_FLAGS = 6
-        const int ncls1 = __builtin_amdgcn_readlane(R0.z, 2);         // R_CLS = 10
-        const int aoff1 = __builtin_amdgcn_readlane(R0.w, 2);         // R_ASM_OFF = 11
-        static_assert(R_RECLEN == 2 && R_NASM == 3 && R_FLAGS == 6 && R_CLS == 10 && R_ASM_OFF == 11, "record header layout");
-        const int clen = nlen < P.reccap ? nlen : P.reccap;   // globally staged fronts keep only their head in LDS
-        if (lane * 4 < clen) reinterpret_cast<int4*>(nrec)[lane] = R0;
-        if ((lane + 64) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 64] = R1;
+      if (nprod > 0) {
+        // products -J_ra J_rb / d_r of the condensed residual rows: one packed word each, pos | ia<<8 | ib<<15 | id<<22
+        // (four rounds in flight: the LDS round trips of a round are dependent, those of different rounds are not)
         wsync();
-        for (int w4 = RN * 64 + lane; w4 * 4 < clen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = rstream[(nxt_off >> 2) + w4];
-        wsync();
-        const int nn_off = nxt_off + nlen;
-        R0 = rstream[(nn_off >> 2) + lane];
-        R1 = rstream[(nn_off >> 2) + lane + 64];
-        const bool nfast = ncls1 == 16 && !(nflags1 & RF_FS_GLOBAL);
-        PREFETCH_VALUES(nrec, aoff1, nfast ? nasm1 : 0)
-        nxt_off = nn_off;
+        const int* pw = rec + raw_off + nraw + l;
+        for (int e = 0; e < nprod; e += 64) {
+          int w[4];
+          double v[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) w[q] = pw[e + 16 * q];  // reads past the list stay inside the LDS record area and are not used
+#pragma unroll
+          for (int q = 0; q < 4; q++) v[q] = jraw[(w[q] >> 8) & 127] * jraw[(w[q] >> 15) & 127] * jraw[(w[q] >> 22) & 127];
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (e + 16 * q < nprod) __hip_atomic_fetch_add(&myFs[w[q] & 255], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
       }
-      STAMP(1)
-      // (4) extend-add the children's update matrices
+      STAMP(0)
+      // (3) extend-add the children's update matrices
       {
         int co = coff;
         for (int ci = 0; ci < nchild; ci++) {
@@ -617,6 +668,35 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       }
       wsync();
       STAMP(2)
+      // (4) next record over the current one (nothing below reads the lists); prefetch the one after and the next front's values
+      int nroff = nxt_off;
+      if (s + 1 < P.nsuper) {
+        int* nrec = recbuf;
+        // header words of the next record straight from the prefetch registers: lane q holds words 4q .. 4q+3
+        const int nlen = __builtin_amdgcn_readlane(R0.z, 0);          // R_RECLEN = 2
+        const int nasm1 = __builtin_amdgcn_readlane(R0.w, 0);         // R_NASM = 3
+        const int nflags1 = __builtin_amdgcn_readlane(R0.z, 1);       // R_FLAGS = 6
+        const int ncls1 = __builtin_amdgcn_readlane(R0.z, 2);         // R_CLS = 10
+        const int aoff1 = __builtin_amdgcn_readlane(R0.w, 2);         // R_ASM_OFF = 11
+        const int nraw1 = __builtin_amdgcn_readlane(R0.z, 3);         // R_NRAW = 14
+        static_assert(R_RECLEN == 2 && R_NASM == 3 && R_FLAGS == 6 && R_CLS == 10 && R_ASM_OFF == 11 && R_NRAW == 14, "record header layout");
+        const int clen = nlen < P.reccap ? nlen : P.reccap;   // globally staged fronts keep only their head in LDS
+        if (lane * 4 < clen) reinterpret_cast<int4*>(nrec)[lane] = R0;
+        if ((lane + 64) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 64] = R1;
+        if ((lane + 128) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 128] = R2;
+        wsync();
+        for (int w4 = RN * 64 + lane; w4 * 4 < clen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = rstream[(nxt_off >> 2) + w4];
+        wsync();
+        const int nn_off = nxt_off + nlen;
+        R0 = rstream[(nn_off >> 2) + lane];
+        R1 = rstream[(nn_off >> 2) + lane + 64];
+        R2 = rstream[(nn_off >> 2) + lane + 128];
+        const bool nfast = ncls1 == 16 && !(nflags1 & RF_FS_GLOBAL);
+        PREFETCH_VALUES(nrec, aoff1, nfast ? nasm1 : 0)
+        PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nfast ? nraw1 : 0)
+        nxt_off = nn_off;
+      }
+      STAMP(1)
       // (5) eliminate in registers, store L rows and the update matrix
 #ifdef CNL_STAMPS
       eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol, st_acc);
@@ -680,7 +760,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     bool primed = false;
     int s = 0;
     while (s < P.nsuper) {
-      int* recw = recbuf + (s & 1) * P.reccap;
+      int* recw = recbuf + (s & 1) * P.breccap;
       if (!primed) {
         const int len = P.brec[boff + B_RECLEN];
         nxt = boff + len;
@@ -723,7 +803,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       double lrn[KB];
       int nboff = nxt;
       if (s + 1 < P.nsuper) {
-        int* nrec = recbuf + ((s + 1) & 1) * P.reccap;
+        int* nrec = recbuf + ((s + 1) & 1) * P.breccap;
         // next header words straight from the prefetch registers (lane 0: words 0..3, lane 1: words 4..7)
         const int nlen = __builtin_amdgcn_readlane(Rb.z, 0);   // B_RECLEN = 2
         const int npiv1 = __builtin_amdgcn_readlane(Rb.x, 0), nupd1 = __builtin_amdgcn_readlane(Rb.y, 0);

@@ -82,12 +82,26 @@ struct Plan {
   int32_t fs2_max = 0;       // doubles of LDS front staging per problem (fronts of order <= 32)
   int64_t gs_doubles = 0;    // doubles of global scratch per problem (large fronts / update matrices)
   int32_t ncls[3] = {0, 0, 0};  // fronts per class (order <=16, <=32, <=64)
+  std::vector<int32_t> v2_cls, v2_fsglob, v2_uglob, v2_uoff, v2_fsoff;  // per front (kept so that the records can be rewritten)
+  // "direct" records: the assembly lists address the ORIGINAL vals / rhs (duplicate rounds) and carry the
+  // products of the condensed residual rows, so the multifrontal kernel condenses on the fly
+  bool rec_direct = false;
+  int32_t nnz_outer = 0, n_outer = 0;  // outer (reference) nnz and N when rec_direct
 };
+
+// contributions of every source of the condensed system in terms of the original arrays (see condense.h)
+struct DirectLists {
+  const int32_t *c_ptr, *c_a, *c_b, *c_d;
+  int32_t nnz_outer, n_outer;
+};
+// (Re)writes P.rec.  D == nullptr: sources are the condensed buffer's slots.  Returns 0, or 1 when the plan
+// cannot be expressed with direct records (then P.rec is left in the indirect form).
+int write_forward_records(Plan& P, const DirectLists* D);
 
 // record layouts shared by analysis.cpp (writer) and kernels2.hip (reader)
 enum {
   R_NPIV = 0, R_NUPD, R_RECLEN, R_NASM, R_NCHILD, R_UOFF, R_FLAGS, R_FSOFF, R_LPTR_LO, R_LPTR_HI, R_CLS,
-  R_ASM_OFF, R_CHILD_OFF, R_PAD13, R_PAD14, R_PAD15, R_HDR = 16
+  R_ASM_OFF, R_CHILD_OFF, R_NPROD, R_NRAW, R_NRD, R_HDR = 16
 };
 enum { RF_U_GLOBAL = 1, RF_FS_GLOBAL = 2 };
 enum { C_UOFF = 0, C_TUC, C_FLAGS, C_PAD, C_HDR = 4 };
