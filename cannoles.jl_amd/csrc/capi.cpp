@@ -458,6 +458,8 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
     if ((rc = upload(h, C.r_jx, &dc.r_jx))) return bail(rc);
     if ((rc = upload(h, C.red_of, &dc.red_of))) return bail(rc);
     if ((rc = upload(h, cidx, &dc.cidx_of))) return bail(rc);
+    if ((rc = upload(h, C.orig_of, &dc.orig_of))) return bail(rc);
+    if ((rc = upload(h, C.r_orig, &dc.r_orig))) return bail(rc);
     dc.N = (int32_t)N; dc.nnz = (int32_t)nnz; dc.nvar = (int32_t)nvar; dc.N2 = (int32_t)C.N2; dc.ncs = (int32_t)C.ncs;
     dc.ncond = (int32_t)C.r_orig.size(); dc.cstride = C.cstride;
     if ((rc = dalloc(h, &h->d_cbuf, (size_t)batch * (size_t)C.cstride))) return bail(rc);

@@ -56,7 +56,7 @@ struct DevCond {
   const uint64_t* c_pack;
   int32_t tile_max, chunk_ncon_max, chunk_nslot_max, tiled_ok;
   const int32_t *r_dsrc, *r_ptr, *r_jsrc, *r_jx;
-  const int32_t *red_of, *cidx_of;
+  const int32_t *red_of, *cidx_of, *orig_of, *r_orig;
   int32_t N, nnz, nvar, N2, ncs, ncond;
   int64_t cstride;
 };

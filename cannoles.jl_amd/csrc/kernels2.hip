@@ -142,19 +142,16 @@ struct Ctx2 {
 #define CNL_DECL(k) double r##k;
 // lanes b > row read past the row: harmless garbage in the unused upper triangle (staging is padded)
 #define CNL_LOAD(k) { const int a_ = top - k > 0 ? top - k : 0; r##k = Fs[tri2(a_) + b]; }  /* rows below 0: unused copies of row 0 */
-// multipliers l_a of the current pivot are published once per pivot in LDS (lane b -> lb[i - b]) and read
-// back two rows at a time with one broadcast 16-byte read: a third of the LDS instructions of a
-// ds_bpermute-per-row scheme (the LDS pipe is shared by all waves of the CU and was the bottleneck)
-#define CNL_STEPA(km1, k)                                                          \
-  r##km1 = fma(-lb[1], w, r##k);                                                   \
-  wn = r##km1;                                                                     \
-  dn = bcast_addr(wn, base + (TE_ - 2) * 4);                                       \
-  lvn = fast_div(wn, dn);
+// The pivot row w (one entry per lane, the pivot d in lane i) is published once per pivot in LDS, undivided
+// (lane b -> lb[i - b], so lb[0] = d).  Every lane reads d, forms ITS OWN multiplier lv = w_b / d, and updates
+// its column with  F(a,b) -= w_a * lv  where the w_a come back two rows at a time with one broadcast 16-byte
+// read.  One LDS round trip per pivot sits on the dependent chain (publish -> read), no cross-lane shuffles.
+#define CNL_STEPA(km1, k) r##km1 = fma(-lb[1], lv, r##k);
 #define CNL_STEPP(km1, k, kp1)                                                     \
   {                                                                                \
     const double2 l2_ = *reinterpret_cast<const double2*>(lb + k);                 \
-    r##km1 = fma(-l2_.x, w, r##k);                                                 \
-    r##k = fma(-l2_.y, w, r##kp1);                                                 \
+    r##km1 = fma(-l2_.x, lv, r##k);                                                \
+    r##k = fma(-l2_.y, lv, r##kp1);                                                \
   }
 #define CNL_CHK(k) if (k >= i) goto rows_done;  /* rows i-k >= 1 only (row 0 is the unused rhs-row diagonal) */
 // Update-matrix rows are stored in ASCENDING row order with all lanes active: the lanes b > a of row a
@@ -201,27 +198,22 @@ struct Ctx2 {
     ALL(LOADM)                                                                                                         \
     ESTAMP(7)                                                                                                          \
     int npos = 0, nzer = 0;                                                                                            \
-    int base = grp4 + (top - (TE_ - 1)) * 4;                                                                           \
-    /* software look-ahead: the pivot value, its broadcast and the division of the NEXT pivot row are     */          \
-    /* started as soon as that row has been updated, and overlap the remaining row updates of this pivot */          \
-    double w = r0;                                                                                                     \
-    double dpiv = bcast_addr(w, base + (TE_ - 1) * 4);                                                                 \
-    double lv = fast_div(w, dpiv);                                                                                     \
+    (void)grp4;                                                                                                        \
     for (int i = top; i > nupd; i--) {                                                                                 \
+      const double w = r0;                                                                                             \
+      {                                                                                                                \
+        int li_ = i - b;                                                                                               \
+        li_ = li_ >= 0 ? li_ : TE_ + 1; /* lanes b > i park their value in an unused slot */                           \
+        lb[li_] = w;                                                                                                   \
+      }                                                                                                                \
+      const double dpiv = lb[0];                                                                                       \
+      const double lv = fast_div(w, dpiv);                                                                             \
       npos += dpiv > eig_tol;                                                                                          \
       nzer += fabs(dpiv) <= eig_tol;                                                                                   \
       if (valid && b <= i) Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;                                                \
-      double wn = 0.0, dn = 1.0, lvn = 0.0;                                                                            \
-      {                                                                                                                \
-        int li_ = i - b;                                                                                               \
-        li_ = li_ > 0 ? li_ : 0; /* lanes b >= i park their value in the unused slot 0 */                              \
-        lb[li_] = lv;                                                                                                  \
-      }                                                                                                                \
       if (1 >= i) goto rows_done;                                                                                      \
       STEPS(CNL_STEPP, CNL_CHK, CNL_STEPA)                                                                             \
-    rows_done:                                                                                                         \
-      base -= 4;                                                                                                       \
-      w = wn; dpiv = dn; lv = lvn;                                                                                     \
+    rows_done:;                                                                                                        \
     }                                                                                                                  \
     ESTAMP(5)                                                                                                          \
     if (b == 0) { cnt[gp * 2] += npos; cnt[gp * 2 + 1] += nzer; }                                                      \
@@ -442,19 +434,20 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     }                                                                                  \
   }
 
+// The source indices are read from the LDS record in one batch BEFORE the wave-uniform guards (a read past
+// the end of a list returns unused garbage): one LDS round trip per list instead of one per round.
 #define PREFETCH_VALUES(RECP, AOFF, NASM)                                              \
   {                                                                                    \
     const int na_ = (NASM);                                                            \
     const int* sp_ = (RECP) + (AOFF) + l;                                              \
+    int src_[PVN];                                                                     \
+    _Pragma("unroll") for (int j = 0; j < PVN; j++) src_[j] = sp_[j * 16];             \
     if (unified) {                                                                     \
       _Pragma("unroll") for (int j = 0; j < PVN; j++)                                  \
-        if (j * 16 < na_) pv[j] = myvals[sp_[j * 16]];                                 \
+        if (j * 16 < na_) pv[j] = myvals[src_[j]];                                     \
     } else {                                                                           \
       _Pragma("unroll") for (int j = 0; j < PVN; j++)                                  \
-        if (j * 16 < na_) {                                                            \
-          const int src_ = sp_[j * 16];                                                \
-          pv[j] = *(src_ >= P.nnz ? rhs_or_vals + src_ : myvals + src_);               \
-        }                                                                              \
+        if (j * 16 < na_) pv[j] = *(src_[j] >= P.nnz ? rhs_or_vals + src_[j] : myvals + src_[j]); \
     }                                                                                  \
   }
 
@@ -464,11 +457,10 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
   {                                                                                    \
     const int nr_ = (NRAW);                                                            \
     const int* sp_ = (RECP) + (ROFF) + l;                                              \
+    int src_[PVR];                                                                     \
+    _Pragma("unroll") for (int j = 0; j < PVR; j++) src_[j] = sp_[j * 16];             \
     _Pragma("unroll") for (int j = 0; j < PVR; j++)                                    \
-      if (j * 16 < nr_) {                                                              \
-        const int src_ = sp_[j * 16];                                                  \
-        pvr[j] = *(src_ >= P.nnz ? rhs_or_vals + src_ : myvals + src_);                \
-      }                                                                                \
+      if (j * 16 < nr_) pvr[j] = *(src_[j] >= P.nnz ? rhs_or_vals + src_[j] : myvals + src_[j]); \
   }
 
 // ==========================================================================================
@@ -503,7 +495,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   Ctx2 c;
   c.vals = A.vals; c.rhs = A.rhs; c.L = A.L; c.gs = A.scratch; c.dout = A.d; c.batch = A.batch;
   const double* myvals = A.vals + pclamp * P.vstride;
-  const double* myrhs = (A.mode == MODE_FACTOR || !A.rhs) ? nullptr : A.rhs + pclamp * P.rstride;
+  const bool has_rhs = !(A.mode == MODE_FACTOR || !A.rhs);  // wave-uniform
+  const double* myrhs = has_rhs ? A.rhs + pclamp * P.rstride : nullptr;
   double* mygs = A.scratch + pclamp * P.gs_doubles;
   const double eig_tol = A.params[0];
   const int xpos = A.extra_pos ? A.extra_pos[pclamp] : 0, xzer = A.extra_zer ? A.extra_zer[pclamp] : 0;
@@ -525,7 +518,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     const double* rhs_or_vals = myrhs ? myrhs - P.nnz : myvals - P.nnz;  // base for entries src >= nnz (dummy when no rhs)
     // condensed systems keep [slots | rho | rhs] in ONE buffer: every source is myvals[src], no pointer select
     const bool unified = A.rhs == A.vals + P.nnz && P.rstride == P.vstride;
-    const bool needs_fix = __any(ovr) || !myrhs;  // wave-uniform: some value must be replaced at assembly time
+    const bool needs_fix = __any(ovr) || !has_rhs;  // wave-uniform: some value must be replaced at assembly time
     int4 R0, R1, R2;  // record prefetch registers (named values: an array would be kept in scratch)
     double pv[PVN], pvr[PVR];
 #pragma unroll
@@ -587,7 +580,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         for (int j = 0; j < PVR; j++)
           if (j * 16 < nraw) {
             double v = pvr[j];
-            if (!myrhs) { if (rec[raw_off + j * 16 + l] >= P.nnz) v = 0.0; }
+            if (!has_rhs) { if (rec[raw_off + j * 16 + l] >= P.nnz) v = 0.0; }
             if (j * 16 < nrd) {  // the first nrd raw values are residual pivots d_r: keep -1/d_r
               const double r = fast_div(-1.0, v);
               v = j * 16 + l < nrd ? r : v;
@@ -603,12 +596,13 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       wsync();
       if (!needs_fix) {
         // common case (no rho override in this wave, rhs present): the prefetched values go in as they are
+        // (positions read in one batch ahead of the guards, see PREFETCH_VALUES)
+        int pos[PVN];
+#pragma unroll
+        for (int j = 0; j < PVN; j++) pos[j] = rec[aoff + nasm + j * 16 + l];
 #pragma unroll
         for (int j = 0; j < PVN; j++)
-          if (j * 16 < nasm) {
-            const int pos = rec[aoff + nasm + j * 16 + l];
-            __hip_atomic_fetch_add(&myFs[pos], pv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
+          if (j * 16 < nasm) __hip_atomic_fetch_add(&myFs[pos[j]], pv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       } else {
 #pragma unroll
         for (int j = 0; j < PVN; j++) {
@@ -655,9 +649,18 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
           const int cu = HDRW(cv, C_UOFF), tuc = HDRW(cv, C_TUC), cfl = HDRW(cv, C_FLAGS);
           const int* dest = rec + co + C_HDR;
           if (!cfl) {
-            const double* U = myU + cu;
-            for (int t = l; t < tuc; t += 16)
-              __hip_atomic_fetch_add(&myFs[dest[t]], U[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            // four rounds in flight; reads past the end of the list / matrix are not used
+            const double* U = myU + cu + l;
+            const int* dl = dest + l;
+            for (int t = 0; t < tuc; t += 64) {
+              int dp[4];
+              double uv[4];
+#pragma unroll
+              for (int q = 0; q < 4; q++) { dp[q] = dl[t + 16 * q]; uv[q] = U[t + 16 * q]; }
+#pragma unroll
+              for (int q = 0; q < 4; q++)
+                if (t + 16 * q + l < tuc) __hip_atomic_fetch_add(&myFs[dp[q]], uv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
           } else {
             const double* Ug = mygs + cu;
             for (int t = l; t < tuc; t += 16)

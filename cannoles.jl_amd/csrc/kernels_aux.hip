@@ -21,6 +21,7 @@ __device__ __forceinline__ DevCond globalize(const DevCond& Cin) {
   C.c_ptr = as_global(Cin.c_ptr); C.c_a = as_global(Cin.c_a); C.c_b = as_global(Cin.c_b); C.c_d = as_global(Cin.c_d);
   C.r_dsrc = as_global(Cin.r_dsrc); C.r_ptr = as_global(Cin.r_ptr); C.r_jsrc = as_global(Cin.r_jsrc); C.r_jx = as_global(Cin.r_jx);
   C.red_of = as_global(Cin.red_of); C.cidx_of = as_global(Cin.cidx_of);
+  C.orig_of = as_global(Cin.orig_of); C.r_orig = as_global(Cin.r_orig);
   return C;
 }
 
@@ -154,53 +155,74 @@ __global__ void __launch_bounds__(256) condense_tiled_kernel(const DevCond Cin, 
   }
 }
 
-// pos_r = #{d_r > eig_tol}, zer_r = #{|d_r| <= eig_tol} over the condensed pivots (src/solver_types.jl:90-95)
+// pos_r = #{d_r > eig_tol}, zer_r = #{|d_r| <= eig_tol} over the condensed pivots (src/solver_types.jl:90-95).
+// One workgroup per problem; the counts are written, not accumulated (no memset before the launch).
 __global__ void __launch_bounds__(256) cond_inertia_kernel(const DevCond Cin, const double* __restrict__ vals, int* extra_pos,
                                                            int* extra_zer, double eig_tol, int batch) {
   const DevCond C = globalize(Cin);
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y;
-  if (b >= batch) return;
+  const int b = blockIdx.x;
+  __shared__ int sp[4], sz[4];
+  const double* v = vals + (long long)b * C.nnz;
   int pos = 0, zer = 0;
-  if (q < C.ncond) {
-    const double d = vals[(long long)b * C.nnz + C.r_dsrc[q]];
-    pos = d > eig_tol;
-    zer = fabs(d) <= eig_tol;
+  for (int q = threadIdx.x; q < C.ncond; q += 256) {
+    const double d = v[C.r_dsrc[q]];
+    pos += d > eig_tol;
+    zer += fabs(d) <= eig_tol;
   }
-  // wave reduction, then one atomic per wave (only when non-zero: the common case adds nothing)
-  const unsigned long long mp = __ballot(pos), mz = __ballot(zer);
-  if ((threadIdx.x & 63) == 0) {
-    if (mp) atomicAdd(&extra_pos[b], __popcll(mp));
-    if (mz) atomicAdd(&extra_zer[b], __popcll(mz));
+  for (int o = 32; o > 0; o >>= 1) { pos += __shfl_xor(pos, o, 64); zer += __shfl_xor(zer, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sp[threadIdx.x >> 6] = pos; sz[threadIdx.x >> 6] = zer; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    extra_pos[b] = sp[0] + sp[1] + sp[2] + sp[3];
+    extra_zer[b] = sz[0] + sz[1] + sz[2] + sz[3];
   }
 }
 
 // d_full from the condensed solution d2 (= -K2^-1 crhs): kept nodes copy; condensed r:
 //   sol_r = (rhs_r - sum_k J_rk sol_xk) / d_r,  d_r_out = -sol_r = -(rhs_r + sum_k J_rk d2_xk) / d_r
+// Workgroups [0, nb_copy) copy 256 kept entries each.  The others recover XRB residual components each: the
+// products J_rk d2_xk are formed entry-per-thread (consecutive threads read consecutive Jacobian entries; a
+// thread-per-row loop reads them with a stride of the row length and re-fetches every line from L2 once per
+// column), parked in LDS and summed row-per-thread.
+constexpr int XRB = 256;    // residual rows per workgroup
+constexpr int XEMAX = 2048; // Jacobian entries staged per workgroup (longer chunks take the row-per-thread loop)
 __global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* __restrict__ vals, const double* __restrict__ rhs,
                                                      const double* __restrict__ d2, const double* __restrict__ cbuf,
                                                      double* __restrict__ dout, const int* __restrict__ success,
-                                                     int copy_rho_tail, int batch) {
+                                                     int copy_rho_tail, int nb_copy, int batch) {
   const DevCond C = globalize(Cin);
-  const int i = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
-  if (b >= batch) return;
-  if (copy_rho_tail && i < C.nvar)
-    vals[(long long)b * C.nnz + (C.nnz - C.nvar) + i] = cbuf[(long long)b * C.cstride + C.ncs + i];
-  if (i >= C.N) return;
-  if (success && !success[b]) return;
-  const double* x2 = d2 + (long long)b * C.N2;
-  const int red = C.red_of[i];
-  double out;
-  if (red >= 0) out = x2[red];
-  else {
-    const int q = C.cidx_of[i];
-    const double* v = vals + (long long)b * C.nnz;
-    double s = rhs[(long long)b * C.N + i];
-    for (int k = C.r_ptr[q]; k < C.r_ptr[q + 1]; k++) s += v[C.r_jsrc[k]] * x2[C.r_jx[k]];
-    out = -s / v[C.r_dsrc[q]];
+  const int t = threadIdx.x;
+  __shared__ double prod[XEMAX];
+  if ((int)blockIdx.x < nb_copy) {
+    const int j = blockIdx.x * 256 + t;
+    if (copy_rho_tail && j < C.nvar) vals[(long long)b * C.nnz + (C.nnz - C.nvar) + j] = cbuf[(long long)b * C.cstride + C.ncs + j];
+    if (success && !success[b]) return;
+    if (j < C.N2) dout[(long long)b * C.N + C.orig_of[j]] = d2[(long long)b * C.N2 + j];
+    return;
   }
-  dout[(long long)b * C.N + i] = out;
+  if (success && !success[b]) return;
+  const int q0 = (blockIdx.x - nb_copy) * XRB;
+  const int q1 = q0 + XRB < C.ncond ? q0 + XRB : C.ncond;
+  const int e0 = C.r_ptr[q0], e1 = C.r_ptr[q1];
+  const double* v = vals + (long long)b * C.nnz;
+  const double* x2 = d2 + (long long)b * C.N2;
+  const bool staged = e1 - e0 <= XEMAX;
+  if (staged) {
+    for (int e = e0 + t; e < e1; e += 256) prod[e - e0] = v[C.r_jsrc[e]] * x2[C.r_jx[e]];
+    __syncthreads();
+  }
+  const int q = q0 + t;
+  if (q >= q1) return;
+  const int i = C.r_orig[q];
+  double s = rhs[(long long)b * C.N + i];
+  const int k0 = C.r_ptr[q], k1 = C.r_ptr[q + 1];
+  if (staged) {
+    for (int k = k0; k < k1; k++) s += prod[k - e0];
+  } else {
+    for (int k = k0; k < k1; k++) s = fma(v[C.r_jsrc[k]], x2[C.r_jx[k]], s);
+  }
+  dout[(long long)b * C.N + i] = -fast_div_aux(s, v[C.r_dsrc[q]]);
 }
 
 hipError_t launch_condense(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int slot_begin, int slot_end,
@@ -227,19 +249,15 @@ hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const dou
 
 hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_pos, int* extra_zer, double eig_tol, int batch,
                                hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(extra_pos, 0, sizeof(int) * batch, stream);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(extra_zer, 0, sizeof(int) * batch, stream);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cond_inertia_kernel, dim3((C.ncond + 255) / 256, batch), dim3(256), 0, stream, C, vals, extra_pos, extra_zer, eig_tol, batch);
+  hipLaunchKernelGGL(cond_inertia_kernel, dim3(batch), dim3(256), 0, stream, C, vals, extra_pos, extra_zer, eig_tol, batch);
   return hipGetLastError();
 }
 
 hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, const double* d2, const double* cbuf, double* dout,
                          const int* success, int copy_rho_tail, int batch, hipStream_t stream) {
-  const int n = (int)C.N;
-  hipLaunchKernelGGL(expand_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, C, vals, rhs, d2, cbuf, dout, success,
-                     copy_rho_tail, batch);
+  const int nb_copy = ((int)C.N2 + 255) / 256, nb_r = ((int)C.ncond + XRB - 1) / XRB;
+  hipLaunchKernelGGL(expand_kernel, dim3(nb_copy + nb_r, batch), dim3(256), 0, stream, C, vals, rhs, d2, cbuf, dout, success,
+                     copy_rho_tail, nb_copy, batch);
   return hipGetLastError();
 }
 
