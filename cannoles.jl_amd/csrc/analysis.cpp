@@ -942,6 +942,12 @@ int write_forward_records(Plan& P, const DirectLists* D) {
       if (!rawidx.count(p_.a)) { rawidx[p_.a] = (int32_t)raw.size(); raw.push_back(p_.a); }
       if (!rawidx.count(p_.b)) { rawidx[p_.b] = (int32_t)raw.size(); raw.push_back(p_.b); }
     }
+    // ascending source order inside the two groups: neighbouring lanes gather neighbouring addresses
+    if (!getenv("CNL_NO_RAWSORT")) {
+      std::sort(raw.begin(), raw.begin() + nrd);
+      std::sort(raw.begin() + nrd, raw.end());
+    }
+    for (size_t i = 0; i < raw.size(); i++) rawidx[raw[i]] = (int32_t)i;
     auto why = [&](const char* w) { if (getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] direct records: front %d (order %d): %s (raw %zu, products %zu)\n", s, 1 + F.nupd + F.npiv, w, raw.size(), prs.size()); return 1; };
     if (raw.size() > 1023) return why("more than 1023 raw values");       // descriptor fields are 10 bits
     if (strided && raw.size() > 128) return why("fast front with more than 128 raw values");  // 7-bit fields, LDS area of 128

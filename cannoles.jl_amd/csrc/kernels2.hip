@@ -25,6 +25,11 @@
 
 #include "kernels.h"
 
+// timing experiments only (tests/support/ablate.py): -DCNL_ABL=<bits> removes pieces of the hot path; results are wrong
+#ifndef CNL_ABL
+#define CNL_ABL 0
+#endif
+
 namespace cnl {
 
 namespace {
@@ -210,8 +215,8 @@ struct Ctx2 {
       const double lv = fast_div(w, dpiv);                                                                             \
       npos += dpiv > eig_tol;                                                                                          \
       nzer += fabs(dpiv) <= eig_tol;                                                                                   \
-      if (valid && b <= i) Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;                                                \
-      if (1 >= i) goto rows_done;                                                                                      \
+      if (valid && b <= i && !(CNL_ABL & 64)) Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;                                                \
+      if (1 >= i || (CNL_ABL & 32)) goto rows_done;                                                                    \
       STEPS(CNL_STEPP, CNL_CHK, CNL_STEPA)                                                                             \
     rows_done:;                                                                                                        \
     }                                                                                                                  \
@@ -222,7 +227,7 @@ struct Ctx2 {
         double* Ug = c.gs + pclamp * P_gs_doubles + uoff;                                                              \
         REV(CNL_USTG)                                                                                                  \
       }                                                                                                                \
-    } else {                                                                                                           \
+    } else if (!(CNL_ABL & 128)) {                                                                                     \
       double* Ul = pb + uoff;                                                                                          \
       REV(CNL_USTL)                                                                                                    \
     }                                                                                                                  \
@@ -434,20 +439,19 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     }                                                                                  \
   }
 
-// The source indices are read from the LDS record in one batch BEFORE the wave-uniform guards (a read past
-// the end of a list returns unused garbage): one LDS round trip per list instead of one per round.
+// The source indices are read from the LDS record in one batch (a read past the end of a list returns
+// unused garbage) and EVERY round issues its load: rounds past the end of the list gather entry 0 (one
+// address per problem, cheap).  Loads under wave-uniform guards looked cheaper but made the compiler merge
+// the guarded values with copies and a vmcnt(0) wait right behind the first gather.
 #define PREFETCH_VALUES(RECP, AOFF, NASM)                                              \
   {                                                                                    \
     const int na_ = (NASM);                                                            \
     const int* sp_ = (RECP) + (AOFF) + l;                                              \
     int src_[PVN];                                                                     \
     _Pragma("unroll") for (int j = 0; j < PVN; j++) src_[j] = sp_[j * 16];             \
-    if (unified) {                                                                     \
-      _Pragma("unroll") for (int j = 0; j < PVN; j++)                                  \
-        if (j * 16 < na_) pv[j] = myvals[src_[j]];                                     \
-    } else {                                                                           \
-      _Pragma("unroll") for (int j = 0; j < PVN; j++)                                  \
-        if (j * 16 < na_) pv[j] = *(src_[j] >= P.nnz ? rhs_or_vals + src_[j] : myvals + src_[j]); \
+    _Pragma("unroll") for (int j = 0; j < PVN; j++) {                                  \
+      const int sj_ = j * 16 < na_ ? src_[j] : 0;                                      \
+      pv[j] = *(sj_ >= P.nnz ? rhs_or_vals + sj_ : myvals + sj_);                      \
     }                                                                                  \
   }
 
@@ -459,8 +463,10 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     const int* sp_ = (RECP) + (ROFF) + l;                                              \
     int src_[PVR];                                                                     \
     _Pragma("unroll") for (int j = 0; j < PVR; j++) src_[j] = sp_[j * 16];             \
-    _Pragma("unroll") for (int j = 0; j < PVR; j++)                                    \
-      if (j * 16 < nr_) pvr[j] = *(src_[j] >= P.nnz ? rhs_or_vals + src_[j] : myvals + src_[j]); \
+    _Pragma("unroll") for (int j = 0; j < PVR; j++) {                                  \
+      const int sj_ = j * 16 < nr_ ? src_[j] : 0;                                      \
+      pvr[j] = *(sj_ >= P.nnz ? rhs_or_vals + sj_ : myvals + sj_);                     \
+    }                                                                                  \
   }
 
 // ==========================================================================================
@@ -516,8 +522,6 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     if (l == 0) { cnt[g * 2] = xpos; cnt[g * 2 + 1] = xzer; }
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
     const double* rhs_or_vals = myrhs ? myrhs - P.nnz : myvals - P.nnz;  // base for entries src >= nnz (dummy when no rhs)
-    // condensed systems keep [slots | rho | rhs] in ONE buffer: every source is myvals[src], no pointer select
-    const bool unified = A.rhs == A.vals + P.nnz && P.rstride == P.vstride;
     const bool needs_fix = __any(ovr) || !has_rhs;  // wave-uniform: some value must be replaced at assembly time
     int4 R0, R1, R2;  // record prefetch registers (named values: an array would be kept in scratch)
     double pv[PVN], pvr[PVR];
@@ -561,20 +565,52 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       const bool uglob = flags & RF_U_GLOBAL;
       if (!fast) {
         // rare: large or globally staged front, handled out of line; the prefetch pipeline restarts after it
-        slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, myrhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, rec, roff, pbase0, cnt, eig_tol, rho, ovr);
+        if (!(CNL_ABL & 2048)) slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, myrhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, rec, roff, pbase0, cnt, eig_tol, rho, ovr);
         gsync();
         roff = nxt_off;
         s++;
         primed = false;
         continue;
       }
-      // (1) zero the strided staging image (f rows of 16), (2) assemble the prefetched values (then any overflow)
+      // (1) zero the strided staging image (all 16 rows of 16: no loop, no predicate)
       {
-        double2* z2 = reinterpret_cast<double2*>(myFs);
-        for (int t = l; t < f * 8; t += 16) z2[t] = make_double2(0.0, 0.0);
+        double2* z2 = reinterpret_cast<double2*>(myFs) + l;
+#pragma unroll
+        for (int j = 0; j < 8; j++) z2[16 * j] = make_double2(0.0, 0.0);
       }
+      wsync();
+      // (2) extend-add the children's update matrices: needs nothing from global memory, so the stores of the
+      //     previous front (L rows) retire behind it before the prefetched values are waited for
+      {
+        int co = coff;
+        for (int ci = 0; ci < ((CNL_ABL & 16) ? 0 : nchild); ci++) {
+          const int cv = rec[co + (lane & 3)];
+          const int cu = HDRW(cv, C_UOFF), tuc = HDRW(cv, C_TUC), cfl = HDRW(cv, C_FLAGS);
+          const int* dest = rec + co + C_HDR;
+          if (!cfl) {
+            // four rounds in flight; reads past the end of the list / matrix are not used
+            const double* U = myU + cu + l;
+            const int* dl = dest + l;
+            for (int t = 0; t < tuc; t += 64) {
+              int dp[4];
+              double uv[4];
+#pragma unroll
+              for (int q = 0; q < 4; q++) { dp[q] = dl[t + 16 * q]; uv[q] = U[t + 16 * q]; }
+#pragma unroll
+              for (int q = 0; q < 4; q++)
+                if (t + 16 * q + l < tuc) __hip_atomic_fetch_add(&myFs[dp[q]], uv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+          } else {
+            const double* Ug = mygs + cu;
+            for (int t = l; t < tuc; t += 16)
+              __hip_atomic_fetch_add(&myFs[dest[t]], Ug[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+          co += C_HDR + ((tuc + 3) & ~3);
+        }
+      }
+      // (3) assemble the prefetched values (then any overflow)
       const int raw_off = aoff + 2 * nasm;
-      if (nraw > 0) {
+      if (nraw > 0 && !(CNL_ABL & 4)) {
         // on-the-fly condensation: raw values to LDS (a missing right-hand side reads as zero)
 #pragma unroll
         for (int j = 0; j < PVR; j++)
@@ -602,7 +638,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         for (int j = 0; j < PVN; j++) pos[j] = rec[aoff + nasm + j * 16 + l];
 #pragma unroll
         for (int j = 0; j < PVN; j++)
-          if (j * 16 < nasm) __hip_atomic_fetch_add(&myFs[pos[j]], pv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (j * 16 < nasm && !(CNL_ABL & 2)) __hip_atomic_fetch_add(&myFs[pos[j]], pv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       } else {
 #pragma unroll
         for (int j = 0; j < PVN; j++) {
@@ -623,7 +659,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         else v = (ovr && src >= P.rho_begin) ? rho : myvals[src];
         __hip_atomic_fetch_add(&myFs[pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
-      if (nprod > 0) {
+      if (nprod > 0 && !(CNL_ABL & 1)) {
         // products -J_ra J_rb / d_r of the condensed residual rows: one packed word each, pos | ia<<8 | ib<<15 | id<<22
         // (four rounds in flight: the LDS round trips of a round are dependent, those of different rounds are not)
         wsync();
@@ -641,34 +677,6 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         }
       }
       STAMP(0)
-      // (3) extend-add the children's update matrices
-      {
-        int co = coff;
-        for (int ci = 0; ci < nchild; ci++) {
-          const int cv = rec[co + (lane & 3)];
-          const int cu = HDRW(cv, C_UOFF), tuc = HDRW(cv, C_TUC), cfl = HDRW(cv, C_FLAGS);
-          const int* dest = rec + co + C_HDR;
-          if (!cfl) {
-            // four rounds in flight; reads past the end of the list / matrix are not used
-            const double* U = myU + cu + l;
-            const int* dl = dest + l;
-            for (int t = 0; t < tuc; t += 64) {
-              int dp[4];
-              double uv[4];
-#pragma unroll
-              for (int q = 0; q < 4; q++) { dp[q] = dl[t + 16 * q]; uv[q] = U[t + 16 * q]; }
-#pragma unroll
-              for (int q = 0; q < 4; q++)
-                if (t + 16 * q + l < tuc) __hip_atomic_fetch_add(&myFs[dp[q]], uv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-          } else {
-            const double* Ug = mygs + cu;
-            for (int t = l; t < tuc; t += 16)
-              __hip_atomic_fetch_add(&myFs[dest[t]], Ug[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
-          co += C_HDR + ((tuc + 3) & ~3);
-        }
-      }
       wsync();
       STAMP(2)
       // (4) next record over the current one (nothing below reads the lists); prefetch the one after and the next front's values
@@ -695,8 +703,10 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         R1 = rstream[(nn_off >> 2) + lane + 64];
         R2 = rstream[(nn_off >> 2) + lane + 128];
         const bool nfast = ncls1 == 16 && !(nflags1 & RF_FS_GLOBAL);
+        if (!(CNL_ABL & 8)) {
         PREFETCH_VALUES(nrec, aoff1, nfast ? nasm1 : 0)
         PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nfast ? nraw1 : 0)
+        }
         nxt_off = nn_off;
       }
       STAMP(1)
@@ -704,7 +714,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
 #ifdef CNL_STAMPS
       eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol, st_acc);
 #else
-      eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
+      if (!(CNL_ABL & 1024)) eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
 #endif
       STAMP(3)
       if (uglob) gsync(); else wsync();
@@ -714,7 +724,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     }
     // ---------------- inertia test and rho ladder (src/solver_types.jl:90-97, src/CaNNOLeS.jl:1023-1047) ----
     wsync();
-    const bool ok = cnt[g * 2] == P.nvar && cnt[g * 2 + 1] == 0;
+    const bool ok = (CNL_ABL != 0) || (cnt[g * 2] == P.nvar && cnt[g * 2 + 1] == 0);
     if (A.mode == MODE_FACTOR) {
       if (valid && l == 0) {
         A.success[prob] = ok ? 1 : 0;
@@ -749,7 +759,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   STAMP(5)
   // ---------------- backward pass (d = -K^-1 rhs), only where the factorisation succeeded -----------
   // (problems that failed still walk the stream with the wave; their output is not stored)
-  if (__any(success)) {
+  if (__any(success) && !(CNL_ABL & 256)) {
     const int4* bstream = reinterpret_cast<const int4*>(P.brec);
     const int* okflag = cnt + 8;
     const bool okme = valid && okflag[g] != 0;
@@ -785,7 +795,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       const int f = 1 + nupd + npiv;
       if (cls != 16) {
         // rare large front: out of line, then restart the pipeline
-        if (cls == 32) {
+        if (CNL_ABL & 4096) {
+        } else if (cls == 32) {
           for (int pass = 0; pass < 2; pass++) {
             if (prob0 + pass * 2 >= A.batch) break;
             back_front_call<32>(P.prob_doubles, P.lsize, P.dstride, A.L, A.d, A.batch, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);

@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcannoles_hip.so")
+LIB_PATH = os.environ.get("CANNOLES_HIP_LIB") or os.path.join(_HERE, "libcannoles_hip.so")  # same override as the Julia glue
 
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _lib = None

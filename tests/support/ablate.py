@@ -1,22 +1,62 @@
-import sys, os; sys.path.insert(0,'.')
+"""Timing experiment (not part of the test-suite; run on the GPU box): kernel time of variants of the
+register-front kernel built with -DCNL_ABL=<bits> (pieces of the hot path removed, results wrong).
+Build the variants first (CPU):  python tests/support/ablate.py build 1 2 4 ...
+Run on the GPU:                  python tests/support/ablate.py run 8192 1 2 4 ..."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUTD = os.path.join(ROOT, "build_abl")
+CSRC = os.path.join(ROOT, "cannoles.jl_amd", "csrc")
+
+
+def libpath(bits):
+    return os.path.join(OUTD, f"libcnl_abl{bits}.so")
+
+
+def build(bits_list):
+    os.makedirs(OUTD, exist_ok=True)
+    procs = []
+    for bits in bits_list:
+        cmd = ["make", "-s", "-C", CSRC, "-B", f"OUT={libpath(bits)}", f"CXXFLAGS=-O3 -std=c++17 -fPIC -DCNL_ABL={bits}"]
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        p.wait()
+
+
+def run_one(B, bits):
+    env = dict(os.environ, CANNOLES_HIP_LIB=libpath(bits))
+    code = f"""
+import sys; sys.path.insert(0, {ROOT!r})
 import numpy as np, torch
 import cannoles_jl_amd
 from cannoles_jl_amd import hipldl, synthetic as syn
 import bench
-s = syn.band_structure(10000,50); rows, cols = s.kkt_pattern()
-B = int(sys.argv[1])
+s = syn.band_structure(10000, 50); rows, cols = s.kkt_pattern()
+B = {B}
 vh, rh = bench.band_batch(s, 512, 3000)
-dev = torch.device("cuda",0)
-vals = torch.from_numpy(np.tile(vh,(B//512,1))).to(dev); rhs = torch.from_numpy(np.tile(rh,(B//512,1))).to(dev)
-d = torch.zeros((B,s.N),dtype=torch.float64,device=dev); ro=torch.zeros(B,dtype=torch.float64,device=dev); rho=torch.zeros_like(ro)
-nf=torch.zeros(B,dtype=torch.int32,device=dev); su=torch.zeros_like(nf)
+dev = torch.device("cuda", 0)
+vals = torch.from_numpy(np.tile(vh, (B // 512, 1))).to(dev); rhs = torch.from_numpy(np.tile(rh, (B // 512, 1))).to(dev)
+d = torch.zeros((B, s.N), dtype=torch.float64, device=dev); ro = torch.zeros(B, dtype=torch.float64, device=dev); rho = torch.zeros_like(ro)
+nf = torch.zeros(B, dtype=torch.int32, device=dev); su = torch.zeros_like(nf)
 L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
 L.set_timing(True)
-for fl in (0,1):
-    p = hipldl.default_params(); p[8] = fl
-    ms=[]
-    for it in range(4):
-        ro.zero_()
-        hipldl.newton_system_dev(L, vals.data_ptr(), rhs.data_ptr(), d.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), su.data_ptr(), p, 0)
-        torch.cuda.synchronize(); ms.append(L.last_kernel_ms())
-    print("B",B,"ablate",fl, "kernel ms", np.round(ms[1:],2))
+p = hipldl.default_params()
+ms = []
+for it in range(4):
+    ro.zero_()
+    hipldl.newton_system_dev(L, vals.data_ptr(), rhs.data_ptr(), d.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), su.data_ptr(), p, 0)
+    torch.cuda.synchronize(); ms.append(L.last_kernel_ms())
+print("B", B, "ablate", {bits}, "kernel ms", np.round(ms[1:], 2))
+"""
+    subprocess.run([sys.executable, "-c", code], env=env)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build([int(x) for x in sys.argv[2:]])
+    else:
+        B = int(sys.argv[2])
+        for bits in sys.argv[3:]:
+            run_one(B, int(bits))
