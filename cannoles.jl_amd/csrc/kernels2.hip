@@ -190,7 +190,11 @@ struct Ctx2 {
     const int grp4 = (lane - b) * 4;                                                                                   \
     const int prob = prob0 + gp;                                                                                       \
     const bool valid = prob < c.batch;                                                                                 \
-    const long long pclamp = valid ? prob : prob0;                                                                     \
+    int pc32_ = valid ? prob : prob0;                                                                                  \
+    /* opaque: the per-lane factor base would otherwise be hoisted out of the fronts loop, live across the   */       \
+    /* out-of-line calls, spilled, and every reload from scratch waits for ALL outstanding prefetches (vmcnt) */       \
+    asm volatile("" : "+v"(pc32_));                                                                                    \
+    const long long pclamp = pc32_;                                                                                    \
     double* pb = pbase0 + gp * P_prob_doubles;                                                                         \
     const double* Fs = GFS ? (c.gs + pclamp * P_gs_doubles + fsoff) : (pb + P_u2_peak);                                \
     double* Lp = c.L + pclamp * P_lsize + lptr;                                                                        \
@@ -532,26 +536,40 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     int roff = 0;     // word offset of the current record
     int nxt_off = 0;  // word offset of the next record
     int s = 0;
-    bool primed = false;
+    // Outer loop: (re)start the pipeline at front s, then either hand a rare large front to the out-of-line path
+    // or run the inner loop over a stretch of fast fronts.  The inner loop contains NO call: values that live
+    // across a call are spilled, and every reload from scratch (a VMEM access) waits for all outstanding
+    // prefetches, which used to stall every front.
     while (s < P.nsuper) {
       int* recw = recbuf;
-      if (!primed) {
-        // (re)start the pipeline at front s: record s synchronously, then prefetch record s+1 and the values of s
+      {
+        // record s synchronously, then prefetch record s+1 and the values of s
         int len = P.rec[roff + R_RECLEN];
         nxt_off = roff + len;
         if (len > P.reccap) len = P.reccap;
         for (int w4 = lane; w4 * 4 < len; w4 += 64) reinterpret_cast<int4*>(recw)[w4] = rstream[(roff >> 2) + w4];
         wsync();
+      }
+      {
+        const int hv0 = recw[lane & 15];
+        const bool fast0 = HDRW(hv0, R_CLS) == 16 && !(HDRW(hv0, R_FLAGS) & RF_FS_GLOBAL);
+        if (!fast0) {
+          // rare: large or globally staged front, handled out of line
+          if (!(CNL_ABL & 2048)) slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, has_rhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, recw, roff, pbase0, cnt, eig_tol, rho, ovr);
+          gsync();
+          roff = nxt_off;
+          s++;
+          continue;
+        }
         R0 = rstream[(nxt_off >> 2) + lane];  // stream is padded: over-read is safe
         R1 = rstream[(nxt_off >> 2) + lane + 64];
         R2 = rstream[(nxt_off >> 2) + lane + 128];
-        const int hv0 = recw[lane & 15];
         const int nasm0 = HDRW(hv0, R_NASM), aoff0 = HDRW(hv0, R_ASM_OFF);
-        const bool fast0 = HDRW(hv0, R_CLS) == 16 && !(HDRW(hv0, R_FLAGS) & RF_FS_GLOBAL);
-        PREFETCH_VALUES(recw, aoff0, fast0 ? nasm0 : 0)
-        PREFETCH_RAW(recw, aoff0 + 2 * nasm0, fast0 ? HDRW(hv0, R_NRAW) : 0)
-        primed = true;
+        PREFETCH_VALUES(recw, aoff0, nasm0)
+        PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRAW))
       }
+      bool more = true;
+      while (more) {
       const int* rec = recw;
       const int hv = rec[lane & 15];
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM);
@@ -560,18 +578,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       const int nprod = HDRW(hv, R_NPROD), nraw = HDRW(hv, R_NRAW), nrd = HDRW(hv, R_NRD);
       const long long lptr = (long long)HDRW(hv, R_LPTR_LO) | ((long long)HDRW(hv, R_LPTR_HI) << 31);
       const int f = 1 + nupd + npiv;
-      const bool gfs = flags & RF_FS_GLOBAL;
-      const bool fast = cls == 16 && !gfs;
       const bool uglob = flags & RF_U_GLOBAL;
-      if (!fast) {
-        // rare: large or globally staged front, handled out of line; the prefetch pipeline restarts after it
-        if (!(CNL_ABL & 2048)) slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, myrhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, rec, roff, pbase0, cnt, eig_tol, rho, ovr);
-        gsync();
-        roff = nxt_off;
-        s++;
-        primed = false;
-        continue;
-      }
+      (void)cls;
       // (1) zero the strided staging image (all 16 rows of 16: no loop, no predicate)
       {
         double2* z2 = reinterpret_cast<double2*>(myFs) + l;
@@ -681,6 +689,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       STAMP(2)
       // (4) next record over the current one (nothing below reads the lists); prefetch the one after and the next front's values
       int nroff = nxt_off;
+      more = false;
       if (s + 1 < P.nsuper) {
         int* nrec = recbuf;
         // header words of the next record straight from the prefetch registers: lane q holds words 4q .. 4q+3
@@ -708,6 +717,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nfast ? nraw1 : 0)
         }
         nxt_off = nn_off;
+        more = nfast;  // a large front ends the stretch: the outer loop takes over
       }
       STAMP(1)
       // (5) eliminate in registers, store L rows and the update matrix
@@ -721,6 +731,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       roff = nroff;
       s++;
       STAMP(4)
+      }
     }
     // ---------------- inertia test and rho ladder (src/solver_types.jl:90-97, src/CaNNOLeS.jl:1023-1047) ----
     wsync();
