@@ -85,13 +85,13 @@ __device__ __forceinline__ double bcast_addr(double v, int addr4) {
 
 // w / d through a refined reciprocal: shorter dependent chain than the IEEE expansion (no scaling /
 // fix-up steps; a zero or non-finite pivot still yields inf/NaN, which fails the inertia test anyway)
+// v_rcp_f64 is good to ~2^-25 (measured on gfx950); one Newton step brings the reciprocal to ~10 ulp, and the
+// residual correction of the quotient squares that error away: q' = q + (w - d q) r = (w/d)(1 - eps^2).
 __device__ __forceinline__ double fast_div(double w, double d) {
   double r = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, r, 1.0);
+  const double e = fma(-d, r, 1.0);
   r = fma(r, e, r);
-  e = fma(-d, r, 1.0);
-  r = fma(r, e, r);
-  double q = w * r;
+  const double q = w * r;
   const double res = fma(-d, q, w);
   return fma(res, r, q);
 }
@@ -238,7 +238,86 @@ struct Ctx2 {
   }
 
 // the rare large classes are real calls so that their register needs do not leak into the hot path
-CNL_DEFINE_ELIM(eliminate16, __forceinline__, 16, false, CNL_ALL16, CNL_REV16, CNL_STEPS16, CNL_LOADS)
+// The hot class (order <= 16, strided LDS image) spelled out by hand: per pivot, the pivot d, the first
+// multiplier and ALL row pairs are read back from LDS in one batch right after the row is published, ahead
+// of the division, so one LDS round trip (instead of two) and the division sit on the dependent chain.
+__device__ __forceinline__ void eliminate16(int P_prob_doubles, int P_u2_peak, long long P_gs_doubles, long long P_lsize, double* cL_,
+                                            double* cgs_, int cbatch, int lane, int prob0, int pass, int f, int nupd,
+                                            long long lptr, int uoff, int fsoff, bool uglob, double* pbase0, int* cnt,
+                                            double eig_tol, unsigned long long* st_ = nullptr) {
+  ESTAMP0
+  double* Lg = as_global(cL_);
+  double* gsg = as_global(cgs_);
+  const int gp = lane >> 4;
+  const int b = lane & 15;
+  const int prob = prob0 + gp;
+  const bool valid = prob < cbatch;
+  int pc32_ = valid ? prob : prob0;
+  // opaque: the per-lane factor base would otherwise be hoisted out of the fronts loop and kept alive (or spilled)
+  asm volatile("" : "+v"(pc32_));
+  const long long pclamp = pc32_;
+  double* pb = pbase0 + gp * P_prob_doubles;
+  const double* Fs = pb + P_u2_peak;
+  double* Lp = Lg + pclamp * P_lsize + lptr;
+  const int tu = tri2(1 + nupd);
+  const int top = f - 1;
+  const double* Fss = Fs + (top - 15) * 16 + b;
+  double* lb = pb + P_u2_peak;  // the LDS staging area is dead once the rows are in registers
+  (void)pass; (void)fsoff;
+  CNL_ALL16(CNL_DECL)
+  CNL_ALL16(CNL_LOADS)
+  ESTAMP(7)
+  int npos = 0, nzer = 0;
+  for (int i = top; i > nupd; i--) {
+    const double w = r0;
+    {
+      int li_ = i - b;
+      li_ = li_ >= 0 ? li_ : 17;  // lanes b > i park their value in an unused slot
+      lb[li_] = w;
+    }
+    const double2* lb2 = reinterpret_cast<const double2*>(lb);
+    const double2 p0 = lb2[0], p2 = lb2[1], p4 = lb2[2], p6 = lb2[3], p8 = lb2[4];  // (d, w_{i-1}), (w_{i-2}, w_{i-3}), ...
+    double2 p10 = p8, p12 = p8, p14 = p8;
+    const bool hi = i > 9;  // rows i-10 .. i-15 exist only in large fronts (wave-uniform)
+    if (hi) { p10 = lb2[5]; p12 = lb2[6]; p14 = lb2[7]; }
+    const double dpiv = p0.x;
+    const double lv = fast_div(w, dpiv);
+    npos += dpiv > eig_tol;
+    nzer += fabs(dpiv) <= eig_tol;
+    if (valid && b <= i && !(CNL_ABL & 64)) Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;
+    if (!(CNL_ABL & 32)) {
+      // F(a, b) -= w_a * lv for the remaining rows; register r<k> holds row i-k, the update shifts it to r<k-1>
+      r0 = fma(-p0.y, lv, r1);
+      r1 = fma(-p2.x, lv, r2);
+      r2 = fma(-p2.y, lv, r3);
+      r3 = fma(-p4.x, lv, r4);
+      r4 = fma(-p4.y, lv, r5);
+      r5 = fma(-p6.x, lv, r6);
+      r6 = fma(-p6.y, lv, r7);
+      r7 = fma(-p8.x, lv, r8);
+      r8 = fma(-p8.y, lv, r9);
+      if (hi) {
+        r9 = fma(-p10.x, lv, r10);
+        r10 = fma(-p10.y, lv, r11);
+        r11 = fma(-p12.x, lv, r12);
+        r12 = fma(-p12.y, lv, r13);
+        r13 = fma(-p14.x, lv, r14);
+        r14 = fma(-p14.y, lv, r15);
+      }
+    }
+  }
+  ESTAMP(5)
+  if (b == 0) { cnt[gp * 2] += npos; cnt[gp * 2 + 1] += nzer; }
+  if (uglob) {
+    if (valid) {
+      double* Ug = gsg + pclamp * P_gs_doubles + uoff;
+      CNL_REV16(CNL_USTG)
+    }
+  } else if (!(CNL_ABL & 128)) {
+    double* Ul = pb + uoff;
+    CNL_REV16(CNL_USTL)
+  }
+}
 CNL_DEFINE_ELIM(eliminate16g, __attribute__((noinline)), 16, true, CNL_ALL16, CNL_REV16, CNL_STEPS16, CNL_LOAD)
 CNL_DEFINE_ELIM(eliminate32, __attribute__((noinline)), 32, false, CNL_ALL32, CNL_REV32, CNL_STEPS32, CNL_LOAD)
 CNL_DEFINE_ELIM(eliminate32g, __attribute__((noinline)), 32, true, CNL_ALL32, CNL_REV32, CNL_STEPS32, CNL_LOAD)
