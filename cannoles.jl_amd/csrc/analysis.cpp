@@ -912,16 +912,31 @@ int write_forward_records(Plan& P, const DirectLists* D) {
           }
         }
     }
-    std::stable_sort(pes.begin(), pes.end(), [](const PE& x, const PE& y) { return x.round < y.round || (x.round == y.round && x.src < y.src); });
+    // entries that read the matrix values come first, entries that read the right-hand side last (each group in
+    // rounds padded to 16): a round of the hot path gathers from ONE array, with a wave-uniform base address
+    const int32_t nnz_thr = D ? D->nnz_outer : (int32_t)P.nnz;  // sources >= nnz_thr address the right-hand side
     ivec asrc, apos;
-    for (size_t i = 0; i < pes.size(); i++) {
-      if (i > 0 && pes[i].round != pes[i - 1].round) {
-        int32_t dk = 0;
-        while (asrc.size() % 16) { asrc.push_back(0); apos.push_back(strided ? 1 + (dk++ % 15) : 0); }
+    int32_t nasmv = 0;
+    for (int grp = 0; grp < 2; grp++) {
+      std::vector<PE> sel;
+      for (auto& e : pes) if ((e.src >= nnz_thr) == (grp == 1)) sel.push_back(e);
+      // duplicate rounds are counted inside the group (positions of the two groups are disjoint: rhs row vs the rest)
+      {
+        std::unordered_map<int32_t, int32_t> occ;
+        for (auto& e : sel) e.round = occ[e.pos]++;
       }
-      asrc.push_back(pes[i].src); apos.push_back(pes[i].pos);
+      std::stable_sort(sel.begin(), sel.end(), [](const PE& x, const PE& y) { return x.round < y.round || (x.round == y.round && x.src < y.src); });
+      const int32_t dsrc = grp == 1 ? nnz_thr : 0;  // padding reads entry 0 of the group's array
+      for (size_t i = 0; i < sel.size(); i++) {
+        if (i > 0 && sel[i].round != sel[i - 1].round) {
+          int32_t dk = 0;
+          while (asrc.size() % 16) { asrc.push_back(dsrc); apos.push_back(strided ? 1 + (dk++ % 15) : 0); }
+        }
+        asrc.push_back(sel[i].src); apos.push_back(sel[i].pos);
+      }
+      { int32_t dk = 0; while (asrc.size() % 16) { asrc.push_back(dsrc); apos.push_back(strided ? 1 + (dk++ % 15) : 0); } }
+      if (grp == 0) nasmv = (int32_t)asrc.size();
     }
-    { int32_t dk = 0; while (asrc.size() % 16) { asrc.push_back(0); apos.push_back(strided ? 1 + (dk++ % 15) : 0); } }
     // products of one position go to different rounds of 16 (same-address LDS atomics of one instruction serialise):
     // order by (occurrence of the position, position)
     {
@@ -938,21 +953,32 @@ int write_forward_records(Plan& P, const DirectLists* D) {
     std::unordered_map<int32_t, int32_t> rawidx;
     for (auto& p_ : prs) if (!rawidx.count(p_.d)) { rawidx[p_.d] = (int32_t)raw.size(); raw.push_back(p_.d); }
     nrd = (int32_t)raw.size();
-    for (auto& p_ : prs) {
-      if (!rawidx.count(p_.a)) { rawidx[p_.a] = (int32_t)raw.size(); raw.push_back(p_.a); }
-      if (!rawidx.count(p_.b)) { rawidx[p_.b] = (int32_t)raw.size(); raw.push_back(p_.b); }
-    }
-    // ascending source order inside the two groups: neighbouring lanes gather neighbouring addresses
-    if (!getenv("CNL_NO_RAWSORT")) {
-      std::sort(raw.begin(), raw.begin() + nrd);
-      std::sort(raw.begin() + nrd, raw.end());
-    }
-    for (size_t i = 0; i < raw.size(); i++) rawidx[raw[i]] = (int32_t)i;
     auto why = [&](const char* w) { if (getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] direct records: front %d (order %d): %s (raw %zu, products %zu)\n", s, 1 + F.nupd + F.npiv, w, raw.size(), prs.size()); return 1; };
+    for (int32_t i = 0; i < nrd; i++) if (raw[i] >= nnz_thr) return why("a pivot read from the right-hand side");
+    // layout: [pivots d | other matrix values | pad to 16 | right-hand-side values | pad to 16], ascending source
+    // order inside each group (neighbouring lanes gather neighbouring addresses)
+    ivec rv, rr;
+    {
+      std::unordered_map<int32_t, int32_t> seen;
+      for (int32_t i = 0; i < nrd; i++) seen[raw[i]] = 1;
+      for (auto& p_ : prs)
+        for (int32_t srcq : {p_.a, p_.b})
+          if (!seen.count(srcq)) { seen[srcq] = 1; (srcq >= nnz_thr ? rr : rv).push_back(srcq); }
+    }
+    for (auto& p_ : prs) if (rawidx.count(p_.a) || rawidx.count(p_.b)) return why("a pivot is also an operand");
+    std::sort(raw.begin(), raw.end());
+    std::sort(rv.begin(), rv.end());
+    std::sort(rr.begin(), rr.end());
+    raw.insert(raw.end(), rv.begin(), rv.end());
+    if (!prs.empty()) while (raw.size() % 16) raw.push_back(raw[0]);
+    const int32_t nrawv = (int32_t)raw.size();
+    raw.insert(raw.end(), rr.begin(), rr.end());
+    if (!prs.empty()) while (raw.size() % 16) raw.push_back(rr.empty() ? raw[0] : rr[0]);
+    rawidx.clear();
+    for (size_t i = 0; i < raw.size(); i++) if (!rawidx.count(raw[i])) rawidx[raw[i]] = (int32_t)i;
     if (raw.size() > 1023) return why("more than 1023 raw values");       // descriptor fields are 10 bits
     if (strided && raw.size() > 128) return why("fast front with more than 128 raw values");  // 7-bit fields, LDS area of 128
-    for (auto& p_ : prs) if (rawidx[p_.a] < nrd || rawidx[p_.b] < nrd) return why("a pivot is also an operand");
-    while (raw.size() % 16) raw.push_back(raw.empty() ? 0 : raw[0]);
+    if (strided && (int32_t)raw.size() - nrawv > 32) return why("fast front with more than 32 right-hand-side operands");
     ivec prod;
     {
       int32_t dk = 0;
@@ -986,9 +1012,9 @@ int write_forward_records(Plan& P, const DirectLists* D) {
     int32_t* H = rec.data() + r0;
     H[R_NPIV] = F.npiv; H[R_NUPD] = F.nupd; H[R_RECLEN] = (int32_t)(rec.size() - r0); H[R_NASM] = (int32_t)asrc.size();
     H[R_NCHILD] = F.child_end - F.child_begin; H[R_UOFF] = uoff2[s];
-    H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0); H[R_FSOFF] = fsoff2[s];
-    H[R_LPTR_LO] = F.lptr_lo; H[R_LPTR_HI] = F.lptr_hi; H[R_CLS] = cls[s]; H[R_ASM_OFF] = asm_off; H[R_CHILD_OFF] = child_off;
-    H[R_NPROD] = (int32_t)(strided ? prod.size() : prod.size() / 2); H[R_NRAW] = (int32_t)raw.size(); H[R_NRD] = nrd;
+    H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0) | (cls[s] << 8); H[R_FSOFF] = fsoff2[s];
+    H[R_LPTR_LO] = F.lptr_lo; H[R_LPTR_HI] = F.lptr_hi; H[R_NASMV] = nasmv; H[R_ASM_OFF] = asm_off; H[R_CHILD_OFF] = child_off;
+    H[R_NPROD] = (int32_t)(strided ? prod.size() : prod.size() / 2); H[R_NRAW] = (int32_t)raw.size(); H[R_NRD] = nrd | (nrawv << 16);
     st_raw += H[R_NRAW]; st_prod += H[R_NPROD]; st_asm += H[R_NASM];
     st_rawmax = std::max<int64_t>(st_rawmax, H[R_NRAW]); st_prodmax = std::max<int64_t>(st_prodmax, H[R_NPROD]);
     st_asmmax = std::max<int64_t>(st_asmmax, H[R_NASM]);

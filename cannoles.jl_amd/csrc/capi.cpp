@@ -156,6 +156,7 @@ int setup_v2(cnl_handle* h) {
   if ((rc = upload(h, rec, &d.rec))) return rc;
   if ((rc = upload(h, brec, &d.brec))) return rc;
   d.nsuper = P.nsuper; d.N = (int32_t)P.N; d.nnz = (int32_t)P.nnz; d.rho_begin = P.rho_begin; d.nvar = (int32_t)P.nvar;
+  d.N0 = (int32_t)P.N;
   d.reccap = (P.rec_maxlen + 64 + 3) & ~3;  // + slack: the product loop reads up to 48 words past a list
   d.breccap = (P.brec_maxlen + 3) & ~3;
   d.recwords = std::max(d.reccap, 2 * d.breccap);
@@ -169,6 +170,7 @@ int setup_v2(cnl_handle* h) {
   if (P.rec_direct) {  // the assembly lists address the caller's arrays
     d.nnz = P.nnz_outer; d.rho_begin = P.nnz_outer - (int32_t)P.nvar;
     d.vstride = P.nnz_outer; d.rstride = P.n_outer;
+    d.N0 = P.n_outer;
   }
   const size_t wave_bytes = ((size_t)(d.recwords >> 1) + 4 * (size_t)d.prob_doubles + 8) * sizeof(double);
   size_t maxlds = std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024);

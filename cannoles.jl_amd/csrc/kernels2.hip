@@ -35,7 +35,7 @@ namespace cnl {
 namespace {
 
 constexpr int RN = 3;    // record prefetch: RN x dwordx4 per lane = RN*256 words
-constexpr int PVR = 7;   // raw-value prefetch of the on-the-fly condensation: PVR*16 values per problem
+constexpr int PVR = 6;   // raw-value prefetch of the on-the-fly condensation: PVR*16 matrix values per problem (+ 2 x 16 rhs values)
 constexpr int PVN = 8;   // value prefetch: PVN doubles per lane = PVN*16 entries per problem
 
 __device__ __forceinline__ int tri2(int i) { return (i * (i + 1)) >> 1; }
@@ -417,7 +417,7 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
   double* myFs = myU + P.u2_peak;
   const int npiv = rfl(rec[R_NPIV]), nupd = rfl(rec[R_NUPD]), nasm = rfl(rec[R_NASM]);
   const int nchild = rfl(rec[R_NCHILD]), uoff = rfl(rec[R_UOFF]), flags = rfl(rec[R_FLAGS]), fsoff = rfl(rec[R_FSOFF]);
-  const int cls = rfl(rec[R_CLS]), aoff = rfl(rec[R_ASM_OFF]), coff = rfl(rec[R_CHILD_OFF]);
+  const int cls = flags >> 8, aoff = rfl(rec[R_ASM_OFF]), coff = rfl(rec[R_CHILD_OFF]);
   const long long lptr = (long long)rfl(rec[R_LPTR_LO]) | ((long long)rfl(rec[R_LPTR_HI]) << 31);
   const int f = 1 + nupd + npiv;
   const int tf = tri2(f);
@@ -522,34 +522,41 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     }                                                                                  \
   }
 
-// The source indices are read from the LDS record in one batch (a read past the end of a list returns
-// unused garbage) and EVERY round issues its load: rounds past the end of the list gather entry 0 (one
-// address per problem, cheap).  Loads under wave-uniform guards looked cheaper but made the compiler merge
-// the guarded values with copies and a vmcnt(0) wait right behind the first gather.
-#define PREFETCH_VALUES(RECP, AOFF, NASM)                                              \
+// Value prefetch of the NEXT front.  The lists of a record hold the entries that read the matrix values first and
+// the entries that read the right-hand side last, so every round of 16 gathers from one array: the address is a
+// wave-uniform base (SGPR pair) plus a 32-bit per-lane byte offset.  All source indices are read from the LDS
+// record in one batch; rounds past the end of a list are skipped (the texture addresser is the busiest shared
+// unit of this kernel) and their register is set to zero: a plain "keep the old value" made the compiler merge the
+// guarded values through copies, with a vmcnt(0) wait right behind the first gather.
+#define GATHER_V(SRC) (*reinterpret_cast<const double*>(vals_wb + (((unsigned)(SRC) << 3) + gofs_v)))
+#define GATHER_R(SRC) (*reinterpret_cast<const double*>(rhs_wb + (((unsigned)(SRC) << 3) + gofs_r)))
+#define PREFETCH_VALUES(RECP, AOFF, NASMV, NASM)                                       \
   {                                                                                    \
-    const int na_ = (NASM);                                                            \
+    const int nv_ = (NASMV);                                                           \
     const int* sp_ = (RECP) + (AOFF) + l;                                              \
-    int src_[PVN];                                                                     \
+    int src_[PVN + 1];                                                                 \
     _Pragma("unroll") for (int j = 0; j < PVN; j++) src_[j] = sp_[j * 16];             \
+    src_[PVN] = sp_[nv_];                                                              \
     _Pragma("unroll") for (int j = 0; j < PVN; j++) {                                  \
-      const int sj_ = j * 16 < na_ ? src_[j] : 0;                                      \
-      pv[j] = *(sj_ >= P.nnz ? rhs_or_vals + sj_ : myvals + sj_);                      \
+      if (j * 16 < nv_) pv[j] = GATHER_V(src_[j]); else pv[j] = 0.0;                   \
     }                                                                                  \
+    if (nv_ < (NASM)) prh = GATHER_R(src_[PVN]); else prh = 0.0;                       \
   }
-
 // Raw values (Jacobian entries, residual pivots, residual right-hand sides) of the products a front's
-// condensed slots are made of: same scheme as PREFETCH_VALUES.
-#define PREFETCH_RAW(RECP, ROFF, NRAW)                                                 \
+// condensed slots are made of: same scheme.
+#define PREFETCH_RAW(RECP, ROFF, NRAWV, NRAW)                                          \
   {                                                                                    \
-    const int nr_ = (NRAW);                                                            \
+    const int nv_ = (NRAWV), nr_ = (NRAW);                                             \
     const int* sp_ = (RECP) + (ROFF) + l;                                              \
-    int src_[PVR];                                                                     \
+    int src_[PVR + 2];                                                                 \
     _Pragma("unroll") for (int j = 0; j < PVR; j++) src_[j] = sp_[j * 16];             \
+    src_[PVR] = sp_[nv_];                                                              \
+    src_[PVR + 1] = sp_[nv_ + 16];                                                     \
     _Pragma("unroll") for (int j = 0; j < PVR; j++) {                                  \
-      const int sj_ = j * 16 < nr_ ? src_[j] : 0;                                      \
-      pvr[j] = *(sj_ >= P.nnz ? rhs_or_vals + sj_ : myvals + sj_);                     \
+      if (j * 16 < nv_) pvr[j] = GATHER_V(src_[j]); else pvr[j] = 0.0;                 \
     }                                                                                  \
+    if (nv_ < nr_) prr[0] = GATHER_R(src_[PVR]); else prr[0] = 0.0;                    \
+    if (nv_ + 16 < nr_) prr[1] = GATHER_R(src_[PVR + 1]); else prr[1] = 0.0;           \
   }
 
 // ==========================================================================================
@@ -589,6 +596,13 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   double* mygs = A.scratch + pclamp * P.gs_doubles;
   const double eig_tol = A.params[0];
   const int xpos = A.extra_pos ? A.extra_pos[pclamp] : 0, xzer = A.extra_zer ? A.extra_zer[pclamp] : 0;
+  // gathers: wave-uniform bases of the first problem of the wave + 32-bit byte offsets (4 problems span < 4 GB)
+  const int prob0u = __builtin_amdgcn_readfirstlane(prob0);
+  const char* vals_wb = reinterpret_cast<const char*>(A.vals + (long long)prob0u * P.vstride);
+  const char* rhs_wb = has_rhs ? reinterpret_cast<const char*>(A.rhs + (long long)prob0u * P.rstride) : vals_wb;
+  const unsigned gsel = valid ? (unsigned)g : 0u;
+  const unsigned gofs_v = gsel * (unsigned)P.vstride * 8u;
+  const unsigned gofs_r = (gsel * (unsigned)(has_rhs ? P.rstride : P.vstride) - (unsigned)P.nnz) * 8u;  // rhs sources are nnz + index
 
   // per-problem ladder state, replicated over the 16 lanes of the group
   double rho = 0.0, wrote = 0.0;
@@ -604,14 +618,14 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     // ---------------- forward pass over the record stream ----------------
     if (l == 0) { cnt[g * 2] = xpos; cnt[g * 2 + 1] = xzer; }
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
-    const double* rhs_or_vals = myrhs ? myrhs - P.nnz : myvals - P.nnz;  // base for entries src >= nnz (dummy when no rhs)
     const bool needs_fix = __any(ovr) || !has_rhs;  // wave-uniform: some value must be replaced at assembly time
     int4 R0, R1, R2;  // record prefetch registers (named values: an array would be kept in scratch)
-    double pv[PVN], pvr[PVR];
+    double pv[PVN], pvr[PVR], prr[2], prh = 0.0;
 #pragma unroll
     for (int j = 0; j < PVN; j++) pv[j] = 0.0;
 #pragma unroll
     for (int j = 0; j < PVR; j++) pvr[j] = 0.0;
+    prr[0] = prr[1] = 0.0;
     int roff = 0;     // word offset of the current record
     int nxt_off = 0;  // word offset of the next record
     int s = 0;
@@ -631,7 +645,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       }
       {
         const int hv0 = recw[lane & 15];
-        const bool fast0 = HDRW(hv0, R_CLS) == 16 && !(HDRW(hv0, R_FLAGS) & RF_FS_GLOBAL);
+        const int fw0 = HDRW(hv0, R_FLAGS);  // flags | class << 8
+        const bool fast0 = (fw0 >> 8) == 16 && !(fw0 & RF_FS_GLOBAL);
         if (!fast0) {
           // rare: large or globally staged front, handled out of line
           if (!(CNL_ABL & 2048)) slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, has_rhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, recw, roff, pbase0, cnt, eig_tol, rho, ovr);
@@ -644,8 +659,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         R1 = rstream[(nxt_off >> 2) + lane + 64];
         R2 = rstream[(nxt_off >> 2) + lane + 128];
         const int nasm0 = HDRW(hv0, R_NASM), aoff0 = HDRW(hv0, R_ASM_OFF);
-        PREFETCH_VALUES(recw, aoff0, nasm0)
-        PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRAW))
+        PREFETCH_VALUES(recw, aoff0, HDRW(hv0, R_NASMV), nasm0)
+        PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRD) >> 16, HDRW(hv0, R_NRAW))
       }
       bool more = true;
       while (more) {
@@ -653,12 +668,12 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       const int hv = rec[lane & 15];
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM);
       const int nchild = HDRW(hv, R_NCHILD), uoff = HDRW(hv, R_UOFF), flags = HDRW(hv, R_FLAGS), fsoff = HDRW(hv, R_FSOFF);
-      const int cls = HDRW(hv, R_CLS), aoff = HDRW(hv, R_ASM_OFF), coff = HDRW(hv, R_CHILD_OFF);
-      const int nprod = HDRW(hv, R_NPROD), nraw = HDRW(hv, R_NRAW), nrd = HDRW(hv, R_NRD);
+      const int nasmv = HDRW(hv, R_NASMV), aoff = HDRW(hv, R_ASM_OFF), coff = HDRW(hv, R_CHILD_OFF);
+      const int nprod = HDRW(hv, R_NPROD), nraw = HDRW(hv, R_NRAW), nrdw = HDRW(hv, R_NRD);
+      const int nrd = nrdw & 0xffff, nrawv = nrdw >> 16;
       const long long lptr = (long long)HDRW(hv, R_LPTR_LO) | ((long long)HDRW(hv, R_LPTR_HI) << 31);
       const int f = 1 + nupd + npiv;
       const bool uglob = flags & RF_U_GLOBAL;
-      (void)cls;
       // (1) zero the strided staging image (all 16 rows of 16: no loop, no predicate)
       {
         double2* z2 = reinterpret_cast<double2*>(myFs) + l;
@@ -698,53 +713,57 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       // (3) assemble the prefetched values (then any overflow)
       const int raw_off = aoff + 2 * nasm;
       if (nraw > 0 && !(CNL_ABL & 4)) {
-        // on-the-fly condensation: raw values to LDS (a missing right-hand side reads as zero)
+        // on-the-fly condensation: raw values to LDS, matrix values first (the first nrd are the residual pivots
+        // d_r: keep -1/d_r), then the right-hand-side operands (a missing right-hand side reads as zero)
 #pragma unroll
         for (int j = 0; j < PVR; j++)
-          if (j * 16 < nraw) {
+          if (j * 16 < nrawv) {
             double v = pvr[j];
-            if (!has_rhs) { if (rec[raw_off + j * 16 + l] >= P.nnz) v = 0.0; }
-            if (j * 16 < nrd) {  // the first nrd raw values are residual pivots d_r: keep -1/d_r
+            if (j * 16 < nrd) {
               const double r = fast_div(-1.0, v);
               v = j * 16 + l < nrd ? r : v;
             }
             jraw[j * 16 + l] = v;
           }
-        for (int e = PVR * 16 + l; e < nraw; e += 16) {
-          const int src = rec[raw_off + e];
-          const double v = src >= P.nnz ? (myrhs ? myrhs[src - P.nnz] : 0.0) : myvals[src];
+        for (int e = PVR * 16 + l; e < nrawv; e += 16) {
+          const double v = myvals[rec[raw_off + e]];
           jraw[e] = e < nrd ? fast_div(-1.0, v) : v;
         }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+          if (nrawv + q * 16 < nraw) jraw[nrawv + q * 16 + l] = has_rhs ? prr[q] : 0.0;
       }
       wsync();
-      if (!needs_fix) {
-        // common case (no rho override in this wave, rhs present): the prefetched values go in as they are
-        // (positions read in one batch ahead of the guards, see PREFETCH_VALUES)
-        int pos[PVN];
+      {
+        // positions read in one batch ahead of the guards (see PREFETCH_VALUES); the prefetched values go in as they
+        // are unless some problem of the wave overrides rho
+        int pos[PVN + 1];
 #pragma unroll
         for (int j = 0; j < PVN; j++) pos[j] = rec[aoff + nasm + j * 16 + l];
+        pos[PVN] = rec[aoff + nasm + nasmv + l];
+        if (!needs_fix) {
 #pragma unroll
-        for (int j = 0; j < PVN; j++)
-          if (j * 16 < nasm && !(CNL_ABL & 2)) __hip_atomic_fetch_add(&myFs[pos[j]], pv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      } else {
+          for (int j = 0; j < PVN; j++)
+            if (j * 16 < nasmv && !(CNL_ABL & 2)) __hip_atomic_fetch_add(&myFs[pos[j]], pv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
 #pragma unroll
-        for (int j = 0; j < PVN; j++) {
-          const int e = j * 16 + l;
-          if (j * 16 < nasm) {
-            const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
-            double v = pv[j];
-            if (src >= P.nnz) { if (!myrhs) v = 0.0; }
-            else if (ovr && src >= P.rho_begin) v = rho;
-            __hip_atomic_fetch_add(&myFs[pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
+          for (int j = 0; j < PVN; j++)
+            if (j * 16 < nasmv) {
+              const int src = rec[aoff + j * 16 + l];
+              const double v = (ovr && src >= P.rho_begin) ? rho : pv[j];
+              __hip_atomic_fetch_add(&myFs[pos[j]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
         }
+        if (nasmv < nasm) __hip_atomic_fetch_add(&myFs[pos[PVN]], has_rhs ? prh : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
-      for (int e = PVN * 16 + l; e < nasm; e += 16) {
+      for (int e = PVN * 16 + l; e < nasmv; e += 16) {  // matrix entries beyond the prefetched rounds
         const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
-        double v = 0.0;
-        if (src >= P.nnz) v = myrhs ? myrhs[src - P.nnz] : 0.0;
-        else v = (ovr && src >= P.rho_begin) ? rho : myvals[src];
+        const double v = (ovr && src >= P.rho_begin) ? rho : myvals[src];
         __hip_atomic_fetch_add(&myFs[pos], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      for (int e = nasmv + 16 + l; e < nasm; e += 16) {  // right-hand-side entries beyond the prefetched round
+        const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
+        __hip_atomic_fetch_add(&myFs[pos], myrhs ? myrhs[src - P.nnz] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
       if (nprod > 0 && !(CNL_ABL & 1)) {
         // products -J_ra J_rb / d_r of the condensed residual rows: one packed word each, pos | ia<<8 | ib<<15 | id<<22
@@ -774,11 +793,12 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         // header words of the next record straight from the prefetch registers: lane q holds words 4q .. 4q+3
         const int nlen = __builtin_amdgcn_readlane(R0.z, 0);          // R_RECLEN = 2
         const int nasm1 = __builtin_amdgcn_readlane(R0.w, 0);         // R_NASM = 3
-        const int nflags1 = __builtin_amdgcn_readlane(R0.z, 1);       // R_FLAGS = 6
-        const int ncls1 = __builtin_amdgcn_readlane(R0.z, 2);         // R_CLS = 10
+        const int nflags1 = __builtin_amdgcn_readlane(R0.z, 1);       // R_FLAGS = 6 (flags | class << 8)
+        const int nasmv1 = __builtin_amdgcn_readlane(R0.z, 2);        // R_NASMV = 10
         const int aoff1 = __builtin_amdgcn_readlane(R0.w, 2);         // R_ASM_OFF = 11
         const int nraw1 = __builtin_amdgcn_readlane(R0.z, 3);         // R_NRAW = 14
-        static_assert(R_RECLEN == 2 && R_NASM == 3 && R_FLAGS == 6 && R_CLS == 10 && R_ASM_OFF == 11 && R_NRAW == 14, "record header layout");
+        const int nrawv1 = __builtin_amdgcn_readlane(R0.w, 3) >> 16;  // R_NRD = 15 (nrd | nrawv << 16)
+        static_assert(R_RECLEN == 2 && R_NASM == 3 && R_FLAGS == 6 && R_NASMV == 10 && R_ASM_OFF == 11 && R_NRAW == 14 && R_NRD == 15, "record header layout");
         const int clen = nlen < P.reccap ? nlen : P.reccap;   // globally staged fronts keep only their head in LDS
         if (lane * 4 < clen) reinterpret_cast<int4*>(nrec)[lane] = R0;
         if ((lane + 64) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 64] = R1;
@@ -790,10 +810,10 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         R0 = rstream[(nn_off >> 2) + lane];
         R1 = rstream[(nn_off >> 2) + lane + 64];
         R2 = rstream[(nn_off >> 2) + lane + 128];
-        const bool nfast = ncls1 == 16 && !(nflags1 & RF_FS_GLOBAL);
+        const bool nfast = (nflags1 >> 8) == 16 && !(nflags1 & RF_FS_GLOBAL);
         if (!(CNL_ABL & 8)) {
-        PREFETCH_VALUES(nrec, aoff1, nfast ? nasm1 : 0)
-        PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nfast ? nraw1 : 0)
+        PREFETCH_VALUES(nrec, aoff1, nfast ? nasmv1 : 0, nfast ? nasm1 : 0)
+        PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nfast ? nrawv1 : 0, nfast ? nraw1 : 0)
         }
         nxt_off = nn_off;
         more = nfast;  // a large front ends the stretch: the outer loop takes over

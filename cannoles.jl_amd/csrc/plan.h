@@ -100,7 +100,7 @@ int write_forward_records(Plan& P, const DirectLists* D);
 
 // record layouts shared by analysis.cpp (writer) and kernels2.hip (reader)
 enum {
-  R_NPIV = 0, R_NUPD, R_RECLEN, R_NASM, R_NCHILD, R_UOFF, R_FLAGS, R_FSOFF, R_LPTR_LO, R_LPTR_HI, R_CLS,
+  R_NPIV = 0, R_NUPD, R_RECLEN, R_NASM, R_NCHILD, R_UOFF, R_FLAGS, R_FSOFF, R_LPTR_LO, R_LPTR_HI, R_NASMV,
   R_ASM_OFF, R_CHILD_OFF, R_NPROD, R_NRAW, R_NRD, R_HDR = 16
 };
 enum { RF_U_GLOBAL = 1, RF_FS_GLOBAL = 2 };
