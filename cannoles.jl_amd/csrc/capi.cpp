@@ -172,6 +172,8 @@ int setup_v2(cnl_handle* h) {
     d.vstride = P.nnz_outer; d.rstride = P.n_outer;
     d.N0 = P.n_outer;
   }
+  // the kernel addresses vals / rhs / L of the 4 problems of a wave with 32-bit byte offsets from the first one
+  if (4 * 8 * (uint64_t)std::max<int64_t>({d.lsize, d.vstride, d.rstride, d.dstride, (int64_t)d.nnz + d.N0}) >= (1ull << 32)) return CNL_OK;
   const size_t wave_bytes = ((size_t)(d.recwords >> 1) + 4 * (size_t)d.prob_doubles + 8) * sizeof(double);
   size_t maxlds = std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024);
   if (wave_bytes + 512 > maxlds) return CNL_OK;  // does not fit: stay on v1

@@ -258,8 +258,11 @@ __device__ __forceinline__ void eliminate16(int P_prob_doubles, int P_u2_peak, l
   const long long pclamp = pc32_;
   double* pb = pbase0 + gp * P_prob_doubles;
   const double* Fs = pb + P_u2_peak;
-  double* Lp = Lg + pclamp * P_lsize + lptr;
+  // factor rows: wave-uniform base + 32-bit byte offset (the 4 problems of a wave span < 4 GB)
+  const int prob0u = __builtin_amdgcn_readfirstlane(prob0);
+  char* L_wb = reinterpret_cast<char*>(Lg + (long long)prob0u * P_lsize + lptr);
   const int tu = tri2(1 + nupd);
+  const unsigned lofs = ((valid ? (unsigned)gp : 0u) * (unsigned)P_lsize + (unsigned)b - (unsigned)tu) * 8u;
   const int top = f - 1;
   const double* Fss = Fs + (top - 15) * 16 + b;
   double* lb = pb + P_u2_peak;  // the LDS staging area is dead once the rows are in registers
@@ -284,7 +287,8 @@ __device__ __forceinline__ void eliminate16(int P_prob_doubles, int P_u2_peak, l
     const double lv = fast_div(w, dpiv);
     npos += dpiv > eig_tol;
     nzer += fabs(dpiv) <= eig_tol;
-    if (valid && b <= i && !(CNL_ABL & 64)) Lp[tri2(i) - tu + b] = (b == i) ? dpiv : lv;
+    if (valid && b <= i && !(CNL_ABL & 64))
+      *reinterpret_cast<double*>(L_wb + (lofs + ((unsigned)tri2(i) << 3))) = (b == i) ? dpiv : lv;
     if (!(CNL_ABL & 32)) {
       // F(a, b) -= w_a * lv for the remaining rows; register r<k> holds row i-k, the update shifts it to r<k-1>
       r0 = fma(-p0.y, lv, r1);
@@ -512,13 +516,15 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
 // First KB rows of a front's L panel, lane l takes entry l of each row (row k of the panel starts
 // k(k+1)/2 + k*(nupd+1) doubles after the panel start).  No clamps: lanes past the end of a row and
 // rows past the last pivot read finite data that is never used (the factor storage is zero-padded).
-#define PREFETCH_ROWS(DST, LPTR, NUPD)                                                 \
+// Same addressing as the forward gathers (wave-uniform base + 32-bit byte offset); rows past the last pivot are
+// not loaded.
+#define PREFETCH_ROWS(DST, LPTR, NUPD, NPIV)                                           \
   {                                                                                    \
-    const double* rp_ = myL + (LPTR) + l;                                              \
-    int ro_ = 0;                                                                       \
+    const char* rb_ = L_wb + ((long long)(LPTR) << 3);                                 \
+    unsigned ro_ = gofs_l;                                                             \
     _Pragma("unroll") for (int k = 0; k < KB; k++) {                                   \
-      DST[k] = rp_[ro_];                                                               \
-      ro_ += (NUPD) + 2 + k;                                                           \
+      if (k < (NPIV)) DST[k] = *reinterpret_cast<const double*>(rb_ + ro_); else DST[k] = 0.0; \
+      ro_ += (unsigned)((NUPD) + 2 + k) << 3;                                          \
     }                                                                                  \
   }
 
@@ -874,6 +880,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     const int* okflag = cnt + 8;
     const bool okme = valid && okflag[g] != 0;
     const double* myL = A.L + pclamp * P.lsize;
+    const char* L_wb = reinterpret_cast<const char*>(A.L + (long long)prob0u * P.lsize);
+    const unsigned gofs_l = (gsel * (unsigned)P.lsize + (unsigned)l) * 8u;
     double* mydout = A.d + pclamp * P.dstride;
     double* xs = myU;  // the x stack reuses the per-problem LDS area
     constexpr int KB = 8;
@@ -893,8 +901,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         const int hb0 = recw[lane & 7];
         const int nupd0 = HDRW(hb0, B_NUPD), npiv0 = HDRW(hb0, B_NPIV);
         const long long lp0 = (long long)HDRW(hb0, B_LPTR_LO) | ((long long)HDRW(hb0, B_LPTR_HI) << 31);
-        (void)npiv0;
-        PREFETCH_ROWS(lr, lp0, nupd0)
+        PREFETCH_ROWS(lr, lp0, nupd0, npiv0)
         primed = true;
       }
       const int* rec = recw;
@@ -940,8 +947,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         const int nn = nxt + nlen;
         Rb = bstream[(nn >> 2) + lane];
         nxt = nn;
-        (void)npiv1;
-        PREFETCH_ROWS(lrn, lp1, nupd1)
+        PREFETCH_ROWS(lrn, lp1, nupd1, npiv1)
       } else {
 #pragma unroll
         for (int k = 0; k < KB; k++) lrn[k] = lr[k];
