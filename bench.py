@@ -155,6 +155,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # SURVEY 8 row f1 (vectors either side of the system, device-resident): timed after the headline region, on the
+    # same shapes; algorithmic bytes = J_F and J_c values + r, lambda, F, c read + rhs written (resp. x, r, lambda, d
+    # read + xt, rt, lambdat, dlambda written)
+    f1 = None
+    if rank == 0:
+        rv = torch.randn((B, s.nequ), dtype=torch.float64, device=dev)
+        lam = torch.randn((B, max(s.ncon, 1)), dtype=torch.float64, device=dev)
+        Fx = torch.randn((B, s.nequ), dtype=torch.float64, device=dev)
+        cx = torch.randn((B, max(s.ncon, 1)), dtype=torch.float64, device=dev)
+        xv = torch.randn((B, s.nvar), dtype=torch.float64, device=dev)
+        rhs2 = torch.empty_like(rhs)
+        nrm = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+        xt, rt, lt, dl = torch.empty_like(xv), torch.empty_like(rv), torch.empty_like(lam), torch.empty_like(lam)
+
+        def timed(fn, reps=5):
+            with torch.cuda.stream(stream):
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(reps):
+                    fn()
+                e1.record(stream)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        ms_rv = timed(lambda: hipldl.residual_vectors_dev(LDLT, vals.data_ptr(), rv.data_ptr(), lam.data_ptr(), Fx.data_ptr(),
+                                                          cx.data_ptr(), rhs2.data_ptr(), nrm.data_ptr(), sh))
+        ms_tp = timed(lambda: hipldl.trial_point_dev(LDLT, xv.data_ptr(), rv.data_ptr(), lam.data_ptr(), d.data_ptr(), 1e4,
+                                                     xt.data_ptr(), rt.data_ptr(), lt.data_ptr(), dl.data_ptr(), sh))
+        nnzj = len(s.jF[0]) + len(s.jc[0])
+        by_rv = 8 * (nnzj + 2 * s.nequ + 2 * s.ncon + s.N)
+        by_tp = 8 * (s.nvar + s.nequ + s.ncon + s.N + s.nvar + s.nequ + 2 * s.ncon)
+        f1 = {"residual_vectors": {"ms": ms_rv, "bytes_per_system": by_rv, "GBps": by_rv * B / (ms_rv * 1e-3) / 1e9,
+                                   "frac": by_rv * B / (ms_rv * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+              "trial_point": {"ms": ms_tp, "bytes_per_system": by_tp, "GBps": by_tp * B / (ms_tp * 1e-3) / 1e9,
+                              "frac": by_tp * B / (ms_tp * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+        del rv, lam, Fx, cx, xv, rhs2, nrm, xt, rt, lt, dl
+
     ok = bool((succ == 1).all().item())
     # parity guard inside the bench: residual of the first problems (size-independent property)
     nchk = min(B, 4)
@@ -195,6 +233,7 @@ def main():
                          "bytes_per_system": b_alg, "kernel_ms": kern_ms, "kernel": "newton2_kernel",
                          "step_ms": step_ms, "step_frac": b_alg * B / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         }
+        out["aux_f1"] = f1  # not part of `value`: rhs assembly + norms, trial point, roofline = HBM
         # CPU baseline: the oracle (restated LDLFactorizations path) on a bounded sample, 1 thread
         ncpu = args.cpu_sample
         if ncpu != 0 and world >= 1:

@@ -56,6 +56,7 @@ struct cnl_handle {
   bool timing = false;
   float last_ms = 0.f;
   bool factorized = false;
+  cnl::DevJt djt{};  // transposed-Jacobian lists (row f1: residual / optimality vectors on the device)
 };
 
 namespace {
@@ -484,6 +485,31 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   if (hipStreamCreate(&h->stream) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipStreamCreate failed"));
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)
     return bail(fail(CNL_ERR_HIP, "hipEventCreate failed"));
+  {
+    // transposed-Jacobian lists from the pattern: entries with column <= nvar < row, in COO order per column
+    std::vector<int32_t> ptrF(nvar + 1, 0), ptrC(nvar + 1, 0), slotF, idxF, slotC, idxC;
+    for (int64_t e = 0; e < nnz; e++) {
+      const int64_t r0 = rows1[e] - 1, c0 = cols1[e] - 1;
+      if (c0 < nvar && r0 >= nvar) (r0 < nvar + nequ ? ptrF : ptrC)[c0 + 1]++;
+    }
+    for (int64_t j2 = 0; j2 < nvar; j2++) { ptrF[j2 + 1] += ptrF[j2]; ptrC[j2 + 1] += ptrC[j2]; }
+    slotF.resize(ptrF[nvar]); idxF.resize(ptrF[nvar]); slotC.resize(ptrC[nvar]); idxC.resize(ptrC[nvar]);
+    std::vector<int32_t> fillF(ptrF.begin(), ptrF.end() - 1), fillC(ptrC.begin(), ptrC.end() - 1);
+    for (int64_t e = 0; e < nnz; e++) {
+      const int64_t r0 = rows1[e] - 1, c0 = cols1[e] - 1;
+      if (!(c0 < nvar && r0 >= nvar)) continue;
+      if (r0 < nvar + nequ) { const int32_t q = fillF[c0]++; slotF[q] = (int32_t)e; idxF[q] = (int32_t)(r0 - nvar); }
+      else { const int32_t q = fillC[c0]++; slotC[q] = (int32_t)e; idxC[q] = (int32_t)(r0 - nvar - nequ); }
+    }
+    cnl::DevJt& J = h->djt;
+    if ((rc = upload(h, ptrF, &J.ptrF))) return bail(rc);
+    if ((rc = upload(h, slotF, &J.slotF))) return bail(rc);
+    if ((rc = upload(h, idxF, &J.idxF))) return bail(rc);
+    if ((rc = upload(h, ptrC, &J.ptrC))) return bail(rc);
+    if ((rc = upload(h, slotC, &J.slotC))) return bail(rc);
+    if ((rc = upload(h, idxC, &J.idxC))) return bail(rc);
+    J.nvar = (int32_t)nvar; J.nequ = (int32_t)nequ; J.ncon = (int32_t)ncon; J.N = (int32_t)N; J.nnz = (int32_t)nnz;
+  }
   *hout = h;
   return CNL_OK;
 }
@@ -502,6 +528,27 @@ int cnl_destroy(cnl_handle* h) {
 }
 
 const cnl_plan* cnl_get_plan(const cnl_handle* h) { return h ? h->plan : nullptr; }
+
+int cnl_residual_vectors_dev(cnl_handle* h, const double* d_vals, const double* d_r, const double* d_lambda, const double* d_Fx,
+                             const double* d_cx, double* d_rhs, double* d_norms, void* stream) {
+  if (!h || !d_vals || !d_r || !d_Fx || !d_rhs || !d_norms) return fail(CNL_ERR_ARG, "null argument");
+  if (h->djt.ncon > 0 && (!d_lambda || !d_cx)) return fail(CNL_ERR_ARG, "lambda / c are required when ncon > 0");
+  HIPCHK(hipSetDevice(h->device));
+  hipError_t e = cnl::launch_residual_vectors(h->djt, d_vals, d_r, d_lambda, d_Fx, d_cx, d_rhs, d_norms, (int)h->batch, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("residual_vectors: ") + hipGetErrorString(e));
+  return CNL_OK;
+}
+
+int cnl_trial_point_dev(cnl_handle* h, const double* d_x, const double* d_r, const double* d_lambda, const double* d_d,
+                        double max_dlambda, double* d_xt, double* d_rt, double* d_lambdat, double* d_dlambda, void* stream) {
+  if (!h || !d_x || !d_r || !d_d || !d_xt || !d_rt) return fail(CNL_ERR_ARG, "null argument");
+  if (h->djt.ncon > 0 && (!d_lambda || !d_lambdat || !d_dlambda)) return fail(CNL_ERR_ARG, "lambda vectors are required when ncon > 0");
+  HIPCHK(hipSetDevice(h->device));
+  hipError_t e = cnl::launch_trial_point(h->djt, d_x, d_r, d_lambda, d_d, max_dlambda, d_xt, d_rt, d_lambdat, d_dlambda, (int)h->batch,
+                                         (hipStream_t)stream);
+  if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("trial_point: ") + hipGetErrorString(e));
+  return CNL_OK;
+}
 
 int cnl_set_timing(cnl_handle* h, int enable) {
   if (!h) return fail(CNL_ERR_ARG, "null handle");

@@ -62,6 +62,14 @@ struct DevCond {
   int64_t cstride;
 };
 
+// Transposed-Jacobian lists of the KKT pattern: for every variable column j the entries of
+// J_F and J_c in COO order, as (slot in vals, index into r resp. lambda).
+struct DevJt {
+  const int32_t *ptrF, *slotF, *idxF;  // [nvar + 1], [nnz(J_F)] x 2
+  const int32_t *ptrC, *slotC, *idxC;  // [nvar + 1], [nnz(J_c)] x 2
+  int32_t nvar, nequ, ncon, N, nnz;
+};
+
 enum { MODE_NEWTON = 0, MODE_FACTOR = 1, MODE_SOLVE = 2 };
 
 struct LaunchArgs {
@@ -93,6 +101,11 @@ hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const dou
                                  int batch, hipStream_t stream);
 hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_pos, int* extra_zer, double eig_tol, int batch,
                                hipStream_t stream);
+hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const double* r, const double* lambda, const double* Fx,
+                                   const double* cx, double* rhs, double* norms, int batch, hipStream_t stream);
+hipError_t launch_trial_point(const DevJt& J, const double* x, const double* r, const double* lambda, const double* d,
+                              double max_dlambda, double* xt, double* rt, double* lambdat, double* dlambda, int batch,
+                              hipStream_t stream);
 hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, const double* d2, const double* cbuf, double* dout,
                          const int* success, int copy_rho_tail, int batch, hipStream_t stream);
 // largest dynamic LDS a workgroup may use on the current device

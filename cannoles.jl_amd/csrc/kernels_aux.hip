@@ -225,6 +225,134 @@ __global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* 
   dout[(long long)b * C.N + i] = -fast_div_aux(s, v[C.r_dsrc[q]]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row f1 of the scope table: the vectors either side of the Newton system, kept on the device.
+//   dual   = Jx' r - Jc' lambda      /root/reference/src/CaNNOLeS.jl:507-508, 519-521 (and 722-724 at the trial point)
+//   primal = [F - r ; c]             :522-524 (725-726)
+//   rhs    = [dual ; primal]         :631-632
+//   norms  = (||dual||_inf, ||primal||_inf)   :528-529 (730-731)
+// The Jacobian values are read from the J_F / J_c segments of `vals` (prepare_newton_system! copies them there,
+// :953-967).  Both transposed products are accumulated per column in COO order, which is the order of the
+// reference's COO mul! (y[col[k]] += val[k] * x[row[k]] for k = 1, 2, ...), and subtracted afterwards as the
+// reference does: the results are bit-identical to that recipe.
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
+  // the bit patterns of non-negative doubles (and of NaN, which must win like in norm(., Inf)) are ordered as integers
+  atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// One thread serves entry i of RPT problems: the index lists are read once and the launch has RPT times fewer
+// wavefronts (with one problem per thread the kernel is bound by the wavefront launch rate).
+constexpr int RPT = 4;
+__global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, const double* __restrict__ vals,
+                                                               const double* __restrict__ r, const double* __restrict__ lambda,
+                                                               const double* __restrict__ Fx, const double* __restrict__ cx,
+                                                               double* __restrict__ rhs, double* __restrict__ norms, int batch) {
+#pragma clang fp contract(off)  // separately rounded multiply and add, as the reference's scalar loops
+  DevJt J = Jin;
+  J.ptrF = as_global(Jin.ptrF); J.slotF = as_global(Jin.slotF); J.idxF = as_global(Jin.idxF);
+  J.ptrC = as_global(Jin.ptrC); J.slotC = as_global(Jin.slotC); J.idxC = as_global(Jin.idxC);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * RPT;
+  long long bq[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; q++) bq[q] = b0 + q < batch ? b0 + q : batch - 1;
+  double out[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; q++) out[q] = 0.0;
+  const bool is_dual = i < J.nvar;
+  if (i < J.N) {
+    if (is_dual) {
+      double s1[RPT], s2[RPT];
+#pragma unroll
+      for (int q = 0; q < RPT; q++) s1[q] = s2[q] = 0.0;
+      for (int k = J.ptrF[i]; k < J.ptrF[i + 1]; k++) {
+        const int sl = J.slotF[k], ix = J.idxF[k];
+#pragma unroll
+        for (int q = 0; q < RPT; q++) { const double t_ = vals[bq[q] * J.nnz + sl] * r[bq[q] * J.nequ + ix]; s1[q] = s1[q] + t_; }
+      }
+      for (int k = J.ptrC[i]; k < J.ptrC[i + 1]; k++) {
+        const int sl = J.slotC[k], ix = J.idxC[k];
+#pragma unroll
+        for (int q = 0; q < RPT; q++) { const double t_ = vals[bq[q] * J.nnz + sl] * lambda[bq[q] * J.ncon + ix]; s2[q] = s2[q] + t_; }
+      }
+#pragma unroll
+      for (int q = 0; q < RPT; q++) out[q] = s1[q] - s2[q];
+    } else if (i < J.nvar + J.nequ) {
+#pragma unroll
+      for (int q = 0; q < RPT; q++) out[q] = Fx[bq[q] * J.nequ + (i - J.nvar)] - r[bq[q] * J.nequ + (i - J.nvar)];
+    } else {
+#pragma unroll
+      for (int q = 0; q < RPT; q++) out[q] = cx[bq[q] * J.ncon + (i - J.nvar - J.nequ)];
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; q++)
+      if (b0 + q < batch) rhs[bq[q] * J.N + i] = out[q];
+  }
+  // infinity norms: a workgroup holds entries of one kind except the (at most two) that straddle a boundary.
+  // NaN must propagate as in norm(., Inf): fmax drops it, so the integer images are compared (they are ordered like
+  // the non-negative doubles, NaN above infinity).
+#pragma unroll
+  for (int q = 0; q < RPT; q++) {
+    const double ad = (i < J.N && is_dual) ? fabs(out[q]) : 0.0, ap = (i < J.N && !is_dual) ? fabs(out[q]) : 0.0;
+    unsigned long long ud = (unsigned long long)__double_as_longlong(ad), up = (unsigned long long)__double_as_longlong(ap);
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long od = __shfl_xor(ud, o, 64), op = __shfl_xor(up, o, 64);
+      ud = od > ud ? od : ud;
+      up = op > up ? op : up;
+    }
+    if ((threadIdx.x & 63) == 0 && b0 + q < batch) {
+      if (ud) atomicMax(reinterpret_cast<unsigned long long*>(norms + 2 * bq[q]), ud);
+      if (up) atomicMax(reinterpret_cast<unsigned long long*>(norms + 2 * bq[q] + 1), up);
+    }
+  }
+}
+
+// Trial point of the extrapolation step, /root/reference/src/CaNNOLeS.jl:661-668 with dlambda = -d[n+m+1:N] (:654):
+//   xt = x + dx, rt = r + dr, dlambda capped at ||dlambda||_2 <= max_dlambda (1e4), lambdat = lambda + dlambda.
+// One workgroup per problem.
+__global__ void __launch_bounds__(256) trial_point_kernel(const DevJt J, const double* __restrict__ x, const double* __restrict__ r,
+                                                          const double* __restrict__ lambda, const double* __restrict__ d,
+                                                          double max_dlambda, double* __restrict__ xt, double* __restrict__ rt,
+                                                          double* __restrict__ lambdat, double* __restrict__ dlambda, int batch) {
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const double* db = d + (long long)b * J.N;
+  __shared__ double part[4];
+  double ss = 0.0;
+  for (int k = t; k < J.ncon; k += 256) { const double v = db[J.nvar + J.nequ + k]; ss += v * v; }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if ((t & 63) == 0) part[t >> 6] = ss;
+  __syncthreads();
+  const double nrm = sqrt(part[0] + part[1] + part[2] + part[3]);
+  const double scale = nrm > max_dlambda ? max_dlambda / nrm : 1.0;
+  for (int k = t; k < J.nvar; k += 256) xt[(long long)b * J.nvar + k] = x[(long long)b * J.nvar + k] + db[k];
+  for (int k = t; k < J.nequ; k += 256) rt[(long long)b * J.nequ + k] = r[(long long)b * J.nequ + k] + db[J.nvar + k];
+  for (int k = t; k < J.ncon; k += 256) {
+    double dl = -db[J.nvar + J.nequ + k];
+    if (nrm > max_dlambda) dl = dl * max_dlambda / nrm;  // same operation order as dλ .= dλ .* Mdλ ./ norm(dλ)
+    (void)scale;
+    dlambda[(long long)b * J.ncon + k] = dl;
+    lambdat[(long long)b * J.ncon + k] = lambda[(long long)b * J.ncon + k] + dl;
+  }
+}
+
+hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const double* r, const double* lambda, const double* Fx,
+                                   const double* cx, double* rhs, double* norms, int batch, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(norms, 0, sizeof(double) * 2 * (size_t)batch, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(residual_vectors_kernel, dim3((J.N + 255) / 256, (batch + RPT - 1) / RPT), dim3(256), 0, stream, J, vals, r, lambda, Fx, cx, rhs,
+                     norms, batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_trial_point(const DevJt& J, const double* x, const double* r, const double* lambda, const double* d,
+                              double max_dlambda, double* xt, double* rt, double* lambdat, double* dlambda, int batch,
+                              hipStream_t stream) {
+  hipLaunchKernelGGL(trial_point_kernel, dim3(batch), dim3(256), 0, stream, J, x, r, lambda, d, max_dlambda, xt, rt, lambdat, dlambda,
+                     batch);
+  return hipGetLastError();
+}
+
 hipError_t launch_condense(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int slot_begin, int slot_end,
                            int batch, hipStream_t stream) {
   const int n = slot_end - slot_begin;

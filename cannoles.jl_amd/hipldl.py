@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "cnl_factorize", "cnl_solve", "cnl_newton_system",
     "cnl_factorize_dev", "cnl_solve_dev", "cnl_newton_system_dev",
     "cnl_set_timing", "cnl_last_kernel_ms", "cnl_get_config",
+    "cnl_residual_vectors_dev", "cnl_trial_point_dev",
 ]
 
 
@@ -73,6 +74,8 @@ def lib():
         L.cnl_factorize_dev.argtypes = [vp, vp, dbl, vp, vp]
         L.cnl_solve_dev.argtypes = [vp, vp, vp, vp]
         L.cnl_newton_system_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cnl_residual_vectors_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cnl_trial_point_dev.argtypes = [vp, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp]
         L.cnl_set_timing.argtypes = [vp, C.c_int]
         L.cnl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cnl_get_config.argtypes = [vp, _i64p]
@@ -268,3 +271,17 @@ def newton_system_dev(LDLT, vals_ptr, rhs_ptr, d_ptr, rho_old_ptr, rho_ptr, nfac
     params = np.ascontiguousarray(params, dtype=np.float64)
     _check(lib().cnl_newton_system_dev(LDLT._h, vals_ptr, rhs_ptr, d_ptr, rho_old_ptr, rho_ptr, nfact_ptr, success_ptr,
                                        params.ctypes.data, stream))
+
+
+def residual_vectors_dev(LDLT, vals_ptr, r_ptr, lambda_ptr, Fx_ptr, cx_ptr, rhs_ptr, norms_ptr, stream=0):
+    """rhs = [dual; primal] with dual = Jx' r - Jc' lambda, primal = [F - r; c], and their infinity norms
+    (src/CaNNOLeS.jl:507-508,519-524,528-529,631-632), batched and device-resident (cnl_residual_vectors_dev).
+    All *_ptr are device addresses; norms_ptr receives [batch][2] doubles."""
+    _check(lib().cnl_residual_vectors_dev(LDLT._h, vals_ptr, r_ptr, lambda_ptr, Fx_ptr, cx_ptr, rhs_ptr, norms_ptr, stream))
+
+
+def trial_point_dev(LDLT, x_ptr, r_ptr, lambda_ptr, d_ptr, max_dlambda, xt_ptr, rt_ptr, lambdat_ptr, dlambda_ptr, stream=0):
+    """xt = x + dx, rt = r + dr, dlambda = -d[n+m+1:N] capped at max_dlambda in the 2-norm, lambdat = lambda + dlambda
+    (src/CaNNOLeS.jl:654,661-668), batched and device-resident (cnl_trial_point_dev)."""
+    _check(lib().cnl_trial_point_dev(LDLT._h, x_ptr, r_ptr, lambda_ptr, d_ptr, float(max_dlambda), xt_ptr, rt_ptr, lambdat_ptr,
+                                     dlambda_ptr, stream))

@@ -109,6 +109,24 @@ int cnl_solve_dev(cnl_handle* h, const double* d_rhs, double* d_d, void* stream)
 int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, double* d_d, double* d_rho_old,
                           double* d_rho, int32_t* d_nfact, int32_t* d_success, const double params[9], void* stream);
 
+/* ---- vectors either side of the Newton system, device-resident ------------------
+ * They let `rhs` and `d` stay in HBM between inner iterations instead of crossing PCIe every call.
+ *
+ * cnl_residual_vectors_dev: rhs = [dual ; primal] and their infinity norms, as src/CaNNOLeS.jl computes them at
+ * :507-508, :519-524, :528-529 (start), :722-726, :730-731 (trial point) and assembles at :631-632:
+ *     dual = Jx' r - Jc' lambda,   primal = [F - r ; c],   norms[2b] = ||dual||_inf, norms[2b+1] = ||primal||_inf.
+ * The Jacobian values are read from the J_F / J_c segments of `vals` (prepare_newton_system!, :953-967).  Both
+ * products are accumulated per column in COO order (the order of the reference's COO mul!) and then subtracted.
+ * Batched layouts: r, Fx [batch][nequ]; lambda, cx [batch][ncon] (may be NULL when ncon == 0); rhs [batch][N].   */
+int cnl_residual_vectors_dev(cnl_handle* h, const double* d_vals, const double* d_r, const double* d_lambda, const double* d_Fx,
+                             const double* d_cx, double* d_rhs, double* d_norms, void* stream);
+
+/* cnl_trial_point_dev: the extrapolation step's trial point, src/CaNNOLeS.jl:654,661-668:
+ *     xt = x + d[1:n],  rt = r + d[n+1:n+m],  dlambda = -d[n+m+1:N], scaled by max_dlambda/||dlambda||_2 when that
+ *     norm exceeds max_dlambda (the reference uses 1e4),  lambdat = lambda + dlambda.                               */
+int cnl_trial_point_dev(cnl_handle* h, const double* d_x, const double* d_r, const double* d_lambda, const double* d_d,
+                        double max_dlambda, double* d_xt, double* d_rt, double* d_lambdat, double* d_dlambda, void* stream);
+
 /* Device time, in milliseconds, of the multifrontal kernel (the dominant kernel) of the last call,
  * measured with HIP events on the call's stream.  Enabling timing makes every call synchronise on
  * its stream, so it is meant for measurement loops, not for production (0 if not enabled).      */

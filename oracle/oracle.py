@@ -212,3 +212,45 @@ def newton_system_batch(LDLT, B, nvar, nequ, ncon, rhs, vals, rho_old, params):
                                    None if ro is None else ro.ctypes.data, _f64(params), LDLT.set_mode,
                                    out.reshape(-1))
     return d, out[:, 0].astype(bool), out[:, 1].copy(), out[:, 2].copy(), out[:, 3].astype(np.int64)
+
+
+# ---- vectors either side of the Newton system --------------------------------------------
+def residual_vectors(rows, cols, vals, nvar, nequ, ncon, r, lam, Fx, cx):
+    """Restates /root/reference/src/CaNNOLeS.jl:507-508,519-524,528-529 (and :722-726,730-731 at the trial
+    point) and the rhs assembly :631-632 for ONE problem:
+        Jxtr = Jx' r; Jcxtλ = Jc' λ  (SparseMatricesCOO mul!: y[col[k]] += val[k] * x[row[k]] for k = 1, 2, ...)
+        dual = Jxtr - Jcxtλ; primal = [Fx - r; cx]; rhs = [dual; primal]; norms = (‖dual‖∞, ‖primal‖∞).
+    The Jacobian values are the J_F / J_c segments of `vals` (prepare_newton_system!, :953-967), identified in the
+    pattern (1-based `rows`, `cols`) as the entries with column <= nvar < row.  Pure-Python loops: small cases only.
+    Test infrastructure, not part of the product."""
+    rows = np.asarray(rows); cols = np.asarray(cols); vals = np.asarray(vals, dtype=np.float64)
+    Jxtr = np.zeros(nvar); Jcxtl = np.zeros(nvar)
+    for k in range(len(rows)):
+        i, j = int(rows[k]) - 1, int(cols[k]) - 1
+        if j < nvar <= i:
+            if i < nvar + nequ:
+                Jxtr[j] += vals[k] * r[i - nvar]
+            else:
+                Jcxtl[j] += vals[k] * lam[i - nvar - nequ]
+    dual = Jxtr - Jcxtl
+    primal = np.concatenate([np.asarray(Fx, dtype=np.float64) - np.asarray(r, dtype=np.float64),
+                             np.asarray(cx, dtype=np.float64) if ncon else np.zeros(0)])
+    rhs = np.concatenate([dual, primal])
+
+    def ninf(v):  # norm(v, Inf): NaN propagates, empty -> 0
+        return float(np.max(np.abs(v))) if len(v) and not np.isnan(v).any() else (float("nan") if len(v) else 0.0)
+
+    return rhs, (ninf(dual), ninf(primal))
+
+
+def trial_point(nvar, nequ, ncon, x, r, lam, d, max_dlambda=1e4):
+    """Restates /root/reference/src/CaNNOLeS.jl:654,661-668: dλ = -d[n+m+1:N]; xt = x + dx; rt = r + dr;
+    if norm(dλ) > Mdλ: dλ = dλ * Mdλ / norm(dλ); λt = λ + dλ.  Returns (xt, rt, λt, dλ)."""
+    d = np.asarray(d, dtype=np.float64)
+    dl = -d[nvar + nequ:nvar + nequ + ncon]
+    xt = np.asarray(x, dtype=np.float64) + d[:nvar]
+    rt = np.asarray(r, dtype=np.float64) + d[nvar:nvar + nequ]
+    nrm = float(np.sqrt(np.sum(dl * dl)))
+    if nrm > max_dlambda:
+        dl = dl * max_dlambda / nrm
+    return xt, rt, np.asarray(lam, dtype=np.float64) + dl, dl

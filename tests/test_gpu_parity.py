@@ -221,3 +221,81 @@ def test_cfg3_batch_properties_full_size(built):
     hipldl.solve_ldl_(rhs, LDLT.factor, d3)
     assert np.abs(d3 - d1).max() <= 1e-10 * np.abs(d1).max()
     LDLT.close()
+
+
+# ---- residual / optimality vectors and trial point, device-resident -------------------------
+def _f1_inputs(s, B, seed):
+    hipldl, syn, O = _mods()
+    rng = np.random.default_rng(seed)
+    if s.name == "band":
+        vals, _ = syn.batch_values(s, B, cfg=4)
+    else:
+        vals = np.stack([syn.random_values(s, seed * 100 + b)[0] for b in range(B)])
+    r = rng.standard_normal((B, s.nequ))
+    lam = rng.standard_normal((B, max(s.ncon, 1)))[:, :s.ncon]
+    Fx = rng.standard_normal((B, s.nequ))
+    cx = rng.standard_normal((B, max(s.ncon, 1)))[:, :s.ncon]
+    return np.ascontiguousarray(vals), r, np.ascontiguousarray(lam), Fx, np.ascontiguousarray(cx)
+
+
+@pytest.mark.parametrize("kind", ["band", "random", "nocon"])
+def test_f1_residual_vectors_bit_exact(built, kind):
+    """rhs = [Jx'r - Jc'λ; F - r; c] and the two infinity norms: per-column COO-order sums, bit-identical to the
+    restated COO mul! (src/CaNNOLeS.jl:507-508,519-524,528-529,631-632)."""
+    import torch
+    hipldl, syn, O = _mods()
+    B = 6
+    if kind == "band":
+        s = syn.band_structure(1000, 10)
+    elif kind == "random":
+        s = syn.random_structure(40, 55, 7, 0.15, seed=3)
+    else:
+        s = syn.random_structure(30, 45, 0, 0.15, seed=5)
+    vals, r, lam, Fx, cx = _f1_inputs(s, B, 11)
+    if kind == "random":
+        r[2, 3] = np.nan  # NaN must reach dual and its norm, as in norm(., Inf)
+    rows, cols = s.kkt_pattern()
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tv, tr, tl, tF, tc = t(vals), t(r), t(lam), t(Fx), t(cx)
+    trhs = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
+    tn = torch.full((B, 2), -1.0, dtype=torch.float64, device=dev)
+    hipldl.residual_vectors_dev(LDLT, tv.data_ptr(), tr.data_ptr(), tl.data_ptr() if s.ncon else 0, tF.data_ptr(),
+                                tc.data_ptr() if s.ncon else 0, trhs.data_ptr(), tn.data_ptr(), 0)
+    torch.cuda.synchronize()
+    rhs, nrm = trhs.cpu().numpy(), tn.cpu().numpy()
+    for b in range(B):
+        rhs0, (nd0, np0) = O.residual_vectors(rows, cols, vals[b], s.nvar, s.nequ, s.ncon, r[b], lam[b], Fx[b], cx[b])
+        assert np.array_equal(rhs[b], rhs0, equal_nan=True)
+        assert np.array_equal(nrm[b], np.array([nd0, np0]), equal_nan=True)
+
+
+def test_f1_trial_point(built):
+    """xt, rt, λt, dλ of the extrapolation step (src/CaNNOLeS.jl:654,661-668), with and without the 1e4 cap on ‖dλ‖."""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(1000, 10)
+    B = 4
+    rng = np.random.default_rng(5)
+    rows, cols = s.kkt_pattern()
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    x, r, lam = rng.standard_normal((B, s.nvar)), rng.standard_normal((B, s.nequ)), rng.standard_normal((B, s.ncon))
+    d = rng.standard_normal((B, s.N))
+    d[1, s.nvar + s.nequ:] *= 1e5  # cap active for problem 1
+    d[3, s.nvar + s.nequ:] = 0.0
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tx, tr, tl, td = t(x), t(r), t(lam), t(d)
+    txt, trt, tlt, tdl = torch.zeros_like(tx), torch.zeros_like(tr), torch.zeros_like(tl), torch.zeros_like(tl)
+    hipldl.trial_point_dev(LDLT, tx.data_ptr(), tr.data_ptr(), tl.data_ptr(), td.data_ptr(), 1e4, txt.data_ptr(), trt.data_ptr(),
+                           tlt.data_ptr(), tdl.data_ptr(), 0)
+    torch.cuda.synchronize()
+    for b in range(B):
+        xt0, rt0, lt0, dl0 = O.trial_point(s.nvar, s.nequ, s.ncon, x[b], r[b], lam[b], d[b], 1e4)
+        assert np.array_equal(txt[b].cpu().numpy(), xt0)
+        assert np.array_equal(trt[b].cpu().numpy(), rt0)
+        # the 2-norm is reduced in a different order: a few ulp on the scaled entries
+        np.testing.assert_allclose(tdl[b].cpu().numpy(), dl0, rtol=4e-15, atol=0)
+        np.testing.assert_allclose(tlt[b].cpu().numpy(), lt0, rtol=4e-15, atol=1e-300)
+    assert np.linalg.norm(tdl[1].cpu().numpy()) <= 1e4 * (1 + 1e-14)

@@ -115,3 +115,40 @@ def test_oracle_rejects_malformed():
         O.Oracle(3, [1, 2, 5], [1, 1, 1])
     with pytest.raises(ValueError):
         O.Oracle(3, [1, 2, 3], [1, 2, 3], perm=[0, 0, 1])
+
+
+# ---- numpy restatements of the vectors either side of the Newton system ------------------------
+def test_f1_residual_vectors_oracle_matches_dense():
+    """O.residual_vectors (COO-order transposed products, src/CaNNOLeS.jl:507-524) against dense J' products."""
+    import cannoles_jl_amd  # noqa: F401
+    from cannoles_jl_amd import synthetic as syn
+    from oracle import oracle as O
+    s = syn.random_structure(25, 40, 6, 0.2, seed=9)
+    vals, _ = syn.random_values(s, 4)
+    rows, cols = s.kkt_pattern()
+    rng = np.random.default_rng(2)
+    r, lam, Fx, cx = rng.standard_normal(s.nequ), rng.standard_normal(s.ncon), rng.standard_normal(s.nequ), rng.standard_normal(s.ncon)
+    rhs, (nd, npr) = O.residual_vectors(rows, cols, vals, s.nvar, s.nequ, s.ncon, r, lam, Fx, cx)
+    K = np.zeros((s.N, s.N))
+    np.add.at(K, (rows - 1, cols - 1), vals)
+    JF = K[s.nvar:s.nvar + s.nequ, :s.nvar]
+    Jc = K[s.nvar + s.nequ:, :s.nvar]
+    dual = JF.T @ r - Jc.T @ lam
+    np.testing.assert_allclose(rhs[:s.nvar], dual, rtol=1e-13, atol=1e-13)
+    assert np.array_equal(rhs[s.nvar:s.nvar + s.nequ], Fx - r)
+    assert np.array_equal(rhs[s.nvar + s.nequ:], cx)
+    assert nd == np.abs(rhs[:s.nvar]).max() and npr == np.abs(rhs[s.nvar:]).max()
+
+
+def test_f1_trial_point_oracle():
+    from oracle import oracle as O
+    n, m, p = 5, 7, 3
+    rng = np.random.default_rng(0)
+    x, r, lam, d = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(p), rng.standard_normal(n + m + p)
+    xt, rt, lt, dl = O.trial_point(n, m, p, x, r, lam, d)
+    assert np.array_equal(xt, x + d[:n]) and np.array_equal(rt, r + d[n:n + m])
+    assert np.array_equal(dl, -d[n + m:]) and np.array_equal(lt, lam - d[n + m:])
+    d[n + m:] *= 1e6
+    _, _, lt2, dl2 = O.trial_point(n, m, p, x, r, lam, d)
+    assert abs(np.linalg.norm(dl2) - 1e4) <= 1e-8
+    np.testing.assert_allclose(lt2, lam + dl2)
