@@ -172,6 +172,7 @@ int setup_v2(cnl_handle* h) {
     d.nnz = P.nnz_outer; d.rho_begin = P.nnz_outer - (int32_t)P.nvar;
     d.vstride = P.nnz_outer; d.rstride = P.n_outer;
     d.N0 = P.n_outer;
+    if (P.d_outer) d.dstride = P.n_outer;
   }
   // the kernel addresses vals / rhs / L of the 4 problems of a wave with 32-bit byte offsets from the first one
   if (4 * 8 * (uint64_t)std::max<int64_t>({d.lsize, d.vstride, d.rstride, d.dstride, (int64_t)d.nnz + d.N0}) >= (1ull << 32)) return CNL_OK;
@@ -224,9 +225,10 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
     if (direct && a.mode == cnl::MODE_NEWTON) {
       e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
       if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
-      a.vals = d_vals; a.rhs = d_rhs; a.d = h->d_d2; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
+      const bool d_outer = h->plan->P.d_outer;  // the kernel writes the kept components of d itself
+      a.vals = d_vals; a.rhs = d_rhs; a.d = d_outer ? d_d : h->d_d2; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
       if ((rc = launch(h, a, stream))) return rc;
-      e = cnl::launch_expand(h->dc, d_vals, d_rhs, h->d_d2, h->d_cbuf, d_d, a.success, 0, B, stream);
+      e = cnl::launch_expand(h->dc, d_vals, d_rhs, d_outer ? nullptr : h->d_d2, h->d_cbuf, d_d, a.success, 0, B, stream);
       if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
     } else if (direct && a.mode == cnl::MODE_FACTOR) {
       e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
@@ -332,6 +334,18 @@ int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows
     const int32_t old_len = p->P.rec_maxlen;
     const size_t old_words = p->P.rec.size();
     int drc = cnl::write_forward_records(p->P, &D);
+    if (!drc) {
+      // the backward records name the solution component of every pivot: switch them to the caller's numbering, so
+      // that the kernel writes the kept components straight into `d` (no reduced solution vector, no copy pass)
+      std::vector<int32_t>& br = p->P.brec;
+      size_t r0 = 0;
+      while (r0 + cnl::B_HDR <= br.size() && br[r0 + cnl::B_RECLEN] > 0) {
+        const int32_t npiv = br[r0 + cnl::B_NPIV], nupd = br[r0 + cnl::B_NUPD];
+        for (int32_t i = nupd + 1; i < 1 + nupd + npiv; i++) br[r0 + cnl::B_HDR + i] = p->C.orig_of[br[r0 + cnl::B_HDR + i]];
+        r0 += (size_t)br[r0 + cnl::B_RECLEN];
+      }
+      p->P.d_outer = true;
+    }
     if (getenv("CNL_VERBOSE"))
       fprintf(stderr, "[cnl] direct records: %s, rec words %zu -> %zu, longest %d -> %d\n", drc ? "not possible" : "ok", old_words,
               p->P.rec.size(), old_len, p->P.rec_maxlen);

@@ -186,9 +186,11 @@ __global__ void __launch_bounds__(256) cond_inertia_kernel(const DevCond Cin, co
 // column), parked in LDS and summed row-per-thread.
 constexpr int XRB = 256;    // residual rows per workgroup
 constexpr int XEMAX = 2048; // Jacobian entries staged per workgroup (longer chunks take the row-per-thread loop)
+// d2 == nullptr: the multifrontal kernel has already written the kept components into dout (caller's numbering);
+// only the residual components are recovered, reading the x components from dout itself.
 __global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* __restrict__ vals, const double* __restrict__ rhs,
-                                                     const double* __restrict__ d2, const double* __restrict__ cbuf,
-                                                     double* __restrict__ dout, const int* __restrict__ success,
+                                                     const double* d2, const double* __restrict__ cbuf,
+                                                     double* dout, const int* __restrict__ success,
                                                      int copy_rho_tail, int nb_copy, int batch) {
   const DevCond C = globalize(Cin);
   const int b = blockIdx.y;
@@ -206,7 +208,8 @@ __global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* 
   const int q1 = q0 + XRB < C.ncond ? q0 + XRB : C.ncond;
   const int e0 = C.r_ptr[q0], e1 = C.r_ptr[q1];
   const double* v = vals + (long long)b * C.nnz;
-  const double* x2 = d2 + (long long)b * C.N2;
+  // x components: reduced index == caller's index for the variables (they are never condensed)
+  const double* x2 = d2 ? d2 + (long long)b * C.N2 : dout + (long long)b * C.N;
   const bool staged = e1 - e0 <= XEMAX;
   if (staged) {
     for (int e = e0 + t; e < e1; e += 256) prod[e - e0] = v[C.r_jsrc[e]] * x2[C.r_jx[e]];
@@ -383,7 +386,7 @@ hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_
 
 hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, const double* d2, const double* cbuf, double* dout,
                          const int* success, int copy_rho_tail, int batch, hipStream_t stream) {
-  const int nb_copy = ((int)C.N2 + 255) / 256, nb_r = ((int)C.ncond + XRB - 1) / XRB;
+  const int nb_copy = d2 ? ((int)C.N2 + 255) / 256 : 0, nb_r = ((int)C.ncond + XRB - 1) / XRB;
   hipLaunchKernelGGL(expand_kernel, dim3(nb_copy + nb_r, batch), dim3(256), 0, stream, C, vals, rhs, d2, cbuf, dout, success,
                      copy_rho_tail, nb_copy, batch);
   return hipGetLastError();
