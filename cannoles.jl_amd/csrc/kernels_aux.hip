@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(256) cond_inertia_kernel(const DevCond Cin, co
 // column), parked in LDS and summed row-per-thread.
 constexpr int XRB = 256;    // residual rows per workgroup
 constexpr int XEMAX = 2048; // Jacobian entries staged per workgroup (longer chunks take the row-per-thread loop)
+constexpr int XPB = 4;      // problems per workgroup: the index lists are read once and reused
 // d2 == nullptr: the multifrontal kernel has already written the kept components into dout (caller's numbering);
 // only the residual components are recovered, reading the x components from dout itself.
 __global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* __restrict__ vals, const double* __restrict__ rhs,
@@ -193,39 +194,63 @@ __global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* 
                                                      double* dout, const int* __restrict__ success,
                                                      int copy_rho_tail, int nb_copy, int batch) {
   const DevCond C = globalize(Cin);
-  const int b = blockIdx.y;
+  const int b0 = blockIdx.y * XPB;
   const int t = threadIdx.x;
   __shared__ double prod[XEMAX];
   if ((int)blockIdx.x < nb_copy) {
     const int j = blockIdx.x * 256 + t;
-    if (copy_rho_tail && j < C.nvar) vals[(long long)b * C.nnz + (C.nnz - C.nvar) + j] = cbuf[(long long)b * C.cstride + C.ncs + j];
-    if (success && !success[b]) return;
-    if (j < C.N2) dout[(long long)b * C.N + C.orig_of[j]] = d2[(long long)b * C.N2 + j];
+    const int oj = j < C.N2 ? C.orig_of[j] : 0;
+    for (int q = 0; q < XPB && b0 + q < batch; q++) {
+      const long long b = b0 + q;
+      if (copy_rho_tail && j < C.nvar) vals[b * C.nnz + (C.nnz - C.nvar) + j] = cbuf[b * C.cstride + C.ncs + j];
+      if (success && !success[b]) continue;
+      if (j < C.N2) dout[b * C.N + oj] = d2[b * C.N2 + j];
+    }
     return;
   }
-  if (success && !success[b]) return;
   const int q0 = (blockIdx.x - nb_copy) * XRB;
   const int q1 = q0 + XRB < C.ncond ? q0 + XRB : C.ncond;
   const int e0 = C.r_ptr[q0], e1 = C.r_ptr[q1];
-  const double* v = vals + (long long)b * C.nnz;
-  // x components: reduced index == caller's index for the variables (they are never condensed)
-  const double* x2 = d2 ? d2 + (long long)b * C.N2 : dout + (long long)b * C.N;
-  const bool staged = e1 - e0 <= XEMAX;
-  if (staged) {
-    for (int e = e0 + t; e < e1; e += 256) prod[e - e0] = v[C.r_jsrc[e]] * x2[C.r_jx[e]];
-    __syncthreads();
+  const bool staged = e1 - e0 <= XEMAX;  // workgroup-uniform
+  // this thread's share of the entry list and its row, read once for all problems of the workgroup
+  constexpr int XE = XEMAX / 256;
+  int js[XE], jx[XE];
+#pragma unroll
+  for (int k = 0; k < XE; k++) {
+    const int e = e0 + t + 256 * k;
+    js[k] = (staged && e < e1) ? C.r_jsrc[e] : 0;
+    jx[k] = (staged && e < e1) ? C.r_jx[e] : 0;
   }
-  const int q = q0 + t;
-  if (q >= q1) return;
-  const int i = C.r_orig[q];
-  double s = rhs[(long long)b * C.N + i];
-  const int k0 = C.r_ptr[q], k1 = C.r_ptr[q + 1];
-  if (staged) {
-    for (int k = k0; k < k1; k++) s += prod[k - e0];
-  } else {
-    for (int k = k0; k < k1; k++) s = fma(v[C.r_jsrc[k]], x2[C.r_jx[k]], s);
+  const int qr = q0 + t;
+  const bool has_row = qr < q1;
+  const int i = has_row ? C.r_orig[qr] : 0;
+  const int k0 = has_row ? C.r_ptr[qr] : 0, k1 = has_row ? C.r_ptr[qr + 1] : 0;
+  const int dsrc = has_row ? C.r_dsrc[qr] : 0;
+  for (int q = 0; q < XPB && b0 + q < batch; q++) {
+    const long long b = b0 + q;
+    if (success && !success[b]) continue;  // workgroup-uniform
+    const double* v = vals + b * C.nnz;
+    // x components: reduced index == caller's index for the variables (they are never condensed)
+    const double* x2 = d2 ? d2 + b * C.N2 : dout + b * C.N;
+    if (staged) {
+      __syncthreads();  // the previous problem's sums are done with prod
+#pragma unroll
+      for (int k = 0; k < XE; k++) {
+        const int e = t + 256 * k;
+        if (e < e1 - e0) prod[e] = v[js[k]] * x2[jx[k]];
+      }
+      __syncthreads();
+    }
+    if (has_row) {
+      double s = rhs[b * C.N + i];
+      if (staged) {
+        for (int k = k0; k < k1; k++) s += prod[k - e0];
+      } else {
+        for (int k = k0; k < k1; k++) s = fma(v[C.r_jsrc[k]], x2[C.r_jx[k]], s);
+      }
+      dout[b * C.N + i] = -fast_div_aux(s, v[dsrc]);
+    }
   }
-  dout[(long long)b * C.N + i] = -fast_div_aux(s, v[C.r_dsrc[q]]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -387,7 +412,7 @@ hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_
 hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, const double* d2, const double* cbuf, double* dout,
                          const int* success, int copy_rho_tail, int batch, hipStream_t stream) {
   const int nb_copy = d2 ? ((int)C.N2 + 255) / 256 : 0, nb_r = ((int)C.ncond + XRB - 1) / XRB;
-  hipLaunchKernelGGL(expand_kernel, dim3(nb_copy + nb_r, batch), dim3(256), 0, stream, C, vals, rhs, d2, cbuf, dout, success,
+  hipLaunchKernelGGL(expand_kernel, dim3(nb_copy + nb_r, (batch + XPB - 1) / XPB), dim3(256), 0, stream, C, vals, rhs, d2, cbuf, dout, success,
                      copy_rho_tail, nb_copy, batch);
   return hipGetLastError();
 }
