@@ -84,12 +84,12 @@ class Structure:
         return o
 
 
-def band_structure(n, p, name="band"):
-    """cfg3/cfg4 family: nequ = n; J_F band |i-j|<=2; H_F lower band of
-    half-width 2; H_c diagonal; J_c row k nonzero on columns (n/p)(k-1)+1..(n/p)k."""
+def band_structure(n, p, name="band", hw=2):
+    """cfg3/cfg4 family: nequ = n; J_F band |i-j|<=hw (hw=2 in the BASELINE configs); H_F lower band of
+    half-width hw; H_c diagonal; J_c row k nonzero on columns (n/p)(k-1)+1..(n/p)k."""
     assert p == 0 or n % p == 0
     jr, jc = [], []
-    for k in range(-2, 3):
+    for k in range(-hw, hw + 1):
         i = np.arange(max(0, -k), min(n, n - k))  # residual row i (0-based), column i+k
         jr.append(i)
         jc.append(i + k)
@@ -98,7 +98,7 @@ def band_structure(n, p, name="band"):
     o = np.lexsort((jc, jr))  # row-major, as a row-wise AD Jacobian would be
     jF = (jr[o] + 1, jc[o] + 1)
     hr, hcl = [], []
-    for k in range(0, 3):
+    for k in range(0, hw + 1):
         j = np.arange(0, n - k)
         hr.append(j + k)
         hcl.append(j)

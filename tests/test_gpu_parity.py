@@ -299,3 +299,17 @@ def test_f1_trial_point(built):
         np.testing.assert_allclose(tdl[b].cpu().numpy(), dl0, rtol=4e-15, atol=0)
         np.testing.assert_allclose(tlt[b].cpu().numpy(), lt0, rtol=4e-15, atol=1e-300)
     assert np.linalg.norm(tdl[1].cpu().numpy()) <= 1e4 * (1 + 1e-14)
+
+
+@pytest.mark.parametrize("hw", [1, 3, 4])
+def test_band_halfwidths_general_residual_pivots(built, hw):
+    """Band families with other Jacobian half-widths: longer raw-value / product lists (several product rounds, raw
+    lists up to the 128-entry limit, records longer than the three prefetch registers) and residual-block pivots
+    d_r that are not -1 (the reference always passes -1, src/CaNNOLeS.jl:306, but the ABI takes `vals` as given)."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(600, 6, hw=hw)
+    vals, rhs = syn.batch_values(s, 5, cfg=7 + hw)
+    off = s.offsets()
+    rng = np.random.default_rng(hw)
+    vals[:, off[4]:off[5]] = -rng.uniform(0.5, 2.0, (5, s.nequ))
+    run_case(s, vals, rhs)
