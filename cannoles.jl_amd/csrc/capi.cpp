@@ -409,6 +409,8 @@ int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* 
   else if (s == "asm_src") { src = P.asm_src.data(); n = (int64_t)P.asm_src.size(); }
   else if (s == "child_idx") { src = P.child_idx.data(); n = (int64_t)P.child_idx.size(); }
   else if (s == "rel_idx") { src = P.rel_idx.data(); n = (int64_t)P.rel_idx.size(); }
+  else if (s == "rec") { src = P.rec.data(); n = P.v2_ok ? (int64_t)P.rec.size() : 0; }     // record streams of the
+  else if (s == "brec") { src = P.brec.data(); n = P.v2_ok ? (int64_t)P.brec.size() : 0; }  // register-front kernel
   else return fail(CNL_ERR_ARG, "unknown plan array: " + s);
   if (out) {
     if (*count < n) return fail(CNL_ERR_ARG, "buffer too small");

@@ -1,0 +1,138 @@
+"""numpy interpreter of the RECORD STREAMS of the register-front kernel (test infrastructure).
+
+Executes, for ONE problem and on the CPU, what cannoles.jl_amd/csrc/kernels2.hip executes from the streams written
+by csrc/analysis.cpp::write_forward_records (layout in csrc/plan.h): plain assembly entries, raw values and products
+of the on-the-fly condensation, the children's extend-add tables, elimination from the highest local index, the
+packed L panels, and the backward records.  It validates the host side of that path without a GPU.
+Never used by the product.
+"""
+import numpy as np
+
+(R_NPIV, R_NUPD, R_RECLEN, R_NASM, R_NCHILD, R_UOFF, R_FLAGS, R_FSOFF, R_LPTR_LO, R_LPTR_HI, R_NASMV, R_ASM_OFF,
+ R_CHILD_OFF, R_NPROD, R_NRAW, R_NRD) = range(16)
+R_HDR = 16
+RF_U_GLOBAL, RF_FS_GLOBAL = 1, 2
+B_NPIV, B_NUPD, B_RECLEN, B_XOFF, B_PXOFF, B_LPTR_LO, B_LPTR_HI, B_CLS = range(8)
+B_HDR = 8
+
+
+def tri(i):
+    return i * (i + 1) // 2
+
+
+class RecSim:
+    def __init__(self, plan, nnz_src, n_rhs):
+        """nnz_src / n_rhs: length of the value array / right-hand side the records address (the caller's arrays when
+        the records condense on the fly, the condensed buffer otherwise)."""
+        self.rec = plan.array("rec").astype(np.int64)
+        self.brec = plan.array("brec").astype(np.int64)
+        assert self.rec.size, "the plan is not served by the register-front kernel"
+        self.ns = plan.info["nsuper"]
+        self.lsize = plan.info["lsize"]
+        self.nnz, self.n_rhs = nnz_src, n_rhs
+
+    def forward(self, vals, rhs, eig_tol):
+        """Returns (L storage, npos, nzero) of the fronts (the condensed residual pivots are NOT included)."""
+        rec = self.rec
+        src_val = lambda s: vals[s] if s < self.nnz else rhs[s - self.nnz]
+        L = np.zeros(self.lsize + 64)
+        U = {}
+        npos = nzer = 0
+        off = 0
+        self.stats = dict(plain=0, products=0, raw=0, strided=0, packed=0)
+        for _ in range(self.ns):
+            H = rec[off:off + R_HDR]
+            npiv, nupd, nasm, nasmv = int(H[R_NPIV]), int(H[R_NUPD]), int(H[R_NASM]), int(H[R_NASMV])
+            flags, cls = int(H[R_FLAGS]) & 0xff, int(H[R_FLAGS]) >> 8
+            aoff, coff = int(H[R_ASM_OFF]), int(H[R_CHILD_OFF])
+            nprod, nraw = int(H[R_NPROD]), int(H[R_NRAW])
+            nrd, nrawv = int(H[R_NRD]) & 0xffff, int(H[R_NRD]) >> 16
+            f = 1 + nupd + npiv
+            strided = cls == 16 and not (flags & RF_FS_GLOBAL)
+            self.stats["strided" if strided else "packed"] += 1
+            img = np.zeros(max(256, tri(f) + 16) if strided else tri(f) + 16)
+            pos_of = (lambda a, b: a * 16 + b) if strided else (lambda a, b: tri(a) + b)
+            r = rec[off:off + int(H[R_RECLEN])]
+            # plain entries: matrix values first, right-hand side last; every group padded to rounds of 16
+            assert nasmv % 16 == 0 and nasm % 16 == 0 and nasmv <= nasm
+            for e in range(nasm):
+                s, p = int(r[aoff + e]), int(r[aoff + nasm + e])
+                assert (s >= self.nnz) == (e >= nasmv), "entries are not grouped by array"
+                img[p] += src_val(s)
+            self.stats["plain"] += nasm
+            # raw values and products
+            raw_off = aoff + 2 * nasm
+            assert nrawv % 16 == 0 and nraw % 16 == 0
+            jraw = np.array([src_val(int(r[raw_off + t])) for t in range(nraw)])
+            for t in range(nraw):
+                assert (int(r[raw_off + t]) >= self.nnz) == (t >= nrawv)
+            jr = jraw.copy()
+            jr[:nrd] = -1.0 / jraw[:nrd]
+            poff = raw_off + nraw
+            for e in range(nprod):
+                if strided:
+                    w = int(r[poff + e])
+                    p, ia, ib, idd = w & 255, (w >> 8) & 127, (w >> 15) & 127, (w >> 22) & 127
+                    if nraw == 0:
+                        continue
+                else:
+                    p, w = int(r[poff + 2 * e]), int(r[poff + 2 * e + 1])
+                    ia, ib, idd = w & 1023, (w >> 10) & 1023, (w >> 20) & 1023
+                img[p] += jr[ia] * jr[ib] * jr[idd]
+            self.stats["products"] += nprod
+            self.stats["raw"] += nraw
+            # extend-add
+            co = coff
+            for _c in range(int(H[R_NCHILD])):
+                cu, tuc, cfl = int(r[co]), int(r[co + 1]), int(r[co + 2])
+                Uc = U.pop((cfl, cu))
+                assert len(Uc) == tuc
+                for t in range(tuc):
+                    img[int(r[co + 4 + t])] += Uc[t]
+                co += 4 + ((tuc + 3) & ~3)
+            # eliminate from the highest local index; L panel: row i at lptr + tri(i) - tri(nupd + 1)
+            F = np.zeros((f, f))
+            for a in range(f):
+                for b in range(a + 1):
+                    F[a, b] = img[pos_of(a, b)]
+            lptr = int(H[R_LPTR_LO]) | (int(H[R_LPTR_HI]) << 31)
+            tu = tri(1 + nupd)
+            for i in range(f - 1, nupd, -1):
+                d = F[i, i]
+                npos += d > eig_tol
+                nzer += abs(d) <= eig_tol
+                w = F[i, :i].copy()
+                lv = w / d
+                L[lptr + tri(i) - tu: lptr + tri(i) - tu + i] = lv
+                L[lptr + tri(i) - tu + i] = d
+                for a in range(i):
+                    F[a, :a + 1] -= w[a] * lv[:a + 1]
+            U[(1 if flags & RF_U_GLOBAL else 0, int(H[R_UOFF]))] = np.array([F[a, b] for a in range(nupd + 1) for b in range(a + 1)])
+            off += int(H[R_RECLEN])
+        assert all(len(u) == 1 for u in U.values()), "update matrices left on the stack"
+        return L, int(npos), int(nzer)
+
+    def backward(self, L, n_out):
+        """d = -x from the factor storage (z = D^-1 L^-1 b sits in column 0 of the panels)."""
+        br = self.brec
+        d = np.full(n_out, np.nan)
+        xs = {}
+        off = 0
+        for _ in range(self.ns):
+            H = br[off:off + B_HDR]
+            npiv, nupd, xoff, pxoff = int(H[B_NPIV]), int(H[B_NUPD]), int(H[B_XOFF]), int(H[B_PXOFF])
+            lptr = int(H[B_LPTR_LO]) | (int(H[B_LPTR_HI]) << 31)
+            f = 1 + nupd + npiv
+            idx = br[off + B_HDR: off + B_HDR + f]
+            x = np.zeros(f)
+            for l in range(1, nupd + 1):
+                x[l] = xs[pxoff + int(idx[l])]
+            tu = tri(1 + nupd)
+            for i in range(nupd + 1, f):
+                row = L[lptr + tri(i) - tu: lptr + tri(i) - tu + i]
+                x[i] = row[0] - np.dot(row[1:i], x[1:i])
+                d[int(idx[i])] = -x[i]
+            for l in range(1, f):
+                xs[xoff + l] = x[l]
+            off += int(H[B_RECLEN])
+        return d

@@ -130,3 +130,40 @@ def test_cfg3_plan_quality(built):
     pl = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon)
     assert pl.info["nnzL_exact"] < 346209
     assert pl.info["v2"]["fronts16"] > 0.95 * pl.info["nsuper"]
+
+
+# ---- record streams of the register-front kernel, interpreted on the CPU -----------------------------------------
+@pytest.mark.parametrize("shape", [(200, 4, 2), (600, 6, 1), (600, 6, 3), (400, 0, 2), (1000, 50, 2)])
+def test_record_streams_reproduce_the_oracle(shape):
+    """tests/support/rec_sim.py executes the forward / backward record streams (direct records: plain entries, raw
+    values, products, extend-add tables, L panels, solution indices in the caller's numbering) for one problem and
+    must reproduce the oracle's inertia and solution."""
+    import cannoles_jl_amd  # noqa: F401
+    from cannoles_jl_amd import hipldl, synthetic as syn
+    from oracle import oracle as O
+    from tests.support.rec_sim import RecSim
+    n, p, hw = shape
+    s = syn.band_structure(n, p, hw=hw)
+    rows, cols = s.kkt_pattern()
+    plan = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon)
+    assert plan.info["v2"] is not None and plan.info["ncond"] == s.nequ
+    vals, rhs = syn.band_values(s, 77)
+    off = s.offsets()
+    vals[off[4]:off[5]] = -np.random.default_rng(1).uniform(0.5, 2.0, s.nequ)  # general residual pivots
+    vals[off[6]:off[7]] = 0.25                                                  # some rho
+    sim = RecSim(plan, s.nnzNS, s.N)
+    eig_tol = 2.220446049250313e-16
+    L, npos, nzer = sim.forward(vals, rhs, eig_tol)
+    assert sim.stats["products"] > 0 and sim.stats["raw"] > 0
+    if p == 50:
+        assert sim.stats["packed"] > 0  # large fronts: packed staging, two-word products
+    d = sim.backward(L, s.N)
+    perm = plan.array("perm").astype(np.int64)
+    orc = O.Oracle(s.N, rows, cols, perm)
+    ok, pos0, zer0 = orc.try_to_factorize(vals, s.nvar, s.nequ, s.ncon, eig_tol, return_inertia=True)
+    d0 = orc.solve_ldl(rhs)
+    dr = vals[off[4]:off[5]]
+    assert npos + int((dr > eig_tol).sum()) == pos0 and nzer + int((np.abs(dr) <= eig_tol).sum()) == zer0
+    kept = ~np.isnan(d)
+    assert kept.sum() == s.N - s.nequ and not kept[s.nvar:s.nvar + s.nequ].any()
+    assert np.abs(d[kept] - d0[kept]).max() <= 1e-10 * np.abs(d0).max()
