@@ -236,7 +236,7 @@ def main():
         out["aux_f1"] = f1  # not part of `value`: rhs assembly + norms, trial point, roofline = HBM
         # CPU baseline: the oracle (restated LDLFactorizations path) on a bounded sample, 1 thread
         ncpu = args.cpu_sample
-        if ncpu != 0 and world >= 1:
+        if ncpu != 0 and world == 1:  # reported at N=1 only (the multi-GPU runs stay short)
             from oracle import oracle as O
             # the oracle gets the product's own fill-reducing order (the fairest CPU baseline; the canonical
             # r/x/lambda order of SURVEY.md has 2.4x the fill)
