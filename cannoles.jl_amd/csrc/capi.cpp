@@ -545,6 +545,22 @@ int cnl_destroy(cnl_handle* h) {
 
 const cnl_plan* cnl_get_plan(const cnl_handle* h) { return h ? h->plan : nullptr; }
 
+int cnl_prepare_newton_system_dev(cnl_handle* h, int64_t nnzhF, int64_t nnzhc, int64_t nnzjF, int64_t nnzjc, const double* d_hF,
+                                  const double* d_hc, const double* d_Jx, const double* d_Jcx, const double* d_delta, double* d_vals,
+                                  void* stream) {
+  if (!h || !d_vals || !d_Jx) return fail(CNL_ERR_ARG, "null argument");
+  const cnl::DevJt& J = h->djt;
+  if (nnzhF < 0 || nnzhc < 0 || nnzjF < 0 || nnzjc < 0 || nnzhF + nnzhc + nnzjF + nnzjc + J.nequ + J.ncon + J.nvar != J.nnz)
+    return fail(CNL_ERR_DIM, "segment sizes do not add up to nnz (7-segment layout of src/CaNNOLeS.jl:256-315)");
+  if (J.ncon > 0 && (!d_hc || !d_Jcx || !d_delta)) return fail(CNL_ERR_ARG, "hc / Jcx / delta are required when ncon > 0");
+  if (J.ncon == 0 && (nnzhc != 0 || nnzjc != 0)) return fail(CNL_ERR_DIM, "constraint segments must be empty when ncon == 0");
+  HIPCHK(hipSetDevice(h->device));
+  hipError_t e = cnl::launch_prepare((int)nnzhF, (int)nnzhc, (int)nnzjF, (int)nnzjc, J.nvar, J.nequ, J.ncon, d_hF, d_hc, d_Jx, d_Jcx,
+                                     d_delta, d_vals, (int)h->batch, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("prepare_newton_system: ") + hipGetErrorString(e));
+  return CNL_OK;
+}
+
 int cnl_residual_vectors_dev(cnl_handle* h, const double* d_vals, const double* d_r, const double* d_lambda, const double* d_Fx,
                              const double* d_cx, double* d_rhs, double* d_norms, void* stream) {
   if (!h || !d_vals || !d_r || !d_Fx || !d_rhs || !d_norms) return fail(CNL_ERR_ARG, "null argument");

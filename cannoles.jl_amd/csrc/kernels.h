@@ -101,6 +101,8 @@ hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const dou
                                  int batch, hipStream_t stream);
 hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_pos, int* extra_zer, double eig_tol, int batch,
                                hipStream_t stream);
+hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon, const double* hF, const double* hc,
+                          const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, hipStream_t stream);
 hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const double* r, const double* lambda, const double* Fx,
                                    const double* cx, double* rhs, double* norms, int batch, hipStream_t stream);
 hipError_t launch_trial_point(const DevJt& J, const double* x, const double* r, const double* lambda, const double* d,

@@ -364,6 +364,37 @@ __global__ void __launch_bounds__(256) trial_point_kernel(const DevJt J, const d
   }
 }
 
+// prepare_newton_system! (/root/reference/src/CaNNOLeS.jl:947-981) for a batch, on the device: copies of the model's
+// value arrays into the segments of `vals` ([H_F | H_c | J_F | J_c | -I | -delta I | rho I], :256-315):
+//   H_F <- hF (left alone when hF == nullptr: Gauss-Newton variants, update_newton_hessian! no-op, hessian_approx.jl:46)
+//   H_c <- -hc (:971-972), J_F <- Jx (:968-969), J_c <- Jcx (:973-974), -delta I <- -delta[b] (:975-976), rho I <- 0 (:978-979);
+//   the -I segment is never written (:306).
+__global__ void __launch_bounds__(256) prepare_kernel(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon,
+                                                      const double* __restrict__ hF, const double* __restrict__ hc,
+                                                      const double* __restrict__ Jx, const double* __restrict__ Jcx,
+                                                      const double* __restrict__ delta, double* __restrict__ vals, int batch) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const long long b = blockIdx.y;
+  const int o1 = nnzhF, o2 = o1 + nnzhc, o3 = o2 + nnzjF, o4 = o3 + nnzjc, o5 = o4 + nequ, o6 = o5 + ncon, nnz = o6 + nvar;
+  if (k >= nnz) return;
+  double* v = vals + b * nnz;
+  if (k < o1) { if (hF) v[k] = hF[b * nnzhF + k]; }
+  else if (k < o2) { if (ncon > 0) v[k] = -hc[b * nnzhc + (k - o1)]; }
+  else if (k < o3) v[k] = Jx[b * nnzjF + (k - o2)];
+  else if (k < o4) { if (ncon > 0) v[k] = Jcx[b * nnzjc + (k - o3)]; }
+  else if (k < o5) {}
+  else if (k < o6) v[k] = -delta[b];
+  else v[k] = 0.0;
+}
+
+hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon, const double* hF, const double* hc,
+                          const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, hipStream_t stream) {
+  const int nnz = nnzhF + nnzhc + nnzjF + nnzjc + nequ + ncon + nvar;
+  hipLaunchKernelGGL(prepare_kernel, dim3((nnz + 255) / 256, batch), dim3(256), 0, stream, nnzhF, nnzhc, nnzjF, nnzjc, nvar, nequ, ncon,
+                     hF, hc, Jx, Jcx, delta, vals, batch);
+  return hipGetLastError();
+}
+
 hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const double* r, const double* lambda, const double* Fx,
                                    const double* cx, double* rhs, double* norms, int batch, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(norms, 0, sizeof(double) * 2 * (size_t)batch, stream);

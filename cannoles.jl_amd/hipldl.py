@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "cnl_factorize", "cnl_solve", "cnl_newton_system",
     "cnl_factorize_dev", "cnl_solve_dev", "cnl_newton_system_dev",
     "cnl_set_timing", "cnl_last_kernel_ms", "cnl_get_config",
-    "cnl_residual_vectors_dev", "cnl_trial_point_dev",
+    "cnl_residual_vectors_dev", "cnl_trial_point_dev", "cnl_prepare_newton_system_dev",
 ]
 
 
@@ -76,6 +76,7 @@ def lib():
         L.cnl_newton_system_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.cnl_residual_vectors_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.cnl_trial_point_dev.argtypes = [vp, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp]
+        L.cnl_prepare_newton_system_dev.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
         L.cnl_set_timing.argtypes = [vp, C.c_int]
         L.cnl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cnl_get_config.argtypes = [vp, _i64p]
@@ -285,3 +286,10 @@ def trial_point_dev(LDLT, x_ptr, r_ptr, lambda_ptr, d_ptr, max_dlambda, xt_ptr, 
     (src/CaNNOLeS.jl:654,661-668), batched and device-resident (cnl_trial_point_dev)."""
     _check(lib().cnl_trial_point_dev(LDLT._h, x_ptr, r_ptr, lambda_ptr, d_ptr, float(max_dlambda), xt_ptr, rt_ptr, lambdat_ptr,
                                      dlambda_ptr, stream))
+
+
+def prepare_newton_system_dev(LDLT, nnzhF, nnzhc, nnzjF, nnzjc, hF_ptr, hc_ptr, Jx_ptr, Jcx_ptr, delta_ptr, vals_ptr, stream=0):
+    """prepare_newton_system! (src/CaNNOLeS.jl:947-981) for a batch on the device (cnl_prepare_newton_system_dev):
+    hF / -hc / Jx / Jcx / -delta / 0 into the segments of vals; hF_ptr = 0 leaves H_F alone (Gauss-Newton variants)."""
+    _check(lib().cnl_prepare_newton_system_dev(LDLT._h, int(nnzhF), int(nnzhc), int(nnzjF), int(nnzjc), hF_ptr, hc_ptr, Jx_ptr,
+                                               Jcx_ptr, delta_ptr, vals_ptr, stream))

@@ -122,6 +122,16 @@ int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, do
 int cnl_residual_vectors_dev(cnl_handle* h, const double* d_vals, const double* d_r, const double* d_lambda, const double* d_Fx,
                              const double* d_cx, double* d_rhs, double* d_norms, void* stream);
 
+/* cnl_prepare_newton_system_dev: prepare_newton_system!(meth, vals, nls, x, lambda, r, Jx_vals, Jcx_vals, delta, Fx) —
+ * src/CaNNOLeS.jl:947-981 — for a batch whose model values already live on the device: the value
+ * arrays are copied into the segments of `vals` ([H_F | H_c | J_F | J_c | -I | -delta I | rho I], sizes nnzhF, nnzhc,
+ * nnzjF, nnzjc, nequ, ncon, nvar):  H_F <- hF (skipped when d_hF == NULL: the Gauss-Newton variants do not touch it),
+ * H_c <- -hc, J_F <- Jx, J_c <- Jcx, -delta I <- -delta[b], rho I <- 0; the -I segment is never written.
+ * Layouts: hF [batch][nnzhF], hc [batch][nnzhc], Jx [batch][nnzjF], Jcx [batch][nnzjc], delta [batch].          */
+int cnl_prepare_newton_system_dev(cnl_handle* h, int64_t nnzhF, int64_t nnzhc, int64_t nnzjF, int64_t nnzjc, const double* d_hF,
+                                  const double* d_hc, const double* d_Jx, const double* d_Jcx, const double* d_delta, double* d_vals,
+                                  void* stream);
+
 /* cnl_trial_point_dev: the extrapolation step's trial point, src/CaNNOLeS.jl:654,661-668:
  *     xt = x + d[1:n],  rt = r + d[n+1:n+m],  dlambda = -d[n+m+1:N], scaled by max_dlambda/||dlambda||_2 when that
  *     norm exceeds max_dlambda (the reference uses 1e4),  lambdat = lambda + dlambda.                               */

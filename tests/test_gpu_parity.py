@@ -313,3 +313,38 @@ def test_band_halfwidths_general_residual_pivots(built, hw):
     rng = np.random.default_rng(hw)
     vals[:, off[4]:off[5]] = -rng.uniform(0.5, 2.0, (5, s.nequ))
     run_case(s, vals, rhs)
+
+
+@pytest.mark.parametrize("gn", [False, True])
+def test_prepare_newton_system_dev_bit_exact(built, gn):
+    """Device twin of prepare_newton_system! (src/CaNNOLeS.jl:947-981) against the oracle's restatement: pure copies and
+    sign flips, so bit-exact (including -0.0 in the H_c segment)."""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(400, 4)
+    B = 5
+    rows, cols = s.kkt_pattern()
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    rng = np.random.default_rng(3)
+    nhF, nhc, njF, njc = len(s.hF[0]), len(s.hc[0]), s.nnzjF, s.nnzjc
+    hF, hc = rng.standard_normal((B, nhF)), rng.standard_normal((B, nhc))
+    hc[:, 0] = 0.0  # -> -0.0
+    Jx, Jcx, delta = rng.standard_normal((B, njF)), rng.standard_normal((B, njc)), rng.uniform(0.01, 1.0, B)
+    vals0 = np.ones((B, s.nnzNS))
+    off = s.offsets()
+    vals0[:, off[4]:off[5]] = -1.0
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    thF, thc, tJx, tJc, tde, tv = t(hF), t(hc), t(Jx), t(Jcx), t(delta), t(vals0)
+    hipldl.prepare_newton_system_dev(LDLT, nhF, nhc, njF, njc, 0 if gn else thF.data_ptr(), thc.data_ptr(), tJx.data_ptr(),
+                                     tJc.data_ptr(), tde.data_ptr(), tv.data_ptr(), 0)
+    torch.cuda.synchronize()
+    got = tv.cpu().numpy()
+    for b in range(B):
+        ref = vals0[b].copy()
+        O.prepare(ref, s.nvar, s.nequ, s.ncon, nhF, nhc, njF, njc, None if gn else hF[b], hc[b], Jx[b], Jcx[b], delta[b])
+        assert np.array_equal(got[b], ref)
+        assert np.array_equal(np.signbit(got[b]), np.signbit(ref))
+    with pytest.raises(hipldl.CnlError):
+        hipldl.prepare_newton_system_dev(LDLT, nhF + 1, nhc, njF, njc, 0, thc.data_ptr(), tJx.data_ptr(), tJc.data_ptr(), tde.data_ptr(),
+                                         tv.data_ptr(), 0)
