@@ -1,2 +1,2 @@
 """MI355X-native Newton-system backend for CaNNOLeS."""
-from . import sharding, synthetic  # noqa: F401
+from . import batch_solve, outer_loop, sharding, synthetic  # noqa: F401

@@ -348,3 +348,24 @@ def test_prepare_newton_system_dev_bit_exact(built, gn):
     with pytest.raises(hipldl.CnlError):
         hipldl.prepare_newton_system_dev(LDLT, nhF + 1, nhc, njF, njc, 0, thc.data_ptr(), tJx.data_ptr(), tJc.data_ptr(), tde.data_ptr(),
                                          tv.data_ptr(), 0)
+
+
+def test_f3_batched_outer_loop_on_the_hip_path(built):
+    """B restated outer loops (src/CaNNOLeS.jl:418-864) over ONE batched handle — every round of
+    Newton systems is one cnl_newton_system call with batch = B — reach the reference's known answers
+    (test/runtests.jl:82-99) and agree with single-problem runs on the CPU oracle."""
+    hipldl, syn, O = _mods()
+    from cannoles_jl_amd import batch_solve
+    from tests.support.outer_loop import SymNLS, solve
+    from tests.test_oracle_pinning import CONSTRAINED, oracle_newton, oracle_solver
+    (F0, c0, x00, xf0), (F1, c1, x01, xf1) = CONSTRAINED[0], CONSTRAINED[1]
+    cases = [(F0, c0, x00, xf0), (F1, c1, x01, xf1), (F1, c1, [-1.0, 0.5], xf1), (F0, c0, [3.0, -2.0], xf0), (F1, c1, [0.0, 0.0], xf1),
+             (F1, c1, [2.0, 2.0], xf1)]
+    p = hipldl.default_params()
+    res, ncalls = batch_solve.solve_batch([SymNLS(F, x0, c) for F, c, x0, xf in cases], p)
+    for k, (F, c, x0, xf) in enumerate(cases):
+        one = solve(SymNLS(F, x0, c), oracle_solver, oracle_newton, p)
+        assert res[k]["status"] == one["status"] and res[k]["status"] in ("first_order", "small_residual")
+        assert np.allclose(res[k]["solution"], xf, atol=1e-4)
+        assert np.allclose(res[k]["solution"], one["solution"], atol=1e-6)
+    assert ncalls < sum(r["nlinsolve"] for r in res)

@@ -92,3 +92,43 @@ def test_gauss_newton_variant(params):
     """method = :Newton_noFHess (test/runtests.jl:205-214): empty H_F segment, still reaches [1, 1]"""
     out = solve(SymNLS(F_Rosen, [-1.2, 1.0]), oracle_solver, oracle_newton, params, method="Newton_noFHess")
     assert np.allclose(out["solution"], [1.0, 1.0], atol=1e-6)
+
+
+# ---- SURVEY 8 row f3: batched outer loop (host threads + one batched Newton call per round) ---------------------
+def _oracle_batched(rows, cols, dims, rhs, vals, rho_old, params):
+    """stand-in for the batched device call on machines without a GPU: the oracle, slot by slot"""
+    N, n, m, p = dims
+    orc = O.Oracle(N, rows, cols, O.canonical_perm(n, m, p))
+    B = rhs.shape[0]
+    d = np.zeros((B, N)); ok = np.zeros(B, bool); rho = np.zeros(B); ro = np.zeros(B); nf = np.zeros(B, int)
+    for b in range(B):
+        d[b], ok[b], rho[b], ro[b], nf[b] = O.newton_system(orc, n, m, p, rhs[b], vals[b], rho_old[b], params)
+    return d, ok, rho, ro, nf
+
+
+def test_batched_outer_loop_matches_single_runs(params):
+    """cannoles_jl_amd.batch_solve: B outer loops over one batched linear solver give the same answers as B separate
+    runs (reference known answers with n = 2, nequ = 2, ncon = 1 — one dense pattern — from several starting points)."""
+    import cannoles_jl_amd  # noqa: F401
+    from cannoles_jl_amd import batch_solve
+    (F0, c0, x00, xf0), (F1, c1, x01, xf1) = CONSTRAINED[0], CONSTRAINED[1]
+    cases = [(F0, c0, x00, xf0), (F1, c1, x01, xf1), (F1, c1, [-1.0, 0.5], xf1), (F0, c0, [3.0, -2.0], xf0), (F1, c1, [0.0, 0.0], xf1)]
+    models = [SymNLS(F, x0, c) for F, c, x0, xf in cases]
+    res, ncalls = batch_solve.solve_batch(models, params, batched_newton=_oracle_batched)
+    singles = [solve(SymNLS(F, x0, c), oracle_solver, oracle_newton, params) for F, c, x0, xf in cases]
+    for k, (F, c, x0, xf) in enumerate(cases):
+        assert res[k]["status"] == singles[k]["status"] and res[k]["iter"] == singles[k]["iter"]
+        assert res[k]["nlinsolve"] == singles[k]["nlinsolve"] and res[k]["nfact"] == singles[k]["nfact"]
+        assert np.array_equal(res[k]["solution"], singles[k]["solution"])
+        assert np.allclose(res[k]["solution"], xf, atol=1e-4)
+    # batching works: as many device calls as the longest problem needs, fewer than the Newton systems solved
+    assert ncalls == max(r["nlinsolve"] for r in res) and ncalls < sum(r["nlinsolve"] for r in res)
+
+
+def test_batched_outer_loop_rejects_mixed_patterns(params):
+    import cannoles_jl_amd  # noqa: F401
+    from cannoles_jl_amd import batch_solve
+    F0, c0, x0, _ = CONSTRAINED[0]
+    F2, c2, x2, _ = CONSTRAINED[2]
+    with pytest.raises(ValueError):
+        batch_solve.solve_batch([SymNLS(F0, x0, c0), SymNLS(F2, x2, c2)], params, batched_newton=_oracle_batched)
