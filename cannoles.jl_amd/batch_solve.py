@@ -8,8 +8,9 @@ created with batch = B (`NewtonBroker`).  Problems that have finished keep their
 simply post less often.  The per-problem logic is exactly the single-problem loop, so a batch of one
 reproduces it.
 
-`batched_newton` can be injected (the tests use the CPU oracle for it on machines without a GPU); the default is
-the HIP path and there is no CPU fallback in the product.
+The batched Newton step is the HIP path (`hipldl.newton_system_`, i.e. `cnl_newton_system`); there is no CPU fallback:
+without the extension or a device the first round raises.  `_test_backend` is a hook for this repository's CPU test-suite
+only (it lets the rendezvous logic be exercised where no GPU exists); the product never passes it.
 """
 import threading
 
@@ -19,9 +20,9 @@ import numpy as np
 class NewtonBroker:
     """Rendezvous of B outer loops on one batched linear-solver handle."""
 
-    def __init__(self, B, device=0, batched_newton=None):
+    def __init__(self, B, device=0, _test_backend=None):
         self.B, self.device = int(B), device
-        self._batched = batched_newton
+        self._batched = _test_backend
         self.cv = threading.Condition()
         self.handle = None
         self.active = self.B
@@ -107,7 +108,7 @@ class NewtonBroker:
         self.handle = None
 
 
-def solve_batch(models, params=None, device=0, batched_newton=None, **kw):
+def solve_batch(models, params=None, device=0, _test_backend=None, **kw):
     """Runs outer_loop.solve for every model of `models` (same pattern), Newton systems batched on the device.
     Returns (list of result dicts, number of batched device calls)."""
     from . import outer_loop
@@ -115,7 +116,7 @@ def solve_batch(models, params=None, device=0, batched_newton=None, **kw):
         from . import hipldl
         params = hipldl.default_params()
     B = len(models)
-    broker = NewtonBroker(B, device, batched_newton)
+    broker = NewtonBroker(B, device, _test_backend)
     results = [None] * B
     errors = [None] * B
 

@@ -162,9 +162,13 @@ int setup_v2(cnl_handle* h) {
   d.breccap = (P.brec_maxlen + 3) & ~3;
   d.recwords = std::max(d.reccap, 2 * d.breccap);
   d.u2_peak = P.u2_peak;
-  d.jraw_off = (int32_t)((P.u2_peak + std::max<int64_t>(P.fs2_max, 64) + 16 + 1) & ~(int64_t)1);
+  d.jraw_off = (int32_t)((P.u2_peak + std::max<int64_t>(P.fs2_max, 64) + 1) & ~(int64_t)1);
   int64_t prob = std::max<int64_t>((int64_t)d.jraw_off + (P.rec_direct ? 128 : 0), P.bwd_peak + 2);
-  d.prob_doubles = (int32_t)((prob + 1) & ~(int64_t)1);
+  // per-problem areas 32 banks apart modulo 64 (prob_doubles = 16 mod 32): the 16 lanes of two neighbouring problems
+  // then touch disjoint LDS banks when they read the same row of their images (env CNL_LDS_PAD=0 disables)
+  prob = (prob + 1) & ~(int64_t)1;
+  if (!(getenv("CNL_LDS_PAD") && !atoi(getenv("CNL_LDS_PAD")))) while (prob % 32 != 16) prob += 2;
+  d.prob_doubles = (int32_t)prob;
   d.gs_doubles = P.gs_doubles + 64;
   d.lsize = P.lsize;
   d.vstride = h->dp.vstride; d.rstride = h->dp.rstride; d.dstride = h->dp.dstride;
