@@ -443,6 +443,35 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     return perm;
   };
 
+  // Variant of an x order: every late node (multiplier / kept residual row) whose neighbours are all variables goes
+  // right behind the last of them instead of to the very end.  Any symmetric permutation has the same inertia
+  // (Sylvester), and the pivots of such a node are -delta minus a positive term, never zero when the x block is
+  // definite; what changes is the fill: a multiplier that covers a contiguous block of a banded problem then stops
+  // riding along in every later update matrix, so the fronts stay small up to the root.
+  auto assemble_perm_early = [&](const ivec& xorder) {
+    ivec posx(nx_, -1);
+    for (int32_t i = 0; i < (int32_t)xorder.size(); i++) posx[xorder[i]] = i;
+    std::vector<ivec> after(xorder.size());
+    ivec tail;
+    for (int32_t v : stageC) {
+      int32_t last = -1;
+      bool ok = g.deg(v) > 0;
+      for (int32_t p = g.ptr[v]; p < g.ptr[v + 1] && ok; p++) {
+        const int32_t u = g.idx[p];
+        if (u >= nx_ || posx[u] < 0) ok = false; else last = std::max(last, posx[u]);
+      }
+      if (ok && last >= 0) after[last].push_back(v); else tail.push_back(v);
+    }
+    ivec perm; perm.reserve(N);
+    perm.insert(perm.end(), stageA.begin(), stageA.end());
+    for (int32_t i = 0; i < (int32_t)xorder.size(); i++) {
+      perm.push_back(xorder[i]);
+      perm.insert(perm.end(), after[i].begin(), after[i].end());
+    }
+    perm.insert(perm.end(), tail.begin(), tail.end());
+    return perm;
+  };
+
   const int relax = opt.relax >= 0 ? opt.relax : 4;
 
   // supernodes + amalgamation + cost for a candidate; returns the final
@@ -571,10 +600,18 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
   };
 
   std::vector<Cand> cands;
+  const bool try_early = !stageC.empty() && !(getenv("CNL_NO_EARLY") && atoi(getenv("CNL_NO_EARLY")));
   auto add_cand = [&](const std::string& name, const ivec& xorder) {
-    Cand c; c.name = name;
-    evaluate(assemble_perm(xorder), c);
-    cands.push_back(std::move(c));
+    {
+      Cand c; c.name = name;
+      evaluate(assemble_perm(xorder), c);
+      cands.push_back(std::move(c));
+    }
+    if (try_early) {
+      Cand c; c.name = name + "+early";
+      evaluate(assemble_perm_early(xorder), c);
+      cands.push_back(std::move(c));
+    }
   };
   int mode = opt.order_mode;
   if (mode == 0 || mode < 0) add_cand("canonical", xs_all);
