@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     const unsigned gofs_l = (gsel * (unsigned)P.lsize + (unsigned)l) * 8u;
     double* mydout = A.d + pclamp * P.dstride;
     double* xs = myU;  // the x stack reuses the per-problem LDS area
-    constexpr int KB = 8;
+    constexpr int KB = 10;  // panel rows prefetched per front (fronts of the chain-like orders hold up to 10 pivots)
     int boff = 0, nxt = 0;
     int4 Rb;
     double lr[KB];     // panel rows of the CURRENT front (first KB pivots), prefetched one front ahead

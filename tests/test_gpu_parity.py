@@ -369,3 +369,19 @@ def test_f3_batched_outer_loop_on_the_hip_path(built):
         assert np.allclose(res[k]["solution"], xf, atol=1e-4)
         assert np.allclose(res[k]["solution"], one["solution"], atol=1e-6)
     assert ncalls < sum(r["nlinsolve"] for r in res)
+
+
+def test_multipliers_last_large_fronts(built, monkeypatch):
+    """With the multipliers ordered last (CNL_NO_EARLY=1: the order the cost model used to pick) the top of the tree holds
+    fronts of order 17..64, which take the out-of-line classes of the register-front kernel (global staging, two-word
+    products, 32- and 64-lane elimination and backward substitution)."""
+    hipldl, syn, O = _mods()
+    monkeypatch.setenv("CNL_NO_EARLY", "1")
+    s = syn.band_structure(2000, 40)
+    rows, cols = s.kkt_pattern()
+    plan = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon)
+    assert plan.info["v2"] is not None and plan.info["v2"]["fronts32"] + plan.info["v2"]["fronts64"] > 0
+    vals, rhs = syn.batch_values(s, 6, cfg=9)
+    run_case(s, vals, rhs)
+    v2, r2 = syn.batch_values(s, 5, cfg=5, stress="ladder")
+    run_case(s, v2, r2, check_fwd=False)
