@@ -773,18 +773,19 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       }
       if (nprod > 0 && !(CNL_ABL & 1)) {
         // products -J_ra J_rb / d_r of the condensed residual rows: one packed word each, pos | ia<<8 | ib<<15 | id<<22
-        // (four rounds in flight: the LDS round trips of a round are dependent, those of different rounds are not)
+        // (PB rounds in flight: the LDS round trips of a round are dependent, those of different rounds are not)
         wsync();
+        constexpr int PB = 8;
         const int* pw = rec + raw_off + nraw + l;
-        for (int e = 0; e < nprod; e += 64) {
-          int w[4];
-          double v[4];
+        for (int e = 0; e < nprod; e += 16 * PB) {
+          int w[PB];
+          double v[PB];
 #pragma unroll
-          for (int q = 0; q < 4; q++) w[q] = pw[e + 16 * q];  // reads past the list stay inside the LDS record area and are not used
+          for (int q = 0; q < PB; q++) w[q] = pw[e + 16 * q];  // reads past the list stay inside the wave's LDS and are not used
 #pragma unroll
-          for (int q = 0; q < 4; q++) v[q] = jraw[(w[q] >> 8) & 127] * jraw[(w[q] >> 15) & 127] * jraw[(w[q] >> 22) & 127];
+          for (int q = 0; q < PB; q++) v[q] = jraw[(w[q] >> 8) & 127] * jraw[(w[q] >> 15) & 127] * jraw[(w[q] >> 22) & 127];
 #pragma unroll
-          for (int q = 0; q < 4; q++)
+          for (int q = 0; q < PB; q++)
             if (e + 16 * q < nprod) __hip_atomic_fetch_add(&myFs[w[q] & 255], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
       }
