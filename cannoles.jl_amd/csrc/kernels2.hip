@@ -954,26 +954,25 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         for (int k = 0; k < KB; k++) lrn[k] = lr[k];
       }
       // x of the update rows from the parent's vector (in place when this front reuses the parent's slot).
-      // Lane l keeps x of local row l; rows not known yet (and the rhs slot, lane 0) hold 0, so the dot product of
-      // a pivot row needs no lane predicate: entries beyond the row multiply zeros.
+      // Lane l keeps x of local row l; rows not known yet hold 0, so the dot product of a pivot row needs no lane
+      // predicate: entries beyond the row multiply zeros.  Lane 0 (the right-hand-side column, where the panel
+      // keeps z = D^-1 L^-1 b) holds -1: the lane sum is then (L x) - z = -x_pivot, no separate broadcast of z.
       const int tu = tri2(1 + nupd);
-      double xb = 0.0;
+      double xb = l == 0 ? -1.0 : 0.0;
       if (pxoff >= 0 && l >= 1 && l <= nupd) xb = xs[pxoff + rec[B_HDR + l]];
       wsync();
 #pragma unroll
       for (int k = 0; k < KB; k++) {
         if (k < npiv) {
           const double sum = gsum<16>(lr[k] * xb);
-          const double z = bcast<16>(lr[k], 0, (lane - l) * 4);
-          if (l == nupd + 1 + k) xb = z - sum;
+          if (l == nupd + 1 + k) xb = -sum;
         }
       }
       for (int k0 = KB; k0 < npiv; k0++) {  // fronts with more than KB pivots: remaining rows loaded on demand
         const int i = nupd + 1 + k0;
         const double lv = myL[lptr + tri2(i) - tu + l];
         const double sum = gsum<16>(lv * xb);
-        const double z = bcast<16>(lv, 0, (lane - l) * 4);
-        if (l == i) xb = z - sum;
+        if (l == i) xb = -sum;
       }
       // d = -x of the pivots: one scattered store per front (rec holds the original index of every pivot)
       if (okme && l > nupd && l < f) mydout[rec[B_HDR + l]] = -xb;
