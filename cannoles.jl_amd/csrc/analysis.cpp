@@ -924,6 +924,8 @@ int write_forward_records(Plan& P, const DirectLists* D) {
   std::vector<int32_t> rec;
   int32_t rec_maxlen = 0;
   int64_t st_raw = 0, st_prod = 0, st_asm = 0, st_rawmax = 0, st_prodmax = 0, st_asmmax = 0;
+  // every condensed residual pivot d_r is "owned" by the first front that stages it: that front counts it in the inertia
+  std::unordered_map<int32_t, char> d_claimed;
   for (int32_t s = 0; s < ns; s++) {
     const FrontHdr& F = P.fronts[s];
     size_t r0 = rec.size();
@@ -1003,7 +1005,18 @@ int write_forward_records(Plan& P, const DirectLists* D) {
           if (!seen.count(srcq)) { seen[srcq] = 1; (srcq >= nnz_thr ? rr : rv).push_back(srcq); }
     }
     for (auto& p_ : prs) if (rawidx.count(p_.a) || rawidx.count(p_.b)) return why("a pivot is also an operand");
-    std::sort(raw.begin(), raw.end());
+    // owned pivots first (each group in ascending source order)
+    int32_t nrd_own = 0;
+    {
+      ivec own, rest;
+      for (int32_t q : raw) (d_claimed.count(q) ? rest : own).push_back(q);
+      for (int32_t q : own) d_claimed[q] = 1;
+      std::sort(own.begin(), own.end());
+      std::sort(rest.begin(), rest.end());
+      nrd_own = (int32_t)own.size();
+      raw = own;
+      raw.insert(raw.end(), rest.begin(), rest.end());
+    }
     std::sort(rv.begin(), rv.end());
     std::sort(rr.begin(), rr.end());
     raw.insert(raw.end(), rv.begin(), rv.end());
@@ -1051,9 +1064,11 @@ int write_forward_records(Plan& P, const DirectLists* D) {
     H[R_NCHILD] = F.child_end - F.child_begin; H[R_UOFF] = uoff2[s];
     H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0) | (cls[s] << 8); H[R_FSOFF] = fsoff2[s];
     H[R_LPTR_LO] = F.lptr_lo; H[R_LPTR_HI] = F.lptr_hi; H[R_NASMV] = nasmv; H[R_ASM_OFF] = asm_off; H[R_CHILD_OFF] = child_off;
-    H[R_NPROD] = (int32_t)(strided ? prod.size() : prod.size() / 2); H[R_NRAW] = (int32_t)raw.size(); H[R_NRD] = nrd | (nrawv << 16);
-    st_raw += H[R_NRAW]; st_prod += H[R_NPROD]; st_asm += H[R_NASM];
-    st_rawmax = std::max<int64_t>(st_rawmax, H[R_NRAW]); st_prodmax = std::max<int64_t>(st_prodmax, H[R_NPROD]);
+    const int32_t nprod_ = (int32_t)(strided ? prod.size() : prod.size() / 2);
+    if (nprod_ >= 65536) return why("more than 65535 products in one front");
+    H[R_NPROD] = nprod_ | (nrd_own << 16); H[R_NRAW] = (int32_t)raw.size(); H[R_NRD] = nrd | (nrawv << 16);
+    st_raw += H[R_NRAW]; st_prod += nprod_; st_asm += H[R_NASM];
+    st_rawmax = std::max<int64_t>(st_rawmax, H[R_NRAW]); st_prodmax = std::max<int64_t>(st_prodmax, nprod_);
     st_asmmax = std::max<int64_t>(st_asmmax, H[R_NASM]);
     // globally staged fronts read their lists from the stream itself: only the header must fit the LDS buffer
     rec_maxlen = std::max(rec_maxlen, fsglob[s] ? (int32_t)R_HDR : H[R_RECLEN]);
@@ -1066,6 +1081,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
   P.rec_maxlen = rec_maxlen;
   P.rec_direct = D != nullptr;
   if (D) { P.nnz_outer = D->nnz_outer; P.n_outer = D->n_outer; }
+  P.d_owned = (int64_t)d_claimed.size();  // condensed pivots whose inertia the kernel counts while staging them
   return 0;
 }
 

@@ -177,6 +177,7 @@ int setup_v2(cnl_handle* h) {
     d.vstride = P.nnz_outer; d.rstride = P.n_outer;
     d.N0 = P.n_outer;
     if (P.d_outer) d.dstride = P.n_outer;
+    d.count_d = P.d_owned == (int64_t)h->plan->C.r_dsrc.size() ? 1 : 0;  // every condensed pivot is staged by some front
   }
   // the kernel addresses vals / rhs / L of the 4 problems of a wave with 32-bit byte offsets from the first one
   if (4 * 8 * (uint64_t)std::max<int64_t>({d.lsize, d.vstride, d.rstride, d.dstride, (int64_t)d.nnz + d.N0}) >= (1ull << 32)) return CNL_OK;
@@ -226,18 +227,24 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
     double* crhs = h->d_cbuf + s_mat;
     hipError_t e = hipSuccess;
     const bool direct = h->use_v2 && h->plan->P.rec_direct;  // the register-front kernel condenses on the fly
+    const bool count_d = direct && h->dp2.count_d;  // the kernel counts the condensed pivots itself
     if (direct && a.mode == cnl::MODE_NEWTON) {
-      e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
-      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
+      if (!count_d) {
+        e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
+        if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
+      }
       const bool d_outer = h->plan->P.d_outer;  // the kernel writes the kept components of d itself
-      a.vals = d_vals; a.rhs = d_rhs; a.d = d_outer ? d_d : h->d_d2; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
+      a.vals = d_vals; a.rhs = d_rhs; a.d = d_outer ? d_d : h->d_d2;
+      a.extra_pos = count_d ? nullptr : h->d_xpos; a.extra_zer = count_d ? nullptr : h->d_xzer;
       if ((rc = launch(h, a, stream))) return rc;
       e = cnl::launch_expand(h->dc, d_vals, d_rhs, d_outer ? nullptr : h->d_d2, h->d_cbuf, d_d, a.success, 0, B, stream);
       if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
     } else if (direct && a.mode == cnl::MODE_FACTOR) {
-      e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
-      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
-      a.vals = d_vals; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
+      if (!count_d) {
+        e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
+        if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
+      }
+      a.vals = d_vals; a.extra_pos = count_d ? nullptr : h->d_xpos; a.extra_zer = count_d ? nullptr : h->d_xzer;
       if ((rc = launch(h, a, stream))) return rc;
       h->last_vals = d_vals;
     } else if (a.mode == cnl::MODE_NEWTON) {

@@ -39,6 +39,7 @@ struct DevPlan2 {
   const int32_t* brec;
   int32_t nsuper, N, nnz, rho_begin, nvar;
   int32_t N0;            // length of the right-hand side the records address (outer N with direct records)
+  int32_t count_d;       // 1: the fronts count the condensed residual pivots they own (no separate inertia pass)
   int32_t reccap;        // words of the forward record buffer (one per wave)
   int32_t breccap;       // words per backward record buffer (two per wave, same LDS area)
   int32_t recwords;      // words of that area = max(reccap, 2 * breccap)

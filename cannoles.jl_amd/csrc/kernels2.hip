@@ -401,7 +401,7 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
                                                      long long P_gs_doubles, long long P_lsize, long long P_vstride, long long P_rstride,
                                                      const double* vals_, const double* rhs_, double* L_,
                                                      double* gs_, int batch, int lane, int prob0, const int* rec, int roff,
-                                                     double* pbase0, int* cnt, double eig_tol, double rho, bool ovr) {
+                                                     double* pbase0, int* cnt, double eig_tol, double rho, bool ovr, bool count_d) {
   SlowArgs P;
   P.prob_doubles = P_prob_doubles; P.u2_peak = P_u2_peak; P.nnz = P_nnz; P.rho_begin = P_rho_begin;
   P.gs_doubles = P_gs_doubles; P.lsize = P_lsize; P.vstride = P_vstride; P.rstride = P_rstride; P.rec = prec_;
@@ -452,7 +452,20 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     }
   }
   // on-the-fly condensation, out-of-line form: two words per product (pos, ia | ib<<10 | id<<20), raw values gathered directly
-  const int nprod = rfl(rec[R_NPROD]), nraw = rfl(rec[R_NRAW]);
+  const int nprodw = rfl(rec[R_NPROD]), nraw = rfl(rec[R_NRAW]);
+  const int nprod = nprodw & 0xffff, nrd_own = count_d ? nprodw >> 16 : 0;
+  if (nrd_own > 0) {
+    // residual pivots owned by this front: counted in the inertia (src/solver_types.jl:90-95)
+    const int raw_off = aoff + 2 * nasm;
+    int np_ = 0, nz_ = 0;
+    for (int t = l; t < nrd_own; t += 16) {
+      const double dv = myvals[grec[raw_off + t]];
+      np_ += dv > eig_tol;
+      nz_ += fabs(dv) <= eig_tol;
+    }
+    if (valid && np_) __hip_atomic_fetch_add(&cnt[g * 2], np_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (valid && nz_) __hip_atomic_fetch_add(&cnt[g * 2 + 1], nz_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
   if (nprod > 0) {
     const int raw_off = aoff + 2 * nasm, prod_off = raw_off + nraw;
     if (gfs) gsync(); else wsync();
@@ -623,6 +636,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     STAMP_BEGIN
     // ---------------- forward pass over the record stream ----------------
     if (l == 0) { cnt[g * 2] = xpos; cnt[g * 2 + 1] = xzer; }
+    int rpos = 0, rzer = 0;  // per-lane tallies of the condensed residual pivots staged by this lane
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
     const bool needs_fix = __any(ovr) || !has_rhs;  // wave-uniform: some value must be replaced at assembly time
     int4 R0, R1, R2;  // record prefetch registers (named values: an array would be kept in scratch)
@@ -655,7 +669,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         const bool fast0 = (fw0 >> 8) == 16 && !(fw0 & RF_FS_GLOBAL);
         if (!fast0) {
           // rare: large or globally staged front, handled out of line
-          if (!(CNL_ABL & 2048)) slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, has_rhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, recw, roff, pbase0, cnt, eig_tol, rho, ovr);
+          if (!(CNL_ABL & 2048)) slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, has_rhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, recw, roff, pbase0, cnt, eig_tol, rho, ovr, P.count_d != 0);
           gsync();
           roff = nxt_off;
           s++;
@@ -675,8 +689,9 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM);
       const int nchild = HDRW(hv, R_NCHILD), uoff = HDRW(hv, R_UOFF), flags = HDRW(hv, R_FLAGS), fsoff = HDRW(hv, R_FSOFF);
       const int nasmv = HDRW(hv, R_NASMV), aoff = HDRW(hv, R_ASM_OFF), coff = HDRW(hv, R_CHILD_OFF);
-      const int nprod = HDRW(hv, R_NPROD), nraw = HDRW(hv, R_NRAW), nrdw = HDRW(hv, R_NRD);
-      const int nrd = nrdw & 0xffff, nrawv = nrdw >> 16;
+      const int nprodw = HDRW(hv, R_NPROD), nraw = HDRW(hv, R_NRAW), nrdw = HDRW(hv, R_NRD);
+      const int nprod = nprodw & 0xffff, nrd = nrdw & 0xffff, nrawv = nrdw >> 16;
+      const int nrd_own = P.count_d ? nprodw >> 16 : 0;  // residual pivots this front counts in the inertia
       const long long lptr = (long long)HDRW(hv, R_LPTR_LO) | ((long long)HDRW(hv, R_LPTR_HI) << 31);
       const int f = 1 + nupd + npiv;
       const bool uglob = flags & RF_U_GLOBAL;
@@ -726,6 +741,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
           if (j * 16 < nrawv) {
             double v = pvr[j];
             if (j * 16 < nrd) {
+              // the pivots d_r this front owns are counted here (src/solver_types.jl:90-95): per-lane tallies, summed
+              // over the 16 lanes once per factorisation
+              const bool own = j * 16 + l < nrd_own;
+              rpos += own && v > eig_tol;
+              rzer += own && fabs(v) <= eig_tol;
               const double r = fast_div(-1.0, v);
               v = j * 16 + l < nrd ? r : v;
             }
@@ -733,6 +753,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
           }
         for (int e = PVR * 16 + l; e < nrawv; e += 16) {
           const double v = myvals[rec[raw_off + e]];
+          rpos += e < nrd_own && v > eig_tol;
+          rzer += e < nrd_own && fabs(v) <= eig_tol;
           jraw[e] = e < nrd ? fast_div(-1.0, v) : v;
         }
 #pragma unroll
@@ -841,12 +863,14 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     }
     // ---------------- inertia test and rho ladder (src/solver_types.jl:90-97, src/CaNNOLeS.jl:1023-1047) ----
     wsync();
-    const bool ok = (CNL_ABL != 0) || (cnt[g * 2] == P.nvar && cnt[g * 2 + 1] == 0);
+    for (int o = 8; o > 0; o >>= 1) { rpos += __shfl_xor(rpos, o, 16); rzer += __shfl_xor(rzer, o, 16); }
+    const int tpos = cnt[g * 2] + rpos, tzer = cnt[g * 2 + 1] + rzer;
+    const bool ok = (CNL_ABL != 0) || (tpos == P.nvar && tzer == 0);
     if (A.mode == MODE_FACTOR) {
       if (valid && l == 0) {
         A.success[prob] = ok ? 1 : 0;
-        if (A.npos) A.npos[prob] = cnt[g * 2];
-        if (A.nzero) A.nzero[prob] = cnt[g * 2 + 1];
+        if (A.npos) A.npos[prob] = tpos;
+        if (A.nzero) A.nzero[prob] = tzer;
       }
       return;
     }

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) cond_inertia_kernel(const DevCond Cin, co
 // column), parked in LDS and summed row-per-thread.
 constexpr int XRB = 256;    // residual rows per workgroup
 constexpr int XEMAX = 2048; // Jacobian entries staged per workgroup (longer chunks take the row-per-thread loop)
-constexpr int XPB = 4;      // problems per workgroup: the index lists are read once and reused
+constexpr int XPB = 8;      // problems per workgroup: the index lists are read once and reused
 // d2 == nullptr: the multifrontal kernel has already written the kept components into dout (caller's numbering);
 // only the residual components are recovered, reading the x components from dout itself.
 __global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* __restrict__ vals, const double* __restrict__ rhs,

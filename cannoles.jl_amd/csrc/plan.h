@@ -86,6 +86,7 @@ struct Plan {
   // "direct" records: the assembly lists address the ORIGINAL vals / rhs (duplicate rounds) and carry the
   // products of the condensed residual rows, so the multifrontal kernel condenses on the fly
   bool rec_direct = false;
+  int64_t d_owned = 0;   // number of condensed residual pivots staged (and counted) by the direct records
   bool d_outer = false;  // backward records name solution components in the caller's numbering (set with rec_direct)
   int32_t nnz_outer = 0, n_outer = 0;  // outer (reference) nnz and N when rec_direct
 };

@@ -40,12 +40,13 @@ class RecSim:
         npos = nzer = 0
         off = 0
         self.stats = dict(plain=0, products=0, raw=0, strided=0, packed=0)
+        self.owned = self.own_pos = self.own_zer = 0  # condensed residual pivots counted by the fronts that own them
         for _ in range(self.ns):
             H = rec[off:off + R_HDR]
             npiv, nupd, nasm, nasmv = int(H[R_NPIV]), int(H[R_NUPD]), int(H[R_NASM]), int(H[R_NASMV])
             flags, cls = int(H[R_FLAGS]) & 0xff, int(H[R_FLAGS]) >> 8
             aoff, coff = int(H[R_ASM_OFF]), int(H[R_CHILD_OFF])
-            nprod, nraw = int(H[R_NPROD]), int(H[R_NRAW])
+            nprod, nrd_own, nraw = int(H[R_NPROD]) & 0xffff, int(H[R_NPROD]) >> 16, int(H[R_NRAW])
             nrd, nrawv = int(H[R_NRD]) & 0xffff, int(H[R_NRD]) >> 16
             f = 1 + nupd + npiv
             strided = cls == 16 and not (flags & RF_FS_GLOBAL)
@@ -66,6 +67,11 @@ class RecSim:
             jraw = np.array([src_val(int(r[raw_off + t])) for t in range(nraw)])
             for t in range(nraw):
                 assert (int(r[raw_off + t]) >= self.nnz) == (t >= nrawv)
+            # the first nrd_own pivots are owned by this front: it counts them in the inertia
+            assert nrd_own <= nrd
+            self.owned += nrd_own
+            self.own_pos += int((jraw[:nrd_own] > eig_tol).sum())
+            self.own_zer += int((np.abs(jraw[:nrd_own]) <= eig_tol).sum())
             jr = jraw.copy()
             jr[:nrd] = -1.0 / jraw[:nrd]
             poff = raw_off + nraw

@@ -165,7 +165,9 @@ def test_record_streams_reproduce_the_oracle(shape, monkeypatch):
     ok, pos0, zer0 = orc.try_to_factorize(vals, s.nvar, s.nequ, s.ncon, eig_tol, return_inertia=True)
     d0 = orc.solve_ldl(rhs)
     dr = vals[off[4]:off[5]]
-    assert npos + int((dr > eig_tol).sum()) == pos0 and nzer + int((np.abs(dr) <= eig_tol).sum()) == zer0
+    assert sim.owned == s.nequ  # every condensed pivot is owned by exactly one front ...
+    assert sim.own_pos == int((dr > eig_tol).sum()) and sim.own_zer == int((np.abs(dr) <= eig_tol).sum())  # ... which counts it
+    assert npos + sim.own_pos == pos0 and nzer + sim.own_zer == zer0
     kept = ~np.isnan(d)
     assert kept.sum() == s.N - s.nequ and not kept[s.nvar:s.nvar + s.nequ].any()
     assert np.abs(d[kept] - d0[kept]).max() <= 1e-10 * np.abs(d0).max()
