@@ -9,14 +9,18 @@
 //    extend-add, update-matrix store) uses 16 lanes per problem; index data is
 //    shared by the four problems, so it is read once per wave.
 //  * a front is eliminated in REGISTERS: lane b holds column b of the packed
-//    lower triangle (register a = row a), the pivot row is broadcast with
-//    ds_bpermute / v_readlane, and the rank-1 update is one FMA per row.  No
-//    LDS traffic, no barrier and no index decode inside the pivot loop.
+//    lower triangle (register k = row top-k, so the pivot row is always r0 and the
+//    update shifts the triangle up as a side effect); per pivot the undivided pivot
+//    row is published in LDS once and read back by all lanes in one batch, every lane
+//    forms its own multiplier, and the rank-1 update is one FMA per row: one LDS round
+//    trip and one division per pivot, no cross-lane shuffle, no index decode.
 //    Fronts of order <= 16 run four problems at once, <= 32 two, <= 64 one.
-//  * the plan is a self-describing record stream (analysis.cpp) read with
-//    coalesced loads into an LDS double buffer; the record of front s+2 and the
-//    values of front s+1 are prefetched into registers while front s is being
-//    eliminated, so no global-memory latency sits on the per-front critical path.
+//  * the plan is a self-describing record stream (analysis.cpp): the record of front
+//    s+2 is prefetched into registers and copied into the wave's LDS buffer when front
+//    s+1's lists are no longer needed; the values of front s+1 are gathered while front
+//    s is being eliminated, so no global-memory latency sits on the per-front critical
+//    path.  With "direct" records the lists address the caller's arrays and carry the
+//    products of the condensed residual block: the kernel condenses on the fly.
 //  * update matrices wait for their parent on a per-problem LDS stack whose
 //    offsets were fixed on the host; the few large ones (and the staging of
 //    fronts of order > 32) use a per-problem global scratch instead.
@@ -76,13 +80,6 @@ __device__ __forceinline__ double bcast(double v, int a, int grp4) {
   }
 }
 
-// value of the lane whose byte address (4 * lane) is `addr4`
-__device__ __forceinline__ double bcast_addr(double v, int addr4) {
-  int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(v));
-  int hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-
 // w / d through a refined reciprocal: shorter dependent chain than the IEEE expansion (no scaling /
 // fix-up steps; a zero or non-finite pivot still yields inf/NaN, which fails the inertia test anyway)
 // v_rcp_f64 is good to ~2^-25 (measured on gfx950); one Newton step brings the reciprocal to ~10 ulp, and the
@@ -140,7 +137,7 @@ struct Ctx2 {
 // Lane b holds column b.  Register r<k> holds row (top - k) where `top` is the highest live row,
 // so the pivot row is always r0; the rank-1 update writes row (top-k) into r<k-1>, which shifts
 // the triangle up by one as a side effect (no moves, no dynamic register index):
-//     r<k-1> = fma(-l[top-k], w, r<k>),   l = w / d broadcast with ds_bpermute.
+//     r<k-1> = fma(-w[top-k], l, r<k>),   w = pivot row read back from LDS, l = this lane's multiplier.
 // The rows are spelled as individual scalars through the X-macro lists of elim_lists.inc.
 #include "elim_lists.inc"
 
