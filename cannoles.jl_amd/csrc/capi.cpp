@@ -35,6 +35,7 @@ struct cnl_handle {
   cnl::KernelConfig cfg{};
   // v2 (register-front kernel): used for newton_system / factorize when every front has order <= 64
   bool use_v2 = false;
+  bool v2_solve = false;  // cnl_solve runs on the register-front kernel too (direct records, every front of the fast class)
   cnl::DevPlan2 dp2{};
   int wpb2 = 1;
   size_t lds2 = 0;
@@ -192,6 +193,7 @@ int setup_v2(cnl_handle* h) {
   h->lds2 = wpb * wave_bytes + 512;
   if ((rc = dalloc(h, &h->d_gs, (size_t)h->batch * (size_t)d.gs_doubles))) return rc;
   h->use_v2 = true;
+  h->v2_solve = P.rec_direct && P.d_outer && P.ncls[1] == 0 && P.ncls[2] == 0 && !(getenv("CNL_V1_SOLVE") && atoi(getenv("CNL_V1_SOLVE")));
   return CNL_OK;
 }
 
@@ -201,7 +203,7 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.scratch = h->d_scratch;
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));  // events bracket the multifrontal kernel only
   hipError_t e;
-  if (h->use_v2 && a.mode != cnl::MODE_SOLVE) {
+  if (h->use_v2 && (a.mode != cnl::MODE_SOLVE || h->v2_solve)) {
     a.scratch = h->d_gs;
     e = cnl::launch_newton2(h->dp2, h->wpb2, h->lds2, a, stream);
   } else {
@@ -264,6 +266,13 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
       a.vals = h->d_cbuf; a.extra_pos = h->d_xpos; a.extra_zer = h->d_xzer;
       if ((rc = launch(h, a, stream))) return rc;
       h->last_vals = d_vals;
+    } else if (direct && h->v2_solve) {
+      // solve_ldl! on the register-front kernel: forward substitution with the stored factor, backward sweep, post-pass
+      if (!h->last_vals) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
+      a.vals = const_cast<double*>(h->last_vals); a.rhs = d_rhs; a.d = d_d;
+      if ((rc = launch(h, a, stream))) return rc;
+      e = cnl::launch_expand(h->dc, const_cast<double*>(h->last_vals), d_rhs, nullptr, h->d_cbuf, d_d, nullptr, 0, B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
     } else {
       if (!h->last_vals) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
       e = C.tiled_ok ? cnl::launch_condense_tiled(h->dc, h->last_vals, d_rhs, h->d_cbuf, 4, C.ch_region[3], B, stream)

@@ -41,6 +41,7 @@ namespace {
 constexpr int RN = 3;    // record prefetch: RN x dwordx4 per lane = RN*256 words
 constexpr int PVR = 6;   // raw-value prefetch of the on-the-fly condensation: PVR*16 matrix values per problem (+ 2 x 16 rhs values)
 constexpr int PVN = 8;   // value prefetch: PVN doubles per lane = PVN*16 entries per problem
+constexpr int KB = 10;   // panel rows prefetched per front in the solve sweeps (chain-like orders: up to 10 pivots per front)
 
 __device__ __forceinline__ int tri2(int i) { return (i * (i + 1)) >> 1; }
 
@@ -619,6 +620,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   const unsigned gsel = valid ? (unsigned)g : 0u;
   const unsigned gofs_v = gsel * (unsigned)P.vstride * 8u;
   const unsigned gofs_r = (gsel * (unsigned)(has_rhs ? P.rstride : P.vstride) - (unsigned)P.nnz) * 8u;  // rhs sources are nnz + index
+  const char* L_wb = reinterpret_cast<const char*>(A.L + (long long)prob0u * P.lsize);
+  const unsigned gofs_l = (gsel * (unsigned)P.lsize + (unsigned)l) * 8u;
 
   // per-problem ladder state, replicated over the 16 lanes of the group
   double rho = 0.0, wrote = 0.0;
@@ -628,8 +631,174 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   const double kdec = A.params[2], kinc = A.params[3], klarge = A.params[4], rho0 = A.params[5], rhomax = A.params[6],
                rhomin = A.params[7];
 
+  // ---------------- MODE_SOLVE: forward substitution with the stored factor (solve_ldl!, src/solver_types.jl:69-77) ------
+  // Only the right-hand-side column of every front is assembled (plain rhs entries, the products -J_ra rhs_r / d_r of the
+  // condensed rows, the children's update vectors), then  c_a -= l_ia c_i  over the pivots from the top and z_i = c_i / d_i
+  // goes into column 0 of the stored panel, where the backward sweep below expects it.  The host sends a plan here only
+  // when every front is of the fast class (order <= 16, LDS staging).
+  if (A.mode == MODE_SOLVE) {
+    const int4* rstream = reinterpret_cast<const int4*>(P.rec);
+    int4 R0, R1, R2;
+    double pvr[PVR], prr[2], prh = 0.0, pv[PVN];
+    double lr[KB], lrn[KB];
+    int roff = 0, nxt_off = 0;
+    int* recw = recbuf;
+    {
+      int len = P.rec[0 + R_RECLEN];
+      nxt_off = len;
+      if (len > P.reccap) len = P.reccap;
+      for (int w4 = lane; w4 * 4 < len; w4 += 64) reinterpret_cast<int4*>(recw)[w4] = rstream[w4];
+      wsync();
+      R0 = rstream[(nxt_off >> 2) + lane];
+      R1 = rstream[(nxt_off >> 2) + lane + 64];
+      R2 = rstream[(nxt_off >> 2) + lane + 128];
+      const int hv0 = recw[lane & 15];
+      const int nasm0 = HDRW(hv0, R_NASM), aoff0 = HDRW(hv0, R_ASM_OFF);
+      PREFETCH_VALUES(recw, aoff0, HDRW(hv0, R_NASMV), nasm0)
+      PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRD) >> 16, HDRW(hv0, R_NRAW))
+      const long long lp0 = (long long)HDRW(hv0, R_LPTR_LO) | ((long long)HDRW(hv0, R_LPTR_HI) << 31);
+      PREFETCH_ROWS(lr, lp0, HDRW(hv0, R_NUPD), HDRW(hv0, R_NPIV))
+    }
+    (void)pv;
+    for (int s = 0; s < P.nsuper; s++) {
+      const int* rec = recw;
+      const int hv = rec[lane & 15];
+      const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM), nasmv = HDRW(hv, R_NASMV);
+      const int nchild = HDRW(hv, R_NCHILD), uoff = HDRW(hv, R_UOFF), flags = HDRW(hv, R_FLAGS) & 0xff;
+      const int aoff = HDRW(hv, R_ASM_OFF), coff = HDRW(hv, R_CHILD_OFF);
+      const int nprod = HDRW(hv, R_NPROD) & 0xffff, nraw = HDRW(hv, R_NRAW), nrdw = HDRW(hv, R_NRD);
+      const int nrd = nrdw & 0xffff, nrawv = nrdw >> 16;
+      const long long lptr = (long long)HDRW(hv, R_LPTR_LO) | ((long long)HDRW(hv, R_LPTR_HI) << 31);
+      const int f = 1 + nupd + npiv;
+      const bool uglob = flags & RF_U_GLOBAL;
+      double* cvec = myFs;  // c_a = entry (a, 0) of the front, a = 0 .. f-1 (a = 0 unused)
+      cvec[l] = 0.0;
+      const int raw_off = aoff + 2 * nasm;
+      if (nraw > 0) {
+#pragma unroll
+        for (int j = 0; j < PVR; j++)
+          if (j * 16 < nrawv) {
+            double v = pvr[j];
+            if (j * 16 < nrd) {
+              const double r = fast_div(-1.0, v);
+              v = j * 16 + l < nrd ? r : v;
+            }
+            jraw[j * 16 + l] = v;
+          }
+        for (int e = PVR * 16 + l; e < nrawv; e += 16) {
+          const double v = myvals[rec[raw_off + e]];
+          jraw[e] = e < nrd ? fast_div(-1.0, v) : v;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+          if (nrawv + q * 16 < nraw) jraw[nrawv + q * 16 + l] = prr[q];
+      }
+      wsync();
+      // plain right-hand-side entries (positions (row, 0); padding entries sit in other columns and are skipped)
+      if (nasmv < nasm) {
+        const int pos = rec[aoff + nasm + nasmv + l];
+        if ((pos & 15) == 0) __hip_atomic_fetch_add(&cvec[pos >> 4], prh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      for (int e = nasmv + 16 + l; e < nasm; e += 16) {
+        const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
+        if ((pos & 15) == 0) __hip_atomic_fetch_add(&cvec[pos >> 4], myrhs[src - P.nnz], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      // products that land in column 0
+      {
+        const int* pw = rec + raw_off + nraw + l;
+        for (int e = 0; e < nprod; e += 16) {
+          const int w = pw[e];
+          if ((w & 15) == 0) {
+            const double v = jraw[(w >> 8) & 127] * jraw[(w >> 15) & 127] * jraw[(w >> 22) & 127];
+            __hip_atomic_fetch_add(&cvec[(w & 255) >> 4], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+        }
+      }
+      // children's update vectors: entry a of a child goes to the row its (a, 0) entry maps to
+      {
+        int co = coff;
+        for (int ci = 0; ci < nchild; ci++) {
+          const int cv4 = rec[co + (lane & 3)];
+          const int cu = HDRW(cv4, C_UOFF), tuc = HDRW(cv4, C_TUC), cfl = HDRW(cv4, C_FLAGS);
+          if (tri2(l) < tuc) {
+            const int prow = rec[co + C_HDR + tri2(l)] >> 4;
+            const double u = cfl ? mygs[cu + l] : myU[cu + l];
+            __hip_atomic_fetch_add(&cvec[prow], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+          co += C_HDR + ((tuc + 3) & ~3);
+        }
+      }
+      wsync();
+      double cv = cvec[l];
+      wsync();
+      // next record over the current one, prefetches for the next front
+      int nroff = nxt_off;
+      if (s + 1 < P.nsuper) {
+        int* nrec = recbuf;
+        const int nlen = __builtin_amdgcn_readlane(R0.z, 0);
+        const int nasm1 = __builtin_amdgcn_readlane(R0.w, 0);
+        const int nasmv1 = __builtin_amdgcn_readlane(R0.z, 2);
+        const int aoff1 = __builtin_amdgcn_readlane(R0.w, 2);
+        const int nraw1 = __builtin_amdgcn_readlane(R0.z, 3);
+        const int nrawv1 = __builtin_amdgcn_readlane(R0.w, 3) >> 16;
+        const int npiv1 = __builtin_amdgcn_readlane(R0.x, 0), nupd1 = __builtin_amdgcn_readlane(R0.y, 0);
+        const long long lp1 = (long long)__builtin_amdgcn_readlane(R0.x, 2) | ((long long)__builtin_amdgcn_readlane(R0.y, 2) << 31);
+        static_assert(R_NPIV == 0 && R_NUPD == 1 && R_LPTR_LO == 8 && R_LPTR_HI == 9, "record header layout");
+        const int clen = nlen < P.reccap ? nlen : P.reccap;
+        if (lane * 4 < clen) reinterpret_cast<int4*>(nrec)[lane] = R0;
+        if ((lane + 64) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 64] = R1;
+        if ((lane + 128) * 4 < clen) reinterpret_cast<int4*>(nrec)[lane + 128] = R2;
+        wsync();
+        for (int w4 = RN * 64 + lane; w4 * 4 < clen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = rstream[(nxt_off >> 2) + w4];
+        wsync();
+        const int nn_off = nxt_off + nlen;
+        R0 = rstream[(nn_off >> 2) + lane];
+        R1 = rstream[(nn_off >> 2) + lane + 64];
+        R2 = rstream[(nn_off >> 2) + lane + 128];
+        PREFETCH_VALUES(nrec, aoff1, nasmv1, nasm1)
+        PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nrawv1, nraw1)
+        PREFETCH_ROWS(lrn, lp1, nupd1, npiv1)
+        nxt_off = nn_off;
+      } else {
+#pragma unroll
+        for (int k = 0; k < KB; k++) lrn[k] = lr[k];
+      }
+      // substitution over the pivots from the top: lane a holds c_a, row i of the panel is (l_i1 .. l_i,i-1, d_i) in lanes 1..i
+      const int tu = tri2(1 + nupd);
+      double* Lcol0 = A.L + pclamp * P.lsize + lptr - tu;  // entry (i, 0) of the panel at tri(i)
+      for (int k0 = npiv - 1; k0 >= KB; k0--) {  // fronts with more than KB pivots: their top rows are loaded on demand
+        const int i = nupd + 1 + k0;
+        const double lv = A.L[pclamp * P.lsize + lptr + tri2(i) - tu + l];
+        const double ci = bcast<16>(cv, i, (lane - l) * 4);
+        if (l == i && valid) Lcol0[tri2(i)] = fast_div(cv, lv);
+        if (l >= 1 && l < i) cv = fma(-lv, ci, cv);
+      }
+#pragma unroll
+      for (int k = KB - 1; k >= 0; k--) {
+        if (k < npiv) {
+          const int i = nupd + 1 + k;
+          const double ci = bcast<16>(cv, i, (lane - l) * 4);
+          if (l == i && valid) Lcol0[tri2(i)] = fast_div(cv, lr[k]);
+          if (l >= 1 && l < i) cv = fma(-lr[k], ci, cv);
+        }
+      }
+      // update vector for the parent (entries 0 .. nupd; entry 0 is the unused corner)
+      if (l <= nupd) {
+        if (uglob) { if (valid) mygs[uoff + l] = cv; }
+        else myU[uoff + l] = cv;
+      }
+      if (uglob) gsync(); else wsync();
+#pragma unroll
+      for (int k = 0; k < KB; k++) lr[k] = lrn[k];
+      roff = nroff;
+    }
+    (void)roff;
+    success = valid;
+    gsync();  // the z column is read back through global memory by the backward sweep
+  }
+
   STAMP_DECL
-  while (true) {
+  while (A.mode != MODE_SOLVE) {
     STAMP_BEGIN
     // ---------------- forward pass over the record stream ----------------
     if (l == 0) { cnt[g * 2] = xpos; cnt[g * 2 + 1] = xzer; }
@@ -902,11 +1071,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     const int* okflag = cnt + 8;
     const bool okme = valid && okflag[g] != 0;
     const double* myL = A.L + pclamp * P.lsize;
-    const char* L_wb = reinterpret_cast<const char*>(A.L + (long long)prob0u * P.lsize);
-    const unsigned gofs_l = (gsel * (unsigned)P.lsize + (unsigned)l) * 8u;
     double* mydout = A.d + pclamp * P.dstride;
     double* xs = myU;  // the x stack reuses the per-problem LDS area
-    constexpr int KB = 10;  // panel rows prefetched per front (fronts of the chain-like orders hold up to 10 pivots)
     int boff = 0, nxt = 0;
     int4 Rb;
     double lr[KB];     // panel rows of the CURRENT front (first KB pivots), prefetched one front ahead
@@ -1009,7 +1175,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   STAMP(6)
   if (lane == 0 && A.npos) for (int k = 0; k < 8; k++) A.npos[(blockIdx.x * WPB + wave) * 8 + k] = (long long)st_acc[k];
 #endif
-  if (valid && l == 0) {
+  if (valid && l == 0 && A.mode == MODE_NEWTON) {
     A.rho[prob] = rho;
     A.rho_old[prob] = rho_old;
     A.nfact[prob] = nfact;

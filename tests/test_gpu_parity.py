@@ -385,3 +385,35 @@ def test_multipliers_last_large_fronts(built, monkeypatch):
     run_case(s, vals, rhs)
     v2, r2 = syn.batch_values(s, 5, cfg=5, stress="ladder")
     run_case(s, v2, r2, check_fwd=False)
+
+
+@pytest.mark.parametrize("shape", [(400, 8, 2), (600, 6, 1), (600, 6, 4), (500, 0, 2), (1000, 10, 2)])
+def test_solve_ldl_on_the_register_front_kernel(built, shape):
+    """try_to_factorize then solve_ldl! (src/solver_types.jl:69-98), the reference's literal call sequence, with several
+    right-hand sides per factorisation, on plans whose fronts are all of the fast class: cnl_solve then runs the forward
+    substitution with the stored factor on the register-front kernel.  Checked against the oracle's solve_ldl!."""
+    hipldl, syn, O = _mods()
+    n, p, hw = shape
+    s = syn.band_structure(n, p, hw=hw)
+    B = 6
+    vals, rhs = syn.batch_values(s, B, cfg=3)
+    off = s.offsets()
+    vals[:, off[4]:off[5]] = -np.random.default_rng(hw).uniform(0.5, 2.0, (B, s.nequ))
+    vals[:, off[6]:off[7]] = 0.125
+    rows, cols = s.kkt_pattern()
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, vals, s.nvar, s.nequ, s.ncon, batch=B)
+    assert LDLT.info["v2"] is not None and LDLT.info["v2"]["fronts32"] + LDLT.info["v2"]["fronts64"] == 0
+    ok = hipldl.try_to_factorize(LDLT, vals, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16)
+    assert ok.all()
+    perm = LDLT.plan_array("perm").astype(np.int64)
+    orc = O.Oracle(s.N, rows, cols, perm)
+    for k in range(3):
+        r = np.ascontiguousarray(rhs * (k + 1) + k)
+        d = np.zeros((B, s.N))
+        hipldl.solve_ldl_(r, LDLT.factor, d)
+        for b in range(B):
+            assert orc.try_to_factorize(vals[b], s.nvar, s.nequ, s.ncon, 2.220446049250313e-16)
+            d0 = orc.solve_ldl(r[b])
+            assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+            assert backward_error(s, vals[b], r[b], d[b]) <= BWD_TOL
+    LDLT.close()
