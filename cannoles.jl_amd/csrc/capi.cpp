@@ -16,6 +16,7 @@
 
 #include "../../include/cannoles_hip.h"
 #include "condense.h"
+#include "dense.h"
 #include "kernels.h"
 #include "plan.h"
 
@@ -24,6 +25,7 @@ struct cnl_plan {
   cnl::Plan P;   // multifrontal plan of the (condensed) system
   int64_t N = 0, nnz = 0, nvar = 0, nequ = 0, ncon = 0;  // outer dimensions, as the reference sees them
   std::vector<int32_t> perm_outer;
+  cnl::DensePlan D;  // dense residual block (BASELINE config 2): served by the dense backend, csrc/dense.h
 };
 
 struct cnl_handle {
@@ -58,6 +60,7 @@ struct cnl_handle {
   float last_ms = 0.f;
   bool factorized = false;
   cnl::DevJt djt{};  // transposed-Jacobian lists (row f1: residual / optimality vectors on the device)
+  cnl::DenseState* dense = nullptr;
 };
 
 namespace {
@@ -220,6 +223,21 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, double* d_d, hipStream_t stream) {
   const cnl::Cond& C = h->plan->C;
   int rc = CNL_OK;
+  if (h->dense) {
+    // dense residual block: GEMM + blocked dense LDL^T (csrc/dense.hip); the rho ladder is decided on the host, so the
+    // call synchronises on the stream
+    std::string err;
+    if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
+    rc = cnl::dense_run(h->dense, h->plan->D, a.mode, d_vals, d_rhs, d_d, a.rho_old, a.rho, a.nfact, a.success, a.npos, a.nzero,
+                        a.params, stream, err);
+    if (rc) return fail(rc == 5 ? CNL_ERR_STATE : CNL_ERR_HIP, "dense backend: " + err);
+    if (h->timing) {
+      HIPCHK(hipEventRecord(h->ev1, stream));
+      HIPCHK(hipEventSynchronize(h->ev1));
+      HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    }
+    return CNL_OK;
+  }
   if (!C.active) {
     a.vals = d_vals; a.rhs = d_rhs; a.d = d_d;
     rc = launch(h, a, stream);
@@ -370,6 +388,7 @@ int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows
       fprintf(stderr, "[cnl] direct records: %s, rec words %zu -> %zu, longest %d -> %d\n", drc ? "not possible" : "ok", old_words,
               p->P.rec.size(), old_len, p->P.rec_maxlen);
   }
+  if (!(getenv("CNL_NO_DENSE") && atoi(getenv("CNL_NO_DENSE")))) cnl::detect_dense(p->D, N, nnz, rows1, cols1, nvar, nequ, ncon);
   // elimination order in the reference's numbering: condensed residual nodes first
   if (p->C.active) {
     p->perm_outer.assign(p->C.r_orig.begin(), p->C.r_orig.end());
@@ -510,6 +529,11 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   }
   if ((rc = choose_config(h))) return bail(rc);
   if ((rc = setup_v2(h))) return bail(rc);
+  if (h->plan->D.active) {
+    std::string derr;
+    int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr);
+    if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
+  }
   {
     // factor storage, zero-filled and padded: the row prefetch of the backward pass reads (never uses) a little past a panel
     const size_t ldoubles = (size_t)batch * (size_t)std::max<int64_t>(P.lsize, 1) + 4096;
@@ -555,6 +579,7 @@ int cnl_destroy(cnl_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->dev_allocs) (void)hipFree(p);
+  cnl::dense_destroy(h->dense);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -619,7 +644,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   std::memset(cfg, 0, 8 * sizeof(int64_t));
   cfg[0] = h->cfg.tpp; cfg[1] = h->cfg.ppb; cfg[2] = (int64_t)h->cfg.lds_bytes; cfg[3] = h->cfg.lds_work;
   cfg[4] = (h->batch + h->cfg.ppb - 1) / h->cfg.ppb;
-  cfg[5] = h->use_v2 ? 2 : 1;
+  cfg[5] = h->dense ? 3 : (h->use_v2 ? 2 : 1);
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;
   return CNL_OK;

@@ -1,0 +1,40 @@
+// dense.h — backend for plans whose residual block is DENSE (BASELINE config 2: every residual row holds all variables,
+// no constraints).  The multifrontal machinery has nothing to exploit there: the condensed system
+//     S = H + rho I - J' diag(1/d_r) J          (n x n, dense; = H + rho I + J'J for the reference's d_r = -1)
+// is formed by a GEMM and factorised by a blocked dense LDL^T without pivoting (panel kernels written here, trailing
+// updates by rocBLAS dgemm: MFMA f64).  Same contract as the other kernels: inertia rule of
+// /root/reference/src/solver_types.jl:90-97, rho ladder of /root/reference/src/CaNNOLeS.jl:1008-1052, d = -K^-1 rhs.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace cnl {
+
+struct DensePlan {
+  bool active = false;
+  int32_t n = 0, m = 0, nnz = 0;  // variables, residual rows, COO entries
+  // slot lists built from the pattern (0-based COO entry numbers)
+  std::vector<int32_t> jslot;     // [m * n] column-major: entry of J(i, j) at i + m * j
+  std::vector<int32_t> dslot;     // [m]  diagonal of the -I block
+  std::vector<int32_t> hslot, hpos;  // H_F entries (any number, duplicates allowed): slot, position i + n * j (i >= j)
+};
+
+// Returns true and fills D when the pattern qualifies: ncon == 0, nequ > 0, every residual row has exactly one entry per
+// variable, one diagonal entry per residual row, no other coupling.
+bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
+                  int64_t ncon);
+
+struct DenseState;  // device buffers + rocBLAS handle
+int dense_create(DenseState** st, const DensePlan& D, int64_t batch, std::string& err);
+void dense_destroy(DenseState* st);
+
+// mode: 0 newton (ladder + solve), 1 factorize, 2 solve.  All pointers are device pointers, problem-major as in the ABI.
+// The calls synchronise on `stream` (the ladder decides on the host between attempts).
+int dense_run(DenseState* st, const DensePlan& D, int mode, double* vals, const double* rhs, double* d, double* rho_old,
+              double* rho, int32_t* nfact, int32_t* success, int64_t* npos, int64_t* nzero, const double params[9],
+              hipStream_t stream, std::string& err);
+
+}  // namespace cnl

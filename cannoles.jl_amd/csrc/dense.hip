@@ -1,0 +1,361 @@
+// dense.hip — dense-residual-block backend (see dense.h).  Panel kernels are written here; the two GEMM-shaped steps
+// (J' W J and the trailing updates of the blocked LDL^T) go to rocBLAS dgemm, i.e. to the fp64 matrix cores.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "dense.h"
+
+namespace cnl {
+
+namespace {
+
+constexpr int NB = 64;  // panel width of the blocked factorisation
+
+#define DCHK(x)                                                                                 \
+  do {                                                                                          \
+    hipError_t e_ = (x);                                                                        \
+    if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return 4; }   \
+  } while (0)
+#define BCHK(x)                                                                                 \
+  do {                                                                                          \
+    rocblas_status s_ = (x);                                                                    \
+    if (s_ != rocblas_status_success) { err = std::string(#x) + ": rocBLAS status " + std::to_string((int)s_); return 4; } \
+  } while (0)
+
+// Jd(i, j) = vals[jslot], JW = diag(w) Jd with w_i = -1 / d_r(i); inertia of the residual pivots
+__global__ void __launch_bounds__(256) gather_kernel(const double* __restrict__ vals, const int* __restrict__ jslot,
+                                                     const int* __restrict__ dslot, int m, int n, double* __restrict__ Jd,
+                                                     double* __restrict__ JW, double* __restrict__ w) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)m * n) return;
+  const int i = (int)(t % m);
+  const double wi = -1.0 / vals[dslot[i]];
+  const double v = vals[jslot[t]];
+  Jd[t] = v;
+  JW[t] = wi * v;
+  if (t < m) w[i] = wi;
+}
+
+__global__ void __launch_bounds__(256) rinertia_kernel(const double* __restrict__ vals, const int* __restrict__ dslot, int m,
+                                                       double eig_tol, int* cnt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const double dv = vals[dslot[i]];
+  if (dv > eig_tol) atomicAdd(&cnt[0], 1);
+  if (fabs(dv) <= eig_tol) atomicAdd(&cnt[1], 1);
+}
+
+__global__ void __launch_bounds__(256) hscatter_kernel(const double* __restrict__ vals, const int* __restrict__ hslot,
+                                                       const int* __restrict__ hpos, int nh, double* S0) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < nh) atomicAdd(&S0[hpos[e]], vals[hslot[e]]);
+}
+
+// S = S0 + diag(rho): rho from the slots of vals (first attempt, as given) or one value for all (ladder retries)
+__global__ void __launch_bounds__(256) shift_kernel(const double* __restrict__ S0, double* __restrict__ S, int n,
+                                                    const double* __restrict__ rho_slots, double rho, int use_slots) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)n * n) return;
+  const int i = (int)(t % n), j = (int)(t / n);
+  double v = S0[t];
+  if (i == j) v += use_slots ? rho_slots[i] : rho;
+  S[t] = v;
+}
+
+// unblocked LDL^T of the nb x nb diagonal block at (k0, k0), one workgroup, block held in LDS
+__global__ void __launch_bounds__(256) panel_kernel(double* S, int n, int k0, int nb, double eig_tol, int* cnt) {
+  __shared__ double a[NB][NB + 1];
+  const int t = threadIdx.x;
+  for (int q = t; q < nb * nb; q += 256) { const int i = q % nb, j = q / nb; a[i][j] = S[(size_t)(k0 + i) + (size_t)n * (k0 + j)]; }
+  __syncthreads();
+  int np = 0, nz = 0;
+  for (int j = 0; j < nb; j++) {
+    const double dj = a[j][j];
+    if (t == 0) { np += dj > eig_tol; nz += fabs(dj) <= eig_tol; }
+    __syncthreads();
+    if (t > j && t < nb) a[t][j] = a[t][j] / dj;  // l_tj
+    __syncthreads();
+    // a(i, k) -= l_ij d_j l_kj for j < k <= i
+    for (int q = t; q < nb * nb; q += 256) {
+      const int i = q % nb, k = q / nb;
+      if (k > j && i >= k) a[i][k] -= a[i][j] * dj * a[k][j];
+    }
+    __syncthreads();
+  }
+  for (int q = t; q < nb * nb; q += 256) { const int i = q % nb, j = q / nb; if (i >= j) S[(size_t)(k0 + i) + (size_t)n * (k0 + j)] = a[i][j]; }
+  if (t == 0) { if (np) atomicAdd(&cnt[0], np); if (nz) atomicAdd(&cnt[1], nz); }
+}
+
+// rows below the panel: l_i = a_i (L11 D)^-T, thread per row; also W21 = L21 D for the trailing update
+__global__ void __launch_bounds__(256) l21_kernel(double* S, int n, int k0, int nb, double* __restrict__ W21, int n2) {
+  __shared__ double L11[NB][NB + 1];
+  __shared__ double dd[NB];
+  const int t = threadIdx.x;
+  for (int q = t; q < nb * nb; q += 256) { const int i = q % nb, j = q / nb; L11[i][j] = S[(size_t)(k0 + i) + (size_t)n * (k0 + j)]; }
+  __syncthreads();
+  if (t < nb) dd[t] = L11[t][t];
+  __syncthreads();
+  const int r = blockIdx.x * 256 + t;  // row of the trailing part
+  if (r >= n2) return;
+  double* row = S + (size_t)(k0 + nb + r) + (size_t)n * k0;  // entry (row, k0 + j) at row[j * n]
+  for (int j = 0; j < nb; j++) {
+    double v = row[(size_t)j * n];
+    for (int q = 0; q < j; q++) v -= W21[(size_t)r + (size_t)n2 * q] * L11[j][q];
+    W21[(size_t)r + (size_t)n2 * j] = v;        // (l_ij d_j) = a_ij - sum_q (l_iq d_q) L11(j, q)
+    row[(size_t)j * n] = v / dd[j];             // l_ij
+  }
+}
+
+__global__ void __launch_bounds__(256) scale_by_diag_kernel(double* __restrict__ y, const double* __restrict__ S, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = y[i] / S[(size_t)i + (size_t)n * i];
+}
+
+__global__ void __launch_bounds__(256) mul_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = a[i] * b[i];
+}
+
+__global__ void __launch_bounds__(256) out_kernel(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ w,
+                                                  double* __restrict__ d, int n, int m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) d[i] = -x[i];
+  else if (i < n + m) d[i] = w[i - n] * u[i - n];  // d_r = -(rhs_r - J x) / d_r
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(double* p, double v, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+inline int blocks(long long n) { return (int)((n + 255) / 256); }
+
+}  // namespace
+
+struct DenseState {
+  rocblas_handle blas = nullptr;
+  int64_t batch = 1;
+  int *jslot = nullptr, *dslot = nullptr, *hslot = nullptr, *hpos = nullptr, *cnt = nullptr;
+  double *Jd = nullptr, *JW = nullptr, *w = nullptr, *S0 = nullptr, *W21 = nullptr, *y = nullptr, *u = nullptr, *tmp = nullptr;
+  double* S = nullptr;  // [batch][n * n] factors (unit lower L below the diagonal, D on it)
+  const double* last_vals = nullptr;
+  std::vector<void*> allocs;
+};
+
+bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
+                  int64_t ncon) {
+  D.active = false;
+  if (ncon != 0 || nequ <= 0 || nvar < 32 || N != nvar + nequ) return false;
+  if ((long long)nvar * nequ > (1ll << 28) || nnz > (1ll << 30)) return false;
+  D.n = (int32_t)nvar; D.m = (int32_t)nequ; D.nnz = (int32_t)nnz;
+  D.jslot.assign((size_t)nvar * nequ, -1);
+  D.dslot.assign(nequ, -1);
+  D.hslot.clear(); D.hpos.clear();
+  const int64_t rho_begin = nnz - nvar;
+  for (int64_t e = 0; e < nnz; e++) {
+    const int64_t i = rows1[e] - 1, j = cols1[e] - 1;
+    if (i < nvar) {  // H_F entry or rho slot (lower triangle, column j <= row i)
+      if (e >= rho_begin) continue;  // rho slots are applied by shift_kernel
+      D.hslot.push_back((int32_t)e); D.hpos.push_back((int32_t)(i + nvar * j));
+    } else if (j < nvar) {
+      int32_t& s = D.jslot[(size_t)(i - nvar) + (size_t)nequ * j];
+      if (s >= 0) return false;  // duplicate Jacobian entry: not handled here
+      s = (int32_t)e;
+    } else if (i == j) {
+      if (D.dslot[i - nvar] >= 0) return false;
+      D.dslot[i - nvar] = (int32_t)e;
+    } else return false;
+  }
+  for (int32_t s : D.jslot) if (s < 0) return false;  // a residual row that does not hold every variable
+  for (int32_t s : D.dslot) if (s < 0) return false;
+  // rho slots must be the diagonal (i, i), in order
+  for (int64_t k = 0; k < nvar; k++) if (rows1[rho_begin + k] - 1 != k || cols1[rho_begin + k] - 1 != k) return false;
+  D.active = true;
+  return true;
+}
+
+template <class T>
+static int dalloc_(DenseState* st, T** p, size_t count, std::string& err) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+  if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return 4; }
+  st->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+int dense_create(DenseState** out, const DensePlan& D, int64_t batch, std::string& err) {
+  DenseState* st = new DenseState();
+  st->batch = batch;
+  *out = st;
+  const size_t n = D.n, m = D.m;
+  int rc;
+  if ((rc = dalloc_(st, &st->jslot, n * m, err))) return rc;
+  if ((rc = dalloc_(st, &st->dslot, m, err))) return rc;
+  if ((rc = dalloc_(st, &st->hslot, D.hslot.size(), err))) return rc;
+  if ((rc = dalloc_(st, &st->hpos, D.hpos.size(), err))) return rc;
+  if ((rc = dalloc_(st, &st->cnt, 4, err))) return rc;
+  if ((rc = dalloc_(st, &st->Jd, n * m, err))) return rc;
+  if ((rc = dalloc_(st, &st->JW, n * m, err))) return rc;
+  if ((rc = dalloc_(st, &st->w, m, err))) return rc;
+  if ((rc = dalloc_(st, &st->S0, n * n, err))) return rc;
+  if ((rc = dalloc_(st, &st->W21, n * NB, err))) return rc;
+  if ((rc = dalloc_(st, &st->y, n, err))) return rc;
+  if ((rc = dalloc_(st, &st->u, m, err))) return rc;
+  if ((rc = dalloc_(st, &st->tmp, m, err))) return rc;
+  if ((rc = dalloc_(st, &st->S, (size_t)batch * n * n, err))) return rc;
+  DCHK(hipMemcpy(st->jslot, D.jslot.data(), n * m * sizeof(int), hipMemcpyHostToDevice));
+  DCHK(hipMemcpy(st->dslot, D.dslot.data(), m * sizeof(int), hipMemcpyHostToDevice));
+  if (!D.hslot.empty()) {
+    DCHK(hipMemcpy(st->hslot, D.hslot.data(), D.hslot.size() * sizeof(int), hipMemcpyHostToDevice));
+    DCHK(hipMemcpy(st->hpos, D.hpos.data(), D.hpos.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  BCHK(rocblas_create_handle(&st->blas));
+  return 0;
+}
+
+void dense_destroy(DenseState* st) {
+  if (!st) return;
+  if (st->blas) rocblas_destroy_handle(st->blas);
+  for (void* p : st->allocs) (void)hipFree(p);
+  delete st;
+}
+
+namespace {
+
+// S_b = L D L^T of (S0 + shift); counts of the dense pivots go to st->cnt[0..1] (added to what is there)
+int factor(DenseState* st, const DensePlan& D, double* S, const double* rho_slots, double rho, int use_slots, double eig_tol,
+           hipStream_t stream, std::string& err) {
+  const int n = D.n;
+  hipLaunchKernelGGL(shift_kernel, dim3(blocks((long long)n * n)), dim3(256), 0, stream, st->S0, S, n, rho_slots, rho, use_slots);
+  const double one = 1.0, mone = -1.0;
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = std::min(NB, n - k0), n2 = n - k0 - nb;
+    hipLaunchKernelGGL(panel_kernel, dim3(1), dim3(256), 0, stream, S, n, k0, nb, eig_tol, st->cnt);
+    if (n2 <= 0) break;
+    hipLaunchKernelGGL(l21_kernel, dim3(blocks(n2)), dim3(256), 0, stream, S, n, k0, nb, st->W21, n2);
+    // S22 -= L21 (L21 D)^T
+    BCHK(rocblas_dgemm(st->blas, rocblas_operation_none, rocblas_operation_transpose, n2, n2, nb, &mone,
+                       S + (size_t)(k0 + nb) + (size_t)n * k0, n, st->W21, n2, &one, S + (size_t)(k0 + nb) + (size_t)n * (k0 + nb), n));
+  }
+  DCHK(hipGetLastError());
+  return 0;
+}
+
+int build(DenseState* st, const DensePlan& D, const double* vals, double eig_tol, hipStream_t stream, std::string& err) {
+  const int n = D.n, m = D.m;
+  DCHK(hipMemsetAsync(st->cnt, 0, 4 * sizeof(int), stream));
+  hipLaunchKernelGGL(gather_kernel, dim3(blocks((long long)m * n)), dim3(256), 0, stream, vals, st->jslot, st->dslot, m, n, st->Jd, st->JW, st->w);
+  hipLaunchKernelGGL(rinertia_kernel, dim3(blocks(m)), dim3(256), 0, stream, vals, st->dslot, m, eig_tol, st->cnt + 2);
+  DCHK(hipMemsetAsync(st->S0, 0, (size_t)n * n * sizeof(double), stream));
+  if (!D.hslot.empty())
+    hipLaunchKernelGGL(hscatter_kernel, dim3(blocks((long long)D.hslot.size())), dim3(256), 0, stream, vals, st->hslot, st->hpos, (int)D.hslot.size(), st->S0);
+  const double one = 1.0;
+  // S0 += J' (W J)
+  BCHK(rocblas_dgemm(st->blas, rocblas_operation_transpose, rocblas_operation_none, n, n, m, &one, st->Jd, m, st->JW, m, &one, st->S0, n));
+  return 0;
+}
+
+// d = -K^-1 rhs with the factor in S (Jd, w of the same problem must be in place)
+int solve(DenseState* st, const DensePlan& D, const double* S, const double* rhs, double* d, hipStream_t stream, std::string& err) {
+  const int n = D.n, m = D.m;
+  const double one = 1.0, mone = -1.0;
+  // y = rhs_x + J' (w .* rhs_r)      (= rhs_x - J' (rhs_r / d_r))
+  hipLaunchKernelGGL(mul_kernel, dim3(blocks(m)), dim3(256), 0, stream, st->w, rhs + n, st->tmp, m);
+  DCHK(hipMemcpyAsync(st->y, rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  BCHK(rocblas_dgemv(st->blas, rocblas_operation_transpose, m, n, &one, st->Jd, m, st->tmp, 1, &one, st->y, 1));
+  BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, n, S, n, st->y, 1));
+  hipLaunchKernelGGL(scale_by_diag_kernel, dim3(blocks(n)), dim3(256), 0, stream, st->y, S, n);
+  BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_unit, n, S, n, st->y, 1));
+  // u = rhs_r - J x
+  DCHK(hipMemcpyAsync(st->u, rhs + n, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  BCHK(rocblas_dgemv(st->blas, rocblas_operation_none, m, n, &mone, st->Jd, m, st->y, 1, &one, st->u, 1));
+  hipLaunchKernelGGL(out_kernel, dim3(blocks(n + m)), dim3(256), 0, stream, st->y, st->u, st->w, d, n, m);
+  DCHK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int dense_run(DenseState* st, const DensePlan& D, int mode, double* vals, const double* rhs, double* d, double* rho_old_d,
+              double* rho_d, int32_t* nfact_d, int32_t* success_d, int64_t* npos_d, int64_t* nzero_d, const double params[9],
+              hipStream_t stream, std::string& err) {
+  const int n = D.n, m = D.m;
+  const size_t N = (size_t)n + m;
+  BCHK(rocblas_set_stream(st->blas, stream));
+  const double eig_tol = params[0], kdec = params[2], kinc = params[3], klarge = params[4], rho0 = params[5], rhomax = params[6],
+               rhomin = params[7];
+  if (mode == 2 && !st->last_vals) { err = "cnl_solve before cnl_factorize"; return 5; }
+  for (int64_t b = 0; b < st->batch; b++) {
+    double* S = st->S + (size_t)b * n * n;
+    double* vb = vals ? vals + (size_t)b * D.nnz : nullptr;
+    int rc;
+    if (mode == 2) {
+      // Jd / w of this problem again (they are shared scratch), then the solve with the stored factor
+      hipLaunchKernelGGL(gather_kernel, dim3(blocks((long long)m * n)), dim3(256), 0, stream, st->last_vals + (size_t)b * D.nnz, st->jslot,
+                         st->dslot, m, n, st->Jd, st->JW, st->w);
+      if ((rc = solve(st, D, S, rhs + b * N, d + b * N, stream, err))) return rc;
+      continue;
+    }
+    if ((rc = build(st, D, vb, eig_tol, stream, err))) return rc;
+    int cnt[4];
+    auto attempt = [&](double rho, int use_slots) -> int {
+      DCHK(hipMemsetAsync(st->cnt, 0, 2 * sizeof(int), stream));
+      int r2 = factor(st, D, S, vb + (D.nnz - n), rho, use_slots, eig_tol, stream, err);
+      if (r2) return r2;
+      DCHK(hipMemcpyAsync(cnt, st->cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+      DCHK(hipStreamSynchronize(stream));
+      return 0;
+    };
+    auto ok = [&]() { return cnt[0] + cnt[2] == n && cnt[1] + cnt[3] == 0; };  // src/solver_types.jl:90-97
+    if (mode == 1) {
+      if ((rc = attempt(0.0, 1))) return rc;
+      const int32_t s32 = ok() ? 1 : 0;
+      DCHK(hipMemcpyAsync(success_d + b, &s32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      if (npos_d) { const int64_t v = cnt[0] + cnt[2]; DCHK(hipMemcpyAsync(npos_d + b, &v, sizeof(int64_t), hipMemcpyHostToDevice, stream)); }
+      if (nzero_d) { const int64_t v = cnt[1] + cnt[3]; DCHK(hipMemcpyAsync(nzero_d + b, &v, sizeof(int64_t), hipMemcpyHostToDevice, stream)); }
+      DCHK(hipStreamSynchronize(stream));
+      continue;
+    }
+    // newton_system!, src/CaNNOLeS.jl:1008-1052
+    double rho_old = 0.0;
+    DCHK(hipMemcpyAsync(&rho_old, rho_old_d + b, sizeof(double), hipMemcpyDeviceToHost, stream));
+    DCHK(hipStreamSynchronize(stream));
+    double rho = 0.0, wrote = 0.0;
+    int nfact = 1;
+    if ((rc = attempt(0.0, 1))) return rc;
+    bool success = ok();
+    if (!success) {
+      rho = rho_old == 0.0 ? rho0 : std::max(rhomin, kdec * rho_old);
+      wrote = rho;
+      if ((rc = attempt(rho, 0))) return rc;
+      success = ok();
+      nfact++;
+      while (!success && rho <= rhomax) {
+        rho = rho_old == 0.0 ? klarge * rho : kinc * rho;
+        if (rho <= rhomax) {
+          wrote = rho;
+          if ((rc = attempt(rho, 0))) return rc;
+          success = ok();
+          nfact++;
+        }
+      }
+      if (rho <= rhomax) rho_old = rho;
+      hipLaunchKernelGGL(fill_kernel, dim3(blocks(n)), dim3(256), 0, stream, vb + (D.nnz - n), wrote, n);
+    }
+    if (success && (rc = solve(st, D, S, rhs + b * N, d + b * N, stream, err))) return rc;
+    const int32_t nf32 = nfact, s32 = success ? 1 : 0;
+    DCHK(hipMemcpyAsync(rho_d + b, &rho, sizeof(double), hipMemcpyHostToDevice, stream));
+    DCHK(hipMemcpyAsync(rho_old_d + b, &rho_old, sizeof(double), hipMemcpyHostToDevice, stream));
+    DCHK(hipMemcpyAsync(nfact_d + b, &nf32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    DCHK(hipMemcpyAsync(success_d + b, &s32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    DCHK(hipStreamSynchronize(stream));
+  }
+  if (mode == 1) st->last_vals = vals;
+  return 0;
+}
+
+}  // namespace cnl

@@ -179,7 +179,7 @@ class HIPLDLStruct:
         cfg = np.zeros(8, np.int64)
         _check(lib().cnl_get_config(h, cfg))
         self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4]),
-                       "kernel": "v2" if cfg[5] == 2 else "v1", "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7])}
+                       "kernel": {2: "v2", 3: "dense"}.get(int(cfg[5]), "v1"), "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7])}
 
     def plan_array(self, name):
         return _plan_array(lib().cnl_get_plan(self._h), name)

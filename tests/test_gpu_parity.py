@@ -417,3 +417,53 @@ def test_solve_ldl_on_the_register_front_kernel(built, shape):
             assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
             assert backward_error(s, vals[b], r[b], d[b]) <= BWD_TOL
     LDLT.close()
+
+
+def test_cfg2_dense_backend_against_oracle(built):
+    """BASELINE config 2 pattern (dense Jacobian, unconstrained) at a size the oracle handles in seconds: served by the dense
+    backend (J'WJ by GEMM, blocked dense LDL^T with rocBLAS trailing updates), including the rho ladder and the literal
+    try_to_factorize / solve_ldl! sequence."""
+    hipldl, syn, O = _mods()
+    s = syn.dense_structure(96, 200)
+    rows, cols = s.kkt_pattern()
+    B = 3
+    vals = np.stack([syn.dense_values(s, 2000 + b)[0] for b in range(B)])
+    rhs = np.stack([syn.dense_values(s, 2000 + b)[1] for b in range(B)])
+    L0 = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=1)
+    assert L0.config["kernel"] == "dense"
+    L0.close()
+    run_case(s, vals, rhs)
+    off = s.offsets()
+    v2 = vals.copy()
+    v2[:, off[0]:off[1]] = -3.0          # indefinite top-left block: the ladder has to climb
+    v2[:, off[4]:off[5]] = -np.random.default_rng(0).uniform(0.5, 2.0, (B, s.nequ))
+    run_case(s, v2, rhs, rho_old=np.array([0.0, 2.0, 0.0]), check_fwd=False)
+    # two-call path
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, vals, s.nvar, s.nequ, s.ncon, batch=B)
+    ok = hipldl.try_to_factorize(LDLT, vals, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16)
+    assert ok.all()
+    for k in range(2):
+        r = np.ascontiguousarray(rhs * (k + 1))
+        d = np.zeros((B, s.N))
+        hipldl.solve_ldl_(r, LDLT.factor, d)
+        for b in range(B):
+            assert backward_error(s, vals[b], r[b], d[b]) <= BWD_TOL
+    LDLT.close()
+
+
+def test_cfg2_dense_full_size_properties(built):
+    """BASELINE config 2 at full size (n = 1000, nequ = 2000, dense Jacobian: 2 004 000 COO entries): backward error of the
+    Newton step and linearity of the solve."""
+    hipldl, syn, O = _mods()
+    s = syn.dense_structure(1000, 2000)
+    rows, cols = s.kkt_pattern()
+    vals, rhs = syn.dense_values(s, 2002)
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=1)
+    assert L.config["kernel"] == "dense"
+    p = hipldl.default_params()
+    d1, ok, rho, ro, nf = hipldl.newton_system_(np.zeros(s.N), s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, 0.0, p)
+    assert ok and nf == 1 and rho == 0.0
+    assert backward_error(s, vals, rhs, d1) <= BWD_TOL
+    d2, ok2, *_ = hipldl.newton_system_(np.zeros(s.N), s.nvar, s.nequ, s.ncon, 3.0 * rhs, vals.copy(), L, 0.0, p)
+    assert ok2 and np.abs(d2 - 3.0 * d1).max() <= 1e-12 * np.abs(d1).max()
+    L.close()
