@@ -12,7 +12,7 @@ namespace cnl {
 
 namespace {
 
-constexpr int NB = 16;  // panel width of the blocked factorisation (measured on MI355X, n = 1000: 64 -> 4.4 ms, 32 -> 2.8 ms, 16 -> 2.3 ms per system: the serial panel kernels dominate)
+constexpr int NB = 16;  // panel width of the blocked factorisation (measured on MI355X, n = 1000, fused panel step: 8 -> 2.14 ms, 16 -> 1.79 ms, 32 -> 2.01 ms per system)
 
 #define DCHK(x)                                                                                 \
   do {                                                                                          \
@@ -65,9 +65,14 @@ __global__ void __launch_bounds__(256) shift_kernel(const double* __restrict__ S
   S[t] = v;
 }
 
-// unblocked LDL^T of the nb x nb diagonal block at (k0, k0), one workgroup, block held in LDS
-__global__ void __launch_bounds__(256) panel_kernel(double* S, int n, int k0, int nb, double eig_tol, int* cnt) {
+// One panel step in ONE launch: every workgroup factorises the nb x nb diagonal block at (k0, k0) in LDS (unblocked
+// LDL^T, redundantly: 16 x 16 is cheaper than a launch), then serves 256 rows below it, thread per row:
+//   (l_ij d_j) = a_ij - sum_q (l_iq d_q) L11(j, q)  -> W21 (for the trailing GEMM),   l_ij -> S.
+// Workgroup 0 writes the factorised diagonal block back and counts its pivots.
+__global__ void __launch_bounds__(256) panel_l21_kernel(double* S, int n, int k0, int nb, double* __restrict__ W21, int n2,
+                                                        double eig_tol, int* cnt) {
   __shared__ double a[NB][NB + 1];
+  __shared__ double dd[NB];
   const int t = threadIdx.x;
   for (int q = t; q < nb * nb; q += 256) { const int i = q % nb, j = q / nb; a[i][j] = S[(size_t)(k0 + i) + (size_t)n * (k0 + j)]; }
   __syncthreads();
@@ -85,27 +90,26 @@ __global__ void __launch_bounds__(256) panel_kernel(double* S, int n, int k0, in
     }
     __syncthreads();
   }
-  for (int q = t; q < nb * nb; q += 256) { const int i = q % nb, j = q / nb; if (i >= j) S[(size_t)(k0 + i) + (size_t)n * (k0 + j)] = a[i][j]; }
-  if (t == 0) { if (np) atomicAdd(&cnt[0], np); if (nz) atomicAdd(&cnt[1], nz); }
-}
-
-// rows below the panel: l_i = a_i (L11 D)^-T, thread per row; also W21 = L21 D for the trailing update
-__global__ void __launch_bounds__(256) l21_kernel(double* S, int n, int k0, int nb, double* __restrict__ W21, int n2) {
-  __shared__ double L11[NB][NB + 1];
-  __shared__ double dd[NB];
-  const int t = threadIdx.x;
-  for (int q = t; q < nb * nb; q += 256) { const int i = q % nb, j = q / nb; L11[i][j] = S[(size_t)(k0 + i) + (size_t)n * (k0 + j)]; }
+  if (t < nb) dd[t] = a[t][t];
   __syncthreads();
-  if (t < nb) dd[t] = L11[t][t];
-  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int q = t; q < nb * nb; q += 256) { const int i = q % nb, j = q / nb; if (i >= j) S[(size_t)(k0 + i) + (size_t)n * (k0 + j)] = a[i][j]; }
+    if (t == 0) { if (np) atomicAdd(&cnt[0], np); if (nz) atomicAdd(&cnt[1], nz); }
+  }
   const int r = blockIdx.x * 256 + t;  // row of the trailing part
   if (r >= n2) return;
   double* row = S + (size_t)(k0 + nb + r) + (size_t)n * k0;  // entry (row, k0 + j) at row[j * n]
-  for (int j = 0; j < nb; j++) {
-    double v = row[(size_t)j * n];
-    for (int q = 0; q < j; q++) v -= W21[(size_t)r + (size_t)n2 * q] * L11[j][q];
-    W21[(size_t)r + (size_t)n2 * j] = v;        // (l_ij d_j) = a_ij - sum_q (l_iq d_q) L11(j, q)
-    row[(size_t)j * n] = v / dd[j];             // l_ij
+  double wv[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    if (j < nb) {
+      double v = row[(size_t)j * n];
+#pragma unroll
+      for (int q = 0; q < j; q++) v -= wv[q] * a[j][q];
+      wv[j] = v;
+      W21[(size_t)r + (size_t)n2 * j] = v;
+      row[(size_t)j * n] = v / dd[j];
+    }
   }
 }
 
@@ -234,9 +238,8 @@ int factor(DenseState* st, const DensePlan& D, double* S, const double* rho_slot
   const double one = 1.0, mone = -1.0;
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int nb = std::min(NB, n - k0), n2 = n - k0 - nb;
-    hipLaunchKernelGGL(panel_kernel, dim3(1), dim3(256), 0, stream, S, n, k0, nb, eig_tol, st->cnt);
+    hipLaunchKernelGGL(panel_l21_kernel, dim3(std::max(1, blocks(n2))), dim3(256), 0, stream, S, n, k0, nb, st->W21, n2, eig_tol, st->cnt);
     if (n2 <= 0) break;
-    hipLaunchKernelGGL(l21_kernel, dim3(blocks(n2)), dim3(256), 0, stream, S, n, k0, nb, st->W21, n2);
     // S22 -= L21 (L21 D)^T
     BCHK(rocblas_dgemm(st->blas, rocblas_operation_none, rocblas_operation_transpose, n2, n2, nb, &mone,
                        S + (size_t)(k0 + nb) + (size_t)n * k0, n, st->W21, n2, &one, S + (size_t)(k0 + nb) + (size_t)n * (k0 + nb), n));
