@@ -61,6 +61,7 @@ struct cnl_handle {
   bool factorized = false;
   cnl::DevJt djt{};  // transposed-Jacobian lists (row f1: residual / optimality vectors on the device)
   cnl::DenseState* dense = nullptr;
+  double* d_cgls_ws = nullptr;  // [batch][2 * nvar] workspace of cnl_cgls_multipliers_dev, allocated on first use
 };
 
 namespace {
@@ -568,6 +569,18 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
     if ((rc = upload(h, ptrC, &J.ptrC))) return bail(rc);
     if ((rc = upload(h, slotC, &J.slotC))) return bail(rc);
     if ((rc = upload(h, idxC, &J.idxC))) return bail(rc);
+    {
+      // J_c by rows (CGLS, row f4)
+      std::vector<int32_t> rptr(ncon + 1, 0), rslot(slotC.size()), rcol(slotC.size());
+      for (int64_t j2 = 0; j2 < nvar; j2++) for (int32_t q = ptrC[j2]; q < ptrC[j2 + 1]; q++) rptr[idxC[q] + 1]++;
+      for (int64_t k2 = 0; k2 < ncon; k2++) rptr[k2 + 1] += rptr[k2];
+      std::vector<int32_t> fillr(rptr.begin(), rptr.end() - 1);
+      for (int64_t j2 = 0; j2 < nvar; j2++)
+        for (int32_t q = ptrC[j2]; q < ptrC[j2 + 1]; q++) { const int32_t w = fillr[idxC[q]]++; rslot[w] = slotC[q]; rcol[w] = (int32_t)j2; }
+      if ((rc = upload(h, rptr, &J.rptrC))) return bail(rc);
+      if ((rc = upload(h, rslot, &J.rslotC))) return bail(rc);
+      if ((rc = upload(h, rcol, &J.rcolC))) return bail(rc);
+    }
     J.nvar = (int32_t)nvar; J.nequ = (int32_t)nequ; J.ncon = (int32_t)ncon; J.N = (int32_t)N; J.nnz = (int32_t)nnz;
   }
   *hout = h;
@@ -603,6 +616,24 @@ int cnl_prepare_newton_system_dev(cnl_handle* h, int64_t nnzhF, int64_t nnzhc, i
   hipError_t e = cnl::launch_prepare((int)nnzhF, (int)nnzhc, (int)nnzjF, (int)nnzjc, J.nvar, J.nequ, J.ncon, d_hF, d_hc, d_Jx, d_Jcx,
                                      d_delta, d_vals, (int)h->batch, (hipStream_t)stream);
   if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("prepare_newton_system: ") + hipGetErrorString(e));
+  return CNL_OK;
+}
+
+int cnl_cgls_multipliers_dev(cnl_handle* h, const double* d_vals, const double* d_r, double* d_lambda, double* d_Jxtr, double atol,
+                             double rtol, int64_t itmax, int ones_if_zero, int32_t* d_iters, void* stream) {
+  if (!h || !d_vals || !d_r) return fail(CNL_ERR_ARG, "null argument");
+  if (h->djt.ncon == 0) return CNL_OK;  // nothing to estimate
+  if (!d_lambda) return fail(CNL_ERR_ARG, "null lambda");
+  if (h->djt.ncon > 1024) return fail(CNL_ERR_DIM, "cnl_cgls_multipliers_dev supports at most 1024 constraints");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->d_cgls_ws) {
+    int rc = dalloc(h, &h->d_cgls_ws, (size_t)h->batch * 2 * (size_t)h->djt.nvar);
+    if (rc) return rc;
+  }
+  if (itmax <= 0) itmax = (int64_t)h->djt.nvar + h->djt.ncon;  // Krylov.jl's default: m + n
+  hipError_t e = cnl::launch_cgls(h->djt, d_vals, d_r, d_lambda, d_Jxtr, h->d_cgls_ws, d_iters, atol, rtol, (int)itmax, ones_if_zero,
+                                  (int)h->batch, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("cgls: ") + hipGetErrorString(e));
   return CNL_OK;
 }
 

@@ -68,6 +68,7 @@ struct DevCond {
 struct DevJt {
   const int32_t *ptrF, *slotF, *idxF;  // [nvar + 1], [nnz(J_F)] x 2
   const int32_t *ptrC, *slotC, *idxC;  // [nvar + 1], [nnz(J_c)] x 2
+  const int32_t *rptrC, *rslotC, *rcolC;  // J_c by rows: [ncon + 1], [nnz(J_c)] x 2 (slot in vals, variable) — CGLS (row f4)
   int32_t nvar, nequ, ncon, N, nnz;
 };
 
@@ -104,6 +105,8 @@ hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_
                                hipStream_t stream);
 hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon, const double* hF, const double* hc,
                           const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, hipStream_t stream);
+hipError_t launch_cgls(const DevJt& J, const double* vals, const double* r, double* lambda, double* Jxtr, double* ws, int32_t* iters,
+                       double atol, double rtol, int itmax, int ones_if_zero, int batch, hipStream_t stream);
 hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const double* r, const double* lambda, const double* Fx,
                                    const double* cx, double* rhs, double* norms, int batch, hipStream_t stream);
 hipError_t launch_trial_point(const DevJt& J, const double* x, const double* r, const double* lambda, const double* d,

@@ -387,6 +387,106 @@ __global__ void __launch_bounds__(256) prepare_kernel(int nnzhF, int nnzhc, int 
   else v[k] = 0.0;
 }
 
+// Row f4 of the scope table: least-squares multiplier estimate  min || Jc' lambda - Jx' r ||  by CGLS, as the reference
+// obtains it from Krylov.jl (`krylov_solve!(cgls_workspace, Jcx', Jxtr)`, /root/reference/src/CaNNOLeS.jl:507-518 and
+// :880-882; Krylov.jl is an un-vendored dependency, Project.toml compat "0.10": its cgls is the textbook recurrence
+//   r = b, s = A'r, p = s, gamma = ||s||^2;  q = A p, alpha = gamma / ||q||^2, x += alpha p, r -= alpha q,
+//   s = A'r, beta = ||s||^2 / gamma, p = s + beta p;   stop when ||s|| <= atol + rtol ||s_0||  or after itmax steps
+// with A = Jc' (nvar x ncon) and b = Jx' r).  One workgroup per problem; the ncon-vectors live in LDS, the two
+// nvar-vectors (residual, q) in a global workspace; reductions in a fixed order (deterministic).
+constexpr int CGLS_PMAX = 1024;
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(256) cgls_kernel(const DevJt Jin, const double* __restrict__ vals, const double* __restrict__ r,
+                                                   double* __restrict__ lambda, double* __restrict__ Jxtr, double* __restrict__ ws,
+                                                   int* __restrict__ iters, double atol, double rtol, int itmax, int ones_if_zero) {
+  DevJt J = Jin;
+  J.ptrF = as_global(Jin.ptrF); J.slotF = as_global(Jin.slotF); J.idxF = as_global(Jin.idxF);
+  J.ptrC = as_global(Jin.ptrC); J.slotC = as_global(Jin.slotC); J.idxC = as_global(Jin.idxC);
+  J.rptrC = as_global(Jin.rptrC); J.rslotC = as_global(Jin.rslotC); J.rcolC = as_global(Jin.rcolC);
+  __shared__ double x[CGLS_PMAX], sv[CGLS_PMAX], pv[CGLS_PMAX];
+  __shared__ double red[4];
+  const long long b = blockIdx.x;
+  const int t = threadIdx.x, n = J.nvar, p = J.ncon;
+  const double* v = vals + b * J.nnz;
+  const double* rb = r + b * J.nequ;
+  double* res = ws + b * 2 * n;  // residual of the least-squares problem
+  double* q = res + n;
+  // b = Jx' r  (mul!(Jxtr, Jx', r), per-column COO-order sums as in residual_vectors_kernel)
+  {
+#pragma clang fp contract(off)  // separately rounded multiply and add, as the reference's scalar loop
+    for (int j = t; j < n; j += 256) {
+      double s1 = 0.0;
+      for (int k = J.ptrF[j]; k < J.ptrF[j + 1]; k++) { const double t_ = v[J.slotF[k]] * rb[J.idxF[k]]; s1 = s1 + t_; }
+      res[j] = s1;
+      if (Jxtr) Jxtr[b * n + j] = s1;
+    }
+  }
+  for (int k = t; k < p; k += 256) x[k] = 0.0;
+  __syncthreads();
+  // s = A' res = Jc res: one wavefront per constraint row
+  auto at_res = [&]() {
+    for (int k = t >> 6; k < p; k += 4) {
+      double acc = 0.0;
+      for (int e = J.rptrC[k] + (t & 63); e < J.rptrC[k + 1]; e += 64) acc += v[J.rslotC[e]] * res[J.rcolC[e]];
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if ((t & 63) == 0) sv[k] = acc;
+    }
+    __syncthreads();
+  };
+  at_res();
+  for (int k = t; k < p; k += 256) pv[k] = sv[k];
+  __syncthreads();
+  double part = 0.0;
+  for (int k = t; k < p; k += 256) part += sv[k] * sv[k];
+  double gamma = block_sum(part, red);
+  const double eps = atol + rtol * sqrt(gamma);
+  int it = 0;
+  while (it < itmax && sqrt(gamma) > eps) {
+    // q = A p = Jc' p: thread per variable
+    part = 0.0;
+    for (int j = t; j < n; j += 256) {
+      double s2 = 0.0;
+      for (int k = J.ptrC[j]; k < J.ptrC[j + 1]; k++) s2 += v[J.slotC[k]] * pv[J.idxC[k]];
+      q[j] = s2;
+      part += s2 * s2;
+    }
+    const double delta = block_sum(part, red);
+    if (delta == 0.0) break;
+    const double alpha = gamma / delta;
+    for (int k = t; k < p; k += 256) x[k] += alpha * pv[k];
+    for (int j = t; j < n; j += 256) res[j] -= alpha * q[j];
+    __syncthreads();
+    at_res();
+    part = 0.0;
+    for (int k = t; k < p; k += 256) part += sv[k] * sv[k];
+    const double gnext = block_sum(part, red);
+    const double beta = gnext / gamma;
+    for (int k = t; k < p; k += 256) pv[k] = sv[k] + beta * pv[k];
+    __syncthreads();
+    gamma = gnext;
+    it++;
+  }
+  // if norm(lambda) == 0: lambda .= 1   (src/CaNNOLeS.jl:515-517)
+  part = 0.0;
+  for (int k = t; k < p; k += 256) part += x[k] * x[k];
+  const double xn = block_sum(part, red);
+  for (int k = t; k < p; k += 256) lambda[b * p + k] = (ones_if_zero && xn == 0.0) ? 1.0 : x[k];
+  if (t == 0 && iters) iters[b] = it;
+}
+
+hipError_t launch_cgls(const DevJt& J, const double* vals, const double* r, double* lambda, double* Jxtr, double* ws, int32_t* iters,
+                       double atol, double rtol, int itmax, int ones_if_zero, int batch, hipStream_t stream) {
+  if (J.ncon > CGLS_PMAX) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cgls_kernel, dim3(batch), dim3(256), 0, stream, J, vals, r, lambda, Jxtr, ws, iters, atol, rtol, itmax, ones_if_zero);
+  return hipGetLastError();
+}
+
 hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon, const double* hF, const double* hc,
                           const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, hipStream_t stream) {
   const int nnz = nnzhF + nnzhc + nnzjF + nnzjc + nequ + ncon + nvar;

@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "cnl_factorize_dev", "cnl_solve_dev", "cnl_newton_system_dev",
     "cnl_set_timing", "cnl_last_kernel_ms", "cnl_get_config",
     "cnl_residual_vectors_dev", "cnl_trial_point_dev", "cnl_prepare_newton_system_dev",
+    "cnl_cgls_multipliers_dev",
 ]
 
 
@@ -77,6 +78,7 @@ def lib():
         L.cnl_residual_vectors_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.cnl_trial_point_dev.argtypes = [vp, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp]
         L.cnl_prepare_newton_system_dev.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+        L.cnl_cgls_multipliers_dev.argtypes = [vp, vp, vp, vp, vp, dbl, dbl, i64, C.c_int, vp, vp]
         L.cnl_set_timing.argtypes = [vp, C.c_int]
         L.cnl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cnl_get_config.argtypes = [vp, _i64p]
@@ -293,3 +295,14 @@ def prepare_newton_system_dev(LDLT, nnzhF, nnzhc, nnzjF, nnzjc, hF_ptr, hc_ptr, 
     hF / -hc / Jx / Jcx / -delta / 0 into the segments of vals; hF_ptr = 0 leaves H_F alone (Gauss-Newton variants)."""
     _check(lib().cnl_prepare_newton_system_dev(LDLT._h, int(nnzhF), int(nnzhc), int(nnzjF), int(nnzjc), hF_ptr, hc_ptr, Jx_ptr,
                                                Jcx_ptr, delta_ptr, vals_ptr, stream))
+
+
+def cgls_multipliers_dev(LDLT, vals_ptr, r_ptr, lambda_ptr, Jxtr_ptr=0, atol=None, rtol=None, itmax=0, ones_if_zero=True, iters_ptr=0,
+                         stream=0):
+    """Least-squares multipliers min ||Jc' lambda - Jx' r|| by CGLS (src/CaNNOLeS.jl:507-518), batched and device-resident
+    (cnl_cgls_multipliers_dev).  Default tolerances: sqrt(eps), as Krylov.jl's."""
+    eps = float(np.finfo(np.float64).eps)
+    atol = np.sqrt(eps) if atol is None else atol
+    rtol = np.sqrt(eps) if rtol is None else rtol
+    _check(lib().cnl_cgls_multipliers_dev(LDLT._h, vals_ptr, r_ptr, lambda_ptr, Jxtr_ptr, float(atol), float(rtol), int(itmax),
+                                          1 if ones_if_zero else 0, iters_ptr, stream))

@@ -132,6 +132,14 @@ int cnl_prepare_newton_system_dev(cnl_handle* h, int64_t nnzhF, int64_t nnzhc, i
                                   const double* d_hc, const double* d_Jx, const double* d_Jcx, const double* d_delta, double* d_vals,
                                   void* stream);
 
+/* cnl_cgls_multipliers_dev: least-squares multiplier estimate  min || Jc' lambda - Jx' r ||  (SURVEY 8 row f4), what the
+ * reference obtains with `mul!(Jxtr, Jx', r); krylov_solve!(cgls_workspace, Jcx', Jxtr)` at src/CaNNOLeS.jl:507-518 and
+ * :880-882: CGLS started at 0, stopped when ||Jc res|| <= atol + rtol ||Jc b|| or after itmax steps (itmax <= 0: nvar + ncon,
+ * Krylov.jl's default; its default tolerances are sqrt(eps)).  ones_if_zero != 0 applies `if norm(lambda) == 0: lambda .= 1`
+ * (:515-517).  d_Jxtr (optional) receives Jx' r, d_iters (optional) the iteration counts.  ncon <= 1024.                */
+int cnl_cgls_multipliers_dev(cnl_handle* h, const double* d_vals, const double* d_r, double* d_lambda, double* d_Jxtr, double atol,
+                             double rtol, int64_t itmax, int ones_if_zero, int32_t* d_iters, void* stream);
+
 /* cnl_trial_point_dev: the extrapolation step's trial point, src/CaNNOLeS.jl:654,661-668:
  *     xt = x + d[1:n],  rt = r + d[n+1:n+m],  dlambda = -d[n+m+1:N], scaled by max_dlambda/||dlambda||_2 when that
  *     norm exceeds max_dlambda (the reference uses 1e4),  lambdat = lambda + dlambda.                               */

@@ -254,3 +254,45 @@ def trial_point(nvar, nequ, ncon, x, r, lam, d, max_dlambda=1e4):
     if nrm > max_dlambda:
         dl = dl * max_dlambda / nrm
     return xt, rt, np.asarray(lam, dtype=np.float64) + dl, dl
+
+
+def cgls_multipliers(rows, cols, vals, nvar, nequ, ncon, r, atol=None, rtol=None, itmax=0, ones_if_zero=True):
+    """Restates /root/reference/src/CaNNOLeS.jl:507-518: Jxtr = Jx' r; lambda = cgls(Jc', Jxtr); lambda = 1 if it is
+    zero.  The CGLS recurrence is Krylov.jl's (un-vendored dependency, Project.toml compat 0.10; textbook CGLS started at 0,
+    stop when ||A' res|| <= atol + rtol ||A' b||, defaults sqrt(eps), itmax = m + n).  Returns (lambda, Jxtr, iterations).
+    Test infrastructure, not part of the product."""
+    eps = np.finfo(np.float64).eps
+    atol = np.sqrt(eps) if atol is None else atol
+    rtol = np.sqrt(eps) if rtol is None else rtol
+    rows = np.asarray(rows); cols = np.asarray(cols); vals = np.asarray(vals, dtype=np.float64)
+    i0, j0 = rows - 1, cols - 1
+    selF = (j0 < nvar) & (i0 >= nvar) & (i0 < nvar + nequ)
+    selC = (j0 < nvar) & (i0 >= nvar + nequ)
+    Jxtr = np.zeros(nvar)
+    np.add.at(Jxtr, j0[selF], vals[selF] * np.asarray(r, dtype=np.float64)[i0[selF] - nvar])
+    A = np.zeros((nvar, ncon))  # A = Jc'
+    np.add.at(A, (j0[selC], i0[selC] - nvar - nequ), vals[selC])
+    x = np.zeros(ncon)
+    res = Jxtr.copy()
+    s = A.T @ res
+    p = s.copy()
+    gamma = float(s @ s)
+    tol = atol + rtol * np.sqrt(gamma)
+    itmax = nvar + ncon if itmax <= 0 else itmax
+    it = 0
+    while it < itmax and np.sqrt(gamma) > tol:
+        q = A @ p
+        delta = float(q @ q)
+        if delta == 0.0:
+            break
+        alpha = gamma / delta
+        x += alpha * p
+        res -= alpha * q
+        s = A.T @ res
+        gnext = float(s @ s)
+        p = s + (gnext / gamma) * p
+        gamma = gnext
+        it += 1
+    if ones_if_zero and ncon and np.linalg.norm(x) == 0:
+        x[:] = 1.0
+    return x, Jxtr, it

@@ -467,3 +467,33 @@ def test_cfg2_dense_full_size_properties(built):
     d2, ok2, *_ = hipldl.newton_system_(np.zeros(s.N), s.nvar, s.nequ, s.ncon, 3.0 * rhs, vals.copy(), L, 0.0, p)
     assert ok2 and np.abs(d2 - 3.0 * d1).max() <= 1e-12 * np.abs(d1).max()
     L.close()
+
+
+def test_f4_cgls_multipliers(built):
+    """batched CGLS estimate of the multipliers (src/CaNNOLeS.jl:507-518) against the restated recurrence
+    (same iteration counts, values to 1e-10) and against the least-squares solution."""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(1000, 10)
+    B = 5
+    vals, _ = syn.batch_values(s, B, cfg=4)
+    rng = np.random.default_rng(8)
+    r = rng.standard_normal((B, s.nequ))
+    r[3] = 0.0  # zero residual -> lambda = ones
+    rows, cols = s.kkt_pattern()
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    dev = torch.device("cuda", 0)
+    tv, tr = torch.from_numpy(vals).to(dev), torch.from_numpy(r).to(dev)
+    tl = torch.zeros((B, s.ncon), dtype=torch.float64, device=dev)
+    tj = torch.zeros((B, s.nvar), dtype=torch.float64, device=dev)
+    ti = torch.zeros(B, dtype=torch.int32, device=dev)
+    hipldl.cgls_multipliers_dev(LDLT, tv.data_ptr(), tr.data_ptr(), tl.data_ptr(), tj.data_ptr(), iters_ptr=ti.data_ptr())
+    torch.cuda.synchronize()
+    lam, jxtr, its = tl.cpu().numpy(), tj.cpu().numpy(), ti.cpu().numpy()
+    for b in range(B):
+        lam0, jx0, it0 = O.cgls_multipliers(rows, cols, vals[b], s.nvar, s.nequ, s.ncon, r[b])
+        assert np.array_equal(jxtr[b], jx0)  # mul!(Jxtr, Jx', r): same COO-order sums, separately rounded
+        assert its[b] == it0
+        np.testing.assert_allclose(lam[b], lam0, rtol=1e-10, atol=1e-12)
+    assert np.array_equal(lam[3], np.ones(s.ncon))
+    LDLT.close()

@@ -152,3 +152,24 @@ def test_f1_trial_point_oracle():
     _, _, lt2, dl2 = O.trial_point(n, m, p, x, r, lam, d)
     assert abs(np.linalg.norm(dl2) - 1e4) <= 1e-8
     np.testing.assert_allclose(lt2, lam + dl2)
+
+
+def test_f4_cgls_oracle_matches_lstsq():
+    """O.cgls_multipliers (Krylov.jl's CGLS recurrence on A = Jc', b = Jx' r; src/CaNNOLeS.jl:507-518) against lstsq."""
+    import cannoles_jl_amd  # noqa: F401
+    from cannoles_jl_amd import synthetic as syn
+    from oracle import oracle as O
+    s = syn.band_structure(300, 6)
+    vals, _ = syn.band_values(s, 5)
+    rows, cols = s.kkt_pattern()
+    r = np.random.default_rng(1).standard_normal(s.nequ)
+    lam, Jxtr, it = O.cgls_multipliers(rows, cols, vals, s.nvar, s.nequ, s.ncon, r)
+    K = np.zeros((s.N, s.N))
+    np.add.at(K, (rows - 1, cols - 1), vals)
+    JF, Jc = K[s.nvar:s.nvar + s.nequ, :s.nvar], K[s.nvar + s.nequ:, :s.nvar]
+    np.testing.assert_allclose(Jxtr, JF.T @ r, rtol=1e-12, atol=1e-12)
+    ref = np.linalg.lstsq(Jc.T, JF.T @ r, rcond=None)[0]
+    assert 0 < it <= s.ncon + 2
+    np.testing.assert_allclose(lam, ref, rtol=1e-6, atol=1e-8)
+    lam0, _, it0 = O.cgls_multipliers(rows, cols, vals, s.nvar, s.nequ, s.ncon, np.zeros(s.nequ))
+    assert it0 == 0 and np.array_equal(lam0, np.ones(s.ncon))  # norm(lambda) == 0 -> ones
