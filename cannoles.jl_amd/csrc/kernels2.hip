@@ -559,6 +559,13 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     }                                                                                  \
     if (nv_ < (NASM)) prh = GATHER_R(src_[PVN]); else prh = 0.0;                       \
   }
+// MODE_SOLVE needs only the right-hand-side round of the plain entries
+#define PREFETCH_RHS_ROUND(RECP, AOFF, NASMV, NASM)                                    \
+  {                                                                                    \
+    const int nv_ = (NASMV);                                                           \
+    const int src_ = ((RECP) + (AOFF) + l)[nv_];                                       \
+    if (nv_ < (NASM)) prh = GATHER_R(src_); else prh = 0.0;                            \
+  }
 // Raw values (Jacobian entries, residual pivots, residual right-hand sides) of the products a front's
 // condensed slots are made of: same scheme.
 #define PREFETCH_RAW(RECP, ROFF, NRAWV, NRAW)                                          \
@@ -639,7 +646,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   if (A.mode == MODE_SOLVE) {
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
     int4 R0, R1, R2;
-    double pvr[PVR], prr[2], prh = 0.0, pv[PVN];
+    double pvr[PVR], prr[2], prh = 0.0;
     double lr[KB], lrn[KB];
     int roff = 0, nxt_off = 0;
     int* recw = recbuf;
@@ -654,12 +661,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       R2 = rstream[(nxt_off >> 2) + lane + 128];
       const int hv0 = recw[lane & 15];
       const int nasm0 = HDRW(hv0, R_NASM), aoff0 = HDRW(hv0, R_ASM_OFF);
-      PREFETCH_VALUES(recw, aoff0, HDRW(hv0, R_NASMV), nasm0)
+      PREFETCH_RHS_ROUND(recw, aoff0, HDRW(hv0, R_NASMV), nasm0)
       PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRD) >> 16, HDRW(hv0, R_NRAW))
       const long long lp0 = (long long)HDRW(hv0, R_LPTR_LO) | ((long long)HDRW(hv0, R_LPTR_HI) << 31);
       PREFETCH_ROWS(lr, lp0, HDRW(hv0, R_NUPD), HDRW(hv0, R_NPIV))
     }
-    (void)pv;
     for (int s = 0; s < P.nsuper; s++) {
       const int* rec = recw;
       const int hv = rec[lane & 15];
@@ -755,7 +761,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
         R0 = rstream[(nn_off >> 2) + lane];
         R1 = rstream[(nn_off >> 2) + lane + 64];
         R2 = rstream[(nn_off >> 2) + lane + 128];
-        PREFETCH_VALUES(nrec, aoff1, nasmv1, nasm1)
+        PREFETCH_RHS_ROUND(nrec, aoff1, nasmv1, nasm1)
         PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nrawv1, nraw1)
         PREFETCH_ROWS(lrn, lp1, nupd1, npiv1)
         nxt_off = nn_off;

@@ -99,4 +99,32 @@ function CaNNOLeS.newton_system!(d::AbstractVector{Float64}, nvar::Integer, nequ
   return d, ok[] != 0, ρ[], ρout[], Int(nfact[])
 end
 
+# ---- optional device-resident helpers (SURVEY rows a4/f1/f2/f4).  They take DEVICE pointers (e.g. `pointer(::ROCArray)` from
+# AMDGPU.jl) and a hipStream_t; batched layouts are problem-major.  Unexecuted here, like the rest of this file. ----------
+
+"rhs = [Jx'r - Jc'λ; F - r; c] and (‖dual‖∞, ‖primal‖∞) per problem — src/CaNNOLeS.jl:507-508,519-524,528-529,631-632"
+residual_vectors_dev!(LDLT::HIPLDLStruct, vals, r, λ, Fx, cx, rhs, norms; stream = C_NULL) =
+  check(ccall((:cnl_residual_vectors_dev, libcnl), Cint,
+    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+    LDLT.factor.handle, vals, r, λ, Fx, cx, rhs, norms, stream))
+
+"xt = x + dx, rt = r + dr, dλ = -d[n+m+1:N] capped at Mdλ, λt = λ + dλ — src/CaNNOLeS.jl:654,661-668"
+trial_point_dev!(LDLT::HIPLDLStruct, x, r, λ, d, Mdλ, xt, rt, λt, dλ; stream = C_NULL) =
+  check(ccall((:cnl_trial_point_dev, libcnl), Cint,
+    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+    LDLT.factor.handle, x, r, λ, d, Mdλ, xt, rt, λt, dλ, stream))
+
+"prepare_newton_system! with model values that already live on the device — src/CaNNOLeS.jl:947-981"
+prepare_newton_system_dev!(LDLT::HIPLDLStruct, nnzhF, nnzhc, nnzjF, nnzjc, hF, hc, Jx, Jcx, δ, vals; stream = C_NULL) =
+  check(ccall((:cnl_prepare_newton_system_dev, libcnl), Cint,
+    (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+    LDLT.factor.handle, nnzhF, nnzhc, nnzjF, nnzjc, hF, hc, Jx, Jcx, δ, vals, stream))
+
+"λ = argmin ‖Jc'λ − Jx'r‖ by CGLS (Krylov.jl defaults) — src/CaNNOLeS.jl:507-518"
+cgls_multipliers_dev!(LDLT::HIPLDLStruct, vals, r, λ; Jxtr = C_NULL, atol = √eps(Float64), rtol = √eps(Float64), itmax = 0,
+                      ones_if_zero = true, iters = C_NULL, stream = C_NULL) =
+  check(ccall((:cnl_cgls_multipliers_dev, libcnl), Cint,
+    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Int64, Cint, Ptr{Int32}, Ptr{Cvoid}),
+    LDLT.factor.handle, vals, r, λ, Jxtr, atol, rtol, itmax, ones_if_zero ? 1 : 0, iters, stream))
+
 end # module
