@@ -1,6 +1,7 @@
-// dense.h — backend for plans whose residual block is DENSE (BASELINE config 2: every residual row holds all variables,
-// no constraints).  The multifrontal machinery has nothing to exploit there: the condensed system
-//     S = H + rho I - J' diag(1/d_r) J          (n x n, dense; = H + rho I + J'J for the reference's d_r = -1)
+// dense.h — backend for plans whose residual block is DENSE (BASELINE config 2: every residual row holds all variables).
+// The multifrontal machinery has nothing to exploit there: the condensed system
+//     S = [ H + rho I - J' diag(1/d_r) J    Jc' ]      (order n + p, dense; top-left = H + rho I + J'J for the
+//         [ Jc                             -dI  ]       reference's d_r = -1; quasi-definite, so no pivoting is needed)
 // is formed by a GEMM and factorised by a blocked dense LDL^T without pivoting (panel kernels written here, trailing
 // updates by rocBLAS dgemm: MFMA f64).  Same contract as the other kernels: inertia rule of
 // /root/reference/src/solver_types.jl:90-97, rho ladder of /root/reference/src/CaNNOLeS.jl:1008-1052, d = -K^-1 rhs.
@@ -15,15 +16,15 @@ namespace cnl {
 
 struct DensePlan {
   bool active = false;
-  int32_t n = 0, m = 0, nnz = 0;  // variables, residual rows, COO entries
+  int32_t n = 0, m = 0, p = 0, nnz = 0;  // variables, residual rows, constraints, COO entries; the dense system has order n + p
   // slot lists built from the pattern (0-based COO entry numbers)
   std::vector<int32_t> jslot;     // [m * n] column-major: entry of J(i, j) at i + m * j
   std::vector<int32_t> dslot;     // [m]  diagonal of the -I block
-  std::vector<int32_t> hslot, hpos;  // H_F entries (any number, duplicates allowed): slot, position i + n * j (i >= j)
+  std::vector<int32_t> hslot, hpos;  // every other entry (H_F, H_c, J_c, -delta I; duplicates allowed): slot, position i' + (n + p) * j'
 };
 
-// Returns true and fills D when the pattern qualifies: ncon == 0, nequ > 0, every residual row has exactly one entry per
-// variable, one diagonal entry per residual row, no other coupling.
+// Returns true and fills D when the pattern qualifies: nequ > 0, every residual row has exactly one entry per variable and
+// one diagonal entry, and the constraint rows (any pattern) couple only to the variables.
 bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
                   int64_t ncon);
 

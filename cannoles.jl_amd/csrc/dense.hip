@@ -55,13 +55,13 @@ __global__ void __launch_bounds__(256) hscatter_kernel(const double* __restrict_
 }
 
 // S = S0 + diag(rho): rho from the slots of vals (first attempt, as given) or one value for all (ladder retries)
-__global__ void __launch_bounds__(256) shift_kernel(const double* __restrict__ S0, double* __restrict__ S, int n,
+__global__ void __launch_bounds__(256) shift_kernel(const double* __restrict__ S0, double* __restrict__ S, int n, int nv,
                                                     const double* __restrict__ rho_slots, double rho, int use_slots) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= (long long)n * n) return;
   const int i = (int)(t % n), j = (int)(t / n);
   double v = S0[t];
-  if (i == j) v += use_slots ? rho_slots[i] : rho;
+  if (i == j && i < nv) v += use_slots ? rho_slots[i] : rho;  // rho I on the variables only
   S[t] = v;
 }
 
@@ -124,10 +124,11 @@ __global__ void __launch_bounds__(256) mul_kernel(const double* __restrict__ a, 
 }
 
 __global__ void __launch_bounds__(256) out_kernel(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ w,
-                                                  double* __restrict__ d, int n, int m) {
+                                                  double* __restrict__ d, int n, int m, int p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) d[i] = -x[i];
   else if (i < n + m) d[i] = w[i - n] * u[i - n];  // d_r = -(rhs_r - J x) / d_r
+  else if (i < n + m + p) d[i] = -x[n + (i - n - m)];  // multipliers: the last p unknowns of the dense system
 }
 
 __global__ void __launch_bounds__(256) fill_kernel(double* p, double v, int n) {
@@ -152,26 +153,34 @@ struct DenseState {
 bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
                   int64_t ncon) {
   D.active = false;
-  if (ncon != 0 || nequ <= 0 || nvar < 32 || N != nvar + nequ) return false;
-  if ((long long)nvar * nequ > (1ll << 28) || nnz > (1ll << 30)) return false;
-  D.n = (int32_t)nvar; D.m = (int32_t)nequ; D.nnz = (int32_t)nnz;
+  if (nequ <= 0 || nvar < 32 || N != nvar + nequ + ncon) return false;
+  if ((long long)nvar * nequ > (1ll << 28) || nnz > (1ll << 30) || (nvar + ncon) > 30000) return false;
+  D.n = (int32_t)nvar; D.m = (int32_t)nequ; D.p = (int32_t)ncon; D.nnz = (int32_t)nnz;
+  const int64_t ns = nvar + ncon;  // order of the dense system
   D.jslot.assign((size_t)nvar * nequ, -1);
   D.dslot.assign(nequ, -1);
   D.hslot.clear(); D.hpos.clear();
   const int64_t rho_begin = nnz - nvar;
   for (int64_t e = 0; e < nnz; e++) {
     const int64_t i = rows1[e] - 1, j = cols1[e] - 1;
-    if (i < nvar) {  // H_F entry or rho slot (lower triangle, column j <= row i)
+    if (i < nvar) {  // H_F / H_c entry or rho slot (lower triangle, column j <= row i)
       if (e >= rho_begin) continue;  // rho slots are applied by shift_kernel
-      D.hslot.push_back((int32_t)e); D.hpos.push_back((int32_t)(i + nvar * j));
-    } else if (j < nvar) {
-      int32_t& s = D.jslot[(size_t)(i - nvar) + (size_t)nequ * j];
-      if (s >= 0) return false;  // duplicate Jacobian entry: not handled here
-      s = (int32_t)e;
-    } else if (i == j) {
-      if (D.dslot[i - nvar] >= 0) return false;
-      D.dslot[i - nvar] = (int32_t)e;
-    } else return false;
+      D.hslot.push_back((int32_t)e); D.hpos.push_back((int32_t)(i + ns * j));
+    } else if (i < nvar + nequ) {
+      if (j < nvar) {
+        int32_t& s = D.jslot[(size_t)(i - nvar) + (size_t)nequ * j];
+        if (s >= 0) return false;  // duplicate Jacobian entry: not handled here
+        s = (int32_t)e;
+      } else if (i == j) {
+        if (D.dslot[i - nvar] >= 0) return false;
+        D.dslot[i - nvar] = (int32_t)e;
+      } else return false;
+    } else {  // constraint row k: Jacobian entries and the -delta diagonal go straight into the dense system
+      const int64_t k = i - nvar - nequ;
+      if (j < nvar) { D.hslot.push_back((int32_t)e); D.hpos.push_back((int32_t)((nvar + k) + ns * j)); }
+      else if (i == j) { D.hslot.push_back((int32_t)e); D.hpos.push_back((int32_t)((nvar + k) + ns * (nvar + k))); }
+      else return false;
+    }
   }
   for (int32_t s : D.jslot) if (s < 0) return false;  // a residual row that does not hold every variable
   for (int32_t s : D.dslot) if (s < 0) return false;
@@ -195,7 +204,7 @@ int dense_create(DenseState** out, const DensePlan& D, int64_t batch, std::strin
   DenseState* st = new DenseState();
   st->batch = batch;
   *out = st;
-  const size_t n = D.n, m = D.m;
+  const size_t n = D.n, m = D.m, ns = (size_t)D.n + D.p;
   int rc;
   if ((rc = dalloc_(st, &st->jslot, n * m, err))) return rc;
   if ((rc = dalloc_(st, &st->dslot, m, err))) return rc;
@@ -205,12 +214,12 @@ int dense_create(DenseState** out, const DensePlan& D, int64_t batch, std::strin
   if ((rc = dalloc_(st, &st->Jd, n * m, err))) return rc;
   if ((rc = dalloc_(st, &st->JW, n * m, err))) return rc;
   if ((rc = dalloc_(st, &st->w, m, err))) return rc;
-  if ((rc = dalloc_(st, &st->S0, n * n, err))) return rc;
-  if ((rc = dalloc_(st, &st->W21, n * NB, err))) return rc;
-  if ((rc = dalloc_(st, &st->y, n, err))) return rc;
+  if ((rc = dalloc_(st, &st->S0, ns * ns, err))) return rc;
+  if ((rc = dalloc_(st, &st->W21, ns * NB, err))) return rc;
+  if ((rc = dalloc_(st, &st->y, ns, err))) return rc;
   if ((rc = dalloc_(st, &st->u, m, err))) return rc;
   if ((rc = dalloc_(st, &st->tmp, m, err))) return rc;
-  if ((rc = dalloc_(st, &st->S, (size_t)batch * n * n, err))) return rc;
+  if ((rc = dalloc_(st, &st->S, (size_t)batch * ns * ns, err))) return rc;
   DCHK(hipMemcpy(st->jslot, D.jslot.data(), n * m * sizeof(int), hipMemcpyHostToDevice));
   DCHK(hipMemcpy(st->dslot, D.dslot.data(), m * sizeof(int), hipMemcpyHostToDevice));
   if (!D.hslot.empty()) {
@@ -233,8 +242,8 @@ namespace {
 // S_b = L D L^T of (S0 + shift); counts of the dense pivots go to st->cnt[0..1] (added to what is there)
 int factor(DenseState* st, const DensePlan& D, double* S, const double* rho_slots, double rho, int use_slots, double eig_tol,
            hipStream_t stream, std::string& err) {
-  const int n = D.n;
-  hipLaunchKernelGGL(shift_kernel, dim3(blocks((long long)n * n)), dim3(256), 0, stream, st->S0, S, n, rho_slots, rho, use_slots);
+  const int n = D.n + D.p;  // order of the dense system
+  hipLaunchKernelGGL(shift_kernel, dim3(blocks((long long)n * n)), dim3(256), 0, stream, st->S0, S, n, D.n, rho_slots, rho, use_slots);
   const double one = 1.0, mone = -1.0;
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int nb = std::min(NB, n - k0), n2 = n - k0 - nb;
@@ -253,30 +262,32 @@ int build(DenseState* st, const DensePlan& D, const double* vals, double eig_tol
   DCHK(hipMemsetAsync(st->cnt, 0, 4 * sizeof(int), stream));
   hipLaunchKernelGGL(gather_kernel, dim3(blocks((long long)m * n)), dim3(256), 0, stream, vals, st->jslot, st->dslot, m, n, st->Jd, st->JW, st->w);
   hipLaunchKernelGGL(rinertia_kernel, dim3(blocks(m)), dim3(256), 0, stream, vals, st->dslot, m, eig_tol, st->cnt + 2);
-  DCHK(hipMemsetAsync(st->S0, 0, (size_t)n * n * sizeof(double), stream));
+  const int ns = n + D.p;
+  DCHK(hipMemsetAsync(st->S0, 0, (size_t)ns * ns * sizeof(double), stream));
   if (!D.hslot.empty())
     hipLaunchKernelGGL(hscatter_kernel, dim3(blocks((long long)D.hslot.size())), dim3(256), 0, stream, vals, st->hslot, st->hpos, (int)D.hslot.size(), st->S0);
   const double one = 1.0;
-  // S0 += J' (W J)
-  BCHK(rocblas_dgemm(st->blas, rocblas_operation_transpose, rocblas_operation_none, n, n, m, &one, st->Jd, m, st->JW, m, &one, st->S0, n));
+  // top-left block: S0(1:n, 1:n) += J' (W J)
+  BCHK(rocblas_dgemm(st->blas, rocblas_operation_transpose, rocblas_operation_none, n, n, m, &one, st->Jd, m, st->JW, m, &one, st->S0, ns));
   return 0;
 }
 
 // d = -K^-1 rhs with the factor in S (Jd, w of the same problem must be in place)
 int solve(DenseState* st, const DensePlan& D, const double* S, const double* rhs, double* d, hipStream_t stream, std::string& err) {
-  const int n = D.n, m = D.m;
+  const int n = D.n, m = D.m, p = D.p, ns = D.n + D.p;
   const double one = 1.0, mone = -1.0;
-  // y = rhs_x + J' (w .* rhs_r)      (= rhs_x - J' (rhs_r / d_r))
+  // y = [rhs_x + J' (w .* rhs_r) ; rhs_c]      (rhs_x - J' (rhs_r / d_r) on the variables)
   hipLaunchKernelGGL(mul_kernel, dim3(blocks(m)), dim3(256), 0, stream, st->w, rhs + n, st->tmp, m);
   DCHK(hipMemcpyAsync(st->y, rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  if (p > 0) DCHK(hipMemcpyAsync(st->y + n, rhs + n + m, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, stream));
   BCHK(rocblas_dgemv(st->blas, rocblas_operation_transpose, m, n, &one, st->Jd, m, st->tmp, 1, &one, st->y, 1));
-  BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, n, S, n, st->y, 1));
-  hipLaunchKernelGGL(scale_by_diag_kernel, dim3(blocks(n)), dim3(256), 0, stream, st->y, S, n);
-  BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_unit, n, S, n, st->y, 1));
+  BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, ns, S, ns, st->y, 1));
+  hipLaunchKernelGGL(scale_by_diag_kernel, dim3(blocks(ns)), dim3(256), 0, stream, st->y, S, ns);
+  BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_unit, ns, S, ns, st->y, 1));
   // u = rhs_r - J x
   DCHK(hipMemcpyAsync(st->u, rhs + n, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, stream));
   BCHK(rocblas_dgemv(st->blas, rocblas_operation_none, m, n, &mone, st->Jd, m, st->y, 1, &one, st->u, 1));
-  hipLaunchKernelGGL(out_kernel, dim3(blocks(n + m)), dim3(256), 0, stream, st->y, st->u, st->w, d, n, m);
+  hipLaunchKernelGGL(out_kernel, dim3(blocks(n + m + p)), dim3(256), 0, stream, st->y, st->u, st->w, d, n, m, p);
   DCHK(hipGetLastError());
   return 0;
 }
@@ -287,13 +298,13 @@ int dense_run(DenseState* st, const DensePlan& D, int mode, double* vals, const 
               double* rho_d, int32_t* nfact_d, int32_t* success_d, int64_t* npos_d, int64_t* nzero_d, const double params[9],
               hipStream_t stream, std::string& err) {
   const int n = D.n, m = D.m;
-  const size_t N = (size_t)n + m;
+  const size_t N = (size_t)n + m + D.p, ns = (size_t)n + D.p;
   BCHK(rocblas_set_stream(st->blas, stream));
   const double eig_tol = params[0], kdec = params[2], kinc = params[3], klarge = params[4], rho0 = params[5], rhomax = params[6],
                rhomin = params[7];
   if (mode == 2 && !st->last_vals) { err = "cnl_solve before cnl_factorize"; return 5; }
   for (int64_t b = 0; b < st->batch; b++) {
-    double* S = st->S + (size_t)b * n * n;
+    double* S = st->S + b * ns * ns;
     double* vb = vals ? vals + (size_t)b * D.nnz : nullptr;
     int rc;
     if (mode == 2) {

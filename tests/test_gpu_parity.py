@@ -497,3 +497,37 @@ def test_f4_cgls_multipliers(built):
         np.testing.assert_allclose(lam[b], lam0, rtol=1e-10, atol=1e-12)
     assert np.array_equal(lam[3], np.ones(s.ncon))
     LDLT.close()
+
+
+def test_dense_backend_with_constraints(built):
+    """Dense residual Jacobian WITH constraints: the constraint rows border the dense system (order nvar + ncon,
+    quasi-definite, factorised without pivoting); includes duplicate H_F / H_c entries and the rho ladder."""
+    hipldl, syn, O = _mods()
+    n, m, p = 64, 150, 6
+    rng = np.random.default_rng(12)
+    jr, jc = np.tile(np.arange(1, m + 1), n), np.repeat(np.arange(1, n + 1), m)          # dense J_F, column-major
+    hd = np.arange(1, n + 1)
+    hF = (np.concatenate([hd, hd[1:]]), np.concatenate([hd, hd[:-1]]))                   # diagonal + first subdiagonal
+    hc = (hd, hd)                                                                         # duplicates of the diagonal
+    cr = np.repeat(np.arange(1, p + 1), 10)
+    cc = np.concatenate([rng.choice(n, 10, replace=False) + 1 for _ in range(p)])
+    s = syn.Structure(n, m, p, hF, hc, (jr, jc), (cr, cc), name="dense+con")
+    rows, cols = s.kkt_pattern()
+    off = s.offsets()
+    B = 3
+    vals = np.zeros((B, s.nnzNS))
+    rhs = rng.standard_normal((B, s.N))
+    for b in range(B):
+        vals[b, off[0]:off[1]] = np.concatenate([rng.uniform(0.2, 1.0, n), rng.uniform(-0.05, 0.05, n - 1)])
+        vals[b, off[1]:off[2]] = rng.uniform(-0.05, 0.05, n)
+        vals[b, off[2]:off[3]] = rng.standard_normal(m * n) / np.sqrt(n)
+        vals[b, off[3]:off[4]] = rng.uniform(-1, 1, len(cr))
+        vals[b, off[4]:off[5]] = -rng.uniform(0.5, 2.0, m)
+        vals[b, off[5]:off[6]] = -0.1
+    L0 = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=1)
+    assert L0.config["kernel"] == "dense"
+    L0.close()
+    run_case(s, vals, rhs)
+    v2 = vals.copy()
+    v2[:, off[0]:off[0] + n] = -4.0  # indefinite: the ladder climbs
+    run_case(s, v2, rhs, check_fwd=False)
