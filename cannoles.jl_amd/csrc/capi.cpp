@@ -26,6 +26,7 @@ struct cnl_plan {
   int64_t N = 0, nnz = 0, nvar = 0, nequ = 0, ncon = 0;  // outer dimensions, as the reference sees them
   std::vector<int32_t> perm_outer;
   cnl::DensePlan D;  // dense residual block (BASELINE config 2): served by the dense backend, csrc/dense.h
+  std::vector<int32_t> gpos;  // non-empty: the condensed system may be treated as ONE dense matrix (position of every K2 slot)
 };
 
 struct cnl_handle {
@@ -61,6 +62,8 @@ struct cnl_handle {
   bool factorized = false;
   cnl::DevJt djt{};  // transposed-Jacobian lists (row f1: residual / optimality vectors on the device)
   cnl::DenseState* dense = nullptr;
+  cnl::DenseState* gdense = nullptr;  // dense treatment of an arbitrary condensed system (irregular sparsity, small batch)
+  cnl::GeneralOps gops{};
   double* d_cgls_ws = nullptr;  // [batch][2 * nvar] workspace of cnl_cgls_multipliers_dev, allocated on first use
 };
 
@@ -239,6 +242,42 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
     }
     return CNL_OK;
   }
+  if (h->gdense) {
+    // condensed system as one dense matrix: condense pass -> dense LDL^T / solves (csrc/dense.hip) -> post-pass
+    const int B = (int)h->batch;
+    const int s_mat = (int)(C.ncs + C.nvar), s_all = (int)C.cstride;
+    hipError_t e = hipSuccess;
+    std::string err;
+    if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
+    if (a.mode == cnl::MODE_SOLVE) {
+      if (!h->last_vals) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
+      e = C.tiled_ok ? cnl::launch_condense_tiled(h->dc, h->last_vals, d_rhs, h->d_cbuf, 4, C.ch_region[3], B, stream)
+                     : cnl::launch_condense(h->dc, h->last_vals, d_rhs, h->d_cbuf, s_mat, s_all, B, stream);
+    } else {
+      const bool nw = a.mode == cnl::MODE_NEWTON;
+      e = C.tiled_ok ? cnl::launch_condense_tiled(h->dc, d_vals, nw ? d_rhs : nullptr, h->d_cbuf, nw ? 7 : 3, C.ch_region[3], B, stream)
+                     : cnl::launch_condense(h->dc, d_vals, nw ? d_rhs : nullptr, h->d_cbuf, 0, nw ? s_all : s_mat, B, stream);
+      if (e == hipSuccess) e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
+    }
+    if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
+    rc = cnl::dense_run_general(h->gdense, h->gops, a.mode, h->d_cbuf, h->d_xpos, h->d_xzer, h->d_d2,
+                                d_vals ? d_vals + (C.nnz - C.nvar) : nullptr, C.nnz, a.rho_old, a.rho, a.nfact, a.success, a.npos, a.nzero,
+                                a.params, stream, err);
+    if (rc) return fail(CNL_ERR_HIP, "dense backend: " + err);
+    if (a.mode == cnl::MODE_FACTOR) h->last_vals = d_vals;
+    else {
+      const double* vsrc = a.mode == cnl::MODE_SOLVE ? h->last_vals : d_vals;
+      e = cnl::launch_expand(h->dc, const_cast<double*>(vsrc), d_rhs, h->d_d2, h->d_cbuf, d_d, a.mode == cnl::MODE_NEWTON ? a.success : nullptr, 0,
+                             B, stream);
+      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
+    }
+    if (h->timing) {
+      HIPCHK(hipEventRecord(h->ev1, stream));
+      HIPCHK(hipEventSynchronize(h->ev1));
+      HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    }
+    return CNL_OK;
+  }
   if (!C.active) {
     a.vals = d_vals; a.rhs = d_rhs; a.d = d_d;
     rc = launch(h, a, stream);
@@ -390,6 +429,14 @@ int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows
               p->P.rec.size(), old_len, p->P.rec_maxlen);
   }
   if (!(getenv("CNL_NO_DENSE") && atoi(getenv("CNL_NO_DENSE")))) cnl::detect_dense(p->D, N, nnz, rows1, cols1, nvar, nequ, ncon);
+  // Irregular sparsity: when the fill makes fronts larger than the register-front kernel takes and the condensed system is of
+  // moderate order, one dense LDL^T of the whole condensed matrix beats the general multifrontal kernel by far
+  // (csrc/dense.h; chosen at handle creation for small batches; CNL_NO_GDENSE=1 disables)
+  if (p->C.active && !p->D.active && !p->P.v2_ok && p->C.N2 >= 96 && p->C.N2 <= 4096 &&
+      !(getenv("CNL_NO_GDENSE") && atoi(getenv("CNL_NO_GDENSE")))) {
+    p->gpos.resize(p->C.ncs);
+    for (int64_t s2 = 0; s2 < p->C.ncs; s2++) p->gpos[s2] = (int32_t)((p->C.rows2[s2] - 1) + p->C.N2 * (p->C.cols2[s2] - 1));
+  }
   // elimination order in the reference's numbering: condensed residual nodes first
   if (p->C.active) {
     p->perm_outer.assign(p->C.r_orig.begin(), p->C.r_orig.end());
@@ -534,6 +581,13 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
     std::string derr;
     int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr);
     if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
+  } else if (!h->plan->gpos.empty() && !h->use_v2 && batch <= 16) {
+    std::string derr;
+    const cnl::Cond& C2 = h->plan->C;
+    int drc = cnl::dense_create_general(&h->gdense, (int32_t)C2.N2, batch, derr);
+    if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
+    h->gops.ns = (int32_t)C2.N2; h->gops.nv = (int32_t)nvar; h->gops.nslots = (int32_t)C2.ncs; h->gops.cstride = C2.cstride;
+    if ((rc = upload(h, h->plan->gpos, &h->gops.d_pos))) return bail(rc);
   }
   {
     // factor storage, zero-filled and padded: the row prefetch of the backward pass reads (never uses) a little past a panel
@@ -593,6 +647,7 @@ int cnl_destroy(cnl_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->dev_allocs) (void)hipFree(p);
   cnl::dense_destroy(h->dense);
+  cnl::dense_destroy(h->gdense);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -675,7 +730,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   std::memset(cfg, 0, 8 * sizeof(int64_t));
   cfg[0] = h->cfg.tpp; cfg[1] = h->cfg.ppb; cfg[2] = (int64_t)h->cfg.lds_bytes; cfg[3] = h->cfg.lds_work;
   cfg[4] = (h->batch + h->cfg.ppb - 1) / h->cfg.ppb;
-  cfg[5] = h->dense ? 3 : (h->use_v2 ? 2 : 1);
+  cfg[5] = (h->dense || h->gdense) ? 3 : (h->use_v2 ? 2 : 1);
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;
   return CNL_OK;

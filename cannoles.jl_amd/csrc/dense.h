@@ -38,4 +38,21 @@ int dense_run(DenseState* st, const DensePlan& D, int mode, double* vals, const 
               double* rho, int32_t* nfact, int32_t* success, int64_t* npos, int64_t* nzero, const double params[9],
               hipStream_t stream, std::string& err);
 
+// ---- the same dense machinery for an ARBITRARY condensed system (csrc/condense.h) of moderate order: plans whose fill makes
+// the fronts larger than the register-front kernel takes (irregular sparsity) and whose batch is small.  The caller (capi.cpp)
+// owns the condensed buffer; per problem it hands over the slots of K2, and gets the factor / solution back.
+struct GeneralOps {
+  int32_t ns = 0, nv = 0;          // order of the condensed system, number of variables (they carry rho)
+  int32_t nslots = 0;              // unique lower-triangular slots of K2 (without the rho entries)
+  const int32_t* d_pos = nullptr;  // device: position i + ns * j of every slot
+  int64_t cstride = 0;             // doubles per problem of the condensed buffer [slots | rho (nv) | rhs (ns)]
+};
+int dense_create_general(DenseState** st, int32_t ns, int64_t batch, std::string& err);
+// cbuf: condensed buffer of the batch (matrix part filled; rhs part filled for mode 0 / 2); xpos / xzer: inertia counts of the
+// condensed residual pivots per problem (device ints); d2: [batch][ns] receives -x (reduced numbering); rho_fill: per problem
+// pointer stride info to write the last rho tried back into the caller's vals (vals + b * nnz + rho_begin, nv entries).
+int dense_run_general(DenseState* st, const GeneralOps& G, int mode, const double* cbuf, const int* xpos, const int* xzer, double* d2,
+                      double* vals_rho0, int64_t vals_stride, double* rho_old, double* rho, int32_t* nfact, int32_t* success,
+                      int64_t* npos, int64_t* nzero, const double params[9], hipStream_t stream, std::string& err);
+
 }  // namespace cnl

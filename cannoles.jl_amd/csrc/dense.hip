@@ -136,6 +136,18 @@ __global__ void __launch_bounds__(256) fill_kernel(double* p, double v, int n) {
   if (i < n) p[i] = v;
 }
 
+// general condensed system: S0(pos[s]) = slot s (positions are unique)
+__global__ void __launch_bounds__(256) slot_scatter_kernel(const double* __restrict__ slots, const int* __restrict__ pos, int nslots,
+                                                           double* __restrict__ S0) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < nslots) S0[pos[e]] = slots[e];
+}
+
+__global__ void __launch_bounds__(256) neg_kernel(const double* __restrict__ y, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = -y[i];
+}
+
 inline int blocks(long long n) { return (int)((n + 255) / 256); }
 
 }  // namespace
@@ -240,10 +252,9 @@ void dense_destroy(DenseState* st) {
 namespace {
 
 // S_b = L D L^T of (S0 + shift); counts of the dense pivots go to st->cnt[0..1] (added to what is there)
-int factor(DenseState* st, const DensePlan& D, double* S, const double* rho_slots, double rho, int use_slots, double eig_tol,
-           hipStream_t stream, std::string& err) {
-  const int n = D.n + D.p;  // order of the dense system
-  hipLaunchKernelGGL(shift_kernel, dim3(blocks((long long)n * n)), dim3(256), 0, stream, st->S0, S, n, D.n, rho_slots, rho, use_slots);
+int factor_ns(DenseState* st, int n, int nv, double* S, const double* rho_slots, double rho, int use_slots, double eig_tol,
+              hipStream_t stream, std::string& err) {
+  hipLaunchKernelGGL(shift_kernel, dim3(blocks((long long)n * n)), dim3(256), 0, stream, st->S0, S, n, nv, rho_slots, rho, use_slots);
   const double one = 1.0, mone = -1.0;
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int nb = std::min(NB, n - k0), n2 = n - k0 - nb;
@@ -255,6 +266,11 @@ int factor(DenseState* st, const DensePlan& D, double* S, const double* rho_slot
   }
   DCHK(hipGetLastError());
   return 0;
+}
+
+int factor(DenseState* st, const DensePlan& D, double* S, const double* rho_slots, double rho, int use_slots, double eig_tol,
+           hipStream_t stream, std::string& err) {
+  return factor_ns(st, D.n + D.p, D.n, S, rho_slots, rho, use_slots, eig_tol, stream, err);
 }
 
 int build(DenseState* st, const DensePlan& D, const double* vals, double eig_tol, hipStream_t stream, std::string& err) {
@@ -369,6 +385,105 @@ int dense_run(DenseState* st, const DensePlan& D, int mode, double* vals, const 
     DCHK(hipStreamSynchronize(stream));
   }
   if (mode == 1) st->last_vals = vals;
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+int dense_create_general(DenseState** out, int32_t ns, int64_t batch, std::string& err) {
+  DenseState* st = new DenseState();
+  st->batch = batch;
+  *out = st;
+  int rc;
+  const size_t n = (size_t)ns;
+  if ((rc = dalloc_(st, &st->cnt, 4, err))) return rc;
+  if ((rc = dalloc_(st, &st->S0, n * n, err))) return rc;
+  if ((rc = dalloc_(st, &st->W21, n * NB, err))) return rc;
+  if ((rc = dalloc_(st, &st->y, n, err))) return rc;
+  if ((rc = dalloc_(st, &st->S, (size_t)batch * n * n, err))) return rc;
+  BCHK(rocblas_create_handle(&st->blas));
+  return 0;
+}
+
+int dense_run_general(DenseState* st, const GeneralOps& G, int mode, const double* cbuf, const int* xpos, const int* xzer, double* d2,
+                      double* vals_rho0, int64_t vals_stride, double* rho_old_d, double* rho_d, int32_t* nfact_d, int32_t* success_d,
+                      int64_t* npos_d, int64_t* nzero_d, const double params[9], hipStream_t stream, std::string& err) {
+  const int ns = G.ns, nv = G.nv;
+  BCHK(rocblas_set_stream(st->blas, stream));
+  const double eig_tol = params[0], kdec = params[2], kinc = params[3], klarge = params[4], rho0 = params[5], rhomax = params[6],
+               rhomin = params[7];
+  for (int64_t b = 0; b < st->batch; b++) {
+    double* S = st->S + (size_t)b * ns * ns;
+    const double* cb = cbuf + (size_t)b * G.cstride;
+    int rc = 0;
+    auto solve_b = [&]() -> int {
+      // x = S^-1 crhs;  d2 = -x
+      DCHK(hipMemcpyAsync(st->y, cb + G.nslots + nv, (size_t)ns * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, ns, S, ns, st->y, 1));
+      hipLaunchKernelGGL(scale_by_diag_kernel, dim3(blocks(ns)), dim3(256), 0, stream, st->y, S, ns);
+      BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_unit, ns, S, ns, st->y, 1));
+      hipLaunchKernelGGL(neg_kernel, dim3(blocks(ns)), dim3(256), 0, stream, st->y, d2 + (size_t)b * ns, ns);
+      DCHK(hipGetLastError());
+      return 0;
+    };
+    if (mode == 2) { if ((rc = solve_b())) return rc; continue; }
+    DCHK(hipMemsetAsync(st->S0, 0, (size_t)ns * ns * sizeof(double), stream));
+    hipLaunchKernelGGL(slot_scatter_kernel, dim3(blocks(G.nslots)), dim3(256), 0, stream, cb, G.d_pos, G.nslots, st->S0);
+    DCHK(hipMemcpyAsync(st->cnt + 2, xpos + b, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    DCHK(hipMemcpyAsync(st->cnt + 3, xzer + b, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    int cnt[4];
+    auto attempt = [&](double rho, int use_slots) -> int {
+      DCHK(hipMemsetAsync(st->cnt, 0, 2 * sizeof(int), stream));
+      int r2 = factor_ns(st, ns, nv, S, cb + G.nslots, rho, use_slots, eig_tol, stream, err);
+      if (r2) return r2;
+      DCHK(hipMemcpyAsync(cnt, st->cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+      DCHK(hipStreamSynchronize(stream));
+      return 0;
+    };
+    auto ok = [&]() { return cnt[0] + cnt[2] == nv && cnt[1] + cnt[3] == 0; };  // src/solver_types.jl:90-97
+    if (mode == 1) {
+      if ((rc = attempt(0.0, 1))) return rc;
+      const int32_t s32 = ok() ? 1 : 0;
+      DCHK(hipMemcpyAsync(success_d + b, &s32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      if (npos_d) { const int64_t v = cnt[0] + cnt[2]; DCHK(hipMemcpyAsync(npos_d + b, &v, sizeof(int64_t), hipMemcpyHostToDevice, stream)); }
+      if (nzero_d) { const int64_t v = cnt[1] + cnt[3]; DCHK(hipMemcpyAsync(nzero_d + b, &v, sizeof(int64_t), hipMemcpyHostToDevice, stream)); }
+      DCHK(hipStreamSynchronize(stream));
+      continue;
+    }
+    // newton_system!, src/CaNNOLeS.jl:1008-1052
+    double rho_old = 0.0;
+    DCHK(hipMemcpyAsync(&rho_old, rho_old_d + b, sizeof(double), hipMemcpyDeviceToHost, stream));
+    DCHK(hipStreamSynchronize(stream));
+    double rho = 0.0, wrote = 0.0;
+    int nfact = 1;
+    if ((rc = attempt(0.0, 1))) return rc;
+    bool success = ok();
+    if (!success) {
+      rho = rho_old == 0.0 ? rho0 : std::max(rhomin, kdec * rho_old);
+      wrote = rho;
+      if ((rc = attempt(rho, 0))) return rc;
+      success = ok();
+      nfact++;
+      while (!success && rho <= rhomax) {
+        rho = rho_old == 0.0 ? klarge * rho : kinc * rho;
+        if (rho <= rhomax) {
+          wrote = rho;
+          if ((rc = attempt(rho, 0))) return rc;
+          success = ok();
+          nfact++;
+        }
+      }
+      if (rho <= rhomax) rho_old = rho;
+      hipLaunchKernelGGL(fill_kernel, dim3(blocks(nv)), dim3(256), 0, stream, vals_rho0 + (size_t)b * vals_stride, wrote, nv);
+    }
+    if (success && (rc = solve_b())) return rc;
+    const int32_t nf32 = nfact, s32 = success ? 1 : 0;
+    DCHK(hipMemcpyAsync(rho_d + b, &rho, sizeof(double), hipMemcpyHostToDevice, stream));
+    DCHK(hipMemcpyAsync(rho_old_d + b, &rho_old, sizeof(double), hipMemcpyHostToDevice, stream));
+    DCHK(hipMemcpyAsync(nfact_d + b, &nf32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    DCHK(hipMemcpyAsync(success_d + b, &s32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    DCHK(hipStreamSynchronize(stream));
+  }
   return 0;
 }
 

@@ -531,3 +531,33 @@ def test_dense_backend_with_constraints(built):
     v2 = vals.copy()
     v2[:, off[0]:off[0] + n] = -4.0  # indefinite: the ladder climbs
     run_case(s, v2, rhs, check_fwd=False)
+
+
+@pytest.mark.parametrize("shape", [(300, 400, 10, 0.02, 1), (200, 260, 0, 0.04, 2)])
+def test_irregular_sparsity_dense_treatment(built, shape):
+    """Irregular sparse Jacobians whose fill gives fronts of order > 64: for a small batch the condensed system (order nvar +
+    kept rows + ncon) is factorised as ONE dense matrix (condense pass -> blocked dense LDL^T -> post-pass).  Newton step with
+    the rho ladder, and the two-call sequence, against the oracle."""
+    hipldl, syn, O = _mods()
+    n, m, p, dens, seed = shape
+    s = syn.random_structure(n, m, p, dens, seed=seed)
+    rows, cols = s.kkt_pattern()
+    B = 3
+    vals = np.stack([syn.random_values(s, 40 + b)[0] for b in range(B)])
+    rhs = np.stack([syn.random_values(s, 40 + b)[1] for b in range(B)])
+    L0 = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    assert L0.info["fmax"] > 64 and L0.config["kernel"] == "dense"
+    L0.close()
+    run_case(s, vals, rhs)
+    v2 = vals.copy()
+    off = s.offsets()
+    v2[:, off[0]:off[1]] *= -20.0  # indefinite top-left block: ladder
+    run_case(s, v2, rhs, check_fwd=False)
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, vals, s.nvar, s.nequ, s.ncon, batch=B)
+    ok = hipldl.try_to_factorize(LDLT, vals, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16)
+    assert ok.all()
+    d = np.zeros((B, s.N))
+    hipldl.solve_ldl_(rhs, LDLT.factor, d)
+    for b in range(B):
+        assert backward_error(s, vals[b], rhs[b], d[b]) <= BWD_TOL
+    LDLT.close()
