@@ -228,8 +228,8 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
   const cnl::Cond& C = h->plan->C;
   int rc = CNL_OK;
   if (h->dense) {
-    // dense residual block: GEMM + blocked dense LDL^T (csrc/dense.hip); the rho ladder is decided on the host, so the
-    // call synchronises on the stream
+    // dense residual block: J'WJ + tiled dense LDL^T on the fp64 matrix cores (csrc/dense.hip); asynchronous, the rho ladder
+    // is decided on the device
     std::string err;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
     rc = cnl::dense_run(h->dense, h->plan->D, a.mode, d_vals, d_rhs, d_d, a.rho_old, a.rho, a.nfact, a.success, a.npos, a.nzero,
@@ -584,10 +584,10 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   } else if (!h->plan->gpos.empty() && !h->use_v2 && batch <= 16) {
     std::string derr;
     const cnl::Cond& C2 = h->plan->C;
-    int drc = cnl::dense_create_general(&h->gdense, (int32_t)C2.N2, batch, derr);
-    if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
     h->gops.ns = (int32_t)C2.N2; h->gops.nv = (int32_t)nvar; h->gops.nslots = (int32_t)C2.ncs; h->gops.cstride = C2.cstride;
     if ((rc = upload(h, h->plan->gpos, &h->gops.d_pos))) return bail(rc);
+    int drc = cnl::dense_create_general(&h->gdense, (int32_t)C2.N2, (int32_t)nvar, (int32_t)C2.ncs, h->gops.d_pos, batch, derr);
+    if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
   }
   {
     // factor storage, zero-filled and padded: the row prefetch of the backward pass reads (never uses) a little past a panel

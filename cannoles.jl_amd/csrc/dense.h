@@ -2,8 +2,8 @@
 // The multifrontal machinery has nothing to exploit there: the condensed system
 //     S = [ H + rho I - J' diag(1/d_r) J    Jc' ]      (order n + p, dense; top-left = H + rho I + J'J for the
 //         [ Jc                             -dI  ]       reference's d_r = -1; quasi-definite, so no pivoting is needed)
-// is formed by a GEMM and factorised by a blocked dense LDL^T without pivoting (panel kernels written here, trailing
-// updates by rocBLAS dgemm: MFMA f64).  Same contract as the other kernels: inertia rule of
+// is formed and factorised in 64 x 64 tiles by hand-written kernels (J'WJ and the trailing updates on the fp64 matrix
+// cores, v_mfma_f64_16x16x4_f64; panel steps in registers), a blocked dense LDL^T without pivoting.  Same contract as the other kernels: inertia rule of
 // /root/reference/src/solver_types.jl:90-97, rho ladder of /root/reference/src/CaNNOLeS.jl:1008-1052, d = -K^-1 rhs.
 #pragma once
 #include <hip/hip_runtime_api.h>
@@ -28,12 +28,12 @@ struct DensePlan {
 bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
                   int64_t ncon);
 
-struct DenseState;  // device buffers + rocBLAS handle
+struct DenseState;  // device buffers
 int dense_create(DenseState** st, const DensePlan& D, int64_t batch, std::string& err);
 void dense_destroy(DenseState* st);
 
 // mode: 0 newton (ladder + solve), 1 factorize, 2 solve.  All pointers are device pointers, problem-major as in the ABI.
-// The calls synchronise on `stream` (the ladder decides on the host between attempts).
+// Asynchronous on `stream`: the rho ladder is decided on the device.
 int dense_run(DenseState* st, const DensePlan& D, int mode, double* vals, const double* rhs, double* d, double* rho_old,
               double* rho, int32_t* nfact, int32_t* success, int64_t* npos, int64_t* nzero, const double params[9],
               hipStream_t stream, std::string& err);
@@ -47,7 +47,8 @@ struct GeneralOps {
   const int32_t* d_pos = nullptr;  // device: position i + ns * j of every slot
   int64_t cstride = 0;             // doubles per problem of the condensed buffer [slots | rho (nv) | rhs (ns)]
 };
-int dense_create_general(DenseState** st, int32_t ns, int64_t batch, std::string& err);
+// d_pos (device, owned by the caller): position i + ns * j of every slot of the condensed system
+int dense_create_general(DenseState** st, int32_t ns, int32_t nv, int32_t nslots, const int32_t* d_pos, int64_t batch, std::string& err);
 // cbuf: condensed buffer of the batch (matrix part filled; rhs part filled for mode 0 / 2); xpos / xzer: inertia counts of the
 // condensed residual pivots per problem (device ints); d2: [batch][ns] receives -x (reduced numbering); rho_fill: per problem
 // pointer stride info to write the last rho tried back into the caller's vals (vals + b * nnz + rho_begin, nv entries).

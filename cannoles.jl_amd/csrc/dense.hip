@@ -1,10 +1,28 @@
-// dense.hip — dense-residual-block backend (see dense.h).  Panel kernels are written here; the two GEMM-shaped steps
-// (J' W J and the trailing updates of the blocked LDL^T) go to rocBLAS dgemm, i.e. to the fp64 matrix cores.
+// dense.hip — dense backend for gfx950 (see dense.h): hand-written fp64 MFMA kernels, no vendor BLAS.
+//
+// The condensed system S = H + rho I - J' diag(1/d_r) J (bordered by the constraint rows) of order ns is kept in
+// 64 x 64 tiles.  One Newton step is a fixed, host-independent sequence of launches on the caller's stream:
+//
+//   dn_gather    J and w = -1/d_r out of the caller's COO values (+ inertia of the residual pivots)
+//   dn_syrk      J' W J by v_mfma_f64_16x16x4_f64, lower tiles only, K split into slabs (fixed summation order)
+//   dn_assemble  S0 = slabs + H entries (COO order), S = S0 + rho slots
+//   per tile column k:  dn_panel (one wavefront factorises the diagonal tile, the others turn the tiles of the column
+//                       into L, as soon as the pivot rows are published in LDS)  +  dn_update (MFMA rank-64 update)
+//   dn_decide    inertia rule of /root/reference/src/solver_types.jl:90-97
+//   dn_ladder    rho ladder of /root/reference/src/CaNNOLeS.jl:1023-1047 for the problems that failed (one workgroup
+//                per problem walks the same device code; exits at once in the common case) — decided on the device
+//   solve        d = -K^-1 rhs by products with G = L^-T D^-1 (see below) and one step of iterative refinement
+//
+// The factorisation carries an identity block below S: the same panel / update steps turn it into G = L^-T D^-1
+// (upper triangular, tiles (I, J >= I)), so S^-1 = G D G' and both triangular solves become tile GEMVs that run on all
+// CUs instead of two latency-bound substitution sweeps.  L itself is only needed inside the step that produces it.
+// Nothing here synchronises with the host.
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <numeric>
 
 #include "dense.h"
 
@@ -12,140 +30,804 @@ namespace cnl {
 
 namespace {
 
-constexpr int NB = 16;  // panel width of the blocked factorisation (measured on MI355X, n = 1000, fused panel step: 8 -> 2.14 ms, 16 -> 1.79 ms, 32 -> 2.01 ms per system)
+constexpr int TS = 64;       // tile order
+constexpr int TT = TS * TS;  // doubles per tile
+typedef double d4 __attribute__((ext_vector_type(4)));
 
-#define DCHK(x)                                                                                 \
-  do {                                                                                          \
-    hipError_t e_ = (x);                                                                        \
-    if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return 4; }   \
-  } while (0)
-#define BCHK(x)                                                                                 \
-  do {                                                                                          \
-    rocblas_status s_ = (x);                                                                    \
-    if (s_ != rocblas_status_success) { err = std::string(#x) + ": rocBLAS status " + std::to_string((int)s_); return 4; } \
+#define DCHK(x)                                                                               \
+  do {                                                                                        \
+    hipError_t e_ = (x);                                                                      \
+    if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return 4; } \
   } while (0)
 
-// Jd(i, j) = vals[jslot], JW = diag(w) Jd with w_i = -1 / d_r(i); inertia of the residual pivots
-__global__ void __launch_bounds__(256) gather_kernel(const double* __restrict__ vals, const int* __restrict__ jslot,
-                                                     const int* __restrict__ dslot, int m, int n, double* __restrict__ Jd,
-                                                     double* __restrict__ JW, double* __restrict__ w) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long long)m * n) return;
-  const int i = (int)(t % m);
-  const double wi = -1.0 / vals[dslot[i]];
-  const double v = vals[jslot[t]];
-  Jd[t] = v;
-  JW[t] = wi * v;
-  if (t < m) w[i] = wi;
+struct DnState {  // per problem, device
+  double rho, rho_old, wrote;
+  int nfact, success, done, pad;
+};
+
+struct DnDev {
+  int ns, nv, T, nsp;        // order of the dense system, variables (they carry rho), tiles per side, 64 T
+  int n, m, p, mp, npj, Tn;  // residual-block form: variables, residual rows (0: general condensed system), constraints, padded sizes
+  int nnz;                   // COO entries per problem of the caller's vals
+  int ks, ntl, nlt;          // K splits of J'WJ, lower tiles of the variable block, lower tiles of S
+  int npos_ok;               // success <=> #positive pivots == npos_ok and no zero pivot
+  const int *jslot, *dslot;  // gather lists
+  const int *lI, *lJ;        // lower tiles of S: tile -> (I, J)
+  const int *ht_ptr, *hu_loc, *hu_ptr, *hslot;  // H entries per lower tile: unique positions, their COO entries in COO order
+  const int* gpos;           // general path: position i + ns j of every slot
+  int nslots;
+  double *Jd, *w, *slab, *S0, *S, *G, *Wn, *dv, *rsh, *y, *x, *jxp;  // Wn: [batch][T] tiles -L(J, k) d_k of the current column
+  double *part1, *part2, *partA, *partB;  // [batch][T * T][64] partial tile products of the solve (summed in a fixed order)
+  // J'WJ work partition: workgroup -> pieces, piece = (problem, lower tile, rows [ch0, ch1) in chunks of KT); pieces of a tile
+  const int *sy_wg, *sy_b, *sy_tl, *sy_ch0, *sy_ch1, *sy_tp;
+  int* cnt;                  // [batch][4]: dense pivots pos/zero, residual pivots pos/zero
+  DnState* st;
+};
+
+__device__ __forceinline__ size_t tile_off(int T, int I, int J) { return ((size_t)J * T + I) * TT; }
+
+__device__ __forceinline__ double recip(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  return fma(r, e, r);
 }
 
-__global__ void __launch_bounds__(256) rinertia_kernel(const double* __restrict__ vals, const int* __restrict__ dslot, int m,
-                                                       double eig_tol, int* cnt) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
-  const double dv = vals[dslot[i]];
-  if (dv > eig_tol) atomicAdd(&cnt[0], 1);
-  if (fabs(dv) <= eig_tol) atomicAdd(&cnt[1], 1);
-}
-
-__global__ void __launch_bounds__(256) hscatter_kernel(const double* __restrict__ vals, const int* __restrict__ hslot,
-                                                       const int* __restrict__ hpos, int nh, double* S0) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < nh) atomicAdd(&S0[hpos[e]], vals[hslot[e]]);
-}
-
-// S = S0 + diag(rho): rho from the slots of vals (first attempt, as given) or one value for all (ladder retries)
-__global__ void __launch_bounds__(256) shift_kernel(const double* __restrict__ S0, double* __restrict__ S, int n, int nv,
-                                                    const double* __restrict__ rho_slots, double rho, int use_slots) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long long)n * n) return;
-  const int i = (int)(t % n), j = (int)(t / n);
-  double v = S0[t];
-  if (i == j && i < nv) v += use_slots ? rho_slots[i] : rho;  // rho I on the variables only
-  S[t] = v;
-}
-
-// One panel step in ONE launch: every workgroup factorises the nb x nb diagonal block at (k0, k0) in LDS (unblocked
-// LDL^T, redundantly: 16 x 16 is cheaper than a launch), then serves 256 rows below it, thread per row:
-//   (l_ij d_j) = a_ij - sum_q (l_iq d_q) L11(j, q)  -> W21 (for the trailing GEMM),   l_ij -> S.
-// Workgroup 0 writes the factorised diagonal block back and counts its pivots.
-__global__ void __launch_bounds__(256) panel_l21_kernel(double* S, int n, int k0, int nb, double* __restrict__ W21, int n2,
-                                                        double eig_tol, int* cnt) {
-  __shared__ double a[NB][NB + 1];
-  __shared__ double dd[NB];
-  const int t = threadIdx.x;
-  for (int q = t; q < nb * nb; q += 256) { const int i = q % nb, j = q / nb; a[i][j] = S[(size_t)(k0 + i) + (size_t)n * (k0 + j)]; }
-  __syncthreads();
+// ---------------------------------------------------------------------------------------------------------------------
+// J(i, j) = vals[jslot], zero-padded to mp x npj; w_i = -1 / d_r(i); inertia of the residual pivots (solver_types.jl:90-95)
+__global__ void __launch_bounds__(256) dn_gather(DnDev D, const double* __restrict__ vals, double eig_tol) {
+  const int b = blockIdx.y;
+  const double* v = vals + (size_t)b * D.nnz;
+  double* Jd = D.Jd + (size_t)b * D.mp * D.npj;
+  double* w = D.w + (size_t)b * D.mp;
+  const long long tot = (long long)D.m * D.n;
   int np = 0, nz = 0;
-  for (int j = 0; j < nb; j++) {
-    const double dj = a[j][j];
-    if (t == 0) { np += dj > eig_tol; nz += fabs(dj) <= eig_tol; }
-    __syncthreads();
-    if (t > j && t < nb) a[t][j] = a[t][j] / dj;  // l_tj
-    __syncthreads();
-    // a(i, k) -= l_ij d_j l_kj for j < k <= i
-    for (int q = t; q < nb * nb; q += 256) {
-      const int i = q % nb, k = q / nb;
-      if (k > j && i >= k) a[i][k] -= a[i][j] * dj * a[k][j];
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < tot; t += (long long)gridDim.x * 256) {
+    const int i = (int)(t % D.m), j = (int)(t / D.m);
+    Jd[(size_t)i + (size_t)D.mp * j] = v[D.jslot[t]];
+    if (j == 0) {
+      const double dvv = v[D.dslot[i]];
+      w[i] = -1.0 / dvv;
+      np += dvv > eig_tol;
+      nz += fabs(dvv) <= eig_tol;
     }
-    __syncthreads();
   }
-  if (t < nb) dd[t] = a[t][t];
+  if (np) atomicAdd(&D.cnt[b * 4 + 2], np);
+  if (nz) atomicAdd(&D.cnt[b * 4 + 3], nz);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// slab[ks][tile (I, J)] = sum over the rows of split ks of  J(:, I)' diag(w) J(:, J)   (64 x 64, lower tiles I >= J).
+// C' = C^T is what the matrix core produces here (D'[c][r]): the 16 lanes that share a register then hold 16 consecutive
+// rows r of one column c, so the tile is written in 128-byte runs.  A operand: rows m of the J columns scaled by w,
+// B operand: the I columns; both staged through LDS 32 rows of J at a time as [column][row] with a stride of 34 doubles
+// (conflict-free for the 16 x 4 operand fetch).  4 waves, 32 x 32 of the tile each, 2 x 2 accumulators.
+constexpr int KT = 32, LDK = 34;
+__global__ void __launch_bounds__(256) dn_syrk(DnDev D) {
+  __shared__ double tA[64 * LDK], tB[64 * LDK];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, lg = lane >> 4;
+  const int col = t >> 2, part = t & 3;
+  const int cq = (wave >> 1) * 32, rq = (wave & 1) * 32;
+  // the (problem, tile, row chunk) space is cut into equal shares, one per workgroup (a share spans at most a few tiles):
+  // every CU gets the same number of matrix-core instructions, whatever the number of tiles
+  for (int pc = D.sy_wg[blockIdx.x]; pc < D.sy_wg[blockIdx.x + 1]; pc++) {
+    const int b = D.sy_b[pc], tl = D.sy_tl[pc], ch0 = D.sy_ch0[pc], ch1 = D.sy_ch1[pc];
+    int J = 0, rem = tl;  // lower tile of the variable block, column by column
+    while (rem >= D.Tn - J) { rem -= D.Tn - J; J++; }
+    const int I = J + rem;
+    const double* Jb = D.Jd + (size_t)b * D.mp * D.npj;
+    const double* wb = D.w + (size_t)b * D.mp;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) acc[a][c] = d4{0.0, 0.0, 0.0, 0.0};
+    const double* pa = Jb + (size_t)D.mp * (64 * J + col) + 8 * part;
+    const double* pb = Jb + (size_t)D.mp * (64 * I + col) + 8 * part;
+    double2 ra[4], rb[4], rw[4];
+#define DN_GLOAD(CH)                                                                  \
+  {                                                                                   \
+    const int m0_ = (CH) * KT;                                                        \
+    _Pragma("unroll") for (int q = 0; q < 4; q++) {                                   \
+      ra[q] = *reinterpret_cast<const double2*>(pa + m0_ + 2 * q);                    \
+      rb[q] = *reinterpret_cast<const double2*>(pb + m0_ + 2 * q);                    \
+      rw[q] = *reinterpret_cast<const double2*>(wb + m0_ + 8 * part + 2 * q);         \
+    }                                                                                 \
+  }
+    DN_GLOAD(ch0)
+    for (int ch = ch0; ch < ch1; ch++) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        *reinterpret_cast<double2*>(&tA[col * LDK + 8 * part + 2 * q]) = make_double2(ra[q].x * rw[q].x, ra[q].y * rw[q].y);
+        *reinterpret_cast<double2*>(&tB[col * LDK + 8 * part + 2 * q]) = rb[q];
+      }
+      __syncthreads();
+      if (ch + 1 < ch1) DN_GLOAD(ch + 1)
+#pragma unroll
+      for (int s = 0; s < KT / 4; s++) {
+        const double a0 = tA[(cq + li) * LDK + 4 * s + lg], a1 = tA[(cq + 16 + li) * LDK + 4 * s + lg];
+        const double b0 = tB[(rq + li) * LDK + 4 * s + lg], b1 = tB[(rq + 16 + li) * LDK + 4 * s + lg];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+#undef DN_GLOAD
+    double* out = D.slab + (size_t)pc * TT;
+#pragma unroll
+    for (int bc = 0; bc < 2; bc++)
+#pragma unroll
+      for (int br = 0; br < 2; br++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) out[(rq + 16 * br + li) + 64 * (cq + 16 * bc + lg + 4 * reg)] = acc[bc][br][reg];
+  }
+}
+
+// S = S0 + shift on the diagonal of one lower tile (pad rows: unit diagonal)
+__device__ __forceinline__ void shift_tile(const DnDev& D, const double* S0t, double* St, int I, int J, const double* rsh, int tid, int nthr) {
+  for (int e = tid; e < TT; e += nthr) {
+    double v = S0t[e];
+    if (I == J) {
+      const int r = e & 63, c = e >> 6;
+      if (r == c) { const int gi = 64 * I + r; v = gi < D.ns ? v + rsh[gi] : 1.0; }
+    }
+    St[e] = v;
+  }
+}
+
+// S0 = sum of the pieces of J'WJ (fixed order) + H entries in COO order; S = S0 + rho slots as given (first attempt)
+__global__ void __launch_bounds__(256) dn_assemble(DnDev D, const double* __restrict__ vals) {
+  __shared__ double tile[TT], sh64[64];
+  const int b = blockIdx.y, lt = blockIdx.x, t = threadIdx.x;
+  const int I = D.lI[lt], J = D.lJ[lt];
+  const double* v = vals + (size_t)b * D.nnz;
+  double* rsh = D.rsh + (size_t)b * D.nsp;
+  const bool has_slab = D.m > 0 && I < D.Tn;
+  const int tl = J * D.Tn - (J * (J - 1)) / 2 + (I - J);
+  int p0 = 0, p1 = 0;
+  if (has_slab) { p0 = D.sy_tp[b * D.ntl + tl]; p1 = D.sy_tp[b * D.ntl + tl + 1]; }
+  double2 s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) s2[q] = make_double2(0.0, 0.0);
+  for (int pc = p0; pc < p1; pc++) {
+    const double2* sp = reinterpret_cast<const double2*>(D.slab + (size_t)pc * TT) + t;
+    double2 g[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) g[q] = sp[256 * q];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { s2[q].x += g[q].x; s2[q].y += g[q].y; }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) reinterpret_cast<double2*>(tile)[t + 256 * q] = s2[q];
+  if (I == J && t < 64) {
+    const int gi = 64 * I + t;
+    const double sv = gi < D.nv ? v[D.nnz - D.nv + gi] : 0.0;
+    rsh[gi] = sv;
+    sh64[t] = sv;
+  }
   __syncthreads();
-  if (blockIdx.x == 0) {
-    for (int q = t; q < nb * nb; q += 256) { const int i = q % nb, j = q / nb; if (i >= j) S[(size_t)(k0 + i) + (size_t)n * (k0 + j)] = a[i][j]; }
-    if (t == 0) { if (np) atomicAdd(&cnt[0], np); if (nz) atomicAdd(&cnt[1], nz); }
+  for (int e = D.ht_ptr[lt] + t; e < D.ht_ptr[lt + 1]; e += 256) {
+    double s = tile[D.hu_loc[e]];
+    for (int q = D.hu_ptr[e]; q < D.hu_ptr[e + 1]; q++) s += v[D.hslot[q]];
+    tile[D.hu_loc[e]] = s;
   }
-  const int r = blockIdx.x * 256 + t;  // row of the trailing part
-  if (r >= n2) return;
-  double* row = S + (size_t)(k0 + nb + r) + (size_t)n * k0;  // entry (row, k0 + j) at row[j * n]
-  double wv[NB];
+  __syncthreads();
+  const size_t off = (size_t)b * D.T * D.T * TT + tile_off(D.T, I, J);
 #pragma unroll
-  for (int j = 0; j < NB; j++) {
-    if (j < nb) {
-      double v = row[(size_t)j * n];
+  for (int q = 0; q < 8; q++) reinterpret_cast<double2*>(D.S0 + off)[t + 256 * q] = reinterpret_cast<const double2*>(tile)[t + 256 * q];
+  shift_tile(D, tile, D.S + off, I, J, sh64 - 64 * I, t, 256);
+}
+
+// general condensed system: S0 from the slots of the condensed buffer (unique positions), rho slots behind them
+__global__ void __launch_bounds__(256) dn_scatter_general(DnDev D, const double* __restrict__ cbuf, long long cstride) {
+  const int b = blockIdx.y;
+  const double* cb = cbuf + (size_t)b * cstride;
+  double* S0 = D.S0 + (size_t)b * D.T * D.T * TT;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < D.nslots; e += gridDim.x * 256) {
+    const int pos = D.gpos[e], i = pos % D.ns, j = pos / D.ns;
+    S0[tile_off(D.T, i >> 6, j >> 6) + (i & 63) + 64 * (j & 63)] = cb[e];
+  }
+  double* rsh = D.rsh + (size_t)b * D.nsp;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < D.nsp; i += gridDim.x * 256) rsh[i] = i < D.nv ? cb[D.nslots + i] : 0.0;
+}
+__global__ void __launch_bounds__(256) dn_shift(DnDev D) {
+  const int b = blockIdx.y, lt = blockIdx.x;
+  const int I = D.lI[lt], J = D.lJ[lt];
+  const size_t off = (size_t)b * D.T * D.T * TT + tile_off(D.T, I, J);
+  shift_tile(D, D.S0 + off, D.S + off, I, J, D.rsh + (size_t)b * D.nsp, threadIdx.x, 256);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Panel step.  Row-per-lane: lane r holds row r of a 64 x 64 tile in registers.  The wave that owns the diagonal tile
+// publishes, per pivot j, the column below the pivot BEFORE it is divided (w_r = a_r[j], one value per lane) in LDS row j
+// and the reciprocal pivot; every row x of the tile column then becomes  l = x[j] / d_j,  x[c] -= l w_c (c > j).
+// The next pivot's column is updated and published first, the rest of the rank-1 update runs while that LDS round
+// trip is in flight.  The other waves consume the published rows eight pivots at a time.
+struct PanelLds {
+  double W[TS * TS];
+  double inv[TS + 8];  // [TS ..]: dump slots, so that "lane 0 stores" needs no branch
+  int pub[12];         // [0]: pivots published; [1 ..]: dump slots
+};
+#define DN_PIN(v) asm volatile("" : "+v"(v))  // the value is computed here, not sunk to its next use
+
+__device__ __forceinline__ void lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The rank-1 update x[c] -= l w_c needs a wave-uniform w_c per instruction.  Fetching it from LDS costs one LDS read per
+// two updates and the LDS latency limits the wave to ~28 cycles per update.  Instead the published column is read ONCE
+// per pivot as four registers (lane i of every 16-lane row holds w[16 k + i]) and each update takes its operand through
+// the DPP row broadcast of the fp64 FMA:  x[c] += W_{c / 16}[row_newbcast: c % 16] * (-l)  — one 8-cycle instruction, no
+// LDS traffic.  (hipcc does not pad hazards inside asm: the DPP source comes from an LDS read, not from a VALU write.)
+#define DN_FMAC_BCAST(X, WK, NL, I) \
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #I " row_mask:0xf bank_mask:0xf" : "+v"(X) : "v"(WK), "v"(NL))
+template <int C>
+__device__ __forceinline__ void fmac_bcast(double& x, const double (&W)[4], double nl) {
+  constexpr int K = C >> 4, I = C & 15;
+  if constexpr (I == 0) DN_FMAC_BCAST(x, W[K], nl, 0);
+  else if constexpr (I == 1) DN_FMAC_BCAST(x, W[K], nl, 1);
+  else if constexpr (I == 2) DN_FMAC_BCAST(x, W[K], nl, 2);
+  else if constexpr (I == 3) DN_FMAC_BCAST(x, W[K], nl, 3);
+  else if constexpr (I == 4) DN_FMAC_BCAST(x, W[K], nl, 4);
+  else if constexpr (I == 5) DN_FMAC_BCAST(x, W[K], nl, 5);
+  else if constexpr (I == 6) DN_FMAC_BCAST(x, W[K], nl, 6);
+  else if constexpr (I == 7) DN_FMAC_BCAST(x, W[K], nl, 7);
+  else if constexpr (I == 8) DN_FMAC_BCAST(x, W[K], nl, 8);
+  else if constexpr (I == 9) DN_FMAC_BCAST(x, W[K], nl, 9);
+  else if constexpr (I == 10) DN_FMAC_BCAST(x, W[K], nl, 10);
+  else if constexpr (I == 11) DN_FMAC_BCAST(x, W[K], nl, 11);
+  else if constexpr (I == 12) DN_FMAC_BCAST(x, W[K], nl, 12);
+  else if constexpr (I == 13) DN_FMAC_BCAST(x, W[K], nl, 13);
+  else if constexpr (I == 14) DN_FMAC_BCAST(x, W[K], nl, 14);
+  else DN_FMAC_BCAST(x, W[K], nl, 15);
+}
+// x[c] += W[c] * nl for c = C0 .. 63
+template <int C0>
+__device__ __forceinline__ void bulk_from(double (&x)[TS], const double (&W)[4], double nl) {
+  if constexpr (C0 < TS) {
+    fmac_bcast<C0>(x[C0], W, nl);
+    bulk_from<C0 + 1>(x, W, nl);
+  }
+}
+// registers k >= K0 of row j of the published columns: lane i of every row of 16 lanes takes w[16 k + i]
+template <int K0>
+__device__ __forceinline__ void load_wrow(const PanelLds& P, int j, int li, double (&W)[4]) {
 #pragma unroll
-      for (int q = 0; q < j; q++) v -= wv[q] * a[j][q];
-      wv[j] = v;
-      W21[(size_t)r + (size_t)n2 * j] = v;
-      row[(size_t)j * n] = v / dd[j];
+  for (int k = 0; k < 4; k++)
+    if (k >= K0) W[k] = P.W[j * 64 + 16 * k + li];
+}
+
+// returns the pivot counts through np / nz (same value in every lane); the pivots stay in P.W[j][j].
+// Software pipeline: the region of pivot J holds the CHAIN of pivot J + 1 (publish its column, read the pivot back,
+// reciprocal, multiplier) next to the BULK of pivot J (the other 62 - J updates), so the 32-cycle dependent-issue gaps
+// of the fp64 chain are filled with independent updates.
+template <int J>
+__device__ __forceinline__ void diag_step(PanelLds& P, double (&a)[TS], double& l, double& rinv, double& d, double (&W)[4], int lane,
+                                          int nreal, double eig_tol, int& np, int& nz) {
+  // here: l = multiplier of pivot J (a[J] / d_J), rinv ~ 1 / d_J, d = d_J, W = row J of the published columns
+  if (J < nreal) { np += d > eig_tol; nz += fabs(d) <= eig_tol; }
+  const double nl = -l;
+  double ln = 0.0, rn = 0.0, dn = 0.0;
+  double Wn[4] = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (J + 1 < TS) {
+    fmac_bcast<J + 1>(a[J + 1], W, nl);
+    P.W[(J + 1) * 64 + lane] = a[J + 1];
+  }
+  // the reciprocal the other waves use is refined off the critical chain
+  {
+    const double e = fma(-d, rinv, 1.0);
+    const double r2 = fma(rinv, e, rinv);
+    P.inv[lane == 0 ? J : TS + (lane & 7)] = r2;  // branch-free "lane 0 stores": no control flow inside the pipeline
+  }
+  // LDS executes one wave's operations in order: the counter becomes visible after the column and the reciprocal
+  // without waiting for them here (a release store would stall the chain for an LDS round trip)
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(&P.pub[lane == 0 ? 0 : 1 + (lane & 7)], J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  if constexpr (J + 1 < TS) {
+    dn = P.W[(J + 1) * 64 + J + 1];
+    load_wrow<((J + 2) >> 4)>(P, J + 1, lane & 15, Wn);
+    // multiplier through the raw reciprocal (2^-25 on gfx950) and one residual correction: error ~ 2^-50, four dependent
+    // operations on the chain instead of six
+    const double r0 = __builtin_amdgcn_rcp(dn);
+    const double l0 = a[J + 1] * r0;
+    const double res = fma(-dn, l0, a[J + 1]);
+    ln = fma(res, r0, l0);
+    const double e0 = fma(-dn, r0, 1.0);
+    rn = fma(r0, e0, r0);
+  }
+  bulk_from<J + 2>(a, W, nl);
+  DN_PIN(ln);
+  __builtin_amdgcn_sched_barrier(0);
+  l = ln; rinv = rn; d = dn;
+#pragma unroll
+  for (int k = 0; k < 4; k++) W[k] = Wn[k];
+  if constexpr (J + 1 < TS) diag_step<J + 1>(P, a, l, rinv, d, W, lane, nreal, eig_tol, np, nz);
+}
+__device__ void panel_diag(PanelLds& P, const double* __restrict__ tile, int nreal, double eig_tol, int& np_out, int& nz_out) {
+  const int lane = threadIdx.x & 63;
+  double a[TS];
+#pragma unroll
+  for (int c = 0; c < TS; c++) a[c] = tile[lane + 64 * c];
+  P.W[lane] = a[0];
+  int np = 0, nz = 0;
+  double W[4];
+  double d = P.W[0];
+  load_wrow<0>(P, 0, lane & 15, W);
+  double rinv = recip(d);
+  double l = a[0] * rinv;
+  diag_step<0>(P, a, l, rinv, d, W, lane, nreal, eig_tol, np, nz);
+  np_out = np; nz_out = nz;
+}
+
+// one 64-row tile of the column: in = tile (or the identity when `ident`), out = L form
+template <int J>
+__device__ __forceinline__ void rows_step(PanelLds& P, double (&x)[TS], double (&W)[4], int li, double* __restrict__ wout, int lane) {
+  if constexpr (J % 8 == 0) {  // eight pivots per wait on the publisher
+    while (__hip_atomic_load(&P.pub[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < J + 8) __builtin_amdgcn_s_sleep(1);
+    load_wrow<((J + 1) >> 4)>(P, J, li, W);
+  }
+  if (wout) wout[lane + 64 * J] = -x[J];  // -l d: the B operand of this column's trailing update (wave-uniform branch)
+  const double l = x[J] * P.inv[J];
+  x[J] = l;
+  const double nl = -l;
+  double Wn[4] = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (J % 8 != 7 && J + 1 < TS) load_wrow<((J + 2) >> 4)>(P, J + 1, li, Wn);
+  bulk_from<J + 1>(x, W, nl);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (J % 8 != 7) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) W[k] = Wn[k];
+  }
+  if constexpr (J + 1 < TS) rows_step<J + 1>(P, x, W, li, wout, lane);
+}
+__device__ void panel_rows(PanelLds& P, const double* __restrict__ in, double* __restrict__ out, double* __restrict__ wout, bool ident) {
+  const int lane = threadIdx.x & 63;
+  double x[TS];
+  if (ident) {
+#pragma unroll
+    for (int c = 0; c < TS; c++) x[c] = c == lane ? 1.0 : 0.0;
+  } else {
+#pragma unroll
+    for (int c = 0; c < TS; c++) x[c] = in[lane + 64 * c];
+  }
+  double W[4] = {0.0, 0.0, 0.0, 0.0};
+  rows_step<0>(P, x, W, lane & 15, wout, lane);
+#pragma unroll
+  for (int c = 0; c < TS; c++) out[lane + 64 * c] = x[c];
+}
+
+// row tile rt of tile column k: the T - 1 - k tiles below the diagonal of S first, then the k + 1 tiles of the G block
+__device__ __forceinline__ void row_tile_ptrs(const DnDev& D, int b, int k, int rt, const double*& in, double*& out, double*& wout, bool& ident) {
+  const size_t pb = (size_t)b * D.T * D.T * TT;
+  const int ntop = D.T - 1 - k;
+  if (rt < ntop) {
+    double* p = D.S + pb + tile_off(D.T, k + 1 + rt, k);
+    in = p; out = p; ident = false;
+    wout = D.Wn + ((size_t)b * D.T + (k + 1 + rt)) * TT;
+  } else {
+    const int I = rt - ntop;
+    double* p = D.G + pb + tile_off(D.T, I, k);
+    in = p; out = p; ident = I == k;
+    wout = nullptr;
+  }
+}
+
+__global__ void __launch_bounds__(256) dn_panel(DnDev D, int k, double eig_tol) {
+  __shared__ PanelLds P;
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef DN_STAMPS
+  const long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+  if (threadIdx.x == 0) P.pub[0] = 0;
+  __syncthreads();
+  if (wave == 0) {
+    int np, nz;
+    panel_diag(P, D.S + (size_t)b * D.T * D.T * TT + tile_off(D.T, k, k), min(64, D.ns - 64 * k), eig_tol, np, nz);
+#ifdef DN_STAMPS
+    if (lane == 0 && blockIdx.x == 0) { long long* sp = reinterpret_cast<long long*>(D.jxp); sp[k * 4 + 0] = __builtin_amdgcn_s_memtime() - st0; }
+#endif
+    if (blockIdx.x == 0) {
+      lds_fence();
+      D.dv[(size_t)b * D.nsp + 64 * k + lane] = P.W[lane * 64 + lane];
+      if (lane == 0) {
+        if (np) atomicAdd(&D.cnt[b * 4 + 0], np);
+        if (nz) atomicAdd(&D.cnt[b * 4 + 1], nz);
+      }
+    }
+  } else {
+    const int rt = blockIdx.x * 3 + wave - 1;
+    if (rt < D.T) {
+      const double* in; double* out; double* wout; bool ident;
+      row_tile_ptrs(D, b, k, rt, in, out, wout, ident);
+      panel_rows(P, in, out, wout, ident);
+#ifdef DN_STAMPS
+      if (lane == 0 && blockIdx.x == 0) { long long* sp = reinterpret_cast<long long*>(D.jxp); sp[k * 4 + wave] = __builtin_amdgcn_s_memtime() - st0; }
+#endif
     }
   }
 }
 
-__global__ void __launch_bounds__(256) scale_by_diag_kernel(double* __restrict__ y, const double* __restrict__ S, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) y[i] = y[i] / S[(size_t)i + (size_t)n * i];
+// ---------------------------------------------------------------------------------------------------------------------
+// C(I, J) -= L(I, k) diag(d) L(J, k)'  (tiles of S, or of the G block with G(I, k) in place of L(I, k)): rank-64 update of
+// one tile on the fp64 matrix cores.  The core produces C' (see dn_syrk); its A operand is the tile -L(J, k) d that the
+// panel step left in Wn, its B operand the L form of the row tile.  One wave per 16 x 16 block: it loads its 16 + 16
+// operand fragments (one fp64 per lane each) straight from L2 in the operand layout, all loads in flight at once, then
+// runs the 16 dependent matrix instructions — no LDS staging, no barriers (the kernel is latency-bound: a whole step has
+// fewer tiles than the chip has CUs).
+__device__ __forceinline__ void update_block(const double* __restrict__ At, const double* __restrict__ Wt, double* __restrict__ Ct, bool czero,
+                                             int blk, int lane) {
+  const int li = lane & 15, lg = lane >> 4, bc = blk >> 2, br = blk & 3;
+  double aop[16], bop[16];
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    aop[s] = Wt[(16 * bc + li) + 64 * (4 * s + lg)];
+    bop[s] = At[(16 * br + li) + 64 * (4 * s + lg)];
+  }
+  d4 acc;
+#pragma unroll
+  for (int reg = 0; reg < 4; reg++) acc[reg] = czero ? 0.0 : Ct[(16 * br + li) + 64 * (16 * bc + lg + 4 * reg)];
+#pragma unroll
+  for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s], bop[s], acc, 0, 0, 0);
+#pragma unroll
+  for (int reg = 0; reg < 4; reg++) Ct[(16 * br + li) + 64 * (16 * bc + lg + 4 * reg)] = acc[reg];
 }
 
-__global__ void __launch_bounds__(256) mul_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = a[i] * b[i];
+// trailing tile idx of step k: lower tiles (I >= J > k) of S first, then the tiles (I <= k, J > k) of the G block
+__device__ __forceinline__ void trailing_tile(const DnDev& D, int b, int k, int idx, const double*& At, const double*& Bt, double*& Ct, bool& czero) {
+  const size_t pb = (size_t)b * D.T * D.T * TT;
+  const int nt = D.T - 1 - k, ntop = nt * (nt + 1) / 2;
+  int I, J;
+  if (idx < ntop) {
+    int c = 0, rem = idx;
+    while (rem >= nt - c) { rem -= nt - c; c++; }
+    J = k + 1 + c; I = J + rem;
+    At = D.S + pb + tile_off(D.T, I, k);
+    Ct = D.S + pb + tile_off(D.T, I, J);
+    czero = false;
+  } else {
+    const int q = idx - ntop;
+    I = q / nt; J = k + 1 + q % nt;
+    At = D.G + pb + tile_off(D.T, I, k);
+    Ct = D.G + pb + tile_off(D.T, I, J);
+    czero = I == k;  // first touch of this tile of the G block
+  }
+  Bt = D.Wn + ((size_t)b * D.T + J) * TT;
 }
 
-__global__ void __launch_bounds__(256) out_kernel(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ w,
-                                                  double* __restrict__ d, int n, int m, int p) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) d[i] = -x[i];
-  else if (i < n + m) d[i] = w[i - n] * u[i - n];  // d_r = -(rhs_r - J x) / d_r
-  else if (i < n + m + p) d[i] = -x[n + (i - n - m)];  // multipliers: the last p unknowns of the dense system
+// one workgroup = one 32 x 32 quadrant of a trailing tile (4 waves, a 16 x 16 block each)
+__global__ void __launch_bounds__(256) dn_update(DnDev D, int k) {
+  const int b = blockIdx.y;
+  const double *At, *Bt; double* Ct; bool czero;
+  trailing_tile(D, b, k, blockIdx.x >> 2, At, Bt, Ct, czero);
+  const int q = blockIdx.x & 3, wave = threadIdx.x >> 6;
+  const int blk = ((q >> 1) * 2 + (wave >> 1)) * 4 + (q & 1) * 2 + (wave & 1);
+  update_block(At, Bt, Ct, czero, blk, threadIdx.x & 63);
 }
 
-__global__ void __launch_bounds__(256) fill_kernel(double* p, double v, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = v;
+// ---------------------------------------------------------------------------------------------------------------------
+// inertia rule + first rung of the ladder state.  mode 0: newton, 1: factorize
+__global__ void __launch_bounds__(256) dn_decide(DnDev D, int batch, int mode, const double* __restrict__ rho_old, int32_t* success,
+                                                 int64_t* npos, int64_t* nzero) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= batch) return;
+  const int tp = D.cnt[b * 4 + 0] + D.cnt[b * 4 + 2], tz = D.cnt[b * 4 + 1] + D.cnt[b * 4 + 3];
+  const bool ok = tp == D.npos_ok && tz == 0;
+  D.cnt[b * 4 + 0] = 0; D.cnt[b * 4 + 1] = 0; D.cnt[b * 4 + 2] = 0; D.cnt[b * 4 + 3] = 0;  // clean for the next call
+  DnState s;
+  s.rho = 0.0; s.wrote = 0.0; s.rho_old = rho_old ? rho_old[b] : 0.0;
+  s.nfact = 1; s.success = ok ? 1 : 0; s.done = (ok || mode == 1) ? 1 : 0; s.pad = 0;
+  D.st[b] = s;
+  if (mode == 1) {
+    success[b] = ok ? 1 : 0;
+    if (npos) npos[b] = tp;
+    if (nzero) nzero[b] = tz;
+  }
 }
 
-// general condensed system: S0(pos[s]) = slot s (positions are unique)
-__global__ void __launch_bounds__(256) slot_scatter_kernel(const double* __restrict__ slots, const int* __restrict__ pos, int nslots,
-                                                           double* __restrict__ S0) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < nslots) S0[pos[e]] = slots[e];
+// rho ladder for the problems whose first factorisation failed: one workgroup per problem repeats the factorisation with
+// S = S0 + rho I (src/CaNNOLeS.jl:1029-1047).  Same device code as the per-step kernels, walked tile by tile.
+constexpr int LNW = 8;
+__global__ void __launch_bounds__(LNW * 64) dn_ladder(DnDev D, double* vals, const double* __restrict__ rho_old_in, double eig_tol, double kdec,
+                                                      double kinc, double klarge, double rho0, double rhomax, double rhomin) {
+  __shared__ PanelLds P;
+  __shared__ int scnt[2];
+  __shared__ int s_first[3];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // inertia rule on the first factorisation (src/solver_types.jl:90-97); the counters are left clean for the next call
+  if (tid == 0) {
+    const int c0 = D.cnt[b * 4 + 0], c1 = D.cnt[b * 4 + 1], c2 = D.cnt[b * 4 + 2], c3 = D.cnt[b * 4 + 3];
+    s_first[0] = (c0 + c2 == D.npos_ok && c1 + c3 == 0) ? 1 : 0; s_first[1] = c2; s_first[2] = c3;
+    D.cnt[b * 4 + 0] = 0; D.cnt[b * 4 + 1] = 0; D.cnt[b * 4 + 2] = 0; D.cnt[b * 4 + 3] = 0;
+  }
+  __syncthreads();
+  DnState s;
+  s.rho = 0.0; s.wrote = 0.0; s.rho_old = rho_old_in[b]; s.nfact = 1; s.success = 1; s.done = 1; s.pad = 0;
+  if (s_first[0]) {
+    if (tid == 0) D.st[b] = s;
+    return;
+  }
+  const size_t pb = (size_t)b * D.T * D.T * TT;
+  double* rsh = D.rsh + (size_t)b * D.nsp;
+  const int rp = s_first[1], rz = s_first[2];
+  double rho = s.rho_old == 0.0 ? rho0 : fmax(rhomin, kdec * s.rho_old);
+  double wrote = rho;
+  int nfact = 1;
+  bool success = false;
+  while (true) {
+    // ---- one attempt at `rho`
+    for (int i = tid; i < D.nsp; i += LNW * 64) rsh[i] = i < D.nv ? rho : 0.0;
+    if (tid == 0) { scnt[0] = 0; scnt[1] = 0; }
+    __threadfence();
+    __syncthreads();
+    for (int lt = 0; lt < D.nlt; lt++) {
+      const int I = D.lI[lt], J = D.lJ[lt];
+      const size_t off = pb + tile_off(D.T, I, J);
+      shift_tile(D, D.S0 + off, D.S + off, I, J, rsh, tid, LNW * 64);
+    }
+    __threadfence();
+    __syncthreads();
+    for (int k = 0; k < D.T; k++) {
+      if (tid == 0) P.pub[0] = 0;
+      __syncthreads();
+      for (int pass = 0; pass * (LNW - 1) < D.T; pass++) {
+        if (wave == 0) {
+          if (pass == 0) {
+            int np, nz;
+            panel_diag(P, D.S + pb + tile_off(D.T, k, k), min(64, D.ns - 64 * k), eig_tol, np, nz);
+            lds_fence();
+            D.dv[(size_t)b * D.nsp + 64 * k + lane] = P.W[lane * 64 + lane];
+            if (lane == 0) { scnt[0] += np; scnt[1] += nz; }
+          }
+        } else {
+          const int rt = pass * (LNW - 1) + wave - 1;
+          if (rt < D.T) {
+            const double* in; double* out; double* wout; bool ident;
+            row_tile_ptrs(D, b, k, rt, in, out, wout, ident);
+            panel_rows(P, in, out, wout, ident);
+          }
+        }
+      }
+      __threadfence();
+      __syncthreads();
+      const int nt = D.T - 1 - k, ntr = nt * (nt + 1) / 2 + (k + 1) * nt;
+      for (int idx = 0; idx < ntr; idx++) {
+        const double *At, *Bt; double* Ct; bool czero;
+        trailing_tile(D, b, k, idx, At, Bt, Ct, czero);
+        update_block(At, Bt, Ct, czero, 2 * wave, lane);
+        update_block(At, Bt, Ct, czero, 2 * wave + 1, lane);
+      }
+      __threadfence();
+      __syncthreads();
+    }
+    nfact++;
+    success = scnt[0] + rp == D.npos_ok && scnt[1] + rz == 0;
+    __syncthreads();
+    if (success || rho > rhomax) break;
+    rho = s.rho_old == 0.0 ? klarge * rho : kinc * rho;
+    if (rho > rhomax) break;
+    wrote = rho;
+  }
+  if (rho <= rhomax) s.rho_old = rho;
+  s.rho = rho; s.wrote = wrote; s.nfact = nfact; s.success = success ? 1 : 0; s.done = 1;
+  if (tid == 0) D.st[b] = s;
+  double* vt = vals + (size_t)b * D.nnz + (D.nnz - D.nv);
+  for (int i = tid; i < D.nv; i += LNW * 64) vt[i] = wrote;
 }
 
-__global__ void __launch_bounds__(256) neg_kernel(const double* __restrict__ y, double* __restrict__ out, int n) {
+// ---------------------------------------------------------------------------------------------------------------------
+// solve: y = [rhs_x - J' (rhs_r / d_r); rhs_c]  ->  x = G D G' y  (+ one refinement step with S)  ->  d
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wave per variable column: y_c = rhs_x[c] + sum_i J(i, c) w_i rhs_r[i]; the constraint part and the pad behind it.
+// t = w .* rhs_r is staged in LDS once per workgroup (2048 rows at a time), the column of J streams through 16-byte loads.
+__global__ void __launch_bounds__(256) dn_yrhs(DnDev D, const double* __restrict__ rhs, int gate) {
+  __shared__ double ts[2048];
+  const int b = blockIdx.y;
+  if (gate && !D.st[b].success) return;
+  const int N = D.n + D.m + D.p;
+  const double* rb = rhs + (size_t)b * N;
+  double* y = D.y + (size_t)b * D.nsp;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const double* w = D.w + (size_t)b * D.mp;
+  const double* Jc = D.Jd + (size_t)b * D.mp * D.npj + (size_t)D.mp * min(c, D.npj - 1);
+  double s = 0.0;
+  for (int i0 = 0; i0 < D.mp; i0 += 2048) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256) { const int gi = i0 + i; ts[i] = gi < D.m ? w[gi] * rb[D.n + gi] : 0.0; }
+    __syncthreads();
+    const int lim = min(2048, D.mp - i0);  // mp is a multiple of 64
+#pragma unroll 4
+    for (int i = 2 * lane; i < lim; i += 128) {
+      const double2 j2 = *reinterpret_cast<const double2*>(Jc + i0 + i);
+      s = fma(j2.x, ts[i], s);
+      s = fma(j2.y, ts[i + 1], s);
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (c < D.n) y[c] = rb[c] + s;
+    else if (c < D.nsp) y[c] = c < D.ns ? rb[D.n + D.m + (c - D.n)] : 0.0;
+  }
+}
+__global__ void __launch_bounds__(256) dn_yrhs_general(DnDev D, const double* __restrict__ cbuf, long long cstride, int gate) {
+  const int b = blockIdx.y;
+  if (gate && !D.st[b].success) return;
+  const double* crhs = cbuf + (size_t)b * cstride + D.nslots + D.nv;
+  double* y = D.y + (size_t)b * D.nsp;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < D.nsp; i += gridDim.x * 256) y[i] = i < D.ns ? crhs[i] : 0.0;
+}
+
+// ---- tile GEMVs of the solve.  Every tile of G (upper, J >= I) resp. S (lower) is one workgroup; a tile product is 64
+// partial sums, and the vector a later kernel needs is summed from the partials in a fixed order by the workgroup that
+// needs it (a few KB), so the results are deterministic and no reduction launches are needed.
+__device__ __forceinline__ size_t part_off(const DnDev& D, int b, int I, int J) { return (((size_t)b * D.T + J) * D.T + I) * 64; }
+
+// row sums out[r] = sum_c tile[r + 64 c] v[c] over the columns with mask(r, c); 256 threads, v in LDS, red = [4][64] LDS
+template <class M>
+__device__ __forceinline__ void tile_rowsum(const double* __restrict__ tile, const double* v, double (*red)[64], double* __restrict__ out, M mask) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double tv[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) tv[q] = tile[lane + 64 * (16 * wave + q)];
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) if (mask(lane, 16 * wave + q)) acc = fma(tv[q], v[16 * wave + q], acc);
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) out[lane] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  __syncthreads();
+}
+// column sums out[c] = sum_r tile[r + 64 c] v[r] over the rows with mask(r, c)
+template <class M>
+__device__ __forceinline__ void tile_colsum(const double* __restrict__ tile, const double* v, double* __restrict__ out, M mask) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double tv[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) tv[q] = tile[lane + 64 * (16 * wave + q)];
+  const double vr = v[lane];
+  double mine = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const double s = wave_sum(mask(lane, 16 * wave + q) ? tv[q] * vr : 0.0);
+    if (lane == q) mine = s;
+  }
+  if (lane < 16) out[16 * wave + lane] = mine;
+}
+struct MaskAll { __device__ bool operator()(int, int) const { return true; } };
+struct MaskLowerEq { __device__ bool operator()(int r, int c) const { return c <= r; } };
+struct MaskStrictLower { __device__ bool operator()(int r, int c) const { return r > c; } };
+
+// residual of the first solve, block I, entry i:  y - shift x - (S x)  from the partial products of dn_resid_part
+__device__ __forceinline__ double resid_entry(const DnDev& D, int b, int I, int i) {
+  const int gi = 64 * I + i;
+  const size_t vb = (size_t)b * D.nsp;
+  const double sh = gi < D.ns ? D.rsh[vb + gi] : 1.0;
+  double s = sh * D.x[vb + gi];
+  for (int J = 0; J <= I; J++) s += D.partA[part_off(D, b, I, J) + i];
+  for (int K = I; K < D.T; K++) s += D.partB[part_off(D, b, K, I) + i];
+  return D.y[vb + gi] - s;
+}
+
+// part1(I, J) = G(I, J)' v_I for the upper tiles; v = y (pass 0) or the residual of the first solve (pass 1)
+__global__ void __launch_bounds__(256) dn_gt_part(DnDev D, int pass, int gate) {
+  __shared__ double vs[64];
+  const int b = blockIdx.y, I = D.lJ[blockIdx.x], J = D.lI[blockIdx.x];  // lower-tile list read transposed: J >= I
+  if (gate && !D.st[b].success) return;
+  if (threadIdx.x < 64) vs[threadIdx.x] = pass == 0 ? D.y[(size_t)b * D.nsp + 64 * I + threadIdx.x] : resid_entry(D, b, I, threadIdx.x);
+  __syncthreads();
+  tile_colsum(D.G + (size_t)b * D.T * D.T * TT + tile_off(D.T, I, J), vs, D.part1 + part_off(D, b, I, J), MaskAll());
+}
+
+// part2(I, J) = G(I, J) u_J with u_J = dv_J .* sum_{I' <= J} part1(I', J)
+__global__ void __launch_bounds__(256) dn_g_part(DnDev D, int gate) {
+  __shared__ double us[64], red[4][64];
+  const int b = blockIdx.y, I = D.lJ[blockIdx.x], J = D.lI[blockIdx.x];
+  if (gate && !D.st[b].success) return;
+  if (threadIdx.x < 64) {
+    double s = 0.0;
+    for (int Ip = 0; Ip <= J; Ip++) s += D.part1[part_off(D, b, Ip, J) + threadIdx.x];
+    us[threadIdx.x] = D.dv[(size_t)b * D.nsp + 64 * J + threadIdx.x] * s;
+  }
+  __syncthreads();
+  tile_rowsum(D.G + (size_t)b * D.T * D.T * TT + tile_off(D.T, I, J), us, red, D.part2 + part_off(D, b, I, J), MaskAll());
+}
+
+// x = sum of part2 (first solve); partA(I, J) = S(I, J) x_J, partB(I, J) = S(I, J)' x_I over the lower tiles of S0
+// (the diagonal tiles hold the lower triangle: A takes c <= r, B the strictly lower part transposed)
+__global__ void __launch_bounds__(256) dn_resid_part(DnDev D, int gate) {
+  __shared__ double xJ[64], xI[64], red[4][64];
+  const int b = blockIdx.y, I = D.lI[blockIdx.x], J = D.lJ[blockIdx.x];
+  if (gate && !D.st[b].success) return;
+  if (threadIdx.x < 128) {
+    const int B0 = threadIdx.x < 64 ? J : I, i = threadIdx.x & 63;
+    double s = 0.0;
+    for (int Jp = B0; Jp < D.T; Jp++) s += D.part2[part_off(D, b, B0, Jp) + i];
+    (threadIdx.x < 64 ? xJ : xI)[i] = s;
+    if (I == J && threadIdx.x < 64) D.x[(size_t)b * D.nsp + 64 * I + i] = s;
+  }
+  __syncthreads();
+  const double* tile = D.S0 + (size_t)b * D.T * D.T * TT + tile_off(D.T, I, J);
+  if (I == J) {
+    tile_rowsum(tile, xJ, red, D.partA + part_off(D, b, I, J), MaskLowerEq());
+    tile_colsum(tile, xI, D.partB + part_off(D, b, I, J), MaskStrictLower());
+  } else {
+    tile_rowsum(tile, xJ, red, D.partA + part_off(D, b, I, J), MaskAll());
+    tile_colsum(tile, xI, D.partB + part_off(D, b, I, J), MaskAll());
+  }
+}
+
+// x += correction of the refinement step (sum of its part2)
+__global__ void __launch_bounds__(64) dn_xfinal(DnDev D, int gate) {
+  const int b = blockIdx.y, I = blockIdx.x, i = threadIdx.x;
+  if (gate && !D.st[b].success) return;
+  double s = D.x[(size_t)b * D.nsp + 64 * I + i];
+  for (int Jp = I; Jp < D.T; Jp++) s += D.part2[part_off(D, b, I, Jp) + i];
+  D.x[(size_t)b * D.nsp + 64 * I + i] = s;
+}
+
+// partial products of J x: rows in blocks of 256, columns in chunks of 32
+__global__ void __launch_bounds__(256) dn_jx(DnDev D, int gate) {
+  const int b = blockIdx.z;
+  if (gate && !D.st[b].success) return;
+  const int i = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+  const double* Jb = D.Jd + (size_t)b * D.mp * D.npj;
+  const double* x = D.x + (size_t)b * D.nsp;
+  double acc = 0.0;
+  if (i < D.mp) {
+#pragma unroll 8
+    for (int c = 32 * ch; c < 32 * ch + 32; c++) acc = fma(Jb[(size_t)i + (size_t)D.mp * c], x[c], acc);
+    D.jxp[((size_t)b * (D.npj / 32) + ch) * D.mp + i] = acc;
+  }
+}
+
+// d = [-x; -(rhs_r - J x) / d_r; -x_c] and the scalars of newton_system!'s return tuple
+__global__ void __launch_bounds__(256) dn_out(DnDev D, const double* __restrict__ rhs, double* __restrict__ d, int mode, double* rho_old,
+                                              double* rho, int32_t* nfact, int32_t* success) {
+  const int b = blockIdx.y;
+  const DnState s = D.st[b];
+  if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    rho[b] = s.rho; rho_old[b] = s.rho_old; nfact[b] = s.nfact; success[b] = s.success;
+  }
+  if (mode == 0 && !s.success) return;
+  const int N = D.n + D.m + D.p;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = -y[i];
+  if (i >= N) return;
+  const double* x = D.x + (size_t)b * D.nsp;
+  double* db = d + (size_t)b * N;
+  if (i < D.n) db[i] = -x[i];
+  else if (i < D.n + D.m) {
+    const int q = i - D.n;
+    double jx = 0.0;
+#pragma unroll 8
+    for (int ch = 0; ch < D.npj / 32; ch++) jx += D.jxp[((size_t)b * (D.npj / 32) + ch) * D.mp + q];
+    db[i] = D.w[(size_t)b * D.mp + q] * (rhs[(size_t)b * N + i] - jx);
+  } else db[i] = -x[D.n + (i - D.n - D.m)];
+}
+__global__ void __launch_bounds__(256) dn_out_general(DnDev D, double* __restrict__ d2, int mode, double* rho_old, double* rho, int32_t* nfact,
+                                                      int32_t* success) {
+  const int b = blockIdx.y;
+  const DnState s = D.st[b];
+  if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    rho[b] = s.rho; rho_old[b] = s.rho_old; nfact[b] = s.nfact; success[b] = s.success;
+  }
+  if (mode == 0 && !s.success) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < D.ns) d2[(size_t)b * D.ns + i] = -D.x[(size_t)b * D.nsp + i];
+}
+// residual pivots counted outside (general path)
+__global__ void __launch_bounds__(256) dn_set_counts(DnDev D, int batch, const int* __restrict__ xpos, const int* __restrict__ xzer) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= batch) return;
+  D.cnt[b * 4 + 0] = 0; D.cnt[b * 4 + 1] = 0;
+  D.cnt[b * 4 + 2] = xpos ? xpos[b] : 0; D.cnt[b * 4 + 3] = xzer ? xzer[b] : 0;
 }
 
 inline int blocks(long long n) { return (int)((n + 255) / 256); }
@@ -153,12 +835,10 @@ inline int blocks(long long n) { return (int)((n + 255) / 256); }
 }  // namespace
 
 struct DenseState {
-  rocblas_handle blas = nullptr;
+  DnDev d{};
   int64_t batch = 1;
-  int *jslot = nullptr, *dslot = nullptr, *hslot = nullptr, *hpos = nullptr, *cnt = nullptr;
-  double *Jd = nullptr, *JW = nullptr, *w = nullptr, *S0 = nullptr, *W21 = nullptr, *y = nullptr, *u = nullptr, *tmp = nullptr;
-  double* S = nullptr;  // [batch][n * n] factors (unit lower L below the diagonal, D on it)
-  const double* last_vals = nullptr;
+  bool general = false;
+  bool factored = false;
   std::vector<void*> allocs;
 };
 
@@ -166,7 +846,7 @@ bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, co
                   int64_t ncon) {
   D.active = false;
   if (nequ <= 0 || nvar < 32 || N != nvar + nequ + ncon) return false;
-  if ((long long)nvar * nequ > (1ll << 28) || nnz > (1ll << 30) || (nvar + ncon) > 30000) return false;
+  if ((long long)nvar * nequ > (1ll << 28) || nnz > (1ll << 30) || (nvar + ncon) > 4096) return false;  // the solve kernels keep a vector of the dense order in LDS
   D.n = (int32_t)nvar; D.m = (int32_t)nequ; D.p = (int32_t)ncon; D.nnz = (int32_t)nnz;
   const int64_t ns = nvar + ncon;  // order of the dense system
   D.jslot.assign((size_t)nvar * nequ, -1);
@@ -176,7 +856,7 @@ bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, co
   for (int64_t e = 0; e < nnz; e++) {
     const int64_t i = rows1[e] - 1, j = cols1[e] - 1;
     if (i < nvar) {  // H_F / H_c entry or rho slot (lower triangle, column j <= row i)
-      if (e >= rho_begin) continue;  // rho slots are applied by shift_kernel
+      if (e >= rho_begin) continue;  // rho slots are applied as a shift of the diagonal
       D.hslot.push_back((int32_t)e); D.hpos.push_back((int32_t)(i + ns * j));
     } else if (i < nvar + nequ) {
       if (j < nvar) {
@@ -202,288 +882,260 @@ bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, co
   return true;
 }
 
+namespace {
+
 template <class T>
-static int dalloc_(DenseState* st, T** p, size_t count, std::string& err) {
+int dalloc_(DenseState* st, T** p, size_t count, std::string& err, bool zero = false) {
   void* q = nullptr;
-  hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
-  if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return 4; }
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) { err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e); return 4; }
   st->allocs.push_back(q);
+  if (zero && hipMemset(q, 0, bytes) != hipSuccess) { err = "hipMemset failed"; return 4; }
   *p = (T*)q;
   return 0;
 }
+template <class T>
+int upload_(DenseState* st, const T** p, const std::vector<T>& v, std::string& err) {
+  T* q = nullptr;
+  int rc = dalloc_(st, &q, v.size(), err);
+  if (rc) return rc;
+  if (!v.empty() && hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy failed"; return 4; }
+  *p = q;
+  return 0;
+}
 
-int dense_create(DenseState** out, const DensePlan& D, int64_t batch, std::string& err) {
+// sizes, tile lists and buffers common to both forms
+int setup_common(DenseState* st, int ns, int nv, int64_t batch, std::string& err) {
+  DnDev& d = st->d;
+  d.ns = ns; d.nv = nv; d.T = (ns + TS - 1) / TS; d.nsp = d.T * TS;
+  d.nlt = d.T * (d.T + 1) / 2;
+  std::vector<int> lI, lJ;
+  for (int J = 0; J < d.T; J++) for (int I = J; I < d.T; I++) { lI.push_back(I); lJ.push_back(J); }
+  int rc;
+  if ((rc = upload_(st, &d.lI, lI, err))) return rc;
+  if ((rc = upload_(st, &d.lJ, lJ, err))) return rc;
+  const size_t B = (size_t)batch, mat = (size_t)d.T * d.T * TT;
+  if ((rc = dalloc_(st, &d.S0, B * mat, err, true))) return rc;
+  if ((rc = dalloc_(st, &d.S, B * mat, err, true))) return rc;
+  if ((rc = dalloc_(st, &d.G, B * mat, err, true))) return rc;
+  if ((rc = dalloc_(st, &d.Wn, B * d.T * TT, err, true))) return rc;
+  for (double** v : {&d.dv, &d.rsh, &d.y, &d.x})
+    if ((rc = dalloc_(st, v, B * d.nsp, err, true))) return rc;
+  for (double** v : {&d.part1, &d.part2, &d.partA, &d.partB})
+    if ((rc = dalloc_(st, v, B * d.T * d.T * 64, err, true))) return rc;
+  if ((rc = dalloc_(st, &d.cnt, B * 4, err, true))) return rc;
+  if ((rc = dalloc_(st, &d.st, B, err, true))) return rc;
+  return 0;
+}
+
+}  // namespace
+
+int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::string& err) {
   DenseState* st = new DenseState();
   st->batch = batch;
   *out = st;
-  const size_t n = D.n, m = D.m, ns = (size_t)D.n + D.p;
+  DnDev& d = st->d;
+  d.n = P.n; d.m = P.m; d.p = P.p; d.nnz = P.nnz;
+  d.mp = ((P.m + 63) / 64) * 64;
+  d.Tn = (P.n + TS - 1) / TS; d.npj = d.Tn * TS;
+  d.ntl = d.Tn * (d.Tn + 1) / 2;
+  d.npos_ok = P.n;
   int rc;
-  if ((rc = dalloc_(st, &st->jslot, n * m, err))) return rc;
-  if ((rc = dalloc_(st, &st->dslot, m, err))) return rc;
-  if ((rc = dalloc_(st, &st->hslot, D.hslot.size(), err))) return rc;
-  if ((rc = dalloc_(st, &st->hpos, D.hpos.size(), err))) return rc;
-  if ((rc = dalloc_(st, &st->cnt, 4, err))) return rc;
-  if ((rc = dalloc_(st, &st->Jd, n * m, err))) return rc;
-  if ((rc = dalloc_(st, &st->JW, n * m, err))) return rc;
-  if ((rc = dalloc_(st, &st->w, m, err))) return rc;
-  if ((rc = dalloc_(st, &st->S0, ns * ns, err))) return rc;
-  if ((rc = dalloc_(st, &st->W21, ns * NB, err))) return rc;
-  if ((rc = dalloc_(st, &st->y, ns, err))) return rc;
-  if ((rc = dalloc_(st, &st->u, m, err))) return rc;
-  if ((rc = dalloc_(st, &st->tmp, m, err))) return rc;
-  if ((rc = dalloc_(st, &st->S, (size_t)batch * ns * ns, err))) return rc;
-  DCHK(hipMemcpy(st->jslot, D.jslot.data(), n * m * sizeof(int), hipMemcpyHostToDevice));
-  DCHK(hipMemcpy(st->dslot, D.dslot.data(), m * sizeof(int), hipMemcpyHostToDevice));
-  if (!D.hslot.empty()) {
-    DCHK(hipMemcpy(st->hslot, D.hslot.data(), D.hslot.size() * sizeof(int), hipMemcpyHostToDevice));
-    DCHK(hipMemcpy(st->hpos, D.hpos.data(), D.hpos.size() * sizeof(int), hipMemcpyHostToDevice));
+  if ((rc = setup_common(st, P.n + P.p, P.n, batch, err))) return rc;
+  // J'WJ work partition: the (problem, tile, row chunk) space in equal shares, two workgroups per CU
+  std::vector<int> sy_tp;
+  int npieces = 0;
+  {
+    const long long nch = d.mp / KT, units = (long long)batch * d.ntl * nch;
+    int nwg = 512;
+    if (const char* e = getenv("CNL_DENSE_SYRK_WGS")) nwg = std::max(1, atoi(e));
+    nwg = (int)std::min<long long>(nwg, units);
+    std::vector<int> wg(nwg + 1, 0), pb, ptl, pc0, pc1;
+    for (int w = 0; w < nwg; w++) {
+      long long u = units * w / nwg;
+      const long long u1 = units * (w + 1) / nwg;
+      while (u < u1) {
+        const long long tile = u / nch, c0 = u % nch, c1 = std::min(nch, c0 + (u1 - u));
+        pb.push_back((int)(tile / d.ntl)); ptl.push_back((int)(tile % d.ntl)); pc0.push_back((int)c0); pc1.push_back((int)c1);
+        u += c1 - c0;
+      }
+      wg[w + 1] = (int)pb.size();
+    }
+    npieces = (int)pb.size();
+    sy_tp.assign((size_t)batch * d.ntl + 1, 0);
+    for (int q = 0; q < npieces; q++) sy_tp[(size_t)pb[q] * d.ntl + ptl[q] + 1]++;
+    for (size_t q = 0; q + 1 < sy_tp.size(); q++) sy_tp[q + 1] += sy_tp[q];  // pieces are generated in (problem, tile, chunk) order
+    d.ks = nwg;
+    if ((rc = upload_(st, &d.sy_wg, wg, err))) return rc;
+    if ((rc = upload_(st, &d.sy_b, pb, err))) return rc;
+    if ((rc = upload_(st, &d.sy_tl, ptl, err))) return rc;
+    if ((rc = upload_(st, &d.sy_ch0, pc0, err))) return rc;
+    if ((rc = upload_(st, &d.sy_ch1, pc1, err))) return rc;
+    if ((rc = upload_(st, &d.sy_tp, sy_tp, err))) return rc;
   }
-  BCHK(rocblas_create_handle(&st->blas));
+  // H entries grouped by lower tile and unique position, COO order inside a position
+  {
+    const int64_t ns = d.ns;
+    std::vector<int> order(P.hslot.size());
+    std::iota(order.begin(), order.end(), 0);
+    auto tkey = [&](int e) {
+      const int64_t pos = P.hpos[e], i = pos % ns, j = pos / ns;
+      const int64_t I = i >> 6, J = j >> 6;
+      const int64_t lt = J * d.T - (J * (J - 1)) / 2 + (I - J);
+      return (lt << 12) | ((i & 63) + 64 * (j & 63));
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tkey(a) < tkey(b); });
+    std::vector<int> ht_ptr(d.nlt + 1, 0), hu_loc, hu_ptr, hslot;
+    int64_t prev = -1;
+    for (int e : order) {
+      const int64_t key = tkey(e);
+      if (key != prev) {
+        hu_loc.push_back((int)(key & 4095)); hu_ptr.push_back((int)hslot.size());
+        ht_ptr[(key >> 12) + 1]++;
+        prev = key;
+      }
+      hslot.push_back(P.hslot[e]);
+    }
+    hu_ptr.push_back((int)hslot.size());
+    for (int t = 0; t < d.nlt; t++) ht_ptr[t + 1] += ht_ptr[t];
+    if ((rc = upload_(st, &d.ht_ptr, ht_ptr, err))) return rc;
+    if ((rc = upload_(st, &d.hu_loc, hu_loc, err))) return rc;
+    if ((rc = upload_(st, &d.hu_ptr, hu_ptr, err))) return rc;
+    if ((rc = upload_(st, &d.hslot, hslot, err))) return rc;
+  }
+  if ((rc = upload_(st, &d.jslot, P.jslot, err))) return rc;
+  if ((rc = upload_(st, &d.dslot, P.dslot, err))) return rc;
+  const size_t B = (size_t)batch;
+  if ((rc = dalloc_(st, &d.Jd, B * d.mp * d.npj, err, true))) return rc;
+  if ((rc = dalloc_(st, &d.w, B * d.mp, err, true))) return rc;
+  if ((rc = dalloc_(st, &d.slab, (size_t)npieces * TT, err))) return rc;
+  if ((rc = dalloc_(st, &d.jxp, B * (d.npj / 32) * d.mp, err))) return rc;
+  return 0;
+}
+
+int dense_create_general(DenseState** out, int32_t ns, int32_t nv, int32_t nslots, const int32_t* d_pos, int64_t batch, std::string& err) {
+  DenseState* st = new DenseState();
+  st->batch = batch;
+  st->general = true;
+  *out = st;
+  DnDev& d = st->d;
+  d.n = ns; d.m = 0; d.p = 0; d.nnz = 0; d.mp = 0; d.npj = 0; d.Tn = 0; d.ntl = 0; d.ks = 1;
+  d.npos_ok = nv;
+  d.nslots = nslots; d.gpos = d_pos;
+  int rc;
+  if ((rc = setup_common(st, ns, nv, batch, err))) return rc;
   return 0;
 }
 
 void dense_destroy(DenseState* st) {
   if (!st) return;
-  if (st->blas) rocblas_destroy_handle(st->blas);
   for (void* p : st->allocs) (void)hipFree(p);
   delete st;
 }
 
 namespace {
 
-// S_b = L D L^T of (S0 + shift); counts of the dense pivots go to st->cnt[0..1] (added to what is there)
-int factor_ns(DenseState* st, int n, int nv, double* S, const double* rho_slots, double rho, int use_slots, double eig_tol,
-              hipStream_t stream, std::string& err) {
-  hipLaunchKernelGGL(shift_kernel, dim3(blocks((long long)n * n)), dim3(256), 0, stream, st->S0, S, n, nv, rho_slots, rho, use_slots);
-  const double one = 1.0, mone = -1.0;
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int nb = std::min(NB, n - k0), n2 = n - k0 - nb;
-    hipLaunchKernelGGL(panel_l21_kernel, dim3(std::max(1, blocks(n2))), dim3(256), 0, stream, S, n, k0, nb, st->W21, n2, eig_tol, st->cnt);
-    if (n2 <= 0) break;
-    // S22 -= L21 (L21 D)^T
-    BCHK(rocblas_dgemm(st->blas, rocblas_operation_none, rocblas_operation_transpose, n2, n2, nb, &mone,
-                       S + (size_t)(k0 + nb) + (size_t)n * k0, n, st->W21, n2, &one, S + (size_t)(k0 + nb) + (size_t)n * (k0 + nb), n));
+// the per-column steps of one factorisation of S (all problems), then the decision
+int enqueue_factor(DenseState* st, double eig_tol, hipStream_t stream, std::string& err) {
+  const DnDev& d = st->d;
+  const int B = (int)st->batch;
+  for (int k = 0; k < d.T; k++) {
+    hipLaunchKernelGGL(dn_panel, dim3((d.T + 2) / 3, B), dim3(256), 0, stream, d, k, eig_tol);
+    const int nt = d.T - 1 - k, ntr = nt * (nt + 1) / 2 + (k + 1) * nt;
+    if (ntr > 0) hipLaunchKernelGGL(dn_update, dim3(4 * ntr, B), dim3(256), 0, stream, d, k);
   }
   DCHK(hipGetLastError());
   return 0;
 }
 
-int factor(DenseState* st, const DensePlan& D, double* S, const double* rho_slots, double rho, int use_slots, double eig_tol,
-           hipStream_t stream, std::string& err) {
-  return factor_ns(st, D.n + D.p, D.n, S, rho_slots, rho, use_slots, eig_tol, stream, err);
-}
-
-int build(DenseState* st, const DensePlan& D, const double* vals, double eig_tol, hipStream_t stream, std::string& err) {
-  const int n = D.n, m = D.m;
-  DCHK(hipMemsetAsync(st->cnt, 0, 4 * sizeof(int), stream));
-  hipLaunchKernelGGL(gather_kernel, dim3(blocks((long long)m * n)), dim3(256), 0, stream, vals, st->jslot, st->dslot, m, n, st->Jd, st->JW, st->w);
-  hipLaunchKernelGGL(rinertia_kernel, dim3(blocks(m)), dim3(256), 0, stream, vals, st->dslot, m, eig_tol, st->cnt + 2);
-  const int ns = n + D.p;
-  DCHK(hipMemsetAsync(st->S0, 0, (size_t)ns * ns * sizeof(double), stream));
-  if (!D.hslot.empty())
-    hipLaunchKernelGGL(hscatter_kernel, dim3(blocks((long long)D.hslot.size())), dim3(256), 0, stream, vals, st->hslot, st->hpos, (int)D.hslot.size(), st->S0);
-  const double one = 1.0;
-  // top-left block: S0(1:n, 1:n) += J' (W J)
-  BCHK(rocblas_dgemm(st->blas, rocblas_operation_transpose, rocblas_operation_none, n, n, m, &one, st->Jd, m, st->JW, m, &one, st->S0, ns));
-  return 0;
-}
-
-// d = -K^-1 rhs with the factor in S (Jd, w of the same problem must be in place)
-int solve(DenseState* st, const DensePlan& D, const double* S, const double* rhs, double* d, hipStream_t stream, std::string& err) {
-  const int n = D.n, m = D.m, p = D.p, ns = D.n + D.p;
-  const double one = 1.0, mone = -1.0;
-  // y = [rhs_x + J' (w .* rhs_r) ; rhs_c]      (rhs_x - J' (rhs_r / d_r) on the variables)
-  hipLaunchKernelGGL(mul_kernel, dim3(blocks(m)), dim3(256), 0, stream, st->w, rhs + n, st->tmp, m);
-  DCHK(hipMemcpyAsync(st->y, rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-  if (p > 0) DCHK(hipMemcpyAsync(st->y + n, rhs + n + m, (size_t)p * sizeof(double), hipMemcpyDeviceToDevice, stream));
-  BCHK(rocblas_dgemv(st->blas, rocblas_operation_transpose, m, n, &one, st->Jd, m, st->tmp, 1, &one, st->y, 1));
-  BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, ns, S, ns, st->y, 1));
-  hipLaunchKernelGGL(scale_by_diag_kernel, dim3(blocks(ns)), dim3(256), 0, stream, st->y, S, ns);
-  BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_unit, ns, S, ns, st->y, 1));
-  // u = rhs_r - J x
-  DCHK(hipMemcpyAsync(st->u, rhs + n, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, stream));
-  BCHK(rocblas_dgemv(st->blas, rocblas_operation_none, m, n, &mone, st->Jd, m, st->y, 1, &one, st->u, 1));
-  hipLaunchKernelGGL(out_kernel, dim3(blocks(n + m + p)), dim3(256), 0, stream, st->y, st->u, st->w, d, n, m, p);
+int enqueue_solve_core(DenseState* st, int gate, hipStream_t stream, std::string& err) {
+  const DnDev& d = st->d;
+  const int B = (int)st->batch;
+  hipLaunchKernelGGL(dn_gt_part, dim3(d.nlt, B), dim3(256), 0, stream, d, 0, gate);
+  hipLaunchKernelGGL(dn_g_part, dim3(d.nlt, B), dim3(256), 0, stream, d, gate);
+  hipLaunchKernelGGL(dn_resid_part, dim3(d.nlt, B), dim3(256), 0, stream, d, gate);
+  hipLaunchKernelGGL(dn_gt_part, dim3(d.nlt, B), dim3(256), 0, stream, d, 1, gate);
+  hipLaunchKernelGGL(dn_g_part, dim3(d.nlt, B), dim3(256), 0, stream, d, gate);
+  hipLaunchKernelGGL(dn_xfinal, dim3(d.T, B), dim3(64), 0, stream, d, gate);
   DCHK(hipGetLastError());
   return 0;
 }
 
 }  // namespace
 
-int dense_run(DenseState* st, const DensePlan& D, int mode, double* vals, const double* rhs, double* d, double* rho_old_d,
-              double* rho_d, int32_t* nfact_d, int32_t* success_d, int64_t* npos_d, int64_t* nzero_d, const double params[9],
-              hipStream_t stream, std::string& err) {
-  const int n = D.n, m = D.m;
-  const size_t N = (size_t)n + m + D.p, ns = (size_t)n + D.p;
-  BCHK(rocblas_set_stream(st->blas, stream));
-  const double eig_tol = params[0], kdec = params[2], kinc = params[3], klarge = params[4], rho0 = params[5], rhomax = params[6],
-               rhomin = params[7];
-  if (mode == 2 && !st->last_vals) { err = "cnl_solve before cnl_factorize"; return 5; }
-  for (int64_t b = 0; b < st->batch; b++) {
-    double* S = st->S + b * ns * ns;
-    double* vb = vals ? vals + (size_t)b * D.nnz : nullptr;
-    int rc;
-    if (mode == 2) {
-      // Jd / w of this problem again (they are shared scratch), then the solve with the stored factor
-      hipLaunchKernelGGL(gather_kernel, dim3(blocks((long long)m * n)), dim3(256), 0, stream, st->last_vals + (size_t)b * D.nnz, st->jslot,
-                         st->dslot, m, n, st->Jd, st->JW, st->w);
-      if ((rc = solve(st, D, S, rhs + b * N, d + b * N, stream, err))) return rc;
-      continue;
-    }
-    if ((rc = build(st, D, vb, eig_tol, stream, err))) return rc;
-    int cnt[4];
-    auto attempt = [&](double rho, int use_slots) -> int {
-      DCHK(hipMemsetAsync(st->cnt, 0, 2 * sizeof(int), stream));
-      int r2 = factor(st, D, S, vb + (D.nnz - n), rho, use_slots, eig_tol, stream, err);
-      if (r2) return r2;
-      DCHK(hipMemcpyAsync(cnt, st->cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
-      DCHK(hipStreamSynchronize(stream));
-      return 0;
-    };
-    auto ok = [&]() { return cnt[0] + cnt[2] == n && cnt[1] + cnt[3] == 0; };  // src/solver_types.jl:90-97
-    if (mode == 1) {
-      if ((rc = attempt(0.0, 1))) return rc;
-      const int32_t s32 = ok() ? 1 : 0;
-      DCHK(hipMemcpyAsync(success_d + b, &s32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
-      if (npos_d) { const int64_t v = cnt[0] + cnt[2]; DCHK(hipMemcpyAsync(npos_d + b, &v, sizeof(int64_t), hipMemcpyHostToDevice, stream)); }
-      if (nzero_d) { const int64_t v = cnt[1] + cnt[3]; DCHK(hipMemcpyAsync(nzero_d + b, &v, sizeof(int64_t), hipMemcpyHostToDevice, stream)); }
-      DCHK(hipStreamSynchronize(stream));
-      continue;
-    }
-    // newton_system!, src/CaNNOLeS.jl:1008-1052
-    double rho_old = 0.0;
-    DCHK(hipMemcpyAsync(&rho_old, rho_old_d + b, sizeof(double), hipMemcpyDeviceToHost, stream));
-    DCHK(hipStreamSynchronize(stream));
-    double rho = 0.0, wrote = 0.0;
-    int nfact = 1;
-    if ((rc = attempt(0.0, 1))) return rc;
-    bool success = ok();
-    if (!success) {
-      rho = rho_old == 0.0 ? rho0 : std::max(rhomin, kdec * rho_old);
-      wrote = rho;
-      if ((rc = attempt(rho, 0))) return rc;
-      success = ok();
-      nfact++;
-      while (!success && rho <= rhomax) {
-        rho = rho_old == 0.0 ? klarge * rho : kinc * rho;
-        if (rho <= rhomax) {
-          wrote = rho;
-          if ((rc = attempt(rho, 0))) return rc;
-          success = ok();
-          nfact++;
-        }
-      }
-      if (rho <= rhomax) rho_old = rho;
-      hipLaunchKernelGGL(fill_kernel, dim3(blocks(n)), dim3(256), 0, stream, vb + (D.nnz - n), wrote, n);
-    }
-    if (success && (rc = solve(st, D, S, rhs + b * N, d + b * N, stream, err))) return rc;
-    const int32_t nf32 = nfact, s32 = success ? 1 : 0;
-    DCHK(hipMemcpyAsync(rho_d + b, &rho, sizeof(double), hipMemcpyHostToDevice, stream));
-    DCHK(hipMemcpyAsync(rho_old_d + b, &rho_old, sizeof(double), hipMemcpyHostToDevice, stream));
-    DCHK(hipMemcpyAsync(nfact_d + b, &nf32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    DCHK(hipMemcpyAsync(success_d + b, &s32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    DCHK(hipStreamSynchronize(stream));
-  }
-  if (mode == 1) st->last_vals = vals;
-  return 0;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-int dense_create_general(DenseState** out, int32_t ns, int64_t batch, std::string& err) {
-  DenseState* st = new DenseState();
-  st->batch = batch;
-  *out = st;
+int dense_run(DenseState* st, const DensePlan& P, int mode, double* vals, const double* rhs, double* dout, double* rho_old, double* rho,
+              int32_t* nfact, int32_t* success, int64_t* npos, int64_t* nzero, const double params[9], hipStream_t stream,
+              std::string& err) {
+  (void)P;
+  const DnDev& d = st->d;
+  const int B = (int)st->batch;
+  const int N = d.n + d.m + d.p;
+  const double eig_tol = params[0];
   int rc;
-  const size_t n = (size_t)ns;
-  if ((rc = dalloc_(st, &st->cnt, 4, err))) return rc;
-  if ((rc = dalloc_(st, &st->S0, n * n, err))) return rc;
-  if ((rc = dalloc_(st, &st->W21, n * NB, err))) return rc;
-  if ((rc = dalloc_(st, &st->y, n, err))) return rc;
-  if ((rc = dalloc_(st, &st->S, (size_t)batch * n * n, err))) return rc;
-  BCHK(rocblas_create_handle(&st->blas));
+  if (mode == 2 && !st->factored) { err = "cnl_solve before cnl_factorize"; return 5; }
+  if (mode != 2) {
+    hipLaunchKernelGGL(dn_gather, dim3(std::min(2048, blocks((long long)d.m * d.n)), B), dim3(256), 0, stream, d, vals, eig_tol);
+    hipLaunchKernelGGL(dn_syrk, dim3(d.ks), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(dn_assemble, dim3(d.nlt, B), dim3(256), 0, stream, d, vals);
+    if ((rc = enqueue_factor(st, eig_tol, stream, err))) return rc;
+    if (mode == 0)
+      hipLaunchKernelGGL(dn_ladder, dim3(B), dim3(LNW * 64), 0, stream, d, vals, rho_old, eig_tol, params[2], params[3], params[4], params[5],
+                         params[6], params[7]);
+    else
+      hipLaunchKernelGGL(dn_decide, dim3(blocks(B)), dim3(256), 0, stream, d, B, mode, nullptr, success, npos, nzero);
+    DCHK(hipGetLastError());
+    st->factored = true;
+#ifdef DN_STAMPS
+    if (mode == 1) {
+      (void)hipStreamSynchronize(stream);
+      std::vector<long long> hs(d.T * 4);
+      (void)hipMemcpy(hs.data(), d.jxp, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      for (int k2 = 0; k2 < d.T; k2++) fprintf(stderr, "[dn stamps] k=%d diag %lld rows %lld %lld %lld\n", k2, hs[k2 * 4], hs[k2 * 4 + 1], hs[k2 * 4 + 2], hs[k2 * 4 + 3]);
+    }
+#endif
+    if (mode == 1) return 0;
+  }
+  const int gate = mode == 0 ? 1 : 0;
+  hipLaunchKernelGGL(dn_yrhs, dim3((d.nsp + 3) / 4, B), dim3(256), 0, stream, d, rhs, gate);
+  if ((rc = enqueue_solve_core(st, gate, stream, err))) return rc;
+  hipLaunchKernelGGL(dn_jx, dim3(d.mp / 256 + (d.mp % 256 ? 1 : 0), d.npj / 32, B), dim3(256), 0, stream, d, gate);
+  hipLaunchKernelGGL(dn_out, dim3(blocks(N), B), dim3(256), 0, stream, d, rhs, dout, mode, rho_old, rho, nfact, success);
+  DCHK(hipGetLastError());
   return 0;
 }
 
 int dense_run_general(DenseState* st, const GeneralOps& G, int mode, const double* cbuf, const int* xpos, const int* xzer, double* d2,
-                      double* vals_rho0, int64_t vals_stride, double* rho_old_d, double* rho_d, int32_t* nfact_d, int32_t* success_d,
-                      int64_t* npos_d, int64_t* nzero_d, const double params[9], hipStream_t stream, std::string& err) {
-  const int ns = G.ns, nv = G.nv;
-  BCHK(rocblas_set_stream(st->blas, stream));
-  const double eig_tol = params[0], kdec = params[2], kinc = params[3], klarge = params[4], rho0 = params[5], rhomax = params[6],
-               rhomin = params[7];
-  for (int64_t b = 0; b < st->batch; b++) {
-    double* S = st->S + (size_t)b * ns * ns;
-    const double* cb = cbuf + (size_t)b * G.cstride;
-    int rc = 0;
-    auto solve_b = [&]() -> int {
-      // x = S^-1 crhs;  d2 = -x
-      DCHK(hipMemcpyAsync(st->y, cb + G.nslots + nv, (size_t)ns * sizeof(double), hipMemcpyDeviceToDevice, stream));
-      BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, ns, S, ns, st->y, 1));
-      hipLaunchKernelGGL(scale_by_diag_kernel, dim3(blocks(ns)), dim3(256), 0, stream, st->y, S, ns);
-      BCHK(rocblas_dtrsv(st->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_unit, ns, S, ns, st->y, 1));
-      hipLaunchKernelGGL(neg_kernel, dim3(blocks(ns)), dim3(256), 0, stream, st->y, d2 + (size_t)b * ns, ns);
-      DCHK(hipGetLastError());
-      return 0;
-    };
-    if (mode == 2) { if ((rc = solve_b())) return rc; continue; }
-    DCHK(hipMemsetAsync(st->S0, 0, (size_t)ns * ns * sizeof(double), stream));
-    hipLaunchKernelGGL(slot_scatter_kernel, dim3(blocks(G.nslots)), dim3(256), 0, stream, cb, G.d_pos, G.nslots, st->S0);
-    DCHK(hipMemcpyAsync(st->cnt + 2, xpos + b, sizeof(int), hipMemcpyDeviceToDevice, stream));
-    DCHK(hipMemcpyAsync(st->cnt + 3, xzer + b, sizeof(int), hipMemcpyDeviceToDevice, stream));
-    int cnt[4];
-    auto attempt = [&](double rho, int use_slots) -> int {
-      DCHK(hipMemsetAsync(st->cnt, 0, 2 * sizeof(int), stream));
-      int r2 = factor_ns(st, ns, nv, S, cb + G.nslots, rho, use_slots, eig_tol, stream, err);
-      if (r2) return r2;
-      DCHK(hipMemcpyAsync(cnt, st->cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
-      DCHK(hipStreamSynchronize(stream));
-      return 0;
-    };
-    auto ok = [&]() { return cnt[0] + cnt[2] == nv && cnt[1] + cnt[3] == 0; };  // src/solver_types.jl:90-97
-    if (mode == 1) {
-      if ((rc = attempt(0.0, 1))) return rc;
-      const int32_t s32 = ok() ? 1 : 0;
-      DCHK(hipMemcpyAsync(success_d + b, &s32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
-      if (npos_d) { const int64_t v = cnt[0] + cnt[2]; DCHK(hipMemcpyAsync(npos_d + b, &v, sizeof(int64_t), hipMemcpyHostToDevice, stream)); }
-      if (nzero_d) { const int64_t v = cnt[1] + cnt[3]; DCHK(hipMemcpyAsync(nzero_d + b, &v, sizeof(int64_t), hipMemcpyHostToDevice, stream)); }
-      DCHK(hipStreamSynchronize(stream));
-      continue;
-    }
-    // newton_system!, src/CaNNOLeS.jl:1008-1052
-    double rho_old = 0.0;
-    DCHK(hipMemcpyAsync(&rho_old, rho_old_d + b, sizeof(double), hipMemcpyDeviceToHost, stream));
-    DCHK(hipStreamSynchronize(stream));
-    double rho = 0.0, wrote = 0.0;
-    int nfact = 1;
-    if ((rc = attempt(0.0, 1))) return rc;
-    bool success = ok();
-    if (!success) {
-      rho = rho_old == 0.0 ? rho0 : std::max(rhomin, kdec * rho_old);
-      wrote = rho;
-      if ((rc = attempt(rho, 0))) return rc;
-      success = ok();
-      nfact++;
-      while (!success && rho <= rhomax) {
-        rho = rho_old == 0.0 ? klarge * rho : kinc * rho;
-        if (rho <= rhomax) {
-          wrote = rho;
-          if ((rc = attempt(rho, 0))) return rc;
-          success = ok();
-          nfact++;
-        }
-      }
-      if (rho <= rhomax) rho_old = rho;
-      hipLaunchKernelGGL(fill_kernel, dim3(blocks(nv)), dim3(256), 0, stream, vals_rho0 + (size_t)b * vals_stride, wrote, nv);
-    }
-    if (success && (rc = solve_b())) return rc;
-    const int32_t nf32 = nfact, s32 = success ? 1 : 0;
-    DCHK(hipMemcpyAsync(rho_d + b, &rho, sizeof(double), hipMemcpyHostToDevice, stream));
-    DCHK(hipMemcpyAsync(rho_old_d + b, &rho_old, sizeof(double), hipMemcpyHostToDevice, stream));
-    DCHK(hipMemcpyAsync(nfact_d + b, &nf32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    DCHK(hipMemcpyAsync(success_d + b, &s32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    DCHK(hipStreamSynchronize(stream));
+                      double* vals_rho0, int64_t vals_stride, double* rho_old, double* rho, int32_t* nfact, int32_t* success,
+                      int64_t* npos, int64_t* nzero, const double params[9], hipStream_t stream, std::string& err) {
+  DnDev d = st->d;
+  const int B = (int)st->batch;
+  const double eig_tol = params[0];
+  int rc;
+  if (mode == 2 && !st->factored) { err = "cnl_solve before cnl_factorize"; return 5; }
+  if (mode != 2) {
+    hipLaunchKernelGGL(dn_set_counts, dim3(blocks(B)), dim3(256), 0, stream, d, B, xpos, xzer);
+    DCHK(hipMemsetAsync(d.S0, 0, (size_t)B * d.T * d.T * TT * sizeof(double), stream));
+    hipLaunchKernelGGL(dn_scatter_general, dim3(std::min(1024, blocks(std::max(d.nslots, d.nsp))), B), dim3(256), 0, stream, d, cbuf, (long long)G.cstride);
+    hipLaunchKernelGGL(dn_shift, dim3(d.nlt, B), dim3(256), 0, stream, d);
+    if ((rc = enqueue_factor(st, eig_tol, stream, err))) return rc;
+    if (mode == 0) {
+      // the ladder writes the last rho tried into the caller's rho slots: vals_rho0 + b * vals_stride, nv entries
+      DnDev dl = d;
+      dl.nnz = (int)vals_stride;  // dn_ladder addresses vals + b * nnz + (nnz - nv)
+      hipLaunchKernelGGL(dn_ladder, dim3(B), dim3(LNW * 64), 0, stream, dl, vals_rho0 - (vals_stride - d.nv), rho_old, eig_tol, params[2], params[3],
+                         params[4], params[5], params[6], params[7]);
+    } else
+      hipLaunchKernelGGL(dn_decide, dim3(blocks(B)), dim3(256), 0, stream, d, B, mode, nullptr, success, npos, nzero);
+    DCHK(hipGetLastError());
+    st->factored = true;
+    if (mode == 1) return 0;
   }
+  const int gate = mode == 0 ? 1 : 0;
+  hipLaunchKernelGGL(dn_yrhs_general, dim3(std::min(256, blocks(d.nsp)), B), dim3(256), 0, stream, d, cbuf, (long long)G.cstride, gate);
+  if ((rc = enqueue_solve_core(st, gate, stream, err))) return rc;
+  hipLaunchKernelGGL(dn_out_general, dim3(blocks(d.ns), B), dim3(256), 0, stream, d, d2, mode, rho_old, rho, nfact, success);
+  DCHK(hipGetLastError());
   return 0;
 }
 
