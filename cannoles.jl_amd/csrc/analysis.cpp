@@ -476,7 +476,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
 
   // supernodes + amalgamation + cost for a candidate; returns the final
   // supernode column lists (in final elimination order) through `sn_out`
-  struct Cand { std::string name; ivec perm; ivec sn_first, sn_indep; double cost = 0; int64_t nnzL = 0, nnzL_exact = 0; };
+  struct Cand { std::string name; ivec perm; ivec sn_first, sn_indep; double cost = 0, cpath = 0; int64_t nnzL = 0, nnzL_exact = 0; bool m2 = false; };
   const int64_t merge_tri_cap = (int64_t)20000;  // do not grow LDS-sized fronts past this by relaxation
   auto evaluate = [&](const ivec& perm0, Cand& c) {
     Symbolic S; symbolic(g, perm0, S);
@@ -589,13 +589,19 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       c.sn_first.push_back((int32_t)order.size());
     }
     c.perm.swap(order);
-    // cost + nnzL with explicit zeros
-    c.cost = 0; c.nnzL = 0;
+    // cost + nnzL with explicit zeros; critical path of the (merged) tree: supernodes are numbered children first
+    c.cost = 0; c.nnzL = 0; c.cpath = 0; c.m2 = m2;
+    std::vector<double> cp(ns, 0.0);
     for (int32_t s = 0; s < ns; s++) if (sn[s].alive) {
       int64_t np = sn[s].np(), nu = sn[s].nupd;
       c.cost += cost_of(sn[s]);
-      if (sn[s].parent >= 0) c.cost += ecost(nu);
+      double mine = cost_of(sn[s]);
+      if (sn[s].parent >= 0) { c.cost += ecost(nu); mine += ecost(nu); }
       c.nnzL += np * nu + np * (np - 1) / 2;
+      double below = 0;
+      for (int32_t k : sn[s].kids) below = std::max(below, cp[k]);
+      cp[s] = below + mine;
+      c.cpath = std::max(c.cpath, cp[s]);
     }
   };
 
@@ -640,6 +646,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     }
     std::vector<int32_t> leaves;
     if (opt.nd_leaf > 0) leaves.push_back(opt.nd_leaf);
+    else if (opt.latency) leaves = {32, 64, 96, 160, 256, 512};
     else leaves = {32, 96, 256, 768, 2048};
     for (int32_t leaf : leaves) {
       if (leaf >= (int32_t)body.size() && leaves.size() > 1 && leaf != leaves.front()) break;
@@ -651,16 +658,22 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     }
   }
   if (cands.empty()) add_cand("canonical", xs_all);
+  // throughput plans minimise the total work; latency plans the critical path plus the work spread over the wavefront
+  // slots a group of four problems can use (only orders the register-front kernel can run are staged)
+  auto score = [&](const Cand& c) {
+    if (!opt.latency) return c.cost;
+    return c.m2 ? c.cpath + c.cost / (double)std::max(1, opt.par) : 1e30 + c.cost;
+  };
   size_t best = 0;
-  for (size_t i = 1; i < cands.size(); i++) if (cands[i].cost < cands[best].cost) best = i;
+  for (size_t i = 1; i < cands.size(); i++) if (score(cands[i]) < score(cands[best])) best = i;
   if (getenv("CNL_VERBOSE")) {
     for (auto& c : cands)
-      fprintf(stderr, "[cnl] order %-10s cost %.3e nnzL %lld (exact %lld) fronts %zu\n", c.name.c_str(), c.cost,
+      fprintf(stderr, "[cnl] order %-12s cost %.3e path %.3e nnzL %lld (exact %lld) fronts %zu\n", c.name.c_str(), c.cost, c.cpath,
               (long long)c.nnzL, (long long)c.nnzL_exact, c.sn_first.size() - 1);
-    fprintf(stderr, "[cnl] chose %s\n", cands[best].name.c_str());
+    fprintf(stderr, "[cnl] chose %s%s\n", cands[best].name.c_str(), opt.latency ? " (latency plan)" : "");
   }
   Cand& C = cands[best];
-  P.order_name = C.name; P.cost = C.cost; P.nnzL = C.nnzL; P.nnzL_exact = C.nnzL_exact;
+  P.order_name = C.name; P.cost = C.cost; P.cpath = C.cpath; P.nnzL = C.nnzL; P.nnzL_exact = C.nnzL_exact;
   P.perm = C.perm;
   P.iperm.assign(N, 0);
   for (int32_t k = 0; k < N; k++) P.iperm[P.perm[k]] = k;
@@ -840,6 +853,44 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
   // ---- v2 streams (register-front kernel) ---------------------------------------------
   P.v2_ok = opt.with_rhs_row && P.fmax <= 64;
   if (const char* e = getenv("CNL_NO_V2")) if (atoi(e)) P.v2_ok = false;
+  // ---- tasks of the staged execution: maximal subtrees of at most task_cap fronts at the bottom (postorder makes a
+  //      subtree a contiguous range of fronts), every front above the cut on its own; stage = 1 + latest child stage
+  ivec task_first(ns, 0), task_root(ns, 0);
+  P.tasks.clear(); P.stage_ptr.clear();
+  if (opt.latency && P.v2_ok && ns > 1) {
+    int cap = opt.task_cap > 0 ? opt.task_cap : 20;
+    if (const char* e = getenv("CNL_TASK_CAP")) cap = std::max(1, atoi(e));
+    ivec nsub(ns, 1), fdesc(ns), stage(ns, 0);
+    for (int32_t s = 0; s < ns; s++) {
+      fdesc[s] = s;
+      for (int32_t c : skids[s]) { nsub[s] += nsub[c]; fdesc[s] = std::min(fdesc[s], fdesc[c]); }
+    }
+    std::vector<Task> ts;
+    for (int32_t s = 0; s < ns; s++) {
+      const bool bottom = nsub[s] <= cap;
+      if (bottom) {
+        stage[s] = 0;
+        if (sparent[s] < 0 || nsub[sparent[s]] > cap) ts.push_back({0, fdesc[s], s + 1, 0, 0, sparent[s] < 0 ? 1 : 0});
+      } else {
+        int32_t st = 0;
+        for (int32_t c : skids[s]) st = std::max(st, stage[c]);
+        stage[s] = st + 1;
+        ts.push_back({stage[s], s, s + 1, 0, 0, sparent[s] < 0 ? 1 : 0});
+      }
+    }
+    if (ts.size() > 1) {
+      std::stable_sort(ts.begin(), ts.end(), [](const Task& x, const Task& y) { return x.stage < y.stage; });
+      P.tasks = ts;
+      for (const Task& t : P.tasks) { task_first[t.f0] = 1; task_root[t.f1 - 1] = 1; }
+      const int32_t nst = P.tasks.back().stage + 1;
+      P.stage_ptr.assign(nst + 1, 0);
+      for (const Task& t : P.tasks) P.stage_ptr[t.stage + 1]++;
+      for (int32_t q = 0; q < nst; q++) P.stage_ptr[q + 1] += P.stage_ptr[q];
+      if (getenv("CNL_VERBOSE"))
+        fprintf(stderr, "[cnl] staged: %zu tasks in %d stages (cap %d fronts), first stage %d tasks\n", P.tasks.size(), nst, cap, P.stage_ptr[1]);
+    }
+  }
+  const bool staged = !P.tasks.empty();
   if (P.v2_ok) {
     const int64_t ubig_thr = getenv("CNL_UBIG") ? tri(atoi(getenv("CNL_UBIG"))) : tri(17);  // update matrices above this size live in global scratch
     int32_t wait_thr = 2;
@@ -855,9 +906,11 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     // fronts of order 17..32 are staged in LDS only when they are common; a few of them would
     // otherwise set the LDS footprint of every problem
     const bool fs32_lds = (int64_t)P.ncls[1] * 20 > ns;
+    int64_t bumpG = 0;  // staged plans: every global slot is used once (tasks run concurrently, a stack would be shared)
     for (int32_t s = 0; s < ns; s++) {
       const FrontHdr& F = P.fronts[s];
       int64_t f = 1 + (int64_t)F.nupd + F.npiv;
+      if (staged && task_first[s]) spL = 0;  // a task starts with an empty LDS stack
       int64_t baseL = spL, baseG = spG;
       bool seenL = false, seenG = false;
       for (int32_t ci = F.child_begin; ci < F.child_end; ci++) {
@@ -871,6 +924,19 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       // they go to the global scratch; only the ones consumed within the next few fronts stay in LDS
       const int32_t wait = F.parent >= 0 ? F.parent - s - 1 : 0;
       uglob[s] = tu > ubig_thr || wait > wait_thr;
+      if (staged) {
+        // a task hands its root's update matrix to the parent's task through the global scratch; inside a task everything
+        // that fits stays in LDS (tasks are short)
+        uglob[s] = task_root[s] || tu > ubig_thr;
+        if (fsglob[s]) { fsoff2[s] = (int32_t)bumpG; bumpG += (tri(f) + 1) & ~(int64_t)1; }
+        else fsmax = std::max(fsmax, tri(f));
+        // + 16: the kernel stores an update matrix as rows of 16 lanes, the last rows run up to 15 doubles past its end
+        if (uglob[s]) { uoff2[s] = (int32_t)bumpG; bumpG += (tu + 16 + 1) & ~(int64_t)1; spL = baseL; }
+        else { uoff2[s] = (int32_t)baseL; spL = baseL + tu; peakL = std::max(peakL, spL); }
+        peakG = bumpG;
+        if (bumpG >= ((int64_t)1 << 30)) { msg = "global scratch of the staged plan too large"; return 2; }
+        continue;
+      }
       if (fsglob[s]) {
         // the staging triangle must not overlap the slot its own update matrix is written to
         // (rows >= 32 of the update matrix are stored while rows < 32 are still read from staging)
@@ -894,19 +960,36 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       const FrontHdr& F = P.fronts[s];
       size_t r0 = P.brec.size();
       P.brec.resize(r0 + B_HDR, 0);
-      for (int32_t l = 0; l <= F.nupd; l++) P.brec.push_back(P.rel_idx[F.rel_begin + l]);
+      const bool px_global = staged && task_root[s] && F.parent >= 0;  // the parent is solved by another task
+      if (px_global) {
+        P.brec.push_back(0);
+        for (int32_t l = 1; l <= F.nupd; l++) P.brec.push_back(P.perm[frows[s][F.nupd - l]]);  // solution components of the update rows
+      } else
+        for (int32_t l = 0; l <= F.nupd; l++) P.brec.push_back(P.rel_idx[F.rel_begin + l]);
       const int32_t f = 1 + F.nupd + F.npiv;
       for (int32_t i = F.nupd + 1; i < f; i++) P.brec.push_back(P.perm[F.first_piv + (f - 1 - i)]);
       while ((P.brec.size() - r0) % 4) P.brec.push_back(0);
       int32_t* H = P.brec.data() + r0;
       H[B_NPIV] = F.npiv; H[B_NUPD] = F.nupd; H[B_RECLEN] = (int32_t)(P.brec.size() - r0); H[B_XOFF] = F.xoff;
-      H[B_PXOFF] = F.parent >= 0 ? P.fronts[F.parent].xoff : -1;
+      H[B_PXOFF] = px_global ? (int32_t)B_PX_GLOBAL : (F.parent >= 0 ? P.fronts[F.parent].xoff : (int32_t)B_PX_NONE);
       H[B_LPTR_LO] = F.lptr_lo; H[B_LPTR_HI] = F.lptr_hi; H[B_CLS] = cls[s];
       P.brec_maxlen = std::max(P.brec_maxlen, H[B_RECLEN]);
     }
+    finalize_tasks(P);
   }
   msg.clear();
   return 0;
+}
+
+void finalize_tasks(Plan& P) {
+  if (P.tasks.empty()) return;
+  const int32_t ns = P.nsuper;
+  ivec rstart(ns + 1, 0), bstart(ns + 1, 0);
+  size_t r0 = 0;
+  for (int32_t s = 0; s < ns; s++) { rstart[s] = (int32_t)r0; r0 += (size_t)P.rec[r0 + R_RECLEN]; }
+  size_t b0 = 0;
+  for (int32_t s = ns - 1; s >= 0; s--) { bstart[s] = (int32_t)b0; b0 += (size_t)P.brec[b0 + B_RECLEN]; }
+  for (Task& t : P.tasks) { t.rec_off = rstart[t.f0]; t.brec_off = bstart[t.f1 - 1]; }
 }
 
 

@@ -25,6 +25,7 @@ struct cnl_plan {
   cnl::Plan P;   // multifrontal plan of the (condensed) system
   int64_t N = 0, nnz = 0, nvar = 0, nequ = 0, ncon = 0;  // outer dimensions, as the reference sees them
   std::vector<int32_t> perm_outer;
+  bool latency = false;  // ordered and cut into tasks for small batches (staged execution, csrc/plan.h)
   cnl::DensePlan D;  // dense residual block (BASELINE config 2): served by the dense backend, csrc/dense.h
   std::vector<int32_t> gpos;  // non-empty: the condensed system may be treated as ONE dense matrix (position of every K2 slot)
 };
@@ -38,6 +39,10 @@ struct cnl_handle {
   cnl::KernelConfig cfg{};
   // v2 (register-front kernel): used for newton_system / factorize when every front has order <= 64
   bool use_v2 = false;
+  bool staged = false;    // newton_system: first attempt stage by stage (tasks of the elimination tree on different wavefronts)
+  const int32_t* d_tasks = nullptr;
+  int* d_gcnt = nullptr;
+  std::vector<int32_t> stage_ptr;
   bool v2_solve = false;  // cnl_solve runs on the register-front kernel too (direct records, every front of the fast class)
   cnl::DevPlan2 dp2{};
   int wpb2 = 1;
@@ -200,6 +205,15 @@ int setup_v2(cnl_handle* h) {
   h->lds2 = wpb * wave_bytes + 512;
   if ((rc = dalloc(h, &h->d_gs, (size_t)h->batch * (size_t)d.gs_doubles))) return rc;
   h->use_v2 = true;
+  h->staged = false;
+  if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && !(getenv("CNL_NO_STAGED") && atoi(getenv("CNL_NO_STAGED")))) {
+    std::vector<int32_t> tk;
+    for (const cnl::Task& t : P.tasks) { tk.push_back(t.rec_off); tk.push_back(t.f1 - t.f0); tk.push_back(t.brec_off); tk.push_back(t.is_root); }
+    if ((rc = upload(h, tk, &h->d_tasks))) return rc;
+    if ((rc = dalloc(h, &h->d_gcnt, (size_t)h->batch * 2))) return rc;
+    h->stage_ptr = P.stage_ptr;
+    h->staged = true;
+  }
   h->v2_solve = P.rec_direct && P.d_outer && P.ncls[1] == 0 && P.ncls[2] == 0 && !(getenv("CNL_V1_SOLVE") && atoi(getenv("CNL_V1_SOLVE")));
   return CNL_OK;
 }
@@ -296,7 +310,22 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
       const bool d_outer = h->plan->P.d_outer;  // the kernel writes the kept components of d itself
       a.vals = d_vals; a.rhs = d_rhs; a.d = d_outer ? d_d : h->d_d2;
       a.extra_pos = count_d ? nullptr : h->d_xpos; a.extra_zer = count_d ? nullptr : h->d_xzer;
-      if ((rc = launch(h, a, stream))) return rc;
+      if (h->staged) {
+        // first attempt (rho as given) stage by stage: the tasks of the elimination tree run on different wavefronts; the
+        // problems that fail it (rare) go through the whole ladder in the classic launch behind it
+        a.batch = (int)h->batch; a.L = h->d_L; a.scratch = h->d_gs;
+        a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0;
+        if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
+        e = cnl::launch_newton2_staged(h->dp2, h->wpb2, h->lds2, a, h->stage_ptr.data(), (int)h->stage_ptr.size() - 1, stream);
+        if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("staged launch: ") + hipGetErrorString(e));
+        a.skip_done = 1;
+        const bool tm = h->timing;
+        h->timing = false;
+        rc = launch(h, a, stream);
+        h->timing = tm;
+        if (rc) return rc;
+        if (h->timing) HIPCHK(hipEventRecord(h->ev1, stream));
+      } else if ((rc = launch(h, a, stream))) return rc;
       e = cnl::launch_expand(h->dc, d_vals, d_rhs, d_outer ? nullptr : h->d_d2, h->d_cbuf, d_d, a.success, 0, B, stream);
       if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
     } else if (direct && a.mode == cnl::MODE_FACTOR) {
@@ -386,13 +415,37 @@ void cnl_default_params(double p[9]) {
   p[8] = std::pow(eps, 0.25);
 }
 
+static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                            int64_t nequ, int64_t ncon, int latency, int par);
+
 int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
                     int64_t nequ, int64_t ncon) {
+  return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0);
+}
+
+static int64_t staged_max_batch() {
+  if (const char* e = getenv("CNL_STAGED_MAX")) return atoll(e);
+  return 1024;
+}
+
+int cnl_plan_create_for_batch(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                              int64_t nequ, int64_t ncon, int64_t batch) {
+  if (batch < 1) return fail(CNL_ERR_ARG, "batch out of range");
+  const int nquads = (int)((batch + 3) / 4);
+  return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch <= staged_max_batch() ? 1 : 0, std::max(1, 2048 / nquads));
+}
+
+// latency != 0: plan for a small batch — order chosen by the critical path, tree cut into tasks (par = wavefront slots per
+// group of four problems)
+static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                            int64_t nequ, int64_t ncon, int latency, int par) {
   if (!plan || !rows1 || !cols1) return fail(CNL_ERR_ARG, "null argument");
   cnl_plan* p = new cnl_plan();
   p->N = N; p->nnz = nnz; p->nvar = nvar; p->nequ = nequ; p->ncon = ncon;
+  p->latency = latency != 0;
   std::string msg;
   cnl::Options opt;
+  opt.latency = latency; opt.par = std::max(1, par);
   int rc = cnl::build_condensation(p->C, N, nnz, rows1, cols1, nvar, nequ, ncon, msg);
   if (!rc) {
     if (p->C.active)
@@ -419,10 +472,15 @@ int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows
       size_t r0 = 0;
       while (r0 + cnl::B_HDR <= br.size() && br[r0 + cnl::B_RECLEN] > 0) {
         const int32_t npiv = br[r0 + cnl::B_NPIV], nupd = br[r0 + cnl::B_NUPD];
-        for (int32_t i = nupd + 1; i < 1 + nupd + npiv; i++) br[r0 + cnl::B_HDR + i] = p->C.orig_of[br[r0 + cnl::B_HDR + i]];
+        // a task root of a staged plan names the solution components of its update rows too
+        const int32_t i0 = br[r0 + cnl::B_PXOFF] == cnl::B_PX_GLOBAL ? 1 : nupd + 1;
+        for (int32_t i = i0; i < 1 + nupd + npiv; i++) br[r0 + cnl::B_HDR + i] = p->C.orig_of[br[r0 + cnl::B_HDR + i]];
         r0 += (size_t)br[r0 + cnl::B_RECLEN];
       }
       p->P.d_outer = true;
+      cnl::finalize_tasks(p->P);  // the records moved
+    } else {
+      p->P.tasks.clear();  // staged execution needs the direct records
     }
     if (getenv("CNL_VERBOSE"))
       fprintf(stderr, "[cnl] direct records: %s, rec words %zu -> %zu, longest %d -> %d\n", drc ? "not possible" : "ok", old_words,
@@ -496,6 +554,8 @@ int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* 
   else if (s == "asm_src") { src = P.asm_src.data(); n = (int64_t)P.asm_src.size(); }
   else if (s == "child_idx") { src = P.child_idx.data(); n = (int64_t)P.child_idx.size(); }
   else if (s == "rel_idx") { src = P.rel_idx.data(); n = (int64_t)P.rel_idx.size(); }
+  else if (s == "tasks") { src = reinterpret_cast<const int32_t*>(P.tasks.data()); n = (int64_t)P.tasks.size() * 6; }  // struct Task, csrc/plan.h
+  else if (s == "stage_ptr") { src = P.stage_ptr.data(); n = (int64_t)P.stage_ptr.size(); }
   else if (s == "rec") { src = P.rec.data(); n = P.v2_ok ? (int64_t)P.rec.size() : 0; }     // record streams of the
   else if (s == "brec") { src = P.brec.data(); n = P.v2_ok ? (int64_t)P.brec.size() : 0; }  // register-front kernel
   else return fail(CNL_ERR_ARG, "unknown plan array: " + s);
@@ -517,7 +577,8 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
     return fail(CNL_ERR_HIP, "no HIP device available (this backend has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(CNL_ERR_ARG, "device index out of range");
   cnl_plan* plan = nullptr;
-  int rc = cnl_plan_create(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon);
+  // small batches cannot fill the chip with one wavefront per four problems: plan for latency (bushy order, tasks)
+  int rc = cnl_plan_create_for_batch(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch);
   if (rc) return rc;
   cnl_handle* h = new cnl_handle();
   h->plan = plan; h->device = device; h->batch = batch;
@@ -730,7 +791,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   std::memset(cfg, 0, 8 * sizeof(int64_t));
   cfg[0] = h->cfg.tpp; cfg[1] = h->cfg.ppb; cfg[2] = (int64_t)h->cfg.lds_bytes; cfg[3] = h->cfg.lds_work;
   cfg[4] = (h->batch + h->cfg.ppb - 1) / h->cfg.ppb;
-  cfg[5] = (h->dense || h->gdense) ? 3 : (h->use_v2 ? 2 : 1);
+  cfg[5] = (h->dense || h->gdense) ? 3 : (h->use_v2 ? (h->staged ? 4 : 2) : 1);
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;
   return CNL_OK;

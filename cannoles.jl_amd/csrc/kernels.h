@@ -91,11 +91,20 @@ struct LaunchArgs {
   double params[9];      // ParamCaNNOLeS; params[0] = eig_tol also for FACTOR
   const int* extra_pos;  // [batch] optional: inertia counts of pivots eliminated outside the kernel (condensed r nodes)
   const int* extra_zer;
+  // staged execution (latency plans, kernels2.hip STAGED): one launch per stage and phase
+  const int32_t* tasks;  // device: 4 words per task {record offset, fronts, backward record offset, 1 if a root of the forest}
+  int task0, ntasks;     // tasks of this launch
+  int phase;             // 0: forward (assembly + elimination) of the tasks, 1: backward sweep of the tasks
+  int nquads;            // groups of four problems
+  int* gcnt;             // [batch][2] pivot counts summed over the tasks
+  int skip_done;         // classic launch behind a staged attempt: problems with success[b] == 1 are left alone
 };
 
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream);
+// one attempt at the rho given in vals, stage by stage (stage_ptr: host array of nstages + 1 task offsets)
+hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, LaunchArgs a, const int32_t* stage_ptr, int nstages, hipStream_t stream);
 hipError_t launch_condense(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int slot_begin, int slot_end,
                            int batch, hipStream_t stream);
 // LDS-tiled variant over all chunks; mask: 1 matrix slots, 2 rho slots, 4 right-hand-side slots

@@ -348,6 +348,7 @@ __device__ __forceinline__ void back_front(int P_prob_doubles, long long P_lsize
   const int tu = tri2(1 + nupd);
   double xb = 0.0;
   if (pxoff >= 0 && b >= 1 && b <= nupd) xb = xs[pxoff + rec[B_HDR + b]];
+  if (pxoff == B_PX_GLOBAL && b >= 1 && b <= nupd) xb = -__hip_atomic_load(c.dout + pclamp * P_dstride + rec[B_HDR + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   wsync();
   // pivots in blocks of KB: the panel rows of a block are loaded together (row i: entries 0..i; lane b takes entry b)
   constexpr int KB = TE - 1 < 8 ? TE - 1 : 8;
@@ -584,7 +585,8 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
   }
 
 // ==========================================================================================
-__global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, const LaunchArgs Ain) {
+template <bool STAGED>
+__global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, const LaunchArgs Ain) {
   DevPlan2 P = Pin;
   P.rec = as_global(Pin.rec); P.brec = as_global(Pin.brec);
   LaunchArgs A = Ain;
@@ -597,10 +599,26 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4, l = lane & 15;
-  const int prob0 = (blockIdx.x * WPB + wave) * 4;
+  int widx = blockIdx.x * WPB + wave;
+  // STAGED: the wave runs ONE task (a subtree of the elimination tree, or a front above the cut) of one group of problems
+  int t_rec = 0, t_nfr = P.nsuper, t_brec = 0, t_root = 1;
+  if constexpr (STAGED) {
+    const int task = widx / A.nquads;
+    if (task >= A.ntasks) return;
+    widx -= task * A.nquads;
+    const int32_t* tk = as_global(A.tasks) + 4 * (A.task0 + task);
+    t_rec = rfl(tk[0]); t_nfr = rfl(tk[1]); t_brec = rfl(tk[2]); t_root = rfl(tk[3]);
+  }
+  const int nfr = t_nfr;
+  const int prob0 = widx * 4;
   if (prob0 >= A.batch) return;
   const int prob = prob0 + g;
-  const bool valid = prob < A.batch;
+  bool valid_ = prob < A.batch;
+  if (!STAGED && A.skip_done) {  // behind a staged attempt: only the problems that failed it are processed
+    if (valid_ && as_global(A.success)[prob] == 1) valid_ = false;
+    if (!__any(valid_)) return;
+  }
+  const bool valid = valid_;
   const long long pclamp = valid ? prob : prob0;
 
   const int wave_doubles = (P.recwords >> 1) + 4 * P.prob_doubles + 8;
@@ -804,10 +822,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   }
 
   STAMP_DECL
-  while (A.mode != MODE_SOLVE) {
+  const bool do_fwd = STAGED ? A.phase == 0 : A.mode != MODE_SOLVE;
+  while (do_fwd) {
     STAMP_BEGIN
     // ---------------- forward pass over the record stream ----------------
-    if (l == 0) { cnt[g * 2] = xpos; cnt[g * 2 + 1] = xzer; }
+    if (l == 0) { cnt[g * 2] = STAGED ? 0 : xpos; cnt[g * 2 + 1] = STAGED ? 0 : xzer; }
     int rpos = 0, rzer = 0;  // per-lane tallies of the condensed residual pivots staged by this lane
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
     const bool needs_fix = __any(ovr) || !has_rhs;  // wave-uniform: some value must be replaced at assembly time
@@ -818,14 +837,14 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
 #pragma unroll
     for (int j = 0; j < PVR; j++) pvr[j] = 0.0;
     prr[0] = prr[1] = 0.0;
-    int roff = 0;     // word offset of the current record
-    int nxt_off = 0;  // word offset of the next record
+    int roff = t_rec;  // word offset of the current record
+    int nxt_off = 0;   // word offset of the next record
     int s = 0;
     // Outer loop: (re)start the pipeline at front s, then either hand a rare large front to the out-of-line path
     // or run the inner loop over a stretch of fast fronts.  The inner loop contains NO call: values that live
     // across a call are spilled, and every reload from scratch (a VMEM access) waits for all outstanding
     // prefetches, which used to stall every front.
-    while (s < P.nsuper) {
+    while (s < nfr) {
       int* recw = recbuf;
       {
         // record s synchronously, then prefetch record s+1 and the values of s
@@ -989,7 +1008,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       // (4) next record over the current one (nothing below reads the lists); prefetch the one after and the next front's values
       int nroff = nxt_off;
       more = false;
-      if (s + 1 < P.nsuper) {
+      if (s + 1 < nfr) {
         int* nrec = recbuf;
         // header words of the next record straight from the prefetch registers: lane q holds words 4q .. 4q+3
         const int nlen = __builtin_amdgcn_readlane(R0.z, 0);          // R_RECLEN = 2
@@ -1037,6 +1056,13 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     wsync();
     for (int o = 8; o > 0; o >>= 1) { rpos += __shfl_xor(rpos, o, 16); rzer += __shfl_xor(rzer, o, 16); }
     const int tpos = cnt[g * 2] + rpos, tzer = cnt[g * 2 + 1] + rzer;
+    if constexpr (STAGED) {  // the counts of all tasks meet in global memory; the backward launches read them
+      if (valid && l == 0) {
+        if (tpos) atomicAdd(as_global(A.gcnt) + prob * 2, tpos);
+        if (tzer) atomicAdd(as_global(A.gcnt) + prob * 2 + 1, tzer);
+      }
+      return;
+    }
     const bool ok = (CNL_ABL != 0) || (tpos == P.nvar && tzer == 0);
     if (A.mode == MODE_FACTOR) {
       if (valid && l == 0) {
@@ -1067,6 +1093,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       for (int i = l; i < P.nvar; i += 16) vt[i] = wrote;
     }
   }
+  if constexpr (STAGED) {  // inertia rule on the sums of the forward launches (src/solver_types.jl:90-97)
+    const int* gc = as_global(A.gcnt) + pclamp * 2;
+    success = valid && gc[0] == P.nvar && gc[1] == 0;
+    nfact = 1;
+  }
   if (l == 0) cnt[8 + g] = (success && valid) ? 1 : 0;
   gsync();
   STAMP(5)
@@ -1079,12 +1110,12 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
     const double* myL = A.L + pclamp * P.lsize;
     double* mydout = A.d + pclamp * P.dstride;
     double* xs = myU;  // the x stack reuses the per-problem LDS area
-    int boff = 0, nxt = 0;
+    int boff = t_brec, nxt = 0;
     int4 Rb;
     double lr[KB];     // panel rows of the CURRENT front (first KB pivots), prefetched one front ahead
     bool primed = false;
     int s = 0;
-    while (s < P.nsuper) {
+    while (s < nfr) {
       int* recw = recbuf + (s & 1) * P.breccap;
       if (!primed) {
         const int len = P.brec[boff + B_RECLEN];
@@ -1127,7 +1158,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       // next record into the other buffer, then prefetch the record after it and the next front's panel rows
       double lrn[KB];
       int nboff = nxt;
-      if (s + 1 < P.nsuper) {
+      if (s + 1 < nfr) {
         int* nrec = recbuf + ((s + 1) & 1) * P.breccap;
         // next header words straight from the prefetch registers (lane 0: words 0..3, lane 1: words 4..7)
         const int nlen = __builtin_amdgcn_readlane(Rb.z, 0);   // B_RECLEN = 2
@@ -1153,6 +1184,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
       const int tu = tri2(1 + nupd);
       double xb = l == 0 ? -1.0 : 0.0;
       if (pxoff >= 0 && l >= 1 && l <= nupd) xb = xs[pxoff + rec[B_HDR + l]];
+      if (pxoff == B_PX_GLOBAL && l >= 1 && l <= nupd)  // the parent was solved by another task: x = -d of the named components
+        xb = -__hip_atomic_load(mydout + rec[B_HDR + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       wsync();
 #pragma unroll
       for (int k = 0; k < KB; k++) {
@@ -1181,7 +1214,10 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel(const DevPlan2 Pin, con
   STAMP(6)
   if (lane == 0 && A.npos) for (int k = 0; k < 8; k++) A.npos[(blockIdx.x * WPB + wave) * 8 + k] = (long long)st_acc[k];
 #endif
-  if (valid && l == 0 && A.mode == MODE_NEWTON) {
+  if constexpr (STAGED) {
+    // first attempt only: rho = 0, rho_old untouched; problems that failed are handed to the classic launch that follows
+    if (valid && l == 0 && t_root) { A.rho[prob] = 0.0; A.nfact[prob] = 1; A.success[prob] = success ? 1 : 0; }
+  } else if (valid && l == 0 && A.mode == MODE_NEWTON) {
     A.rho[prob] = rho;
     A.rho_old[prob] = rho_old;
     A.nfact[prob] = nfact;
@@ -1193,13 +1229,27 @@ hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const La
   if (wpb < 1 || wpb > 4) return hipErrorInvalidConfiguration;
   const int waves = (a.batch + 3) / 4;
   const int grid = (waves + wpb - 1) / wpb;
-  static size_t attr_set = 0;
-  if (lds_bytes > attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(newton2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    attr_set = lds_bytes;
-  }
-  hipLaunchKernelGGL(newton2_kernel, dim3(grid), dim3(64 * wpb), lds_bytes, stream, P, a);
+  // per device and cheap: set on every launch (a process may drive several devices)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(newton2_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(newton2_kernel_t<false>, dim3(grid), dim3(64 * wpb), lds_bytes, stream, P, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, LaunchArgs a, const int32_t* stage_ptr, int nstages, hipStream_t stream) {
+  if (wpb < 1 || wpb > 4) return hipErrorInvalidConfiguration;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(newton2_kernel_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  a.nquads = (a.batch + 3) / 4;
+  e = hipMemsetAsync(a.gcnt, 0, (size_t)a.batch * 2 * sizeof(int), stream);
+  if (e != hipSuccess) return e;
+  for (int pass = 0; pass < 2; pass++)
+    for (int q = 0; q < nstages; q++) {
+      const int st = pass == 0 ? q : nstages - 1 - q;  // forward: children first; backward: parents first
+      a.phase = pass; a.task0 = stage_ptr[st]; a.ntasks = stage_ptr[st + 1] - stage_ptr[st];
+      const long long waves = (long long)a.ntasks * a.nquads;
+      hipLaunchKernelGGL(newton2_kernel_t<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
+    }
   return hipGetLastError();
 }
 

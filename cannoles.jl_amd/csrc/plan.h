@@ -40,6 +40,18 @@ struct Options {
   int relax = -1;          // relaxed-amalgamation budget (extra zeros per merged column); -1 = default
   int lds_budget_doubles = 0; // 0 = default
   int with_rhs_row = 1;
+  // staged execution for small batches (kernels2.hip, STAGED): choose the order by the critical path of the elimination
+  // tree and cut the tree into tasks that run on different wavefronts.  par = wavefront slots available per group of four
+  // problems (the throughput term of the score), task_cap = largest number of fronts of a bottom task.
+  int latency = 0;
+  int par = 256;
+  int task_cap = 0;
+};
+
+// One task of the staged execution: fronts [f0, f1) (a complete subtree, or a single front above the cut) processed by
+// one wavefront; tasks of a stage are independent, a task's children belong to earlier stages.
+struct Task {
+  int32_t stage, f0, f1, rec_off, brec_off, is_root;
 };
 
 struct Plan {
@@ -89,7 +101,13 @@ struct Plan {
   int64_t d_owned = 0;   // number of condensed residual pivots staged (and counted) by the direct records
   bool d_outer = false;  // backward records name solution components in the caller's numbering (set with rec_direct)
   int32_t nnz_outer = 0, n_outer = 0;  // outer (reference) nnz and N when rec_direct
+  // staged execution (empty: the plan runs as one sequential stream per group of four problems)
+  std::vector<Task> tasks;          // sorted by stage
+  std::vector<int32_t> stage_ptr;   // tasks of stage s: [stage_ptr[s], stage_ptr[s + 1])
+  double cpath = 0;                 // model cost of the critical path of the chosen order
 };
+// offsets of the tasks inside the record streams (call again after the forward records are rewritten)
+void finalize_tasks(Plan& P);
 
 // contributions of every source of the condensed system in terms of the original arrays (see condense.h)
 struct DirectLists {
@@ -108,6 +126,7 @@ enum {
 enum { RF_U_GLOBAL = 1, RF_FS_GLOBAL = 2 };
 enum { C_UOFF = 0, C_TUC, C_FLAGS, C_PAD, C_HDR = 4 };
 enum { B_NPIV = 0, B_NUPD, B_RECLEN, B_XOFF, B_PXOFF, B_LPTR_LO, B_LPTR_HI, B_CLS, B_HDR = 8 };
+enum { B_PX_NONE = -1, B_PX_GLOBAL = -2 };  // B_PXOFF: no parent / parent solved by another task: the update rows name solution components
 
 // Builds the plan.  rows1/cols1: 1-based COO of the lower triangle, duplicates
 // allowed (summed).  Returns 0 or an error code (see cannoles_hip.h); msg gets

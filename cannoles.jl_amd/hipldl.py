@@ -29,7 +29,7 @@ _lib = None
 # symbols declared in include/cannoles_hip.h (checked by the CPU test-suite)
 ABI_SYMBOLS = [
     "cnl_last_error", "cnl_version", "cnl_default_params",
-    "cnl_plan_create", "cnl_plan_destroy", "cnl_plan_info", "cnl_plan_get", "cnl_plan_order_name",
+    "cnl_plan_create", "cnl_plan_create_for_batch", "cnl_plan_destroy", "cnl_plan_info", "cnl_plan_get", "cnl_plan_order_name",
     "cnl_create", "cnl_destroy", "cnl_get_plan",
     "cnl_factorize", "cnl_solve", "cnl_newton_system",
     "cnl_factorize_dev", "cnl_solve_dev", "cnl_newton_system_dev",
@@ -59,6 +59,7 @@ def lib():
         L.cnl_version.restype = i32
         L.cnl_default_params.argtypes = [vp]
         L.cnl_plan_create.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64]
+        L.cnl_plan_create_for_batch.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64, i64]
         L.cnl_plan_destroy.argtypes = [vp]
         L.cnl_plan_destroy.restype = None
         L.cnl_plan_info.argtypes = [vp, _i64p]
@@ -134,10 +135,14 @@ class Plan:
     """Host-only symbolic analysis (what `ldl_analyze` is to the reference).
     Needs no GPU; used by the CPU test-suite and for sizing."""
 
-    def __init__(self, N, rows, cols, nvar, nequ, ncon):
+    def __init__(self, N, rows, cols, nvar, nequ, ncon, batch=None):
         self.rows, self.cols = _i64(rows), _i64(cols)
         p = C.c_void_p()
-        _check(lib().cnl_plan_create(C.byref(p), int(N), len(self.rows), self.rows, self.cols, int(nvar), int(nequ), int(ncon)))
+        if batch is None:  # the large-batch analysis
+            _check(lib().cnl_plan_create(C.byref(p), int(N), len(self.rows), self.rows, self.cols, int(nvar), int(nequ), int(ncon)))
+        else:              # what cnl_create(batch) runs
+            _check(lib().cnl_plan_create_for_batch(C.byref(p), int(N), len(self.rows), self.rows, self.cols, int(nvar), int(nequ),
+                                                   int(ncon), int(batch)))
         self._p = p
         self.info = _plan_info(p)
 
@@ -181,7 +186,7 @@ class HIPLDLStruct:
         cfg = np.zeros(8, np.int64)
         _check(lib().cnl_get_config(h, cfg))
         self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4]),
-                       "kernel": {2: "v2", 3: "dense"}.get(int(cfg[5]), "v1"), "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7])}
+                       "kernel": {2: "v2", 3: "dense", 4: "v2-staged"}.get(int(cfg[5]), "v1"), "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7])}
 
     def plan_array(self, name):
         return _plan_array(lib().cnl_get_plan(self._h), name)

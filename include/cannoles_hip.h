@@ -59,6 +59,11 @@ void cnl_default_params(double params[9]);
  *      src/solver_types.jl:61-65: sparse()+triu()+ldl_analyze) ---------------- */
 int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
                     int64_t nvar, int64_t nequ, int64_t ncon);
+/* The analysis cnl_create(batch) runs: batches too small to give every CU a wavefront get an order with a bushy elimination
+ * tree, cut into tasks that run on different wavefronts (plan arrays "tasks", "stage_ptr"); large batches get the order with
+ * the least total work (one sequential record stream per four problems).  cnl_plan_create is the large-batch analysis.      */
+int cnl_plan_create_for_batch(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
+                              int64_t nvar, int64_t nequ, int64_t ncon, int64_t batch);
 void cnl_plan_destroy(cnl_plan* plan);
 /* info[0]=N [1]=nnz [2]=unique nnz(K) [3]=nsuper [4]=nnz(L) stored (strictly lower, with relaxed zeros)
  * [5]=nnz(L) of the ordering without relaxation [6]=factor storage doubles/problem [7]=largest front order
@@ -73,7 +78,8 @@ int cnl_plan_info(const cnl_plan* plan, int64_t info[16]);
  * "fronts" (16 int32 per front, struct FrontHdr in csrc/plan.h), "seg_ptr", "asm_pos", "asm_src",
  * "child_idx", "rel_idx".  Condensation lists (csrc/condense.h): "c_ptr", "c_a", "c_b", "c_d", "orig_of",
  * "r_orig", "r_dsrc", "r_ptr", "r_jsrc", "r_jx".  Record streams of the register-front kernel (csrc/plan.h; empty when that
- * kernel does not serve the plan): "rec", "brec".  With out == NULL only *count is set.
+ * kernel does not serve the plan): "rec", "brec".  Staged plans: "tasks" (6 int32 per task, struct Task in csrc/plan.h: stage,
+ * first front, end front, record offset, backward record offset, 1 if a root), "stage_ptr".  With out == NULL only *count is set.
  * Used by the tests' plan simulator and to hand the ordering to the oracle.                          */
 int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* count);
 const char* cnl_plan_order_name(const cnl_plan* plan);
@@ -155,7 +161,7 @@ int cnl_last_kernel_ms(cnl_handle* h, float* ms);
 /* Kernel configuration actually chosen: cfg[0]=threads per problem, [1]=problems per workgroup,
  * [2]=LDS bytes per workgroup, [3]=1 if the work stack lives in LDS else 0 (global scratch),
  * [4]=grid size (those five describe the general kernel, kernels.hip), [5]=2 if the register-front
- * kernel (kernels2.hip) serves newton_system/factorize else 1, [6]=its wavefronts per workgroup,
+ * kernel (kernels2.hip) serves newton_system/factorize (4: with staged execution of the first attempt), 3 dense backend, else 1, [6]=its wavefronts per workgroup,
  * [7]=its LDS bytes per workgroup.                                                              */
 int cnl_get_config(const cnl_handle* h, int64_t cfg[8]);
 

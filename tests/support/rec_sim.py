@@ -142,3 +142,131 @@ class RecSim:
                 xs[xoff + l] = x[l]
             off += int(H[B_RECLEN])
         return d
+
+
+class StagedSim(RecSim):
+    """The same streams executed the way the STAGED kernel runs a latency plan (csrc/plan.h, struct Task): stage by stage,
+    every task with an empty LDS stack of its own, task roots handing their update matrix over through the global scratch
+    and reading the parent's solution from d.  Update matrices are stored like the kernel stores them — rows of 16 lanes,
+    ascending, so that up to 15 doubles past the matrix are clobbered (NaN here) — which is what makes overlapping slots
+    visible.  `order` permutes the tasks of a stage (they must be independent)."""
+
+    def __init__(self, plan, nnz_src, n_rhs):
+        super().__init__(plan, nnz_src, n_rhs)
+        self.tasks = plan.array("tasks").astype(np.int64).reshape(-1, 6)
+        self.stage_ptr = plan.array("stage_ptr").astype(np.int64)
+        assert len(self.tasks) > 1, "not a staged plan"
+
+    def _store_u(self, mem, uoff, F, nupd):
+        for a in range(nupd + 1):
+            row = np.full(16, np.nan)
+            row[:a + 1] = F[a, :a + 1]
+            mem[uoff + tri(a): uoff + tri(a) + 16] = row
+
+    def run(self, vals, rhs, eig_tol, n_out, reverse=False, gs_doubles=None, lds_doubles=4096):
+        rec, br = self.rec, self.brec
+        src_val = lambda s: vals[s] if s < self.nnz else rhs[s - self.nnz]
+        L = np.zeros(self.lsize + 64)
+        gs = np.full((gs_doubles or 1 << 22) + 64, np.nan)
+        npos = nzer = 0
+        nst = len(self.stage_ptr) - 1
+        covered = np.zeros(self.ns, bool)
+        # ---- forward, children first
+        for st in range(nst):
+            tl = list(range(int(self.stage_ptr[st]), int(self.stage_ptr[st + 1])))
+            for t in (reversed(tl) if reverse else tl):
+                stage, f0, f1, off, boff, is_root = (int(v) for v in self.tasks[t])
+                assert stage == st
+                lds = np.full(lds_doubles, np.nan)
+                for s in range(f0, f1):
+                    assert not covered[s]
+                    covered[s] = True
+                    H = rec[off:off + R_HDR]
+                    npiv, nupd, nasm, nasmv = int(H[R_NPIV]), int(H[R_NUPD]), int(H[R_NASM]), int(H[R_NASMV])
+                    flags, cls = int(H[R_FLAGS]) & 0xff, int(H[R_FLAGS]) >> 8
+                    aoff, coff = int(H[R_ASM_OFF]), int(H[R_CHILD_OFF])
+                    nprod, nrd_own, nraw = int(H[R_NPROD]) & 0xffff, int(H[R_NPROD]) >> 16, int(H[R_NRAW])
+                    nrd = int(H[R_NRD]) & 0xffff
+                    f = 1 + nupd + npiv
+                    strided = cls == 16 and not (flags & RF_FS_GLOBAL)
+                    img = np.zeros(max(256, tri(f) + 16) if strided else tri(f) + 16)
+                    pos_of = (lambda a, b: a * 16 + b) if strided else (lambda a, b: tri(a) + b)
+                    r = rec[off:off + int(H[R_RECLEN])]
+                    for e in range(nasm):
+                        img[int(r[aoff + nasm + e])] += src_val(int(r[aoff + e]))
+                    raw_off = aoff + 2 * nasm
+                    jraw = np.array([src_val(int(r[raw_off + q])) for q in range(nraw)])
+                    npos += int((jraw[:nrd_own] > eig_tol).sum())
+                    nzer += int((np.abs(jraw[:nrd_own]) <= eig_tol).sum())
+                    jr = jraw.copy()
+                    jr[:nrd] = -1.0 / jraw[:nrd]
+                    poff = raw_off + nraw
+                    for e in range(nprod):
+                        if strided:
+                            w = int(r[poff + e])
+                            p, ia, ib, idd = w & 255, (w >> 8) & 127, (w >> 15) & 127, (w >> 22) & 127
+                            if nraw == 0:
+                                continue
+                        else:
+                            p, w = int(r[poff + 2 * e]), int(r[poff + 2 * e + 1])
+                            ia, ib, idd = w & 1023, (w >> 10) & 1023, (w >> 20) & 1023
+                        img[p] += jr[ia] * jr[ib] * jr[idd]
+                    co = coff
+                    for _c in range(int(H[R_NCHILD])):
+                        cu, tuc, cfl = int(r[co]), int(r[co + 1]), int(r[co + 2])
+                        Uc = (gs if cfl else lds)[cu:cu + tuc]
+                        assert not np.isnan(Uc).any(), f"front {s}: child update matrix at {'global' if cfl else 'LDS'} offset {cu} is not intact"
+                        for q in range(tuc):
+                            img[int(r[co + 4 + q])] += Uc[q]
+                        co += 4 + ((tuc + 3) & ~3)
+                    F = np.zeros((f, f))
+                    for a in range(f):
+                        for b in range(a + 1):
+                            F[a, b] = img[pos_of(a, b)]
+                    lptr = int(H[R_LPTR_LO]) | (int(H[R_LPTR_HI]) << 31)
+                    tu = tri(1 + nupd)
+                    for i in range(f - 1, nupd, -1):
+                        dd = F[i, i]
+                        npos += dd > eig_tol
+                        nzer += abs(dd) <= eig_tol
+                        w = F[i, :i].copy()
+                        lv = w / dd
+                        L[lptr + tri(i) - tu: lptr + tri(i) - tu + i] = lv
+                        L[lptr + tri(i) - tu + i] = dd
+                        for a in range(i):
+                            F[a, :a + 1] -= w[a] * lv[:a + 1]
+                    uglob = bool(flags & RF_U_GLOBAL)
+                    if s == f1 - 1:
+                        assert uglob, "a task root must leave its update matrix in the global scratch"
+                    self._store_u(gs if uglob else lds, int(H[R_UOFF]), F, nupd)
+                    off += int(H[R_RECLEN])
+        assert covered.all(), "fronts outside every task"
+        # ---- backward, parents first
+        d = np.full(n_out, np.nan)
+        for st in range(nst - 1, -1, -1):
+            tl = list(range(int(self.stage_ptr[st]), int(self.stage_ptr[st + 1])))
+            for t in (reversed(tl) if reverse else tl):
+                stage, f0, f1, off, boff, is_root = (int(v) for v in self.tasks[t])
+                xs = {}
+                for _ in range(f1 - f0):
+                    H = br[boff:boff + B_HDR]
+                    npiv, nupd, xoff, pxoff = int(H[B_NPIV]), int(H[B_NUPD]), int(H[B_XOFF]), int(H[B_PXOFF])
+                    lptr = int(H[B_LPTR_LO]) | (int(H[B_LPTR_HI]) << 31)
+                    f = 1 + nupd + npiv
+                    idx = br[boff + B_HDR: boff + B_HDR + f]
+                    x = np.zeros(f)
+                    for l in range(1, nupd + 1):
+                        if pxoff == -2:
+                            x[l] = -d[int(idx[l])]
+                        else:
+                            x[l] = xs[pxoff + int(idx[l])]
+                    assert not np.isnan(x).any(), "solution of the parent not available"
+                    tu = tri(1 + nupd)
+                    for i in range(nupd + 1, f):
+                        row = L[lptr + tri(i) - tu: lptr + tri(i) - tu + i]
+                        x[i] = row[0] - np.dot(row[1:i], x[1:i])
+                        d[int(idx[i])] = -x[i]
+                    for l in range(1, f):
+                        xs[xoff + l] = x[l]
+                    boff += int(H[B_RECLEN])
+        return d, int(npos), int(nzer)

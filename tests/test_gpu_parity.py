@@ -387,12 +387,16 @@ def test_multipliers_last_large_fronts(built, monkeypatch):
     run_case(s, v2, r2, check_fwd=False)
 
 
+@pytest.mark.parametrize("plan_kind", ["throughput", "latency"])
 @pytest.mark.parametrize("shape", [(400, 8, 2), (600, 6, 1), (600, 6, 4), (500, 0, 2), (1000, 10, 2)])
-def test_solve_ldl_on_the_register_front_kernel(built, shape):
+def test_solve_ldl_on_the_register_front_kernel(built, shape, plan_kind, monkeypatch):
     """try_to_factorize then solve_ldl! (src/solver_types.jl:69-98), the reference's literal call sequence, with several
-    right-hand sides per factorisation, on plans whose fronts are all of the fast class: cnl_solve then runs the forward
-    substitution with the stored factor on the register-front kernel.  Checked against the oracle's solve_ldl!."""
+    right-hand sides per factorisation.  "throughput": the large-batch analysis, whose fronts are all of the fast class:
+    cnl_solve then runs the forward substitution with the stored factor on the register-front kernel.  "latency": the
+    small-batch analysis (bushy order, tasks), whatever kernels serve it.  Checked against the oracle's solve_ldl!."""
     hipldl, syn, O = _mods()
+    if plan_kind == "throughput":
+        monkeypatch.setenv("CNL_STAGED_MAX", "0")
     n, p, hw = shape
     s = syn.band_structure(n, p, hw=hw)
     B = 6
@@ -402,7 +406,9 @@ def test_solve_ldl_on_the_register_front_kernel(built, shape):
     vals[:, off[6]:off[7]] = 0.125
     rows, cols = s.kkt_pattern()
     LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, vals, s.nvar, s.nequ, s.ncon, batch=B)
-    assert LDLT.info["v2"] is not None and LDLT.info["v2"]["fronts32"] + LDLT.info["v2"]["fronts64"] == 0
+    if plan_kind == "throughput":
+        assert LDLT.info["v2"] is not None and LDLT.info["v2"]["fronts32"] + LDLT.info["v2"]["fronts64"] == 0
+        assert LDLT.config["kernel"] == "v2"
     ok = hipldl.try_to_factorize(LDLT, vals, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16)
     assert ok.all()
     perm = LDLT.plan_array("perm").astype(np.int64)

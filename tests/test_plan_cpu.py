@@ -171,3 +171,33 @@ def test_record_streams_reproduce_the_oracle(shape, monkeypatch):
     kept = ~np.isnan(d)
     assert kept.sum() == s.N - s.nequ and not kept[s.nvar:s.nvar + s.nequ].any()
     assert np.abs(d[kept] - d0[kept]).max() <= 1e-10 * np.abs(d0).max()
+
+
+@pytest.mark.parametrize("shape", [(200, 4, 2, 1), (1000, 10, 2, 64), (1000, 10, 2, 1), (600, 6, 3, 8), (400, 0, 2, 4)])
+def test_staged_plans_reproduce_the_oracle(shape):
+    """Latency plans (what cnl_create builds for small batches: bushy order, elimination tree cut into tasks) executed by
+    tests/support/rec_sim.py::StagedSim the way the STAGED kernel runs them — every task on its own LDS stack, task roots
+    through the global scratch, tasks of a stage in either order — must reproduce the oracle's inertia and solution."""
+    from tests.support.rec_sim import StagedSim
+    n, p, hw, batch = shape
+    s = syn.band_structure(n, p, hw=hw)
+    rows, cols = s.kkt_pattern()
+    plan = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=batch)
+    tasks = plan.array("tasks").reshape(-1, 6)
+    assert len(tasks) > 1 and plan.array("stage_ptr")[-1] == len(tasks)
+    vals, rhs = syn.band_values(s, 78)
+    off = s.offsets()
+    vals[off[4]:off[5]] = -np.random.default_rng(2).uniform(0.5, 2.0, s.nequ)
+    vals[off[6]:off[7]] = 0.125
+    eig_tol = 2.220446049250313e-16
+    perm = plan.array("perm").astype(np.int64)
+    orc = O.Oracle(s.N, rows, cols, perm)
+    ok, pos0, zer0 = orc.try_to_factorize(vals, s.nvar, s.nequ, s.ncon, eig_tol, return_inertia=True)
+    d0 = orc.solve_ldl(rhs)
+    for reverse in (False, True):
+        sim = StagedSim(plan, s.nnzNS, s.N)
+        d, npos, nzer = sim.run(vals, rhs, eig_tol, s.N, reverse=reverse)
+        assert (npos, nzer) == (pos0, zer0)
+        kept = ~np.isnan(d)
+        assert kept.sum() == s.N - s.nequ
+        assert np.abs(d[kept] - d0[kept]).max() <= 1e-10 * np.abs(d0).max()
