@@ -2,11 +2,13 @@
 """Newton systems/s (fp64) on a batch of constrained band NLS problems — BASELINE.json's metric.
 
 One "step" = one `newton_system!` (KKT assembly + LDL^T + inertia + rho ladder + solve,
-/root/reference/src/CaNNOLeS.jl:1008-1052) over a batch of B independent problems that share the
-sparsity pattern of BASELINE config 3 (n = nequ = 1e4, ncon = 50, band Jacobians), inputs already
-resident in HBM.  N > 1 GPUs: every rank owns its own shard of B problems (weak scaling, no
-collective on the data path; torch.distributed is used only for the barrier and the max-over-ranks
-time).  Prints ONE JSON line on rank 0.
+/root/reference/src/CaNNOLeS.jl:1008-1052) over a batch of independent problems that share the sparsity
+pattern of BASELINE config 3 (n = nequ = 1e4, ncon = 50, band Jacobians), inputs already resident in HBM.
+N > 1 GPUs: one process per GPU, every rank owns a contiguous shard of the problems
+(cannoles.jl_amd/sharding.py), no collective on the data path; torch.distributed is used only for the
+barrier and the max-over-ranks time.  Default: weak scaling, `--batch` problems per GPU.  `--strong --total T`
+splits T problems over the ranks (BASELINE config 4: `--strong --total 256 --n 1000 --ncon 10`).
+Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
@@ -23,8 +25,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy rate
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_MEASURED_GBPS = 6290.0  # float4 copy rate measured on MI355X (same guide)
+FP64_MFMA_SPEC_TFLOPS = 78.6       # datasheet fp64 matrix peak
+FP64_MFMA_MEASURED_TFLOPS = 47.8   # v_mfma_f64_16x16x4_f64 loop, 4 waves/SIMD x 8 accumulators (profiles/r02_microbench.json)
 CANONICAL_NNZL_CFG3 = 346209  # nnz(L) of the order "r, x natural, lambda" at n=1e4, p=50
+TRAFFIC_FILE = "r02_traffic.json"
 
 
 def band_batch(s, B, seed):
@@ -55,236 +61,337 @@ def band_batch(s, B, seed):
     return vals, rhs
 
 
+def backward_error(s, rows, cols, vals, rhs, d):
+    import scipy.sparse as sp
+    Kl = sp.coo_matrix((vals, (rows - 1, cols - 1)), shape=(s.N, s.N)).tocsr()
+    Ks = Kl + sp.tril(Kl, -1).T
+    res = Ks @ d + rhs
+    return float(np.abs(res).max() / (abs(Ks).sum(axis=1).max() * np.abs(d).max() + np.abs(rhs).max()))
+
+
+class DeviceProblem:
+    """device-resident buffers + handle for `B` problems of one pattern, and a timed loop over cnl_newton_system_dev"""
+
+    def __init__(self, torch, hipldl, s, rows, cols, vals, rhs, B, device_index, stream):
+        self.torch, self.hipldl, self.s, self.B = torch, hipldl, s, B
+        dev = vals.device
+        self.vals, self.rhs = vals, rhs
+        self.d = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
+        self.rho_old = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.rho = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.nfact = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.succ = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.params = hipldl.default_params()
+        self.L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, device=device_index)
+        self.stream = stream
+
+    def step(self):
+        self.rho_old.zero_()
+        self.hipldl.newton_system_dev(self.L, self.vals.data_ptr(), self.rhs.data_ptr(), self.d.data_ptr(), self.rho_old.data_ptr(),
+                                      self.rho.data_ptr(), self.nfact.data_ptr(), self.succ.data_ptr(), self.params, self.stream.cuda_stream)
+
+    def timed(self, steps, warmup):
+        """ms per step by HIP events on the launch stream"""
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                self.step()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            for _ in range(steps):
+                self.step()
+            e1.record(self.stream)
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / max(steps, 1)
+
+    def counts(self):
+        return [self.B, int((self.succ == 1).sum().item())]
+
+    def close(self):
+        self.L.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CNL_BENCH_BATCH", 8192)), help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CNL_BENCH_BATCH", 8192)), help="problems per GPU (weak scaling)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --total problems split over the ranks")
+    ap.add_argument("--total", type=int, default=256, help="total problems with --strong")
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--ncon", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="problems timed on the CPU oracle (-1 auto, 0 off)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small-batch, PCIe-inclusive, cfg2 and f1 blocks")
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    import cannoles_jl_amd  # noqa: F401
+    from cannoles_jl_amd import hipldl, sharding, synthetic as syn
+
+    rank, local_rank, world = sharding.env_rank()
+    if world != args.gpus and rank == 0:
+        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_.init_process_group("nccl", rank=rank, world_size=world)
-        dist = dist_
-
-    import cannoles_jl_amd  # noqa: F401
-    from cannoles_jl_amd import hipldl, synthetic as syn
+    dist = sharding.init("nccl")
 
     s = syn.band_structure(args.n, args.ncon, name="cfg3")
     rows, cols = s.kkt_pattern()
-    B = args.batch
+    total = args.total if args.strong else args.batch * world
     dev = torch.device("cuda", local_rank)
-    # synthetic inputs are generated on the host in chunks (bounded host memory) and uploaded; only the first
-    # chunk stays on the host, for the parity guard and the CPU-baseline sample
-    vals = torch.empty((B, s.nnzNS), dtype=torch.float64, device=dev)
-    rhs = torch.empty((B, s.N), dtype=torch.float64, device=dev)
-    CH = 512
-    vals_h = rhs_h = None
-    for ci, b0 in enumerate(range(0, B, CH)):
-        nb = min(CH, B - b0)
-        vh, rh = band_batch(s, nb, seed=3000 + 1000 * rank + ci)
-        vals[b0:b0 + nb].copy_(torch.from_numpy(vh))
-        rhs[b0:b0 + nb].copy_(torch.from_numpy(rh))
-        if ci == 0:
-            vals_h, rhs_h = vh, rh
-    d = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
-    rho_old = torch.zeros(B, dtype=torch.float64, device=dev)
-    rho = torch.zeros(B, dtype=torch.float64, device=dev)
-    nfact = torch.zeros(B, dtype=torch.int32, device=dev)
-    succ = torch.zeros(B, dtype=torch.int32, device=dev)
-    params = hipldl.default_params()
-
-    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, device=local_rank)
     stream = torch.cuda.Stream(device=dev)
-    sh = stream.cuda_stream
+    host_chunk = {}
 
-    def step():
-        rho_old.zero_()
-        hipldl.newton_system_dev(LDLT, vals.data_ptr(), rhs.data_ptr(), d.data_ptr(), rho_old.data_ptr(), rho.data_ptr(),
-                                 nfact.data_ptr(), succ.data_ptr(), params, sh)
+    def make_executor(g0, g1):
+        """this rank's shard: problems [g0, g1) of the job, generated on the host in chunks (bounded host memory) and uploaded;
+        only the first chunk stays on the host, for the parity guard and the CPU-baseline sample.  Seeds follow the global
+        problem number."""
+        nloc = g1 - g0
+        vals = torch.empty((nloc, s.nnzNS), dtype=torch.float64, device=dev)
+        rhs = torch.empty((nloc, s.N), dtype=torch.float64, device=dev)
+        CH = 512
+        for b0 in range(0, nloc, CH):
+            nb = min(CH, nloc - b0)
+            vh, rh = band_batch(s, nb, seed=3000 + (g0 + b0))
+            vals[b0:b0 + nb].copy_(torch.from_numpy(vh))
+            rhs[b0:b0 + nb].copy_(torch.from_numpy(rh))
+            if b0 == 0:
+                host_chunk["vals"], host_chunk["rhs"] = vh, rh
+        return DeviceProblem(torch, hipldl, s, rows, cols, vals, rhs, nloc, local_rank, stream)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    # the per-rank driver shared with the CPU (gloo) test: shard, warm-up, barrier + synchronize on both sides of exactly
+    # `steps` steps, max over ranks, job-wide counts
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        for _ in range(args.steps):
-            step()
-        ev1.record(stream)
-        barrier()
-        t1 = time.perf_counter()
-    elapsed = t1 - t0
-    step_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # HIP events on the launch stream: whole step (3 kernels)
-    # duration of the dominant kernel alone (the multifrontal kernel), HIP events inside the library on the same
-    # stream, measured over a few extra launches AFTER the timed region (timing mode synchronises every call)
+        elapsed, counts, prob, (g0, g1) = sharding.run_shard(total, make_executor, args.steps, args.warmup, dist,
+                                                             sync=torch.cuda.synchronize, device=dev)
+    B = g1 - g0
+    vals_h, rhs_h = host_chunk.get("vals"), host_chunk.get("rhs")
+    vals, rhs = (prob.vals, prob.rhs) if prob else (None, None)
+
+    if rank != 0:
+        if prob:
+            prob.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    LDLT = prob.L
+    step_ms = prob.timed(min(10, max(2, args.steps)), 1)  # HIP events on the launch stream: the whole step of this rank
+    # duration of the dominant kernel alone (the multifrontal kernel), HIP events inside the library on the launch
+    # stream, over a few extra launches AFTER the timed region (timing mode synchronises every call)
     LDLT.set_timing(True)
     kms = []
     with torch.cuda.stream(stream):
         for _ in range(min(5, max(2, args.steps))):
-            step()
+            prob.step()
             kms.append(LDLT.last_kernel_ms())
     LDLT.set_timing(False)
     kern_ms = float(np.mean(kms))
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # SURVEY 8 row f1 (vectors either side of the system, device-resident): timed after the headline region, on the
-    # same shapes; algorithmic bytes = J_F and J_c values + r, lambda, F, c read + rhs written (resp. x, r, lambda, d
-    # read + xt, rt, lambdat, dlambda written)
-    f1 = None
-    if rank == 0:
-        rv = torch.randn((B, s.nequ), dtype=torch.float64, device=dev)
-        lam = torch.randn((B, max(s.ncon, 1)), dtype=torch.float64, device=dev)
-        Fx = torch.randn((B, s.nequ), dtype=torch.float64, device=dev)
-        cx = torch.randn((B, max(s.ncon, 1)), dtype=torch.float64, device=dev)
-        xv = torch.randn((B, s.nvar), dtype=torch.float64, device=dev)
-        rhs2 = torch.empty_like(rhs)
-        nrm = torch.zeros((B, 2), dtype=torch.float64, device=dev)
-        xt, rt, lt, dl = torch.empty_like(xv), torch.empty_like(rv), torch.empty_like(lam), torch.empty_like(lam)
-
-        def timed(fn, reps=5):
-            with torch.cuda.stream(stream):
-                fn()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                for _ in range(reps):
-                    fn()
-                e1.record(stream)
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
-
-        ms_rv = timed(lambda: hipldl.residual_vectors_dev(LDLT, vals.data_ptr(), rv.data_ptr(), lam.data_ptr(), Fx.data_ptr(),
-                                                          cx.data_ptr(), rhs2.data_ptr(), nrm.data_ptr(), sh))
-        ms_tp = timed(lambda: hipldl.trial_point_dev(LDLT, xv.data_ptr(), rv.data_ptr(), lam.data_ptr(), d.data_ptr(), 1e4,
-                                                     xt.data_ptr(), rt.data_ptr(), lt.data_ptr(), dl.data_ptr(), sh))
-        nnzj = len(s.jF[0]) + len(s.jc[0])
-        by_rv = 8 * (nnzj + 2 * s.nequ + 2 * s.ncon + s.N)
-        by_tp = 8 * (s.nvar + s.nequ + s.ncon + s.N + s.nvar + s.nequ + 2 * s.ncon)
-        f1 = {"residual_vectors": {"ms": ms_rv, "bytes_per_system": by_rv, "GBps": by_rv * B / (ms_rv * 1e-3) / 1e9,
-                                   "frac": by_rv * B / (ms_rv * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-              "trial_point": {"ms": ms_tp, "bytes_per_system": by_tp, "GBps": by_tp * B / (ms_tp * 1e-3) / 1e9,
-                              "frac": by_tp * B / (ms_tp * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
-        del rv, lam, Fx, cx, xv, rhs2, nrm, xt, rt, lt, dl
-
-    ok = bool((succ == 1).all().item())
-    # parity guard inside the bench: residual of the first problems (size-independent property)
+    ok = counts[1] == counts[0]
     nchk = min(B, 4)
-    import scipy.sparse as sp
-    d_h = d[:nchk].cpu().numpy()
-    berr = 0.0
-    for b in range(nchk):
-        Kl = sp.coo_matrix((vals_h[b], (rows - 1, cols - 1)), shape=(s.N, s.N)).tocsr()
-        Ks = Kl + sp.tril(Kl, -1).T
-        res = Ks @ d_h[b] + rhs_h[b]
-        berr = max(berr, np.abs(res).max() / (abs(Ks).sum(axis=1).max() * np.abs(d_h[b]).max() + np.abs(rhs_h[b]).max()))
+    d_h = prob.d[:nchk].cpu().numpy()
+    berr = max(backward_error(s, rows, cols, vals_h[b], rhs_h[b], d_h[b]) for b in range(nchk))
 
-    if rank == 0:
-        systems = B * args.steps * world
-        value = systems / elapsed
-        nnzL_own = LDLT.info["nnzL"]
-        nnzL_star = min(nnzL_own, CANONICAL_NNZL_CFG3) if (args.n, args.ncon) == (10000, 50) else nnzL_own
-        b_alg = 12 * s.nnzNS + 24 * s.N + 32 * nnzL_star
-        achieved = b_alg * B / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (see profiles/)
-            tj = json.load(open(tpath))
-            if tj.get("batch") == B and tj.get("workload") == [args.n, args.ncon]:
-                traffic = tj.get("hbm_bytes_per_launch")
-        out = {
-            "metric": "Newton systems/sec (fp64), batched n=1e4 NLS; achieved HBM GB/s vs peak",
-            "value": value, "unit": "systems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg3 band constrained NLS n={args.n} nequ={args.n} ncon={args.ncon}, "
-                                   f"{B} independent problems per GPU, one newton_system! per problem per step",
-                       "batch_per_gpu": B, "sharding": f"independent problems, {world} shard(s), no collective",
-                       "ordering": LDLT.info["order"], "nnzL": nnzL_own, "fronts": LDLT.info["nsuper"],
-                       "kernel": LDLT.config, "all_success": ok, "backward_error": berr},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "bytes_per_system": b_alg, "kernel_ms": kern_ms, "kernel": "newton2_kernel",
-                         "step_ms": step_ms, "step_frac": b_alg * B / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-        }
-        out["aux_f1"] = f1  # not part of `value`: rhs assembly + norms, trial point, roofline = HBM
-        # CPU baseline: the oracle (restated LDLFactorizations path) on a bounded sample, 1 thread
-        ncpu = args.cpu_sample
-        if ncpu != 0 and world == 1:  # reported at N=1 only (the multi-GPU runs stay short)
-            from oracle import oracle as O
-            # the oracle gets the product's own fill-reducing order (the fairest CPU baseline; the canonical
-            # r/x/lambda order of SURVEY.md has 2.4x the fill)
-            orc = O.Oracle(s.N, rows, cols, LDLT.plan_array("perm").astype(np.int64))
-            if ncpu < 0:
-                tt = time.perf_counter()
-                O.newton_system_batch(orc, 1, s.nvar, s.nequ, s.ncon, rhs_h[:1], vals_h[:1].copy(), None, params)
-                one = time.perf_counter() - tt
-                ncpu = int(max(4, min(len(vals_h), 12.0 / max(one, 1e-4))))
-            tt = time.perf_counter()
-            d0, ok0, _, _, nf0 = O.newton_system_batch(orc, ncpu, s.nvar, s.nequ, s.ncon, rhs_h[:ncpu], vals_h[:ncpu].copy(), None, params)
-            tc = time.perf_counter() - tt
-            dg = d[:min(ncpu, 8)].cpu().numpy()
-            perr = float(np.abs(dg - d0[:len(dg)]).max() / np.abs(d0[:len(dg)]).max())
-            out["cpu_baseline"] = {"value": ncpu / tc, "unit": "systems/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {ncpu} problems of rank 0's batch, oracle/cnl_oracle.c (restated "
-                                             f"LDLFactorizations up-looking LDL^T, the product's own ordering, nnzL={orc.nnzL}), "
-                                             f"host has {os.cpu_count()} logical cores",
-                                   "max_rel_diff_vs_gpu": perr}
-            # the same port on all host cores, one problem per thread ("(ii) all host cores"); each thread
-            # owns an oracle object, the ctypes calls release the GIL.  Bounded to a few seconds; reported beside the
-            # single-core figure, `cores` above stays the contract's figure.
-            try:
-                import concurrent.futures as cf
-                nthr = max(1, min(len(os.sched_getaffinity(0)), 64, len(vals_h)))
-                per = max(1, len(vals_h) // nthr)                   # problems per thread (its slice of the first chunk)
-                perm64 = LDLT.plan_array("perm").astype(np.int64)
-                orcs = [O.Oracle(s.N, rows, cols, perm64) for _ in range(nthr)]
-                deadline = time.perf_counter() + 4.0  # bounded: every thread repeats its slice for about 4 s
-                done = [0] * nthr
-
-                def work(k):
-                    lo = k * per
-                    while time.perf_counter() < deadline:
-                        O.newton_system_batch(orcs[k], per, s.nvar, s.nequ, s.ncon, rhs_h[lo:lo + per], vals_h[lo:lo + per].copy(), None, params)
-                        done[k] += per
-
-                tt = time.perf_counter()
-                with cf.ThreadPoolExecutor(nthr) as ex:
-                    list(ex.map(work, range(nthr)))
-                ta = time.perf_counter() - tt
-                out["cpu_baseline"]["all_cores"] = {"value": sum(done) / ta, "threads": nthr, "systems": sum(done)}
-            except Exception as e:  # the baseline is a reported figure, never a reason to fail the bench
-                out["cpu_baseline"]["all_cores"] = {"error": str(e)}
-        print(json.dumps(out))
-    LDLT.close()
+    systems = counts[0] * args.steps
+    value = systems / elapsed
+    info = LDLT.info
+    headline = (args.n, args.ncon) == (10000, 50)
+    # SURVEY.md §8d: B_alg = 12 nnzNS + 24 N + 32 nnz(L*), nnz(L*) = min(fill of the build's own ordering WITHOUT the
+    # explicit zeros of relaxed supernodes, canonical fill) — padding must not inflate the score
+    nnzL_star = min(info["nnzL_exact"], CANONICAL_NNZL_CFG3) if headline else info["nnzL_exact"]
+    b_alg = 12 * s.nnzNS + 24 * s.N + 32 * nnzL_star
+    achieved = b_alg * B / (kern_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    if os.path.exists(tpath):  # HBM bytes per launch of the dominant kernel from separate rocprofv3 PMC passes of this command
+        tj = json.load(open(tpath))
+        if tj.get("batch") == B and tj.get("workload") == [args.n, args.ncon]:
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_src = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, not measured by this run)"
+    out = {
+        "metric": "Newton systems/sec (fp64), batched n=1e4 NLS; achieved HBM GB/s vs peak",
+        "value": value, "unit": "systems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"cfg3 band constrained NLS n={args.n} nequ={args.n} ncon={args.ncon}, "
+                               + (f"{total} independent problems split over {world} GPU(s)" if args.strong else f"{B} independent problems per GPU")
+                               + ", one newton_system! per problem per step",
+                   "batch_per_gpu": B, "total_problems": counts[0], "sharding": f"independent problems, {world} contiguous shard(s), no collective",
+                   "ordering": info["order"], "nnzL_stored": info["nnzL"], "nnzL_exact": info["nnzL_exact"], "fronts": info["nsuper"],
+                   "kernel": LDLT.config, "all_success": ok, "backward_error": berr},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "frac_of_measured_copy_rate": achieved / HBM_MEASURED_GBPS, "peak_measured_copy": HBM_MEASURED_GBPS,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "measured_hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                     "bytes_per_system": b_alg, "nnzL_star": nnzL_star, "kernel_ms": kern_ms, "kernel": "newton2_kernel",
+                     "step_ms": step_ms, "step_frac": b_alg * B / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+    }
+    extras = (not args.no_extras) and world == 1 and not args.strong
+    if extras:
+        extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_h, prob, B, dev, local_rank, stream, args)
+    if args.cpu_sample != 0 and world == 1:
+        cpu_baseline(out, s, rows, cols, vals_h, rhs_h, prob, LDLT, args)
+    print(json.dumps(out))
+    prob.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_h, prob, B, dev, local_rank, stream, args):
+    """Reported beside `value`, never part of it: small batches, the host-pointer (PCIe-inclusive) entry,
+    BASELINE config 2 on the dense backend, and the vectors either side of the system (row f1)."""
+    # ---- small batches of the same pattern: handles planned for latency (staged execution of the elimination tree)
+    sb = {}
+    for bs in (256, 1):
+        if bs > B:
+            continue
+        p2 = DeviceProblem(torch, hipldl, s, rows, cols, vals[:bs], rhs[:bs], bs, local_rank, stream)
+        ms = p2.timed(20, 3)
+        dh = p2.d[:1].cpu().numpy()
+        sb[f"B{bs}"] = {"systems_per_s": bs / (ms * 1e-3), "ms_per_call": ms, "ordering": p2.L.info["order"], "kernel": p2.L.config["kernel"],
+                        "fronts": p2.L.info["nsuper"], "all_success": bool((p2.succ == 1).all().item()),
+                        "backward_error": backward_error(s, rows, cols, vals_h[0], rhs_h[0], dh[0])}
+        p2.close()
+    out["small_batch"] = sb
+    # ---- PCIe-inclusive: cnl_newton_system with HOST pointers (what the Julia glue calls): H2D of vals/rhs, the step, D2H of d
+    nb = min(len(vals_h), B)
+    Lh = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=nb, device=local_rank)
+    vv = vals_h[:nb].copy()
+    dd = np.zeros((nb, s.N))
+    ro = np.zeros(nb)
+    hipldl.newton_system_(dd, s.nvar, s.nequ, s.ncon, rhs_h[:nb], vv, Lh, ro, prob.params)
+    reps = 3
+    tt = time.perf_counter()
+    for _ in range(reps):
+        hipldl.newton_system_(dd, s.nvar, s.nequ, s.ncon, rhs_h[:nb], vv, Lh, ro, prob.params)
+    tw = (time.perf_counter() - tt) / reps
+    bytes_sys = 8 * (s.nnzNS + 2 * s.N + s.nvar)
+    out["pcie_inclusive"] = {"systems_per_s": nb / tw, "batch": nb, "ms_per_call": tw * 1e3, "bytes_per_system_over_pcie": bytes_sys,
+                             "link_GBps": nb * bytes_sys / tw / 1e9, "entry": "cnl_newton_system (host pointers)"}
+    Lh.close()
+    # ---- BASELINE config 2: dense Jacobian n = 1000, nequ = 2000 on the dense backend (fp64 MFMA roofline)
+    try:
+        s2 = syn.dense_structure(1000, 2000)
+        r2, c2 = s2.kkt_pattern()
+        flop = 2000 * 1000 ** 2 + 1000 ** 3 / 3  # SURVEY 8d: m n^2 + n^3 / 3
+        c2blk = {"flop_per_system": flop, "peak_spec_TFLOPs": FP64_MFMA_SPEC_TFLOPS, "peak_measured_TFLOPs": FP64_MFMA_MEASURED_TFLOPS}
+        for bs in (1, 8):
+            vh = np.stack([syn.dense_values(s2, 2002 + b)[0] for b in range(bs)])
+            rh = np.stack([syn.dense_values(s2, 2002 + b)[1] for b in range(bs)])
+            pv, pr = torch.from_numpy(vh).to(dev), torch.from_numpy(rh).to(dev)
+            p3 = DeviceProblem(torch, hipldl, s2, r2, c2, pv, pr, bs, local_rank, stream)
+            ms = p3.timed(20, 3)
+            dh = p3.d[0].cpu().numpy()
+            tf = flop * bs / (ms * 1e-3) / 1e12
+            c2blk[f"B{bs}"] = {"ms_per_system": ms / bs, "TFLOPs": tf, "frac_of_spec": tf / FP64_MFMA_SPEC_TFLOPS,
+                               "frac_of_measured_mfma": tf / FP64_MFMA_MEASURED_TFLOPS, "kernel": p3.L.config["kernel"],
+                               "all_success": bool((p3.succ == 1).all().item()), "backward_error": backward_error(s2, r2, c2, vh[0], rh[0], dh)}
+            p3.close()
+            del pv, pr
+        out["cfg2_dense"] = c2blk
+    except Exception as e:  # reported figure, never a reason to fail the bench
+        out["cfg2_dense"] = {"error": str(e)}
+    # ---- SURVEY 8 row f1 (vectors either side of the system, device-resident), on the headline shapes; algorithmic bytes =
+    # J_F and J_c values + r, lambda, F, c read + rhs written (resp. x, r, lambda, d read + xt, rt, lambdat, dlambda written)
+    LDLT = prob.L
+    sh = stream.cuda_stream
+    rv = torch.randn((B, s.nequ), dtype=torch.float64, device=dev)
+    lam = torch.randn((B, max(s.ncon, 1)), dtype=torch.float64, device=dev)
+    Fx = torch.randn((B, s.nequ), dtype=torch.float64, device=dev)
+    cx = torch.randn((B, max(s.ncon, 1)), dtype=torch.float64, device=dev)
+    xv = torch.randn((B, s.nvar), dtype=torch.float64, device=dev)
+    rhs2 = torch.empty_like(rhs)
+    nrm = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+    xt, rt, lt, dl = torch.empty_like(xv), torch.empty_like(rv), torch.empty_like(lam), torch.empty_like(lam)
+
+    def timed(fn, reps=5):
+        with torch.cuda.stream(stream):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                fn()
+            e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_rv = timed(lambda: hipldl.residual_vectors_dev(LDLT, vals.data_ptr(), rv.data_ptr(), lam.data_ptr(), Fx.data_ptr(),
+                                                      cx.data_ptr(), rhs2.data_ptr(), nrm.data_ptr(), sh))
+    ms_tp = timed(lambda: hipldl.trial_point_dev(LDLT, xv.data_ptr(), rv.data_ptr(), lam.data_ptr(), prob.d.data_ptr(), 1e4,
+                                                 xt.data_ptr(), rt.data_ptr(), lt.data_ptr(), dl.data_ptr(), sh))
+    nnzj = len(s.jF[0]) + len(s.jc[0])
+    by_rv = 8 * (nnzj + 2 * s.nequ + 2 * s.ncon + s.N)
+    by_tp = 8 * (s.nvar + s.nequ + s.ncon + s.N + s.nvar + s.nequ + 2 * s.ncon)
+    out["aux_f1"] = {"residual_vectors": {"ms": ms_rv, "bytes_per_system": by_rv, "GBps": by_rv * B / (ms_rv * 1e-3) / 1e9,
+                                          "frac": by_rv * B / (ms_rv * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                     "trial_point": {"ms": ms_tp, "bytes_per_system": by_tp, "GBps": by_tp * B / (ms_tp * 1e-3) / 1e9,
+                                     "frac": by_tp * B / (ms_tp * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+
+
+def cpu_baseline(out, s, rows, cols, vals_h, rhs_h, prob, LDLT, args):
+    """The oracle (restated LDLFactorizations path) on a bounded sample of the same workload, on the GPU box's host cores.
+    A reported baseline, not the optimisation target."""
+    from oracle import oracle as O
+    params = prob.params
+    # the oracle gets the product's own fill-reducing order (the fairest CPU baseline; the canonical r/x/lambda order of
+    # SURVEY.md has 2.4x the fill)
+    perm64 = LDLT.plan_array("perm").astype(np.int64)
+    orc = O.Oracle(s.N, rows, cols, perm64)
+    ncpu = args.cpu_sample
+    if ncpu < 0:
+        tt = time.perf_counter()
+        O.newton_system_batch(orc, 1, s.nvar, s.nequ, s.ncon, rhs_h[:1], vals_h[:1].copy(), None, params)
+        one = time.perf_counter() - tt
+        ncpu = int(max(4, min(len(vals_h), 10.0 / max(one, 1e-4))))
+    ncpu = min(ncpu, len(vals_h))
+    tt = time.perf_counter()
+    d0, ok0, _, _, nf0 = O.newton_system_batch(orc, ncpu, s.nvar, s.nequ, s.ncon, rhs_h[:ncpu], vals_h[:ncpu].copy(), None, params)
+    tc = time.perf_counter() - tt
+    dg = prob.d[:min(ncpu, 8)].cpu().numpy()
+    perr = float(np.abs(dg - d0[:len(dg)]).max() / np.abs(d0[:len(dg)]).max())
+    cb = {"value": ncpu / tc, "unit": "systems/s", "cores": 1, "kind": "port",
+          "sample": f"first {ncpu} problems of rank 0's batch, oracle/cnl_oracle.c (restated LDLFactorizations up-looking LDL^T, scatter-map "
+                    f"set_vals!, the product's own ordering, nnzL={orc.nnzL}), host has {os.cpu_count()} logical cores",
+          "max_rel_diff_vs_gpu": perr}
+    # the variant whose assembly mimics the reference's set_vals! literally: one binary search per entry in a CSC column
+    # (/root/reference/src/solver_types.jl:53-59) — what the reference actually pays per factorisation
+    try:
+        orb = O.Oracle(s.N, rows, cols, perm64)
+        orb.set_mode = 1
+        nb = max(2, ncpu // 4)
+        tt = time.perf_counter()
+        O.newton_system_batch(orb, nb, s.nvar, s.nequ, s.ncon, rhs_h[:nb], vals_h[:nb].copy(), None, params)
+        cb["set_vals_binary_search"] = {"value": nb / (time.perf_counter() - tt), "systems": nb, "cores": 1}
+    except Exception as e:
+        cb["set_vals_binary_search"] = {"error": str(e)}
+    # the same port on ALL host cores, one problem per thread (SURVEY 8d: "(ii) all host cores"); each thread owns an oracle
+    # object, the ctypes calls release the GIL.  Bounded to a few seconds; `cores` above stays the contract's figure.
+    try:
+        import concurrent.futures as cf
+        nthr = max(1, min(len(os.sched_getaffinity(0)), len(vals_h)))
+        per = max(1, len(vals_h) // nthr)  # problems per thread (its slice of the first chunk)
+        orcs = [O.Oracle(s.N, rows, cols, perm64) for _ in range(nthr)]
+        deadline = time.perf_counter() + 4.0
+        done = [0] * nthr
+
+        def work(k):
+            lo = k * per
+            while time.perf_counter() < deadline:
+                O.newton_system_batch(orcs[k], per, s.nvar, s.nequ, s.ncon, rhs_h[lo:lo + per], vals_h[lo:lo + per].copy(), None, params)
+                done[k] += per
+
+        tt = time.perf_counter()
+        with cf.ThreadPoolExecutor(nthr) as ex:
+            list(ex.map(work, range(nthr)))
+        ta = time.perf_counter() - tt
+        cb["all_cores"] = {"value": sum(done) / ta, "threads": nthr, "systems": sum(done)}
+    except Exception as e:
+        cb["all_cores"] = {"error": str(e)}
+    out["cpu_baseline"] = cb
 
 
 if __name__ == "__main__":

@@ -1,6 +1,7 @@
-"""The N > 1 path: contiguous shards of independent problems, no data-path collective.  Two CPU
-processes over gloo: every rank runs its shard (here through the oracle, the only CPU executor) and the
-aggregated counts and the max-over-ranks timing helper behave as bench.py expects."""
+"""The N > 1 path: contiguous shards of independent problems, no data-path collective.  CPU processes over gloo run
+the SAME per-rank driver bench.py runs on the GPU box (cannoles.jl_amd/sharding.py::run_shard: shard of the job, executor,
+warm-up, barrier-bracketed timed region, max-over-ranks time, job-wide counts) with a stub executor in place of the HIP
+handle (the stub solves its shard with the CPU oracle, the only CPU executor there is)."""
 import os
 import socket
 
@@ -13,14 +14,16 @@ from cannoles_jl_amd import sharding, synthetic as syn
 
 
 def test_shard_range_covers_batch():
-    for total in (1, 7, 256, 257):
-        for world in (1, 2, 3, 8):
-            seen = []
+    for total in (0, 1, 5, 7, 10, 256, 257):
+        for world in (1, 2, 3, 4, 8):
+            seen, sizes = [], []
             for r in range(world):
                 a, b = sharding.shard_range(total, world, r)
                 assert 0 <= a <= b <= total
                 seen += list(range(a, b))
+                sizes.append(b - a)
             assert seen == list(range(total))
+            assert max(sizes) - min(sizes) <= 1   # balanced: 10 over 4 is 3, 3, 2, 2 (not 3, 3, 3, 1)
 
 
 def _free_port():
@@ -31,27 +34,42 @@ def _free_port():
     return p
 
 
+class _StubExecutor:
+    """what bench.py's DeviceProblem is on the GPU: owns the shard's inputs, step() = one newton_system! over the shard"""
+
+    def __init__(self, g0, g1, total):
+        from oracle import oracle as O
+        self.O = O
+        self.s = syn.band_structure(60, 3)
+        rows, cols = self.s.kkt_pattern()
+        vals, rhs = syn.batch_values(self.s, total, cfg=4)   # every rank can regenerate the whole synthetic batch
+        self.vals, self.rhs, self.n = vals[g0:g1], rhs[g0:g1], g1 - g0
+        self.orc = O.Oracle(self.s.N, rows, cols, O.canonical_perm(self.s.nvar, self.s.nequ, self.s.ncon))
+        self.nsteps = 0
+
+    def step(self):
+        s = self.s
+        self.d, self.ok, _, _, self.nf = self.O.newton_system_batch(self.orc, self.n, s.nvar, s.nequ, s.ncon, self.rhs, self.vals.copy(), None,
+                                                                    self.O.default_params())
+        self.nsteps += 1
+
+    def counts(self):
+        return [self.n, int(self.ok.sum()), int(self.nf.sum())]
+
+
 def _worker(rank, world, port, total, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from oracle import oracle as O
     dist = sharding.init("gloo")
-    s = syn.band_structure(60, 3)
-    rows, cols = s.kkt_pattern()
-    a, b = sharding.shard_range(total, world, rank)
-    vals, rhs = syn.batch_values(s, total, cfg=4)   # every rank can regenerate the whole synthetic batch
-    orc = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
-    d, ok, rho, ro, nf = O.newton_system_batch(orc, b - a, s.nvar, s.nequ, s.ncon, rhs[a:b], vals[a:b].copy(), None, O.default_params())
-    dist.barrier()
-    counts = sharding.gather_counts([b - a, int(ok.sum()), int(nf.sum())], dist)
+    elapsed, counts, ex, (g0, g1) = sharding.run_shard(total, lambda a, b: _StubExecutor(a, b, total), steps=2, warmup=1, dist=dist)
     tmax = sharding.max_over_ranks(1.0 + rank, dist)
-    q.put((rank, counts, tmax, float(np.abs(d).sum())))
+    q.put((rank, counts, tmax, float(np.abs(ex.d).sum()) if ex else 0.0, ex.nsteps if ex else 0, elapsed, (g0, g1)))
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_sharding():
-    world, total = 2, 9
+@pytest.mark.parametrize("world,total", [(2, 9), (3, 2)])
+def test_gloo_sharding_runs_the_per_rank_driver(world, total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -62,9 +80,14 @@ def test_two_rank_gloo_sharding():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, counts, tmax, _ in res:
+    ranges = []
+    for rank, counts, tmax, _, nsteps, elapsed, rng in res:
         assert counts == [total, total, total]   # every problem solved once, one factorisation each
-        assert tmax == 2.0                       # max over ranks
+        assert tmax == float(world)              # max over ranks
+        assert nsteps == (3 if rng[1] > rng[0] else 0)  # warm-up + timed steps; an empty shard only joins the barriers
+        assert elapsed > 0
+        ranges.append(rng)
+    assert [r[0] for r in ranges] == [0] + [r[1] for r in ranges[:-1]] and ranges[-1][1] == total  # contiguous cover
     # the shards are disjoint pieces of the same batch: checksums differ and add up to the unsharded run
     from oracle import oracle as O
     s = syn.band_structure(60, 3)
