@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cannoles_hip.h"
@@ -397,6 +398,34 @@ int ensure_staging(cnl_handle* h) {
 
 }  // namespace
 
+struct cnl_multi {
+  std::vector<cnl_handle*> h;
+  std::vector<int64_t> start, count;
+  std::vector<int> device;
+  int64_t N = 0, nnz = 0, batch = 0;
+};
+
+namespace {
+// runs f(i) for every shard on its own host thread; the first failure (in shard order) becomes the caller's error
+template <class F>
+int multi_run(cnl_multi* m, F f) {
+  const size_t n = m->h.size();
+  std::vector<int> rc(n, CNL_OK);
+  std::vector<std::string> msg(n);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < n; i++)
+    th.emplace_back([&, i]() {
+      rc[i] = f(i);
+      if (rc[i]) msg[i] = g_err;  // thread-local in the worker: carry it over
+    });
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < n; i++)
+    if (rc[i]) return fail(rc[i], "shard " + std::to_string(i) + " (device " + std::to_string(m->device[i]) + "): " + msg[i]);
+  return CNL_OK;
+}
+}  // namespace
+
+
 extern "C" {
 
 const char* cnl_last_error(void) { return g_err.c_str(); }
@@ -573,8 +602,10 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   *hout = nullptr;
   if (batch < 1 || batch > (1 << 24)) return fail(CNL_ERR_ARG, "batch out of range");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    return fail(CNL_ERR_HIP, "no HIP device available (this backend has no CPU fallback)");
+  const hipError_t ce = hipGetDeviceCount(&ndev);
+  if (ce != hipSuccess || ndev == 0)
+    return fail(CNL_ERR_HIP, std::string("no HIP device available (this backend has no CPU fallback): hipGetDeviceCount -> ") +
+                                 hipGetErrorString(ce) + ", " + std::to_string(ndev) + " device(s)");
   if (device < 0 || device >= ndev) return fail(CNL_ERR_ARG, "device index out of range");
   cnl_plan* plan = nullptr;
   // small batches cannot fill the chip with one wavefront per four problems: plan for latency (bushy order, tasks)
@@ -917,6 +948,82 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   HIPCHK(hipStreamSynchronize(h->stream));
   h->factorized = true;
   return CNL_OK;
+}
+
+
+// ---- one caller, several devices: contiguous balanced shards of the batch, one handle + one host thread per
+//      device, no collective — the devices never exchange data --------------------------------------------------------------
+int cnl_multi_create(cnl_multi** mout, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
+                     int64_t ncon, int64_t batch, const int* devices, int ndev) {
+  if (!mout || !devices) return fail(CNL_ERR_ARG, "null argument");
+  *mout = nullptr;
+  if (ndev < 1 || ndev > 64 || batch < 1) return fail(CNL_ERR_ARG, "need 1 <= ndev <= 64 and batch >= 1");
+  cnl_multi* m = new cnl_multi();
+  m->N = N; m->nnz = nnz; m->batch = batch;
+  const int64_t base = batch / ndev, rem = batch % ndev;
+  for (int i = 0; i < ndev; i++) {
+    const int64_t cnt = base + (i < rem ? 1 : 0);
+    if (cnt == 0) continue;  // more devices than problems: the surplus devices stay idle
+    m->start.push_back(i * base + std::min<int64_t>(i, rem));
+    m->count.push_back(cnt);
+    m->device.push_back(devices[i]);
+  }
+  for (size_t i = 0; i < m->count.size(); i++) {
+    cnl_handle* h = nullptr;
+    const int rc = cnl_create(&h, N, nnz, rows1, cols1, nvar, nequ, ncon, m->count[i], m->device[i]);
+    if (rc) {
+      const std::string keep = g_err;
+      cnl_multi_destroy(m);
+      return fail(rc, "shard " + std::to_string(i) + ": " + keep);
+    }
+    m->h.push_back(h);
+  }
+  *mout = m;
+  return CNL_OK;
+}
+
+int cnl_multi_destroy(cnl_multi* m) {
+  if (!m) return CNL_OK;
+  for (cnl_handle* h : m->h) cnl_destroy(h);
+  delete m;
+  return CNL_OK;
+}
+
+int cnl_multi_shards(const cnl_multi* m, int64_t* nshards, int64_t* start, int64_t* count, int32_t* device) {
+  if (!m || !nshards) return fail(CNL_ERR_ARG, "null argument");
+  *nshards = (int64_t)m->h.size();
+  for (size_t i = 0; i < m->h.size(); i++) {
+    if (start) start[i] = m->start[i];
+    if (count) count[i] = m->count[i];
+    if (device) device[i] = m->device[i];
+  }
+  return CNL_OK;
+}
+
+int cnl_multi_factorize(cnl_multi* m, const double* vals, double eig_tol, int32_t* success, int64_t* npos, int64_t* nzero) {
+  if (!m || !vals || !success) return fail(CNL_ERR_ARG, "null argument");
+  return multi_run(m, [&](size_t i) {
+    const int64_t s = m->start[i];
+    return cnl_factorize(m->h[i], vals + s * m->nnz, eig_tol, success + s, npos ? npos + s : nullptr, nzero ? nzero + s : nullptr);
+  });
+}
+
+int cnl_multi_solve(cnl_multi* m, const double* rhs, double* d) {
+  if (!m || !rhs || !d) return fail(CNL_ERR_ARG, "null argument");
+  return multi_run(m, [&](size_t i) {
+    const int64_t s = m->start[i];
+    return cnl_solve(m->h[i], rhs + s * m->N, d + s * m->N);
+  });
+}
+
+int cnl_multi_newton_system(cnl_multi* m, double* vals, const double* rhs, double* d, const double* rho_old, const double params[9],
+                            double* rho, double* rho_old_out, int32_t* nfact, int32_t* success) {
+  if (!m || !vals || !rhs || !d || !params || !rho || !rho_old_out || !nfact || !success) return fail(CNL_ERR_ARG, "null argument");
+  return multi_run(m, [&](size_t i) {
+    const int64_t s = m->start[i];
+    return cnl_newton_system(m->h[i], vals + s * m->nnz, rhs + s * m->N, d + s * m->N, rho_old ? rho_old + s : nullptr, params, rho + s,
+                             rho_old_out + s, nfact + s, success + s);
+  });
 }
 
 }  // extern "C"

@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "cnl_set_timing", "cnl_last_kernel_ms", "cnl_get_config",
     "cnl_residual_vectors_dev", "cnl_trial_point_dev", "cnl_prepare_newton_system_dev",
     "cnl_cgls_multipliers_dev",
+    "cnl_multi_create", "cnl_multi_destroy", "cnl_multi_shards", "cnl_multi_factorize", "cnl_multi_solve", "cnl_multi_newton_system",
 ]
 
 
@@ -80,6 +81,12 @@ def lib():
         L.cnl_trial_point_dev.argtypes = [vp, vp, vp, vp, vp, dbl, vp, vp, vp, vp, vp]
         L.cnl_prepare_newton_system_dev.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
         L.cnl_cgls_multipliers_dev.argtypes = [vp, vp, vp, vp, vp, dbl, dbl, i64, C.c_int, vp, vp]
+        L.cnl_multi_create.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64, i64, vp, C.c_int]
+        L.cnl_multi_destroy.argtypes = [vp]
+        L.cnl_multi_shards.argtypes = [vp, C.POINTER(i64), vp, vp, vp]
+        L.cnl_multi_factorize.argtypes = [vp, vp, dbl, vp, vp, vp]
+        L.cnl_multi_solve.argtypes = [vp, vp, vp]
+        L.cnl_multi_newton_system.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.cnl_set_timing.argtypes = [vp, C.c_int]
         L.cnl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cnl_get_config.argtypes = [vp, _i64p]
@@ -311,3 +318,55 @@ def cgls_multipliers_dev(LDLT, vals_ptr, r_ptr, lambda_ptr, Jxtr_ptr=0, atol=Non
     rtol = np.sqrt(eps) if rtol is None else rtol
     _check(lib().cnl_cgls_multipliers_dev(LDLT._h, vals_ptr, r_ptr, lambda_ptr, Jxtr_ptr, float(atol), float(rtol), int(itmax),
                                           1 if ones_if_zero else 0, iters_ptr, stream))
+
+
+class MultiHIPLDLStruct:
+    """One solver object over several devices (cnl_multi_*): the batch is cut into contiguous balanced shards, one handle and
+    one host thread per device, no collective.  Same call surface as a batched HIPLDLStruct for the host-pointer calls."""
+
+    def __init__(self, N, rows, cols, nvar, nequ, ncon, batch, devices):
+        self.N, self.nvar, self.nequ, self.ncon, self.batch = int(N), int(nvar), int(nequ), int(ncon), int(batch)
+        self.rows, self.cols = _i64(rows), _i64(cols)
+        self.nnz = len(self.rows)
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        m = C.c_void_p()
+        _check(lib().cnl_multi_create(C.byref(m), self.N, self.nnz, self.rows, self.cols, self.nvar, self.nequ, self.ncon, self.batch,
+                                      dv.ctypes.data, len(dv)))
+        self._m = m
+        n = C.c_int64(0)
+        _check(lib().cnl_multi_shards(m, C.byref(n), None, None, None))
+        st, ct, dd = np.zeros(n.value, np.int64), np.zeros(n.value, np.int64), np.zeros(n.value, np.int32)
+        _check(lib().cnl_multi_shards(m, C.byref(n), st.ctypes.data, ct.ctypes.data, dd.ctypes.data))
+        self.shards = [(int(a), int(b), int(c)) for a, b, c in zip(st, ct, dd)]  # (first problem, problems, device)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            lib().cnl_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def try_to_factorize(self, vals, eig_tol):
+        vals = _f64c(vals)
+        succ = np.zeros(self.batch, np.int32)
+        _check(lib().cnl_multi_factorize(self._m, vals.ctypes.data, float(eig_tol), succ.ctypes.data, None, None))
+        return succ.astype(bool)
+
+    def solve_ldl_(self, rhs, d):
+        _check(lib().cnl_multi_solve(self._m, _f64c(rhs).ctypes.data, _f64c(d).ctypes.data))
+        return True
+
+    def newton_system_(self, d, rhs, vals, rho_old, params):
+        B = self.batch
+        vals, rhs, d = _f64c(vals), _f64c(rhs), _f64c(d)
+        ro = np.ascontiguousarray(np.broadcast_to(np.asarray(rho_old, dtype=np.float64), (B,)))
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        rho, ro_out = np.zeros(B), np.zeros(B)
+        nfact, succ = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        _check(lib().cnl_multi_newton_system(self._m, vals.ctypes.data, rhs.ctypes.data, d.ctypes.data, ro.ctypes.data, params.ctypes.data,
+                                             rho.ctypes.data, ro_out.ctypes.data, nfact.ctypes.data, succ.ctypes.data))
+        return d, succ.astype(bool), rho, ro_out, nfact.astype(np.int64)

@@ -18,6 +18,10 @@
  *     pattern (batch = 1 is the reference's one-solver-one-problem case).
  *     Batched arrays are problem-major: vals[b*nnz + k], rhs[b*N + i].
  *   - Host-pointer entry points copy in/out and keep no pointer afterwards.
+ *   - cnl_solve / cnl_solve_dev use the LAST factorisation of the handle, whichever call made it (cnl_factorize or
+ *     cnl_newton_system, with the rho it ended on).  The `_dev` twins keep the caller's d_vals pointer for that
+ *     (sparse backends re-read the Jacobian entries during the solve): d_vals must stay alive and unmodified between a
+ *     `_dev` factorisation and the `_dev` solves that use it.  The dense backend snapshots what it needs.
  *     `_dev` entry points take device pointers (HBM-resident data) and a
  *     hipStream_t passed as void*; they are asynchronous on that stream.
  *   - Return value: 0 = OK, otherwise one of CNL_ERR_*; cnl_last_error()
@@ -151,6 +155,24 @@ int cnl_cgls_multipliers_dev(cnl_handle* h, const double* d_vals, const double* 
  *     norm exceeds max_dlambda (the reference uses 1e4),  lambdat = lambda + dlambda.                               */
 int cnl_trial_point_dev(cnl_handle* h, const double* d_x, const double* d_r, const double* d_lambda, const double* d_d,
                         double max_dlambda, double* d_xt, double* d_rt, double* d_lambdat, double* d_dlambda, void* stream);
+
+/* ---- one caller, several devices -------------------------------------------------------------------------
+ * The path shards only across independent problems: `batch` problems are cut into contiguous balanced shards, one per entry
+ * of `devices` (the first batch % ndev shards hold one problem more; with batch < ndev the surplus devices stay idle), each
+ * shard with a handle of its own on its device.  The calls below take the arrays of the WHOLE batch (problem-major, as the
+ * single-handle calls), run every shard from a host thread of its own and return when all are done; there is no collective
+ * and no traffic between the devices.  This is what a single `cannoles()`-style caller (one backend object selected at
+ * src/CaNNOLeS.jl:322-332) uses to drive all GPUs of a node without becoming one process per GPU.                          */
+typedef struct cnl_multi cnl_multi;
+int cnl_multi_create(cnl_multi** m, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
+                     int64_t ncon, int64_t batch, const int* devices, int ndev);
+int cnl_multi_destroy(cnl_multi* m);
+/* shards actually created: *nshards, and (optional arrays of that length) first problem, problems, device index */
+int cnl_multi_shards(const cnl_multi* m, int64_t* nshards, int64_t* start, int64_t* count, int32_t* device);
+int cnl_multi_factorize(cnl_multi* m, const double* vals, double eig_tol, int32_t* success, int64_t* npos, int64_t* nzero);
+int cnl_multi_solve(cnl_multi* m, const double* rhs, double* d);
+int cnl_multi_newton_system(cnl_multi* m, double* vals, const double* rhs, double* d, const double* rho_old, const double params[9],
+                            double* rho, double* rho_old_out, int32_t* nfact, int32_t* success);
 
 /* Device time, in milliseconds, of the multifrontal kernel (the dominant kernel) of the last call,
  * measured with HIP events on the call's stream.  Enabling timing makes every call synchronise on
