@@ -184,7 +184,7 @@ int setup_v2(cnl_handle* h) {
   if (!(getenv("CNL_LDS_PAD") && !atoi(getenv("CNL_LDS_PAD")))) while (prob % 32 != 16) prob += 2;
   d.prob_doubles = (int32_t)prob;
   d.gs_doubles = P.gs_doubles + 64;
-  d.lsize = P.lsize;
+  d.lsize = h->dp.lsize;  // padded stride, see cnl_create
   d.vstride = h->dp.vstride; d.rstride = h->dp.rstride; d.dstride = h->dp.dstride;
   if (P.rec_direct) {  // the assembly lists address the caller's arrays
     d.nnz = P.nnz_outer; d.rho_begin = P.nnz_outer - (int32_t)P.nvar;
@@ -626,7 +626,12 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   if ((rc = upload(h, P.perm, &dp.perm))) return bail(rc);
   dp.nsuper = P.nsuper; dp.N = (int32_t)P.N; dp.nnz = (int32_t)P.nnz; dp.rho_begin = P.rho_begin;
   dp.nvar = (int32_t)P.nvar; dp.nequ = (int32_t)P.nequ; dp.ncon = (int32_t)P.ncon;
-  dp.fmax = (P.fmax + 1) & ~1; dp.lsize = P.lsize;
+  dp.fmax = (P.fmax + 1) & ~1;
+  // factor storage stride per problem: + 16 zero doubles that are never written.  The solve sweeps read a panel row as 16
+  // lanes, so the last rows of a problem's factor are over-read by up to 15 entries, which are multiplied by zeros; without
+  // the pad they would be the first entries of the NEXT problem's factor, and a NaN / Inf there (a neighbour whose
+  // factorisation broke down) would turn 0 * x into NaN in this problem's solution
+  dp.lsize = P.lsize + 16;
   const cnl::Cond& C = plan->C;
   dp.vstride = C.active ? C.cstride : (int64_t)nnz;
   dp.rstride = C.active ? C.cstride : N;
@@ -683,7 +688,7 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   }
   {
     // factor storage, zero-filled and padded: the row prefetch of the backward pass reads (never uses) a little past a panel
-    const size_t ldoubles = (size_t)batch * (size_t)std::max<int64_t>(P.lsize, 1) + 4096;
+    const size_t ldoubles = (size_t)batch * (size_t)dp.lsize + 4096;
     if ((rc = dalloc(h, &h->d_L, ldoubles))) return bail(rc);
     if (hipMemset(h->d_L, 0, ldoubles * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
   }
@@ -924,8 +929,6 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   HIPCHK(hipMemcpyAsync(h->d_rhs, rhs, B * P.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (rho_old) HIPCHK(hipMemcpyAsync(h->d_rho_old, rho_old, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
   else HIPCHK(hipMemsetAsync(h->d_rho_old, 0, B * sizeof(double), h->stream));
-  // d is only written for problems that succeed; give the others zeros rather than stale data
-  HIPCHK(hipMemsetAsync(h->d_d, 0, B * P.N * sizeof(double), h->stream));
   cnl::LaunchArgs a{};
   a.mode = cnl::MODE_NEWTON;
   a.rho_old = h->d_rho_old; a.rho = h->d_rho;
@@ -936,11 +939,22 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   std::memcpy(a.params, params, 9 * sizeof(double));
   if ((rc = run(h, a, h->d_vals, h->d_rhs, h->d_d, h->stream))) return rc;
   h->last_vals = h->d_vals;
-  HIPCHK(hipMemcpyAsync(d, h->d_d, B * P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  // the reference leaves d untouched when the factorisation fails (src/CaNNOLeS.jl:1049): copy back the rows that succeeded
+  HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  {
+    size_t b0 = 0;
+    while (b0 < B) {  // maximal runs of successful problems: one copy in the common case
+      while (b0 < B && !success[b0]) b0++;
+      size_t b1 = b0;
+      while (b1 < B && success[b1]) b1++;
+      if (b1 > b0) HIPCHK(hipMemcpyAsync(d + b0 * P.N, h->d_d + b0 * P.N, (b1 - b0) * P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      b0 = b1;
+    }
+  }
   HIPCHK(hipMemcpyAsync(rho, h->d_rho, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(rho_old_out, h->d_rho_old, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(nfact, h->d_nfact, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   // rho tail of vals (the reference mutates get_vals(LDLT)[end-nvar+1:end], src/CaNNOLeS.jl:1031,1038)
   if (P.nvar > 0)
     HIPCHK(hipMemcpy2DAsync(vals + (P.nnz - P.nvar), (size_t)P.nnz * sizeof(double), h->d_vals + (P.nnz - P.nvar),

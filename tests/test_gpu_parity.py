@@ -786,3 +786,24 @@ def test_multi_device_handle_shards_one_caller(built):
     M2 = hipldl.MultiHIPLDLStruct(s.N, rows, cols, s.nvar, s.nequ, s.ncon, 2, [0, 0, 0, 0])
     assert [(a, c) for a, c, _ in M2.shards] == [(0, 1), (1, 1)]
     M2.close()
+
+
+def test_failed_problems_leave_d_untouched(built):
+    """newton_system! solves only after a successful factorisation (src/CaNNOLeS.jl:1049): the caller's d of a problem whose
+    ladder runs out (rho > rho_max) is left as it was, through the host-pointer call."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(300, 4)
+    rows, cols = s.kkt_pattern()
+    B = 6
+    vals, rhs = syn.batch_values(s, B, cfg=4)
+    off = s.offsets()
+    vals[2, off[0]:off[1]] = np.nan   # no rho repairs a NaN Hessian: the ladder runs out
+    p = hipldl.default_params()
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    d = np.full((B, s.N), 7.0)
+    d, ok, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, np.zeros(B), p)
+    L.close()
+    assert list(ok) == [True, True, False, True, True, True] and rho[2] > p[6]
+    assert np.array_equal(d.reshape(B, -1)[2], np.full(s.N, 7.0))
+    for b in (0, 1, 3, 5):
+        assert backward_error(s, vals[b], rhs[b], d.reshape(B, -1)[b]) <= BWD_TOL
