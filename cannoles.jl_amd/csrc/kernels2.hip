@@ -320,6 +320,71 @@ __device__ __forceinline__ void eliminate16(int P_prob_doubles, int P_u2_peak, l
     CNL_REV16(CNL_USTL)
   }
 }
+// The hot class again, without the LDS round trip per pivot (CNL_DPP_ELIM=0 keeps the version above).  Rows are absolute
+// (R<a> = row a of the front, lane b = column b).  A problem is 16 lanes = one DPP row, so "the value of lane a for every
+// lane of the problem" is the DPP row broadcast of the fp64 FMA:
+//     pivot i:  d = w[lane i],  l_b = w_b / d,   R<a>[b] += w[lane a] * (-l_b)   for a < i
+//               as  v_fmac_f64_dpp R<a>, w row_newbcast:a, nl      (w = R<i>)
+// One instruction per row update, no publish / read-back through LDS (the LDS pipe is the busiest unit of this kernel)
+// and a shorter dependent chain per pivot (broadcast -> division -> update).  Lane numbers are immediates, hence one
+// block per pivot position (elim_dpp.inc), entered by wave-uniform branches.
+#ifndef CNL_DPP_ELIM
+#define CNL_DPP_ELIM 1
+#endif
+#include "elim_dpp.inc"
+#define CNL_DPPF(X, W, NL, A) \
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #A " row_mask:0xf bank_mask:0xf" : "+v"(X) : "v"(W), "v"(NL));
+// first DPP read of a row the previous pivot's updates wrote: hipcc pads no hazards inside asm (VALU write -> DPP read: 2 wait states)
+#define CNL_DPPF_NOP(X, W, NL, A) \
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #A " row_mask:0xf bank_mask:0xf" : "+v"(X) : "v"(W), "v"(NL));
+#define CNL_DPP_DECL(a) double R##a = Fs[a * 16 + b];
+#define CNL_DPP_PRE(i)                                                                                    \
+  const double lv = fast_div(w_, dpiv);                                                                   \
+  npos += dpiv > eig_tol;                                                                                 \
+  nzer += fabs(dpiv) <= eig_tol;                                                                          \
+  if (valid && b <= i) *reinterpret_cast<double*>(L_wb + (lofs + ((unsigned)tri2(i) << 3))) = (b == i) ? dpiv : lv; \
+  const double nl_ = -lv;
+#define CNL_DPP_POST(i)
+#define CNL_DPP_USTG(a) if (a <= nupd) Ug[tri2(a) + b] = R##a;
+#define CNL_DPP_USTL(a) if (a <= nupd) Ul[tri2(a) + b] = R##a;
+__device__ __forceinline__ void eliminate16_dpp(int P_prob_doubles, int P_u2_peak, long long P_gs_doubles, long long P_lsize, double* cL_,
+                                                double* cgs_, int cbatch, int lane, int prob0, int f, int nupd, long long lptr, int uoff,
+                                                bool uglob, double* pbase0, int* cnt, double eig_tol) {
+  double* Lg = as_global(cL_);
+  double* gsg = as_global(cgs_);
+  const int gp = lane >> 4;
+  const int b = lane & 15;
+  const int prob = prob0 + gp;
+  const bool valid = prob < cbatch;
+  int pc32_ = valid ? prob : prob0;
+  asm volatile("" : "+v"(pc32_));  // opaque: see eliminate16
+  const long long pclamp = pc32_;
+  double* pb = pbase0 + gp * P_prob_doubles;
+  const double* Fs = pb + P_u2_peak + b;
+  const int prob0u = __builtin_amdgcn_readfirstlane(prob0);
+  char* L_wb = reinterpret_cast<char*>(Lg + (long long)prob0u * P_lsize + lptr);
+  const int tu = tri2(1 + nupd);
+  const unsigned lofs = ((valid ? (unsigned)gp : 0u) * (unsigned)P_lsize + (unsigned)b - (unsigned)tu) * 8u;
+  const int top = f - 1;
+  { const double* Fs_ = Fs; (void)Fs_; }
+#undef CNL_DPP_DECL
+#define CNL_DPP_DECL(a) double R##a = Fs[a * 16];
+  CNL_DPP_ROWS(CNL_DPP_DECL)
+  int npos = 0, nzer = 0;
+  const double one_ = 1.0;
+  CNL_DPP_PIVOTS(CNL_DPP_PRE, CNL_DPP_POST)
+  if (b == 0) { cnt[gp * 2] += npos; cnt[gp * 2 + 1] += nzer; }
+  // update matrix: rows 0 .. nupd in ascending order with all lanes active (see CNL_USTG)
+  if (uglob) {
+    if (valid) {
+      double* Ug = gsg + pclamp * P_gs_doubles + uoff;
+      CNL_DPP_ROWS(CNL_DPP_USTG)
+    }
+  } else {
+    double* Ul = pb + uoff;
+    CNL_DPP_ROWS(CNL_DPP_USTL)
+  }
+}
 CNL_DEFINE_ELIM(eliminate16g, __attribute__((noinline)), 16, true, CNL_ALL16, CNL_REV16, CNL_STEPS16, CNL_LOAD)
 CNL_DEFINE_ELIM(eliminate32, __attribute__((noinline)), 32, false, CNL_ALL32, CNL_REV32, CNL_STEPS32, CNL_LOAD)
 CNL_DEFINE_ELIM(eliminate32g, __attribute__((noinline)), 32, true, CNL_ALL32, CNL_REV32, CNL_STEPS32, CNL_LOAD)
@@ -1042,6 +1107,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
       // (5) eliminate in registers, store L rows and the update matrix
 #ifdef CNL_STAMPS
       eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol, st_acc);
+#elif CNL_DPP_ELIM
+      eliminate16_dpp(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol);
 #else
       if (!(CNL_ABL & 1024)) eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
 #endif
