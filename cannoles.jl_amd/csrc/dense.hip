@@ -107,7 +107,11 @@ constexpr int KT = 32, LDK = 34;
 __global__ void __launch_bounds__(256) dn_syrk(DnDev D) {
   __shared__ double tA[64 * LDK], tB[64 * LDK];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, lg = lane >> 4;
+#ifdef DN_SYRK_COLLANE
+  const int col = lane, part = wave;  // conflict-free 16-byte LDS writes (8 consecutive columns -> 32 distinct banks), 64-byte global pieces
+#else
   const int col = t >> 2, part = t & 3;
+#endif
   const int cq = (wave >> 1) * 32, rq = (wave & 1) * 32;
   // the (problem, tile, row chunk) space is cut into equal shares, one per workgroup (a share spans at most a few tiles):
   // every CU gets the same number of matrix-core instructions, whatever the number of tiles
