@@ -331,6 +331,13 @@ __device__ __forceinline__ void eliminate16(int P_prob_doubles, int P_u2_peak, l
 #ifndef CNL_DPP_ELIM
 #define CNL_DPP_ELIM 1
 #endif
+// Row-per-lane backward sweep through the same broadcast (one FMA per position on the chain instead of a product and a
+// four-step lane reduction per pivot): correct, but MEASURED SLOWER — 886k against 944k systems/s at B = 8192: every lane then
+// loads 16 entries of its own row (16 row segments per instruction) instead of 10 coalesced panel rows, and the vector-memory
+// path is already half busy.  Kept behind -DCNL_DPP_BACK=1.
+#ifndef CNL_DPP_BACK
+#define CNL_DPP_BACK 0
+#endif
 // w / d through the raw reciprocal (2^-25 on gfx950) and ONE residual correction of the quotient: relative error ~2^-50, four
 // dependent fp64 operations on the per-pivot chain instead of the six of fast_div (-DCNL_DPP_QUICKDIV=1; off by default)
 __device__ __forceinline__ double quick_div(double w, double d) {
@@ -355,8 +362,8 @@ __device__ __forceinline__ double quick_div(double w, double d) {
   const double lv = CNL_DPP_DIV(w_, dpiv);                                                                \
   npos += dpiv > eig_tol;                                                                                 \
   nzer += fabs(dpiv) <= eig_tol;                                                                          \
-  if (valid && b <= i) *reinterpret_cast<double*>(L_wb + (lofs + ((unsigned)tri2(i) << 3))) = (b == i) ? dpiv : lv; \
-  const double nl_ = -lv;
+  if (valid && b <= i && !(CNL_ABL & 64)) *reinterpret_cast<double*>(L_wb + (lofs + ((unsigned)tri2(i) << 3))) = (b == i) ? dpiv : lv; \
+  const double nl_ = (CNL_ABL & 32) ? 0.0 : -lv;
 #define CNL_DPP_POST(i)
 #define CNL_DPP_USTG(a) if (a <= nupd) Ug[tri2(a) + b] = R##a;
 #define CNL_DPP_USTL(a) if (a <= nupd) Ul[tri2(a) + b] = R##a;
@@ -393,7 +400,7 @@ __device__ __forceinline__ void eliminate16_dpp(int P_prob_doubles, int P_u2_pea
       double* Ug = gsg + pclamp * P_gs_doubles + uoff;
       CNL_DPP_ROWS(CNL_DPP_USTG)
     }
-  } else {
+  } else if (!(CNL_ABL & 128)) {
     double* Ul = pb + uoff;
     CNL_DPP_ROWS(CNL_DPP_USTL)
   }
@@ -618,6 +625,23 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     }                                                                                  \
   }
 
+// Backward sweep, row-per-lane form: lane l takes the first 16 entries of ITS OWN panel row (local row l of the front:
+// z_l in column 0, then l_l1 .. l_l,l-1); lanes without a row (update rows, lanes past the front) and entries at or past
+// the diagonal read as zero.  Same addressing as above; entries no lane of the front needs (j >= f - 1) are not loaded.
+#define PREFETCH_LROWS(DST, LPTR, NUPD, NPIV)                                                    \
+  {                                                                                              \
+    const int nu_ = (NUPD), f_ = 1 + nu_ + (NPIV);                                               \
+    const bool has_ = l > nu_ && l < f_;                                                         \
+    const char* rb_ = L_wb + ((long long)(LPTR) << 3);                                           \
+    const unsigned ro_ = gofs_l0 + (has_ ? (unsigned)(tri2(l) - tri2(1 + nu_)) << 3 : 0u);       \
+    _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                                          \
+      double2 v_ = make_double2(0.0, 0.0);                                                       \
+      if (j < f_ - 1) v_ = *reinterpret_cast<const double2*>(rb_ + (ro_ + 8u * j));   /* 16-byte piece of the row */ \
+      DST[j] = (has_ && j < l) ? v_.x : 0.0;                                                     \
+      DST[j + 1] = (has_ && j + 1 < l) ? v_.y : 0.0;                                             \
+    }                                                                                            \
+  }
+
 // Value prefetch of the NEXT front.  The lists of a record hold the entries that read the matrix values first and
 // the entries that read the right-hand side last, so every round of 16 gathers from one array: the address is a
 // wave-uniform base (SGPR pair) plus a 32-bit per-lane byte offset.  All source indices are read from the LDS
@@ -725,6 +749,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
   const unsigned gofs_r = (gsel * (unsigned)(has_rhs ? P.rstride : P.vstride) - (unsigned)P.nnz) * 8u;  // rhs sources are nnz + index
   const char* L_wb = reinterpret_cast<const char*>(A.L + (long long)prob0u * P.lsize);
   const unsigned gofs_l = (gsel * (unsigned)P.lsize + (unsigned)l) * 8u;
+  const unsigned gofs_l0 = gsel * (unsigned)P.lsize * 8u;
 
   // per-problem ladder state, replicated over the 16 lanes of the group
   double rho = 0.0, wrote = 0.0;
@@ -1121,7 +1146,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
 #ifdef CNL_STAMPS
       eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol, st_acc);
 #elif CNL_DPP_ELIM
-      eliminate16_dpp(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol);
+      if (!(CNL_ABL & 1024)) eliminate16_dpp(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol);
 #else
       if (!(CNL_ABL & 1024)) eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
 #endif
@@ -1192,7 +1217,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
     double* xs = myU;  // the x stack reuses the per-problem LDS area
     int boff = t_brec, nxt = 0;
     int4 Rb;
+#if CNL_DPP_BACK
+    double lr[16];     // this lane's panel row of the CURRENT front, prefetched one front ahead
+#else
     double lr[KB];     // panel rows of the CURRENT front (first KB pivots), prefetched one front ahead
+#endif
     bool primed = false;
     int s = 0;
     while (s < nfr) {
@@ -1206,7 +1235,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
         const int hb0 = recw[lane & 7];
         const int nupd0 = HDRW(hb0, B_NUPD), npiv0 = HDRW(hb0, B_NPIV);
         const long long lp0 = (long long)HDRW(hb0, B_LPTR_LO) | ((long long)HDRW(hb0, B_LPTR_HI) << 31);
+#if CNL_DPP_BACK
+        PREFETCH_LROWS(lr, lp0, nupd0, npiv0)
+#else
         PREFETCH_ROWS(lr, lp0, nupd0, npiv0)
+#endif
         primed = true;
       }
       const int* rec = recw;
@@ -1236,7 +1269,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
         continue;
       }
       // next record into the other buffer, then prefetch the record after it and the next front's panel rows
+#if CNL_DPP_BACK
+      double lrn[16];
+#else
       double lrn[KB];
+#endif
       int nboff = nxt;
       if (s + 1 < nfr) {
         int* nrec = recbuf + ((s + 1) & 1) * P.breccap;
@@ -1252,10 +1289,14 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
         const int nn = nxt + nlen;
         Rb = bstream[(nn >> 2) + lane];
         nxt = nn;
+#if CNL_DPP_BACK
+        PREFETCH_LROWS(lrn, lp1, nupd1, npiv1)
+#else
         PREFETCH_ROWS(lrn, lp1, nupd1, npiv1)
+#endif
       } else {
 #pragma unroll
-        for (int k = 0; k < KB; k++) lrn[k] = lr[k];
+        for (int k = 0; k < (CNL_DPP_BACK ? 16 : KB); k++) lrn[k] = lr[k];
       }
       // x of the update rows from the parent's vector (in place when this front reuses the parent's slot).
       // Lane l keeps x of local row l; rows not known yet hold 0, so the dot product of a pivot row needs no lane
@@ -1267,6 +1308,24 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
       if (pxoff == B_PX_GLOBAL && l >= 1 && l <= nupd)  // the parent was solved by another task: x = -d of the named components
         xb = -__hip_atomic_load(mydout + rec[B_HDR + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       wsync();
+#if CNL_DPP_BACK
+      // Row-per-lane sweep: lane l accumulates s_l = sum_j L(l, j) x_j over the columns j < l of its row as the x_j become
+      // known — x_j is fetched from lane j with the DPP row broadcast of the fp64 FMA (a problem is one DPP row).  Column 0
+      // holds z and lane 0 holds -1, so s_l = -x_l once every column is in; position j turns lane j's sum into x_j first when
+      // j is a pivot.  One FMA per position on the dependent chain, instead of a product and a four-step lane reduction
+      // per pivot.  Positions are immediates: the sixteen steps are spelled out, skipped by wave-uniform tests.
+      {
+        double s_ = 0.0;
+#define CNL_BSTEP(J)                                                                                                    \
+        if (J < f) {                                                                                                     \
+          if (J > nupd) xb = (l == J) ? -s_ : xb;                                                                        \
+          asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(s_) : "v"(xb), "v"(lr[J])); \
+        }
+        CNL_BSTEP(0) CNL_BSTEP(1) CNL_BSTEP(2) CNL_BSTEP(3) CNL_BSTEP(4) CNL_BSTEP(5) CNL_BSTEP(6) CNL_BSTEP(7)
+        CNL_BSTEP(8) CNL_BSTEP(9) CNL_BSTEP(10) CNL_BSTEP(11) CNL_BSTEP(12) CNL_BSTEP(13) CNL_BSTEP(14) CNL_BSTEP(15)
+#undef CNL_BSTEP
+      }
+#else
 #pragma unroll
       for (int k = 0; k < KB; k++) {
         if (k < npiv) {
@@ -1280,12 +1339,13 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
         const double sum = gsum<16>(lv * xb);
         if (l == i) xb = -sum;
       }
+#endif
       // d = -x of the pivots: one scattered store per front (rec holds the original index of every pivot)
       if (okme && l > nupd && l < f) mydout[rec[B_HDR + l]] = -xb;
       if (l >= 1 && l < f) xs[xoff + l] = xb;
       wsync();
 #pragma unroll
-      for (int k = 0; k < KB; k++) lr[k] = lrn[k];
+      for (int k = 0; k < (CNL_DPP_BACK ? 16 : KB); k++) lr[k] = lrn[k];
       boff = nboff;
       s++;
     }
