@@ -7,7 +7,7 @@ pattern of BASELINE config 3 (n = nequ = 1e4, ncon = 50, band Jacobians), inputs
 N > 1 GPUs: one process per GPU, every rank owns a contiguous shard of the problems
 (cannoles.jl_amd/sharding.py), no collective on the data path; torch.distributed is used only for the
 barrier and the max-over-ranks time.  Default: weak scaling, `--batch` problems per GPU.  `--strong --total T`
-splits T problems over the ranks (BASELINE config 4: `--strong --total 256 --n 1000 --ncon 10`).
+splits T problems over the ranks (BASELINE config 4: `--strong --total 256 --nvar 1000 --ncon 10`).
 Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("CNL_BENCH_BATCH", 8192)), help="problems per GPU (weak scaling)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --total problems split over the ranks")
     ap.add_argument("--total", type=int, default=256, help="total problems with --strong")
-    ap.add_argument("--n", type=int, default=10000)
+    ap.add_argument("--nvar", "--n", dest="n", type=int, default=10000, help="variables = residuals per problem (spelled --nvar under torch.distributed.run, whose own options make --n ambiguous)")
     ap.add_argument("--ncon", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="problems timed on the CPU oracle (-1 auto, 0 off)")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch, PCIe-inclusive, cfg2 and f1 blocks")
@@ -135,8 +135,14 @@ def main():
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # CNL_BENCH_ONE_DEVICE=1 + CNL_DIST_BACKEND=gloo: several ranks on ONE GPU (dry run of the multi-process path on a
+    # single-GPU box; RCCL refuses two ranks on one device, gloo carries the barrier and the reductions instead)
+    if os.environ.get("CNL_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("CNL_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
-    dist = sharding.init("nccl")
+    dist = sharding.init(backend)
+    red_dev = torch.device("cuda", local_rank) if backend == "nccl" else "cpu"
 
     s = syn.band_structure(args.n, args.ncon, name="cfg3")
     rows, cols = s.kkt_pattern()
@@ -166,7 +172,7 @@ def main():
     # `steps` steps, max over ranks, job-wide counts
     with torch.cuda.stream(stream):
         elapsed, counts, prob, (g0, g1) = sharding.run_shard(total, make_executor, args.steps, args.warmup, dist,
-                                                             sync=torch.cuda.synchronize, device=dev)
+                                                             sync=torch.cuda.synchronize, device=red_dev)
     B = g1 - g0
     vals_h, rhs_h = host_chunk.get("vals"), host_chunk.get("rhs")
     vals, rhs = (prob.vals, prob.rhs) if prob else (None, None)

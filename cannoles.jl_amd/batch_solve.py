@@ -9,8 +9,10 @@ simply post less often.  The per-problem logic is exactly the single-problem loo
 reproduces it.
 
 The batched Newton step is the HIP path (`hipldl.newton_system_`, i.e. `cnl_newton_system`); there is no CPU fallback:
-without the extension or a device the first round raises.  `_test_backend` is a hook for this repository's CPU test-suite
-only (it lets the rendezvous logic be exercised where no GPU exists); the product never passes it.
+without the extension or a device the first round raises.  The batched executor is a parameter of the broker
+(`executor(vals, rhs, rho_old, params, dims) -> (d, ok, rho, rho_old, nfact)`, like the per-rank executor of
+sharding.run_shard); its default is the HIP handle, the CPU test-suite passes one built on the oracle to exercise the
+rendezvous logic where no GPU exists.
 """
 import threading
 
@@ -20,9 +22,9 @@ import numpy as np
 class NewtonBroker:
     """Rendezvous of B outer loops on one batched linear-solver handle."""
 
-    def __init__(self, B, device=0, _test_backend=None):
+    def __init__(self, B, device=0, executor=None):
         self.B, self.device = int(B), device
-        self._batched = _test_backend
+        self._batched = executor
         self.cv = threading.Condition()
         self.handle = None
         self.active = self.B
@@ -108,7 +110,7 @@ class NewtonBroker:
         self.handle = None
 
 
-def solve_batch(models, params=None, device=0, _test_backend=None, **kw):
+def solve_batch(models, params=None, device=0, executor=None, **kw):
     """Runs outer_loop.solve for every model of `models` (same pattern), Newton systems batched on the device.
     Returns (list of result dicts, number of batched device calls)."""
     from . import outer_loop
@@ -116,7 +118,7 @@ def solve_batch(models, params=None, device=0, _test_backend=None, **kw):
         from . import hipldl
         params = hipldl.default_params()
     B = len(models)
-    broker = NewtonBroker(B, device, _test_backend)
+    broker = NewtonBroker(B, device, executor)
     results = [None] * B
     errors = [None] * B
 

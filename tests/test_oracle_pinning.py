@@ -114,7 +114,7 @@ def test_batched_outer_loop_matches_single_runs(params):
     (F0, c0, x00, xf0), (F1, c1, x01, xf1) = CONSTRAINED[0], CONSTRAINED[1]
     cases = [(F0, c0, x00, xf0), (F1, c1, x01, xf1), (F1, c1, [-1.0, 0.5], xf1), (F0, c0, [3.0, -2.0], xf0), (F1, c1, [0.0, 0.0], xf1)]
     models = [SymNLS(F, x0, c) for F, c, x0, xf in cases]
-    res, ncalls = batch_solve.solve_batch(models, params, _test_backend=_oracle_batched)
+    res, ncalls = batch_solve.solve_batch(models, params, executor=_oracle_batched)
     singles = [solve(SymNLS(F, x0, c), oracle_solver, oracle_newton, params) for F, c, x0, xf in cases]
     for k, (F, c, x0, xf) in enumerate(cases):
         assert res[k]["status"] == singles[k]["status"] and res[k]["iter"] == singles[k]["iter"]
@@ -131,4 +131,4 @@ def test_batched_outer_loop_rejects_mixed_patterns(params):
     F0, c0, x0, _ = CONSTRAINED[0]
     F2, c2, x2, _ = CONSTRAINED[2]
     with pytest.raises(ValueError):
-        batch_solve.solve_batch([SymNLS(F0, x0, c0), SymNLS(F2, x2, c2)], params, _test_backend=_oracle_batched)
+        batch_solve.solve_batch([SymNLS(F0, x0, c0), SymNLS(F2, x2, c2)], params, executor=_oracle_batched)
