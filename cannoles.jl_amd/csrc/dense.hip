@@ -674,6 +674,20 @@ __global__ void __launch_bounds__(256) dn_yrhs_general(DnDev D, const double* __
 // needs it (a few KB), so the results are deterministic and no reduction launches are needed.
 __device__ __forceinline__ size_t part_off(const DnDev& D, int b, int I, int J) { return (((size_t)b * D.T + J) * D.T + I) * 64; }
 
+// sum_{q = q0}^{q1 - 1} base[q * stride] in index order; the loads of eight terms are in flight together (a plain loop waits
+// an L2 round trip per term: these reductions were most of the time of the small solve kernels)
+__device__ __forceinline__ double sum_strided(const double* __restrict__ base, size_t stride, int q0, int q1) {
+  double s = 0.0;
+  for (int c0 = q0; c0 < q1; c0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = c0 + q < q1 ? base[(size_t)(c0 + q) * stride] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) s += v[q];
+  }
+  return s;
+}
+
 // row sums out[r] = sum_c tile[r + 64 c] v[c] over the columns with mask(r, c); 256 threads, v in LDS, red = [4][64] LDS
 template <class M>
 __device__ __forceinline__ void tile_rowsum(const double* __restrict__ tile, const double* v, double (*red)[64], double* __restrict__ out, M mask) {
@@ -715,8 +729,8 @@ __device__ __forceinline__ double resid_entry(const DnDev& D, int b, int I, int 
   const size_t vb = (size_t)b * D.nsp;
   const double sh = gi < D.ns ? D.rsh[vb + gi] : 1.0;
   double s = sh * D.x[vb + gi];
-  for (int J = 0; J <= I; J++) s += D.partA[part_off(D, b, I, J) + i];
-  for (int K = I; K < D.T; K++) s += D.partB[part_off(D, b, K, I) + i];
+  s += sum_strided(D.partA + part_off(D, b, I, 0) + i, (size_t)D.T * 64, 0, I + 1);   // J = 0 .. I: part_off advances by T * 64 per J
+  s += sum_strided(D.partB + part_off(D, b, 0, I) + i, 64, I, D.T);                     // K = I .. T - 1: by 64 per K
   return D.y[vb + gi] - s;
 }
 
@@ -736,8 +750,7 @@ __global__ void __launch_bounds__(256) dn_g_part(DnDev D, int gate) {
   const int b = blockIdx.y, I = D.lJ[blockIdx.x], J = D.lI[blockIdx.x];
   if (gate && !D.st[b].success) return;
   if (threadIdx.x < 64) {
-    double s = 0.0;
-    for (int Ip = 0; Ip <= J; Ip++) s += D.part1[part_off(D, b, Ip, J) + threadIdx.x];
+    const double s = sum_strided(D.part1 + part_off(D, b, 0, J) + threadIdx.x, 64, 0, J + 1);
     us[threadIdx.x] = D.dv[(size_t)b * D.nsp + 64 * J + threadIdx.x] * s;
   }
   __syncthreads();
@@ -752,8 +765,7 @@ __global__ void __launch_bounds__(256) dn_resid_part(DnDev D, int gate) {
   if (gate && !D.st[b].success) return;
   if (threadIdx.x < 128) {
     const int B0 = threadIdx.x < 64 ? J : I, i = threadIdx.x & 63;
-    double s = 0.0;
-    for (int Jp = B0; Jp < D.T; Jp++) s += D.part2[part_off(D, b, B0, Jp) + i];
+    const double s = sum_strided(D.part2 + part_off(D, b, B0, 0) + i, (size_t)D.T * 64, B0, D.T);
     (threadIdx.x < 64 ? xJ : xI)[i] = s;
     if (I == J && threadIdx.x < 64) D.x[(size_t)b * D.nsp + 64 * I + i] = s;
   }
@@ -772,8 +784,7 @@ __global__ void __launch_bounds__(256) dn_resid_part(DnDev D, int gate) {
 __global__ void __launch_bounds__(64) dn_xfinal(DnDev D, int gate) {
   const int b = blockIdx.y, I = blockIdx.x, i = threadIdx.x;
   if (gate && !D.st[b].success) return;
-  double s = D.x[(size_t)b * D.nsp + 64 * I + i];
-  for (int Jp = I; Jp < D.T; Jp++) s += D.part2[part_off(D, b, I, Jp) + i];
+  const double s = D.x[(size_t)b * D.nsp + 64 * I + i] + sum_strided(D.part2 + part_off(D, b, I, 0) + i, (size_t)D.T * 64, I, D.T);
   D.x[(size_t)b * D.nsp + 64 * I + i] = s;
 }
 
@@ -809,9 +820,7 @@ __global__ void __launch_bounds__(256) dn_out(DnDev D, const double* __restrict_
   if (i < D.n) db[i] = -x[i];
   else if (i < D.n + D.m) {
     const int q = i - D.n;
-    double jx = 0.0;
-#pragma unroll 8
-    for (int ch = 0; ch < D.npj / 32; ch++) jx += D.jxp[((size_t)b * (D.npj / 32) + ch) * D.mp + q];
+    const double jx = sum_strided(D.jxp + (size_t)b * (D.npj / 32) * D.mp + q, (size_t)D.mp, 0, D.npj / 32);
     db[i] = D.w[(size_t)b * D.mp + q] * (rhs[(size_t)b * N + i] - jx);
   } else db[i] = -x[D.n + (i - D.n - D.m)];
 }
@@ -1112,13 +1121,18 @@ int run_cached(DenseState* st, const GraphKey& key, hipStream_t stream, std::str
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return enqueue(stream);  // the caller captures
   if (!st->cap && hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking) != hipSuccess) { st->use_graph = false; return enqueue(stream); }
-  if (hipStreamBeginCapture(st->cap, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); st->use_graph = false; return enqueue(stream); }
+  if (hipStreamBeginCapture(st->cap, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    if (getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] dense: hipStreamBeginCapture failed, plain launches\n");
+    (void)hipGetLastError(); st->use_graph = false; return enqueue(stream);
+  }
   const int rc = enqueue(st->cap);
   GraphEntry ge;
   ge.key = key;
   const hipError_t e1 = hipStreamEndCapture(st->cap, &ge.graph);
   if (rc) { if (ge.graph) (void)hipGraphDestroy(ge.graph); return rc; }
-  if (e1 != hipSuccess || hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0) != hipSuccess) {
+  hipError_t e2 = hipSuccess;
+  if (e1 != hipSuccess || (e2 = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0)) != hipSuccess) {
+    if (getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] dense: graph capture failed (%s / %s), plain launches\n", hipGetErrorString(e1), hipGetErrorString(e2));
     (void)hipGetLastError();
     if (ge.graph) (void)hipGraphDestroy(ge.graph);
     st->use_graph = false;
@@ -1130,6 +1144,7 @@ int run_cached(DenseState* st, const GraphKey& key, hipStream_t stream, std::str
     st->graphs.erase(st->graphs.begin());
   }
   st->graphs.push_back(ge);
+  if (getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] dense: call sequence captured as a graph (%zu cached)\n", st->graphs.size());
   DCHK(hipGraphLaunch(ge.exec, stream));
   return 0;
 }

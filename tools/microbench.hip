@@ -77,6 +77,24 @@ __global__ void __launch_bounds__(64) chain_kernel(double* out, int iters, long 
 __global__ void __launch_bounds__(256) tiny_kernel(double* p, int k) {
   if (threadIdx.x == 0) p[blockIdx.x] += k;
 }
+struct BigArgs { double* p[40]; int v[24]; };  // ~416 bytes of kernel arguments, like the dense backend's DnDev
+__global__ void __launch_bounds__(256) tiny_big(BigArgs a, int k) {
+  if (threadIdx.x == 0) a.p[k & 7][blockIdx.x] += a.v[k & 15];
+}
+__global__ void __launch_bounds__(1024) tiny_lds(BigArgs a, int k) {
+  __shared__ double buf[5000];
+  buf[threadIdx.x] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) a.p[k & 7][blockIdx.x] += buf[(k * 7) & 1023];
+}
+__global__ void __launch_bounds__(256) tiny_empty(int k) {
+  if (k == 0x7fffffff) __builtin_trap();
+}
+// reads a value the previous kernel wrote (the dependent chain of the dense steps) from a different 2 MB region each time
+__global__ void __launch_bounds__(256) tiny_dep(double* base, int k) {
+  double* p = base + ((size_t)(k & 63) << 18);
+  if (threadIdx.x == 0) p[blockIdx.x + 256] = p[blockIdx.x] + 1.0;
+}
 
 int main() {
   int dev = 0;
@@ -185,6 +203,28 @@ int main() {
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
     printf(", \"kernel_boundary_us_grid%d\": %.3f", grid, ms * 1e3 / n);
   }
+  {
+    double* depbuf = nullptr;
+    CHK(hipMalloc(&depbuf, ((size_t)64 << 21) + (1 << 20)));  // 64 regions of 2 MB
+    CHK(hipMemset(depbuf, 0, ((size_t)64 << 21) + (1 << 20)));
+    BigArgs ba; for (int i = 0; i < 40; i++) ba.p[i] = out + 4096 * i; for (int i = 0; i < 24; i++) ba.v[i] = i;
+    const int n = 2000;
+    for (int variant = 0; variant < 3; variant++) {
+      auto go = [&](int i) {
+        if (variant == 0) hipLaunchKernelGGL(tiny_empty, dim3(136), dim3(256), 0, 0, i);
+        else if (variant == 1) hipLaunchKernelGGL(tiny_big, dim3(136), dim3(256), 0, 0, ba, i);
+        else hipLaunchKernelGGL(tiny_dep, dim3(136), dim3(256), 0, 0, depbuf, i);
+      };
+      for (int i = 0; i < 10; i++) go(i);
+      CHK(hipDeviceSynchronize());
+      CHK(hipEventRecord(e0));
+      for (int i = 0; i < n; i++) go(i);
+      CHK(hipEventRecord(e1));
+      CHK(hipEventSynchronize(e1));
+      float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+      printf(", \"kernel_boundary_us_%s\": %.3f", variant == 0 ? "no_memory" : (variant == 1 ? "416B_args" : "dependent_load_store"), ms * 1e3 / n);
+    }
+  }
   // the same through a captured graph (no host launch cost in the timed region)
   {
     hipStream_t st; CHK(hipStreamCreate(&st));
@@ -192,6 +232,26 @@ int main() {
     CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
     for (int i = 0; i < 200; i++) hipLaunchKernelGGL(tiny_kernel, dim3(136), dim3(256), 0, st, out, i);
     CHK(hipStreamEndCapture(st, &g));
+    {
+      BigArgs ba; for (int i = 0; i < 40; i++) ba.p[i] = out + 4096 * i; for (int i = 0; i < 24; i++) ba.v[i] = i;
+      for (int variant = 0; variant < 2; variant++) {
+        hipGraph_t g2; hipGraphExec_t ge2;
+        CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < 200; i++) {
+          if (variant == 0) hipLaunchKernelGGL(tiny_big, dim3(136), dim3(256), 0, st, ba, i);
+          else hipLaunchKernelGGL(tiny_lds, dim3(136), dim3(1024), 0, st, ba, i);
+        }
+        CHK(hipStreamEndCapture(st, &g2));
+        CHK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
+        CHK(hipGraphLaunch(ge2, st)); CHK(hipStreamSynchronize(st));
+        CHK(hipEventRecord(e0, st));
+        for (int r = 0; r < 10; r++) CHK(hipGraphLaunch(ge2, st));
+        CHK(hipEventRecord(e1, st));
+        CHK(hipEventSynchronize(e1));
+        float ms2; CHK(hipEventElapsedTime(&ms2, e0, e1));
+        printf(", \"graph_kernel_boundary_us_%s\": %.3f", variant == 0 ? "416B_args" : "416B_args_1024thr_40KB_lds", ms2 * 1e3 / 2000);
+      }
+    }
     CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     CHK(hipGraphLaunch(ge, st)); CHK(hipStreamSynchronize(st));
     CHK(hipEventRecord(e0, st));
