@@ -858,7 +858,9 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
   ivec task_first(ns, 0), task_root(ns, 0);
   P.tasks.clear(); P.stage_ptr.clear();
   if (opt.latency && P.v2_ok && ns > 1) {
-    int cap = opt.task_cap > 0 ? opt.task_cap : 12;  // measured: 8 .. 12 fronts per bottom task are best from 1 to 256 problems
+    // measured (cfg3): 8 fronts per bottom task are best for a handful of problems (every task has a wavefront slot of its own),
+    // 12 from 64 problems on
+    int cap = opt.task_cap > 0 ? opt.task_cap : (opt.par >= 256 ? 8 : 12);
     if (const char* e = getenv("CNL_TASK_CAP")) cap = std::max(1, atoi(e));
     ivec nsub(ns, 1), fdesc(ns), stage(ns, 0);
     for (int32_t s = 0; s < ns; s++) {
