@@ -238,6 +238,16 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   return CNL_OK;
 }
 
+// one staged pass over the tasks of a latency plan (first attempt of newton_system, try_to_factorize, or solve_ldl!)
+int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
+  a.batch = (int)h->batch; a.L = h->d_L; a.scratch = h->d_gs;
+  a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
+  hipError_t e = cnl::launch_newton2_staged(h->dp2, h->wpb2, h->lds2, a, h->stage_ptr.data(), (int)h->stage_ptr.size() - 1, stream);
+  if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("staged launch: ") + hipGetErrorString(e));
+  return CNL_OK;
+}
+
 // One call of the path on device-resident data: [condense ->] multifrontal kernel [-> expand].
 int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, double* d_d, hipStream_t stream) {
   const cnl::Cond& C = h->plan->C;
@@ -314,11 +324,7 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
       if (h->staged) {
         // first attempt (rho as given) stage by stage: the tasks of the elimination tree run on different wavefronts; the
         // problems that fail it (rare) go through the whole ladder in the classic launch behind it
-        a.batch = (int)h->batch; a.L = h->d_L; a.scratch = h->d_gs;
-        a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0;
-        if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
-        e = cnl::launch_newton2_staged(h->dp2, h->wpb2, h->lds2, a, h->stage_ptr.data(), (int)h->stage_ptr.size() - 1, stream);
-        if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("staged launch: ") + hipGetErrorString(e));
+        if ((rc = launch_staged(h, a, stream))) return rc;
         a.skip_done = 1;
         const bool tm = h->timing;
         h->timing = false;
@@ -335,7 +341,10 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
         if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("condense: ") + hipGetErrorString(e));
       }
       a.vals = d_vals; a.extra_pos = count_d ? nullptr : h->d_xpos; a.extra_zer = count_d ? nullptr : h->d_xzer;
-      if ((rc = launch(h, a, stream))) return rc;
+      if (h->staged) {  // try_to_factorize stage by stage (the elimination tree's tasks on different wavefronts)
+        if ((rc = launch_staged(h, a, stream))) return rc;
+        if (h->timing) HIPCHK(hipEventRecord(h->ev1, stream));
+      } else if ((rc = launch(h, a, stream))) return rc;
       h->last_vals = d_vals;
     } else if (a.mode == cnl::MODE_NEWTON) {
       e = C.tiled_ok ? cnl::launch_condense_tiled(h->dc, d_vals, d_rhs, h->d_cbuf, 7, C.ch_region[3], B, stream)
@@ -358,7 +367,10 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
       // solve_ldl! on the register-front kernel: forward substitution with the stored factor, backward sweep, post-pass
       if (!h->last_vals) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
       a.vals = const_cast<double*>(h->last_vals); a.rhs = d_rhs; a.d = d_d;
-      if ((rc = launch(h, a, stream))) return rc;
+      if (h->staged) {  // solve_ldl! stage by stage: forward substitution of the tasks, then their backward sweeps
+        if ((rc = launch_staged(h, a, stream))) return rc;
+        if (h->timing) HIPCHK(hipEventRecord(h->ev1, stream));
+      } else if ((rc = launch(h, a, stream))) return rc;
       e = cnl::launch_expand(h->dc, const_cast<double*>(h->last_vals), d_rhs, nullptr, h->d_cbuf, d_d, nullptr, 0, B, stream);
       if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
     } else {

@@ -764,18 +764,18 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
   // condensed rows, the children's update vectors), then  c_a -= l_ia c_i  over the pivots from the top and z_i = c_i / d_i
   // goes into column 0 of the stored panel, where the backward sweep below expects it.  The host sends a plan here only
   // when every front is of the fast class (order <= 16, LDS staging).
-  if (A.mode == MODE_SOLVE) {
+  if (A.mode == MODE_SOLVE && (!STAGED || A.phase == 0)) {
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
     int4 R0, R1, R2;
     double pvr[PVR], prr[2], prh = 0.0;
     double lr[KB], lrn[KB];
-    int roff = 0, nxt_off = 0;
+    int roff = t_rec, nxt_off = 0;
     int* recw = recbuf;
     {
-      int len = P.rec[0 + R_RECLEN];
-      nxt_off = len;
+      int len = P.rec[t_rec + R_RECLEN];
+      nxt_off = t_rec + len;
       if (len > P.reccap) len = P.reccap;
-      for (int w4 = lane; w4 * 4 < len; w4 += 64) reinterpret_cast<int4*>(recw)[w4] = rstream[w4];
+      for (int w4 = lane; w4 * 4 < len; w4 += 64) reinterpret_cast<int4*>(recw)[w4] = rstream[(t_rec >> 2) + w4];
       wsync();
       R0 = rstream[(nxt_off >> 2) + lane];
       R1 = rstream[(nxt_off >> 2) + lane + 64];
@@ -787,7 +787,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
       const long long lp0 = (long long)HDRW(hv0, R_LPTR_LO) | ((long long)HDRW(hv0, R_LPTR_HI) << 31);
       PREFETCH_ROWS(lr, lp0, HDRW(hv0, R_NUPD), HDRW(hv0, R_NPIV))
     }
-    for (int s = 0; s < P.nsuper; s++) {
+    for (int s = 0; s < nfr; s++) {
       const int* rec = recw;
       const int hv = rec[lane & 15];
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM), nasmv = HDRW(hv, R_NASMV);
@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
       wsync();
       // next record over the current one, prefetches for the next front
       int nroff = nxt_off;
-      if (s + 1 < P.nsuper) {
+      if (s + 1 < nfr) {
         int* nrec = recbuf;
         const int nlen = __builtin_amdgcn_readlane(R0.z, 0);
         const int nasm1 = __builtin_amdgcn_readlane(R0.w, 0);
@@ -922,10 +922,11 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
     (void)roff;
     success = valid;
     gsync();  // the z column is read back through global memory by the backward sweep
+    if constexpr (STAGED) return;  // the backward sweep of the tasks comes in launches of its own
   }
 
   STAMP_DECL
-  const bool do_fwd = STAGED ? A.phase == 0 : A.mode != MODE_SOLVE;
+  const bool do_fwd = STAGED ? (A.phase == 0 && A.mode != MODE_SOLVE) : A.mode != MODE_SOLVE;
   while (do_fwd) {
     STAMP_BEGIN
     // ---------------- forward pass over the record stream ----------------
@@ -1200,7 +1201,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
   }
   if constexpr (STAGED) {  // inertia rule on the sums of the forward launches (src/solver_types.jl:90-97)
     const int* gc = as_global(A.gcnt) + pclamp * 2;
-    success = valid && gc[0] == P.nvar && gc[1] == 0;
+    success = valid && (A.mode == MODE_SOLVE || (gc[0] == P.nvar && gc[1] == 0));  // solve_ldl! follows a successful factorisation
     nfact = 1;
   }
   if (l == 0) cnt[8 + g] = (success && valid) ? 1 : 0;
@@ -1356,7 +1357,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
 #endif
   if constexpr (STAGED) {
     // first attempt only: rho = 0, rho_old untouched; problems that failed are handed to the classic launch that follows
-    if (valid && l == 0 && t_root) { A.rho[prob] = 0.0; A.nfact[prob] = 1; A.success[prob] = success ? 1 : 0; }
+    if (valid && l == 0 && t_root && A.mode == MODE_NEWTON) { A.rho[prob] = 0.0; A.nfact[prob] = 1; A.success[prob] = success ? 1 : 0; }
   } else if (valid && l == 0 && A.mode == MODE_NEWTON) {
     A.rho[prob] = rho;
     A.rho_old[prob] = rho_old;
@@ -1376,20 +1377,36 @@ hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const La
   return hipGetLastError();
 }
 
+// try_to_factorize on a staged plan: the inertia rule on the counts the forward launches summed (src/solver_types.jl:90-97)
+__global__ void __launch_bounds__(256) staged_decide_kernel(const int* __restrict__ gcnt, int nvar, int batch, int32_t* success, int64_t* npos,
+                                                            int64_t* nzero) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= batch) return;
+  const int tp = gcnt[2 * b], tz = gcnt[2 * b + 1];
+  success[b] = (tp == nvar && tz == 0) ? 1 : 0;
+  if (npos) npos[b] = tp;
+  if (nzero) nzero[b] = tz;
+}
+
 hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, LaunchArgs a, const int32_t* stage_ptr, int nstages, hipStream_t stream) {
   if (wpb < 1 || wpb > 4) return hipErrorInvalidConfiguration;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(newton2_kernel_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
   a.nquads = (a.batch + 3) / 4;
-  e = hipMemsetAsync(a.gcnt, 0, (size_t)a.batch * 2 * sizeof(int), stream);
-  if (e != hipSuccess) return e;
-  for (int pass = 0; pass < 2; pass++)
+  if (a.mode != MODE_SOLVE) {
+    e = hipMemsetAsync(a.gcnt, 0, (size_t)a.batch * 2 * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+  }
+  // newton: forward + backward; factorize: forward only, then the decision; solve: forward substitution + backward
+  for (int pass = 0; pass < (a.mode == MODE_FACTOR ? 1 : 2); pass++)
     for (int q = 0; q < nstages; q++) {
       const int st = pass == 0 ? q : nstages - 1 - q;  // forward: children first; backward: parents first
       a.phase = pass; a.task0 = stage_ptr[st]; a.ntasks = stage_ptr[st + 1] - stage_ptr[st];
       const long long waves = (long long)a.ntasks * a.nquads;
       hipLaunchKernelGGL(newton2_kernel_t<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
     }
+  if (a.mode == MODE_FACTOR)
+    hipLaunchKernelGGL(staged_decide_kernel, dim3((a.batch + 255) / 256), dim3(256), 0, stream, a.gcnt, P.nvar, a.batch, a.success, a.npos, a.nzero);
   return hipGetLastError();
 }
 

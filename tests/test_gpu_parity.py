@@ -807,3 +807,33 @@ def test_failed_problems_leave_d_untouched(built):
     assert np.array_equal(d.reshape(B, -1)[2], np.full(s.N, 7.0))
     for b in (0, 1, 3, 5):
         assert backward_error(s, vals[b], rhs[b], d.reshape(B, -1)[b]) <= BWD_TOL
+
+
+def test_two_call_sequence_single_system_latency_plan(built):
+    """try_to_factorize + solve_ldl! (the reference's literal sequence, src/solver_types.jl:69-98) on ONE system of the cfg3
+    shape: the latency plan runs both calls stage by stage as well.  Oracle comparison + the inertia counts."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(10000, 50)
+    rows, cols = s.kkt_pattern()
+    vals, rhs = syn.band_values(s, 3001)
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, vals, s.nvar, s.nequ, s.ncon)
+    assert L.config["kernel"] == "v2-staged"
+    ok, npos, nzer = hipldl.try_to_factorize(L, vals, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16, return_inertia=True)
+    assert ok and npos == s.nvar and nzer == 0
+    orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
+    assert orc.try_to_factorize(vals, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16)
+    for k in range(2):
+        r = rhs * (k + 1) - k
+        d = np.zeros(s.N)
+        hipldl.solve_ldl_(r, L.factor, d)
+        d0 = orc.solve_ldl(r)
+        assert np.abs(d - d0).max() <= FWD_TOL * np.abs(d0).max()
+        assert backward_error(s, vals, r, d) <= BWD_TOL
+    # an indefinite Hessian: the Bool and the counts of a failed factorisation
+    v2 = vals.copy()
+    off = s.offsets()
+    v2[off[0]:off[1]] = -5.0
+    ok2, npos2, nzer2 = hipldl.try_to_factorize(L, v2, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16, return_inertia=True)
+    ok0, npos0, nzer0 = orc.try_to_factorize(v2, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16, return_inertia=True)
+    assert (ok2, npos2, nzer2) == (ok0, npos0, nzer0) and not ok2
+    L.close()
