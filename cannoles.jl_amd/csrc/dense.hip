@@ -472,13 +472,17 @@ __device__ __forceinline__ void update_block(const double* __restrict__ At, cons
     aop[s] = Wt[(16 * bc + li) + 64 * (4 * s + lg)];
     bop[s] = At[(16 * br + li) + 64 * (4 * s + lg)];
   }
-  d4 acc;
+  // two accumulators (even / odd k-steps): a dependent fp64 MFMA waits 196 cycles, two independent chains issue every ~150
+  d4 acc, acc2 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int reg = 0; reg < 4; reg++) acc[reg] = czero ? 0.0 : Ct[(16 * br + li) + 64 * (16 * bc + lg + 4 * reg)];
 #pragma unroll
-  for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s], bop[s], acc, 0, 0, 0);
+  for (int s = 0; s < 16; s += 2) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s], bop[s], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s + 1], bop[s + 1], acc2, 0, 0, 0);
+  }
 #pragma unroll
-  for (int reg = 0; reg < 4; reg++) Ct[(16 * br + li) + 64 * (16 * bc + lg + 4 * reg)] = acc[reg];
+  for (int reg = 0; reg < 4; reg++) Ct[(16 * br + li) + 64 * (16 * bc + lg + 4 * reg)] = acc[reg] + acc2[reg];
 }
 
 // trailing tile idx of step k: lower tiles (I >= J > k) of S first, then the tiles (I <= k, J > k) of the G block
