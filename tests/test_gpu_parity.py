@@ -837,3 +837,35 @@ def test_two_call_sequence_single_system_latency_plan(built):
     ok0, npos0, nzer0 = orc.try_to_factorize(v2, s.nvar, s.nequ, s.ncon, 2.220446049250313e-16, return_inertia=True)
     assert (ok2, npos2, nzer2) == (ok0, npos0, nzer0) and not ok2
     L.close()
+
+
+@pytest.mark.parametrize("shape", [(300, 4), (300, 0), (600, 6)])
+def test_f3_device_resident_lockstep_outer_loop(built, shape):
+    """SURVEY 8 row f3, device-resident: B problems of a closed-form band family run the reference's outer/inner loop
+    (src/CaNNOLeS.jl:418-864, line search :1054-1112) in LOCKSTEP with vals, rhs and d in HBM throughout (device_loop.py:
+    cnl_prepare_newton_system_dev, cnl_residual_vectors_dev, cnl_newton_system_dev, cnl_trial_point_dev,
+    cnl_cgls_multipliers_dev).  Each problem must take the decisions it takes alone: status, outer iterations, Newton
+    systems, factorisations and backtracking steps equal those of the single-problem loop (outer_loop.solve, pinned to the
+    reference's known answers) run with the CPU oracle as linear solver, and the solutions agree."""
+    import torch
+    hipldl, syn, O = _mods()
+    from cannoles_jl_amd import device_loop as DL, outer_loop
+    from tests.test_oracle_pinning import oracle_newton, oracle_solver
+    n, p = shape
+    s = syn.band_structure(n, p)
+    B = 12
+    fam = DL.BandQuadFamily(s, B, seed=n + p, torch=torch, device="cuda:0", curvature=1.5, start=1.0, noise=0.5)
+    prm = hipldl.default_params()
+    got = DL.solve_batch_device(fam, prm)
+    work = 0
+    for b in range(B):
+        one = outer_loop.solve(fam.host_model(b), oracle_solver, oracle_newton, prm)
+        assert one["status"] == "first_order" and got["status"][b] == one["status"]
+        assert (got["iter"][b], got["nlinsolve"][b], got["nfact"][b], got["nbk"][b]) == (one["iter"], one["nlinsolve"], one["nfact"], one["nbk"]), b
+        assert np.allclose(got["solution"][b], one["solution"], atol=1e-7, rtol=1e-7)
+        if p:
+            assert np.allclose(got["multipliers"][b], one["multipliers"], atol=1e-6, rtol=1e-6)
+        assert abs(got["objective"][b] - one["objective"]) <= 1e-9 * max(1.0, one["objective"])
+        work += one["nlinsolve"]
+    assert got["nfact"].sum() > got["nlinsolve"].sum()        # the rho ladder was climbed somewhere
+    assert got["steps"] < work                                 # lockstep: far fewer batched rounds than Newton systems
