@@ -336,6 +336,18 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
                                           "frac": by_rv * B / (ms_rv * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                      "trial_point": {"ms": ms_tp, "bytes_per_system": by_tp, "GBps": by_tp * B / (ms_tp * 1e-3) / 1e9,
                                      "frac": by_tp * B / (ms_tp * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+    # ---- row f3: whole outer loops (src/CaNNOLeS.jl:418-864) of a closed-form family, device-resident and in lockstep
+    from cannoles_jl_amd import device_loop as DL
+    Bf = 2048
+    fam = DL.BandQuadFamily(syn.band_structure(300, 4), Bf, seed=7, torch=torch, device=dev, curvature=1.5, start=1.0, noise=0.5)
+    prm = hipldl.default_params()
+    DL.solve_batch_device(fam, prm, device_index=local_rank)
+    t0 = time.perf_counter()
+    got = DL.solve_batch_device(fam, prm, device_index=local_rank)
+    dt = time.perf_counter() - t0
+    out["aux_f3"] = {"workload": "band family n=300 p=4 (cfg4 pattern), B=2048 complete solves in lockstep", "problems_per_s": Bf / dt,
+                     "global_steps": got["steps"], "ms_per_step": 1e3 * dt / got["steps"], "newton_systems": int(got["nlinsolve"].sum()),
+                     "factorisations": int(got["nfact"].sum()), "first_order": int(sum(st == "first_order" for st in got["status"]))}
 
 
 def cpu_baseline(out, s, rows, cols, vals_h, rhs_h, prob, LDLT, args):
