@@ -46,6 +46,7 @@ struct DevPlan2 {
   int32_t u2_peak;       // doubles: per-problem LDS update stack; the staging triangle follows it
   int32_t prob_doubles;  // doubles of LDS per problem
   int32_t jraw_off;      // doubles: offset of the raw-value area of the on-the-fly condensation inside the per-problem LDS
+  int32_t bpanel_off;    // doubles: offset of the backward sweep's two panel buffers inside the per-problem LDS (behind the x stack)
   int64_t gs_doubles;    // doubles of global scratch per problem
   int64_t lsize;
   int64_t vstride, rstride, dstride;  // per-problem strides (doubles) of vals / rhs / d

@@ -117,11 +117,19 @@ __device__ __forceinline__ double gsum(double v) {
 #ifdef CNL_STAMPS
 #define STAMP_DECL unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP_BEGIN { __builtin_amdgcn_sched_barrier(0); st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#if CNL_STAMPS == 2   // the backward sweep in detail (BSTAMP 0..5); everything else in slot 7
+#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[7] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); }
+#define BSTAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
 #define STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); }
+#endif
 #else
 #define STAMP_DECL
 #define STAMP_BEGIN
 #define STAMP(k)
+#endif
+#ifndef BSTAMP
+#define BSTAMP(k)
 #endif
 
 struct Ctx2 {
@@ -338,6 +346,51 @@ __device__ __forceinline__ void eliminate16(int P_prob_doubles, int P_u2_peak, l
 #ifndef CNL_DPP_BACK
 #define CNL_DPP_BACK 0
 #endif
+// Round 2, second experiment: the backward sweep of the fast fronts rebuilt around that chain (-DCNL_GLDS_BACK=1):
+//  * the 8 header words of a front through the SCALAR cache (s_load from the record stream, constant address space), three
+//    fronts ahead, straight into SGPRs; the index words by LDS-DMA: no LDS copy of the record;
+//  * the panel of a front is a CONTIGUOUS piece of the factor storage (packed rows nupd+1 .. f-1), so the whole wave copies
+//    it as it lies into LDS with `global_load_lds_dwordx4` (one instruction per problem: 64 lanes x 16 bytes, no register
+//    staging, TWO fronts ahead into three buffers) and every pivot lane reads ITS OWN row from LDS (immediate offsets);
+//  * the dependent chain is one DPP-broadcast FMA per position, with the accumulator itself as the broadcast source.
+// Parity-green (the whole -m gpu suite), and MEASURED NO FASTER: 921k against 947k systems/s at B = 8192, 0.180 against
+// 0.171 ms at B = 1.  In-kernel stamps: the chain fell from 1150 to 350 cycles per front and wave and the header wait went
+// away, yet the sweep stayed at ~3800 cycles per front: at B = 8192 it streams the 9.5 GB of the factor in 1.9 ms = 5 TB/s,
+// i.e. it sits on the HBM read rate of this access pattern (address translation is not it: 12 k UTCL1 misses in 965 M
+// requests), whatever the per-wave latency chain looks like.  What shortens it is fewer bytes of L, not this.
+#ifndef CNL_GLDS_BACK
+#define CNL_GLDS_BACK 0
+#endif
+#define CNL_BPANEL_SLOT 152   // doubles per panel: 135 (f = 16, no update rows) + the 16-entry over-read of a row
+#define CNL_BPANEL_BUF 160    // doubles per buffer: the panel and 16 index words
+#define CNL_BPANEL_NBUF 3
+typedef __attribute__((address_space(3))) void* cnl_lds_ptr;
+typedef const __attribute__((address_space(4))) int* cnl_const_ptr;
+// 16 bytes per lane from base + off (8-byte alignment is enough, measured) to LDS byte address lds_addr + lane * 16 (wave-uniform
+// SGPR value).  The compiler does not count this load: the consumer waits with an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void glds16(const char* base, unsigned off, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_addr) : "memory");
+}
+// same, 4 bytes per lane
+__device__ __forceinline__ void glds4(const char* base, unsigned off, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_byte_address(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(cnl_lds_ptr)p);
+}
+struct BHdr { int w[8]; };
+// header of the backward record at word offset woff (wave-uniform) through the scalar cache
+__device__ __forceinline__ BHdr load_bhdr(const int* stream, int woff) {
+  cnl_const_ptr p = (cnl_const_ptr)(stream) + __builtin_amdgcn_readfirstlane(woff);
+  BHdr h;
+#pragma unroll
+  for (int k = 0; k < 8; k++) h.w[k] = p[k];
+  return h;
+}
 // w / d through the raw reciprocal (2^-25 on gfx950) and ONE residual correction of the quotient: relative error ~2^-50, four
 // dependent fp64 operations on the per-pivot chain instead of the six of fast_div (-DCNL_DPP_QUICKDIV=1; off by default)
 __device__ __forceinline__ double quick_div(double w, double d) {
@@ -640,6 +693,26 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
       DST[j] = (has_ && j < l) ? v_.x : 0.0;                                                     \
       DST[j + 1] = (has_ && j + 1 < l) ? v_.y : 0.0;                                             \
     }                                                                                            \
+  }
+
+// Panel of a front -> LDS buffer BUF of every problem of the wave (see CNL_GLDS_BACK): problem q is copied by all 64 lanes.
+#define GLDS_PANEL(LPTR, NUPD, NPIV, BUF)                                                                      \
+  {                                                                                                            \
+    const int pbytes_ = __builtin_amdgcn_readfirstlane((tri2(1 + (NUPD) + (NPIV)) - tri2(1 + (NUPD))) << 3);   \
+    const char* rb_ = L_wb + ((long long)(LPTR) << 3);                                                         \
+    const unsigned lo_ = (unsigned)lane * 16u;                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                         \
+      const unsigned qo_ = (prob0 + q_ < A.batch ? (unsigned)q_ : 0u) * (unsigned)P.lsize * 8u;                \
+      const unsigned dst_ = lds_panel0 + (unsigned)(q_ * P.prob_doubles + (BUF) * CNL_BPANEL_BUF) * 8u;        \
+      if ((int)lo_ < pbytes_) glds16(rb_, qo_ + lo_, dst_);                                                    \
+    }                                                                                                          \
+    if (pbytes_ > 1024) { /* only a front of order 16 without update rows */                                   \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                       \
+        const unsigned qo_ = (prob0 + q_ < A.batch ? (unsigned)q_ : 0u) * (unsigned)P.lsize * 8u;              \
+        const unsigned dst_ = lds_panel0 + (unsigned)(q_ * P.prob_doubles + (BUF) * CNL_BPANEL_BUF) * 8u;      \
+        if ((int)lo_ + 1024 < pbytes_) glds16(rb_, qo_ + 1024u + lo_, dst_ + 1024u);                           \
+      }                                                                                                        \
+    }                                                                                                          \
   }
 
 // Value prefetch of the NEXT front.  The lists of a record hold the entries that read the matrix values first and
@@ -1144,7 +1217,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
       }
       STAMP(1)
       // (5) eliminate in registers, store L rows and the update matrix
-#ifdef CNL_STAMPS
+#if defined(CNL_STAMPS) && !CNL_DPP_ELIM
       eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol, st_acc);
 #elif CNL_DPP_ELIM
       if (!(CNL_ABL & 1024)) eliminate16_dpp(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol);
@@ -1216,6 +1289,149 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
     const double* myL = A.L + pclamp * P.lsize;
     double* mydout = A.d + pclamp * P.dstride;
     double* xs = myU;  // the x stack reuses the per-problem LDS area
+#if CNL_GLDS_BACK
+    {
+      // Every asynchronous load of this loop is an LDS-DMA the compiler does not count (panels, index words): the waits are
+      // explicit.  Prefetch distance: TWO fronts (three LDS buffers) — at one front the sweep ran at the concurrency limit of
+      // HBM (4 KB per wave in flight x 2048 waves x ~2 us), not at its bandwidth.
+      const int* bw = P.brec;
+      const unsigned lds_panel0 = lds_byte_address(pbase0 + P.bpanel_off);   // buffers of the wave's first problem
+      const char* bwc = reinterpret_cast<const char*>(bw);
+      // buffer k of a problem: [panel: CNL_BPANEL_SLOT doubles | 16 index words (first problem's copy only)]
+#define GLDS_FRONT(HH, BOFF, BUF)                                                                                  \
+      {                                                                                                            \
+        const long long lp_ = (long long)HH.w[B_LPTR_LO] | ((long long)HH.w[B_LPTR_HI] << 31);                     \
+        if (!(CNL_ABL & 16384)) GLDS_PANEL(lp_, HH.w[B_NUPD], HH.w[B_NPIV], BUF)                                   \
+        if (lane < 16 && !(CNL_ABL & 262144)) glds4(bwc, (unsigned)((BOFF) + B_HDR + lane) * 4u, lds_panel0 + (unsigned)((BUF) * CNL_BPANEL_BUF + CNL_BPANEL_SLOT) * 8u); \
+      }
+      int boff = t_brec;
+      BHdr H = load_bhdr(bw, boff);
+      int boff1 = boff + H.w[B_RECLEN];
+      BHdr H1 = load_bhdr(bw, boff1);   // the stream is zero-padded: reading records past the end is harmless
+      int boff2 = boff1 + H1.w[B_RECLEN];
+      BHdr H2 = load_bhdr(bw, boff2);
+      bool primed = false, deep = false;
+      int b0 = 0, b1 = 1, b2 = 2;       // LDS buffers of fronts s, s+1, s+2
+      // the scattered store of a front's pivots is issued behind the NEXT front's drain: stores count in vmcnt on gfx9, a
+      // store issued right before the drain would put a full memory round trip on every front's critical path
+      double dpend = 0.0;
+      int ipend = -1;
+      int s = 0;
+      while (s < nfr) {
+        const int npiv = H.w[B_NPIV], nupd = H.w[B_NUPD], xoff = H.w[B_XOFF], pxoff = H.w[B_PXOFF], cls = H.w[B_CLS];
+        const long long lptr = (long long)H.w[B_LPTR_LO] | ((long long)H.w[B_LPTR_HI] << 31);
+        const int f = 1 + nupd + npiv;
+        const int boff3 = boff2 + H2.w[B_RECLEN];
+        if (cls != 16) {
+          // rare large front: its record goes to LDS for the out-of-line sweep, then the pipeline restarts
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (ipend >= 0) mydout[ipend] = dpend;
+          ipend = -1;
+          const int len = H.w[B_RECLEN];
+          for (int w4 = lane; w4 * 4 < len; w4 += 64) reinterpret_cast<int4*>(recbuf)[w4] = bstream[(boff >> 2) + w4];
+          wsync();
+          const int* rec = recbuf;
+          if (CNL_ABL & 4096) {
+          } else if (cls == 32) {
+            for (int pass = 0; pass < 2; pass++) {
+              if (prob0 + pass * 2 >= A.batch) break;
+              back_front_call<32>(P.prob_doubles, P.lsize, P.dstride, A.L, A.d, A.batch, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);
+            }
+          } else {
+            for (int pass = 0; pass < 4; pass++) {
+              if (prob0 + pass >= A.batch) break;
+              back_front_call<64>(P.prob_doubles, P.lsize, P.dstride, A.L, A.d, A.batch, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);
+            }
+          }
+          wsync();
+          boff = boff1; boff1 = boff2; boff2 = boff3;
+          H = H1; H1 = H2;
+          H2 = load_bhdr(bw, boff2);
+          s++;
+          primed = false;
+          continue;
+        }
+        const bool next_fast = s + 1 < nfr && H1.w[B_CLS] == 16;
+        if (!primed) {
+          GLDS_FRONT(H, boff, b0)
+          if (next_fast) GLDS_FRONT(H1, boff1, b1)
+          primed = true;
+          deep = false;
+        }
+        // this front's panel and index words were issued two fronts ago; behind them the queue holds one store and the five
+        // loads of the next front (more only makes the wait stricter); right after a restart: drain
+        BSTAMP(5)
+        if (deep) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BSTAMP(0)
+        if (ipend >= 0 && !(CNL_ABL & 65536)) mydout[ipend] = dpend;
+        // the front after the next: panel and index words; the header after that
+        deep = false;
+        if (next_fast && s + 2 < nfr && H2.w[B_CLS] == 16) {
+          GLDS_FRONT(H2, boff2, b2)
+          deep = true;
+        }
+        const BHdr H3 = load_bhdr(bw, boff3);
+        BSTAMP(1)
+        const int idx = (CNL_ABL & 262144) ? l : reinterpret_cast<const int*>(pbase0 + P.bpanel_off + b0 * CNL_BPANEL_BUF + CNL_BPANEL_SLOT)[l];
+        // x of the update rows from the parent's vector; lane 0 (right-hand-side column, z in the panel) holds -1 (see below)
+        double xb = l == 0 ? -1.0 : 0.0;
+        if (pxoff >= 0 && l >= 1 && l <= nupd && !(CNL_ABL & 131072)) xb = xs[pxoff + idx];
+        if (pxoff == B_PX_GLOBAL && l >= 1 && l <= nupd) {  // the parent was solved by another task: x = -d of the named components
+          xb = -__hip_atomic_load(mydout + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // this lane's row of the panel.  Lanes without a pivot row read row 0; entries at or past the diagonal are whatever
+        // follows in the buffer: a lane's sum is final before they are added and is not used afterwards.
+        double lr[16];
+        {
+          const bool has_ = l > nupd && l < f;
+          const double* prow_ = myU + P.bpanel_off + b0 * CNL_BPANEL_BUF + (has_ ? tri2(l) - tri2(1 + nupd) : 0);
+#pragma unroll
+          for (int j = 0; j < 16; j++) lr[j] = (CNL_ABL & 32768) ? 1.0 : prow_[j];
+        }
+        wsync();
+#if defined(CNL_STAMPS) && CNL_STAMPS == 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        BSTAMP(2)
+        {
+          // s_l = sum_j L(l, j) x_j over the columns j < l, one DPP-broadcast FMA per position.  Update rows: x_j comes from
+          // lane j of xb.  Pivots: x_j = -s_j, so the accumulator itself is the broadcast source and the row entry enters
+          // negated (nlr, formed off the chain): the dependent chain per pivot is ONE instruction (+ the DPP read hazard).
+          // The solution of pivot J is captured when its sum is final (later steps add over-read entries to that lane).
+          double s_ = 0.0, xcap = 0.0;
+#define CNL_BSTEP(J)                                                                                                    \
+          if (J < f && !(CNL_ABL & 8192)) {                                                                                \
+            if (J <= nupd) {                                                                                               \
+              asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(s_) : "v"(xb), "v"(lr[J])); \
+            } else {                                                                                                       \
+              const double nlr_ = -lr[J];                                                                                  \
+              xcap = (l == J) ? s_ : xcap;                                                                                 \
+              asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(s_) : "v"(nlr_)); \
+            }                                                                                                              \
+          }
+          CNL_BSTEP(0) CNL_BSTEP(1) CNL_BSTEP(2) CNL_BSTEP(3) CNL_BSTEP(4) CNL_BSTEP(5) CNL_BSTEP(6) CNL_BSTEP(7)
+          CNL_BSTEP(8) CNL_BSTEP(9) CNL_BSTEP(10) CNL_BSTEP(11) CNL_BSTEP(12) CNL_BSTEP(13) CNL_BSTEP(14) CNL_BSTEP(15)
+#undef CNL_BSTEP
+          if (l > nupd && l < f) xb = -xcap;
+        }
+        BSTAMP(3)
+        // d = -x of the pivots: one scattered store per front (the index word names the solution component of every pivot)
+        ipend = (okme && l > nupd && l < f) ? idx : -1;
+        dpend = -xb;
+        if (l >= 1 && l < f && !(CNL_ABL & 131072)) xs[xoff + l] = xb;
+        wsync();
+        boff = boff1; boff1 = boff2; boff2 = boff3;
+        H = H1; H1 = H2; H2 = H3;
+        { const int t_ = b0; b0 = b1; b1 = b2; b2 = t_; }
+        s++;
+        BSTAMP(4)
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (ipend >= 0) mydout[ipend] = dpend;
+#undef GLDS_FRONT
+    }
+#else
     int boff = t_brec, nxt = 0;
     int4 Rb;
 #if CNL_DPP_BACK
@@ -1350,6 +1566,7 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
       boff = nboff;
       s++;
     }
+#endif
   }
 #ifdef CNL_STAMPS
   STAMP(6)

@@ -12,14 +12,21 @@ CSRC = os.path.join(ROOT, "cannoles.jl_amd", "csrc")
 
 
 def libpath(bits):
-    return os.path.join(OUTD, f"libcnl_abl{bits}.so")
+    """a variant is a number (CNL_ABL bits) or NAME=VALUE[,NAME=VALUE...] (arbitrary -D flags)"""
+    return os.path.join(OUTD, "libcnl_abl" + str(bits).replace("=", "-").replace(",", "_") + ".so")
+
+
+def flags(bits):
+    if "=" in str(bits):
+        return " ".join("-D" + f for f in str(bits).split(","))
+    return f"-DCNL_ABL={bits}"
 
 
 def build(bits_list):
     os.makedirs(OUTD, exist_ok=True)
     procs = []
     for bits in bits_list:
-        cmd = ["make", "-s", "-C", CSRC, "-B", f"OUT={libpath(bits)}", f"CXXFLAGS=-O3 -std=c++17 -fPIC -DCNL_ABL={bits}"]
+        cmd = ["make", "-s", "-C", CSRC, "-B", f"OUT={libpath(bits)}", f"CXXFLAGS=-O3 -std=c++17 -fPIC {flags(bits)}"]
         procs.append(subprocess.Popen(cmd))
     for p in procs:
         p.wait()
@@ -48,15 +55,15 @@ for it in range(4):
     ro.zero_()
     hipldl.newton_system_dev(L, vals.data_ptr(), rhs.data_ptr(), d.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), su.data_ptr(), p, 0)
     torch.cuda.synchronize(); ms.append(L.last_kernel_ms())
-print("B", B, "ablate", {bits}, "kernel ms", np.round(ms[1:], 2))
+print("B", B, "ablate", {str(bits)!r}, "kernel ms", np.round(ms[1:], 2))
 """
     subprocess.run([sys.executable, "-c", code], env=env)
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "build":
-        build([int(x) for x in sys.argv[2:]])
+        build(sys.argv[2:])
     else:
         B = int(sys.argv[2])
         for bits in sys.argv[3:]:
-            run_one(B, int(bits))
+            run_one(B, bits)

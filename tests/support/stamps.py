@@ -10,27 +10,34 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "cannoles.jl_amd", "csrc")
-subprocess.check_call(["make", "-s", "-C", csrc, "-B", "CXXFLAGS=-O3 -std=c++17 -fPIC -DCNL_STAMPS"])
+if not os.environ.get("CANNOLES_HIP_LIB"):  # otherwise: a variant built beforehand (tests/support/ablate.py build CNL_STAMPS=1,...)
+    subprocess.check_call(["make", "-s", "-C", csrc, "-B", "CXXFLAGS=-O3 -std=c++17 -fPIC -DCNL_STAMPS"])
 import cannoles_jl_amd  # noqa
 from cannoles_jl_amd import hipldl, synthetic as syn
 
 n, p, B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000, int(sys.argv[2]) if len(sys.argv) > 2 else 50, int(sys.argv[3]) if len(sys.argv) > 3 else 256
 s = syn.band_structure(n, p)
 rows, cols = s.kkt_pattern()
-vals, rhs = syn.batch_values(s, 8, cfg=3)
+import bench
+vals, rhs = bench.band_batch(s, 8, 3000)   # the bench's values: no rho ladder
 vals = np.tile(vals, (B // 8, 1)); rhs = np.tile(rhs, (B // 8, 1))
 L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
 d = np.zeros((B, s.N))
 prm = hipldl.default_params()
-for it in range(2):
-    hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, np.zeros(B), prm)
+L.set_timing(True)
+for it in range(3):
+    _, ok_, _, _, nf_ = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, np.zeros(B), prm)
+print("kernel ms", L.last_kernel_ms(), "success", ok_.all(), "nfact max", nf_.max())
 lib = hipldl.lib()
 nw = B // 4
 out = np.zeros(nw * 8, np.int64)
 lib.cnl_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 assert lib.cnl_debug_stamps(L._h, out.ctypes.data, out.size) == 0
 st = out.reshape(nw, 8).astype(float)
-names = ["zero+asm", "rec+prefetch", "extend-add", "eliminate(all)", "sync", "el:pivots(+ladder)", "backward", "el:loads"]
+if os.environ.get("CNL_STAMP_NAMES") == "backward":   # library built with -DCNL_STAMPS=2
+    names = ["b:wait vmcnt", "b:issue prefetch", "b:idx,x,row reads", "b:chain", "b:stores+rotate", "b:loop head", "(unused)", "forward+ladder"]
+else:
+  names = ["zero+asm", "rec+prefetch", "extend-add", "eliminate(all)", "sync", "el:pivots(+ladder)", "backward", "el:loads"]
 tot = st.sum(axis=1).mean()
 print(L.info)
 print("cycles per wave (s_memtime ticks): total %.3e" % tot)
