@@ -179,7 +179,7 @@ int setup_v2(cnl_handle* h) {
   d.jraw_off = (int32_t)((P.u2_peak + std::max<int64_t>(P.fs2_max, 64) + 1) & ~(int64_t)1);
   // backward sweep: the x stack, then three buffers of 160 doubles (panel + index words; kernels2.hip, CNL_GLDS_BACK)
   d.bpanel_off = (int32_t)((P.bwd_peak + 2 + 1) & ~(int64_t)1);
-  int64_t prob = std::max<int64_t>((int64_t)d.jraw_off + (P.rec_direct ? 128 : 0), (int64_t)d.bpanel_off + 3 * 160);
+  int64_t prob = std::max<int64_t>((int64_t)d.jraw_off + (P.rec_direct ? 128 : 0), (int64_t)d.bpanel_off + cnl::newton2_backward_lds_doubles());
   // per-problem areas 32 banks apart modulo 64 (prob_doubles = 16 mod 32): the 16 lanes of two neighbouring problems
   // then touch disjoint LDS banks when they read the same row of their images (env CNL_LDS_PAD=0 disables)
   prob = (prob + 1) & ~(int64_t)1;

@@ -104,6 +104,7 @@ struct LaunchArgs {
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream);
+int newton2_backward_lds_doubles();  // per-problem LDS the backward sweep needs behind the x stack (0 unless built with CNL_GLDS_BACK)
 // one attempt at the rho given in vals, stage by stage (stage_ptr: host array of nstages + 1 task offsets)
 hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, LaunchArgs a, const int32_t* stage_ptr, int nstages, hipStream_t stream);
 hipError_t launch_condense(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int slot_begin, int slot_end,

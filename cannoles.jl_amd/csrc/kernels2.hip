@@ -760,8 +760,11 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
   }
 
 // ==========================================================================================
+#ifndef CNL_WAVES_PER_SIMD
+#define CNL_WAVES_PER_SIMD 2
+#endif
 template <bool STAGED>
-__global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, const LaunchArgs Ain) {
+__global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(const DevPlan2 Pin, const LaunchArgs Ain) {
   DevPlan2 P = Pin;
   P.rec = as_global(Pin.rec); P.brec = as_global(Pin.brec);
   LaunchArgs A = Ain;
@@ -1582,6 +1585,8 @@ __global__ void __launch_bounds__(256, 2) newton2_kernel_t(const DevPlan2 Pin, c
     A.success[prob] = success ? 1 : 0;
   }
 }
+
+int newton2_backward_lds_doubles() { return CNL_GLDS_BACK ? CNL_BPANEL_NBUF * CNL_BPANEL_BUF : 0; }
 
 hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream) {
   if (wpb < 1 || wpb > 4) return hipErrorInvalidConfiguration;

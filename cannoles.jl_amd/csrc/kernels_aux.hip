@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* 
   const DevCond C = globalize(Cin);
   const int b0 = blockIdx.y * XPB;
   const int t = threadIdx.x;
-  __shared__ double prod[XEMAX];
+  __shared__ double prod[2 * XEMAX];
   if ((int)blockIdx.x < nb_copy) {
     const int j = blockIdx.x * 256 + t;
     const int oj = j < C.N2 ? C.orig_of[j] : 0;
@@ -226,28 +226,62 @@ __global__ void __launch_bounds__(256) expand_kernel(const DevCond Cin, double* 
   const int i = has_row ? C.r_orig[qr] : 0;
   const int k0 = has_row ? C.r_ptr[qr] : 0, k1 = has_row ? C.r_ptr[qr + 1] : 0;
   const int dsrc = has_row ? C.r_dsrc[qr] : 0;
-  for (int q = 0; q < XPB && b0 + q < batch; q++) {
+  const int nq = batch - b0 < XPB ? batch - b0 : XPB;
+  if (staged) {
+    // Problems are pipelined: the operands of problem q + 1 are loaded into registers before the products of problem q are
+    // parked and summed (two LDS buffers, one barrier per problem), so the loads of the next problem are in flight while
+    // this one is reduced.
+    double jv[XE], xv[XE], rh = 0.0, dv = 1.0;
+    bool ok_cur = false;
+    auto load = [&](int q, double (&jv_)[XE], double (&xv_)[XE], double& rh_, double& dv_) -> bool {
+      const long long b = b0 + q;
+      if (q >= nq || (success && !success[b])) return false;  // workgroup-uniform
+      const double* v = vals + b * C.nnz;
+      const double* x2 = d2 ? d2 + b * C.N2 : dout + b * C.N;
+#pragma unroll
+      for (int k = 0; k < XE; k++) {
+        const bool in = t + 256 * k < e1 - e0;
+        jv_[k] = in ? v[js[k]] : 0.0;
+        xv_[k] = in ? x2[jx[k]] : 0.0;
+      }
+      rh_ = has_row ? rhs[b * C.N + i] : 0.0;
+      dv_ = has_row ? v[dsrc] : 1.0;
+      return true;
+    };
+    ok_cur = load(0, jv, xv, rh, dv);
+    for (int q = 0; q < nq; q++) {
+      double jn[XE], xn[XE], rhn = 0.0, dvn = 1.0;
+      const bool ok_next = load(q + 1, jn, xn, rhn, dvn);
+      if (ok_cur) {
+        double* pb = prod + (q & 1) * XEMAX;
+#pragma unroll
+        for (int k = 0; k < XE; k++) {
+          const int e = t + 256 * k;
+          if (e < e1 - e0) pb[e] = jv[k] * xv[k];
+        }
+      }
+      __syncthreads();  // (also orders the reads of this buffer two problems ago before the writes above)
+      if (ok_cur && has_row) {
+        const double* pb = prod + (q & 1) * XEMAX;
+        double s = rh;
+        for (int k = k0; k < k1; k++) s += pb[k - e0];
+        dout[(long long)(b0 + q) * C.N + i] = -fast_div_aux(s, dv);
+      }
+#pragma unroll
+      for (int k = 0; k < XE; k++) { jv[k] = jn[k]; xv[k] = xn[k]; }
+      rh = rhn; dv = dvn; ok_cur = ok_next;
+    }
+    return;
+  }
+  for (int q = 0; q < nq; q++) {
     const long long b = b0 + q;
     if (success && !success[b]) continue;  // workgroup-uniform
     const double* v = vals + b * C.nnz;
     // x components: reduced index == caller's index for the variables (they are never condensed)
     const double* x2 = d2 ? d2 + b * C.N2 : dout + b * C.N;
-    if (staged) {
-      __syncthreads();  // the previous problem's sums are done with prod
-#pragma unroll
-      for (int k = 0; k < XE; k++) {
-        const int e = t + 256 * k;
-        if (e < e1 - e0) prod[e] = v[js[k]] * x2[jx[k]];
-      }
-      __syncthreads();
-    }
     if (has_row) {
       double s = rhs[b * C.N + i];
-      if (staged) {
-        for (int k = k0; k < k1; k++) s += prod[k - e0];
-      } else {
-        for (int k = k0; k < k1; k++) s = fma(v[C.r_jsrc[k]], x2[C.r_jx[k]], s);
-      }
+      for (int k = k0; k < k1; k++) s = fma(v[C.r_jsrc[k]], x2[C.r_jx[k]], s);
       dout[b * C.N + i] = -fast_div_aux(s, v[dsrc]);
     }
   }
