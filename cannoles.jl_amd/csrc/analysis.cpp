@@ -953,7 +953,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     P.fs2_max = (int32_t)((fsmax + 1) & ~(int64_t)1);
     P.gs_doubles = (peakG + 1) & ~(int64_t)1;
     P.v2_cls = cls; P.v2_fsglob = fsglob; P.v2_uglob = uglob; P.v2_uoff = uoff2; P.v2_fsoff = fsoff2;
-    for (int32_t s = 0; s < ns; s++) if (cls[s] == 16 && !fsglob[s]) fsmax = std::max<int64_t>(fsmax, 16 * 16);
+    for (int32_t s = 0; s < ns; s++) if (cls[s] == 16 && !fsglob[s]) fsmax = std::max<int64_t>(fsmax, FAST_IMG_DOUBLES);
     P.fs2_max = (int32_t)((fsmax + 1) & ~(int64_t)1);
     write_forward_records(P, nullptr);
     // backward records, reverse post-order
@@ -999,13 +999,7 @@ void finalize_tasks(Plan& P) {
 int write_forward_records(Plan& P, const DirectLists* D) {
   const int32_t ns = P.nsuper;
   const ivec &cls = P.v2_cls, &fsglob = P.v2_fsglob, &uglob = P.v2_uglob, &uoff2 = P.v2_uoff, &fsoff2 = P.v2_fsoff;
-  // fast fronts (order <= 16, LDS staging) use a strided image: (a, b) -> a*16 + b instead of a(a+1)/2 + b
-  auto stride_pos = [&](int32_t packed) -> int32_t {
-    int32_t a = (int32_t)((std::sqrt(8.0 * packed + 1.0) - 1.0) * 0.5);
-    while (tri(a + 1) <= packed) a++;
-    while (tri(a) > packed) a--;
-    return a * 16 + (packed - (int32_t)tri(a));
-  };
+  // fast fronts (order <= 16, LDS staging): packed triangle + FAST_IMG_DOUBLES - FAST_IMG_TRI slots for the padding entries
   std::vector<int32_t> rec;
   int32_t rec_maxlen = 0;
   int64_t st_raw = 0, st_prod = 0, st_asm = 0, st_rawmax = 0, st_prodmax = 0, st_asmmax = 0;
@@ -1018,7 +1012,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
     const bool strided = cls[s] == 16 && !fsglob[s];
     // plain entries (pos, src) grouped in rounds: all positions of a round are distinct, rounds are applied in
     // order (COO-order sums of duplicates); every round is padded to a multiple of 16 with entries that add
-    // some value to an UNUSED slot (strided image: the free upper part of row 0, distinct positions)
+    // some value to an UNUSED slot (fast fronts: the slots behind the triangle, distinct positions)
     struct PE { int32_t round, src, pos; };
     std::vector<PE> pes;
     struct PR { int32_t pos, a, b, d; };
@@ -1027,7 +1021,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
       std::unordered_map<int32_t, int32_t> occ;  // position -> plain entries so far
       for (int32_t r = F.seg_begin; r < F.seg_end; r++)
         for (int32_t e = P.seg_ptr[r]; e < P.seg_ptr[r + 1]; e++) {
-          const int32_t pos = strided ? stride_pos(P.asm_pos[e]) : P.asm_pos[e];
+          const int32_t pos = P.asm_pos[e];
           const int32_t src = P.asm_src[e];
           if (!D) { pes.push_back({occ[pos]++, src, pos}); continue; }
           for (int32_t c = D->c_ptr[src]; c < D->c_ptr[src + 1]; c++) {
@@ -1054,11 +1048,11 @@ int write_forward_records(Plan& P, const DirectLists* D) {
       for (size_t i = 0; i < sel.size(); i++) {
         if (i > 0 && sel[i].round != sel[i - 1].round) {
           int32_t dk = 0;
-          while (asrc.size() % 16) { asrc.push_back(dsrc); apos.push_back(strided ? 1 + (dk++ % 15) : 0); }
+          while (asrc.size() % 16) { asrc.push_back(dsrc); apos.push_back(strided ? FAST_IMG_TRI + (dk++ % 16) : 0); }
         }
         asrc.push_back(sel[i].src); apos.push_back(sel[i].pos);
       }
-      { int32_t dk = 0; while (asrc.size() % 16) { asrc.push_back(dsrc); apos.push_back(strided ? 1 + (dk++ % 15) : 0); } }
+      { int32_t dk = 0; while (asrc.size() % 16) { asrc.push_back(dsrc); apos.push_back(strided ? FAST_IMG_TRI + (dk++ % 16) : 0); } }
       if (grp == 0) nasmv = (int32_t)asrc.size();
     }
     // products of one position go to different rounds of 16 (same-address LDS atomics of one instruction serialise):
@@ -1119,7 +1113,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
       int32_t dk = 0;
       if (strided) {  // one word per product: pos | ia << 8 | ib << 15 | id << 22
         for (auto& p_ : prs) prod.push_back(p_.pos | (rawidx[p_.a] << 8) | (rawidx[p_.b] << 15) | (rawidx[p_.d] << 22));
-        while (prod.size() % 16) prod.push_back(1 + (dk++ % 15));
+        while (prod.size() % 16) prod.push_back(FAST_IMG_TRI + (dk++ % 16));
       } else {        // two words: pos, ia | ib << 10 | id << 20
         for (auto& p_ : prs) { prod.push_back(p_.pos); prod.push_back(rawidx[p_.a] | (rawidx[p_.b] << 10) | (rawidx[p_.d] << 20)); }
         while ((prod.size() / 2) % 16) { prod.push_back(0); prod.push_back(0); }
@@ -1140,7 +1134,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
       rec.push_back(uoff2[c]); rec.push_back(tuc); rec.push_back(uglob[c] ? 1 : 0); rec.push_back(0);
       const int32_t* rel = P.rel_idx.data() + C.rel_begin;
       for (int32_t a = 0; a <= C.nupd; a++)
-        for (int32_t b = 0; b <= a; b++) rec.push_back(strided ? rel[a] * 16 + rel[b] : (int32_t)(tri(rel[a]) + rel[b]));
+        for (int32_t b = 0; b <= a; b++) rec.push_back((int32_t)(tri(rel[a]) + rel[b]));
       while ((rec.size() - r0) % 4) rec.push_back(0);
     }
     while ((rec.size() - r0) % 4) rec.push_back(0);

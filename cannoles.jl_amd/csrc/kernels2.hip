@@ -44,6 +44,13 @@ constexpr int PVN = 8;   // value prefetch: PVN doubles per lane = PVN*16 entrie
 constexpr int KB = 10;   // panel rows prefetched per front in the solve sweeps (chain-like orders: up to 10 pivots per front)
 
 __device__ __forceinline__ int tri2(int i) { return (i * (i + 1)) >> 1; }
+// row a of the packed position a(a+1)/2 + b of a fast front's image (pos < FAST_IMG_DOUBLES)
+__device__ __forceinline__ int tri_row(int pos) {
+  int a = (int)((__builtin_sqrtf(8.0f * (float)pos + 1.0f) - 1.0f) * 0.5f);
+  a += tri2(a + 1) <= pos;
+  a -= tri2(a) > pos;
+  return a;
+}
 
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -171,9 +178,9 @@ struct Ctx2 {
 #define CNL_USTG(k) { const int a_ = nupd - k; if (a_ >= 0) Ug[tri2(a_) + b] = r##k; }
 #define CNL_USTL(k) { const int a_ = nupd - k; if (a_ >= 0) Ul[tri2(a_) + b] = r##k; }
 
-// fast fronts (order <= 16, LDS staging) use a strided staging image: row a at a*16, so the 16 row
-// loads are one base address plus immediate offsets (rows below 0 read unused garbage)
-#define CNL_LOADS(k) r##k = Fss[(15 - k) * 16];
+// fast fronts (order <= 16, LDS staging): the image is the packed triangle (plan.h, FAST_IMG_*), row a at a(a+1)/2, so the
+// 16 row loads are one base address plus immediate offsets; lanes past the diagonal read entries of later rows (never used)
+#define CNL_LOADS(k) r##k = Fss[((15 - k) * (16 - k)) / 2];
 #ifdef CNL_STAMPS
 #define ESTAMP0 unsigned long long et0_ = 0; if (st_) { __builtin_amdgcn_sched_barrier(0); et0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #define ESTAMP(k) if (st_) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[k] += t_ - et0_; et0_ = t_; __builtin_amdgcn_sched_barrier(0); }
@@ -410,7 +417,7 @@ __device__ __forceinline__ double quick_div(double w, double d) {
 // first DPP read of a row the previous pivot's updates wrote: hipcc pads no hazards inside asm (VALU write -> DPP read: 2 wait states)
 #define CNL_DPPF_NOP(X, W, NL, A) \
   asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #A " row_mask:0xf bank_mask:0xf" : "+v"(X) : "v"(W), "v"(NL));
-#define CNL_DPP_DECL(a) double R##a = Fs[a * 16 + b];
+#define CNL_DPP_DECL(a) double R##a = Fs[(a * (a + 1)) / 2 + b];
 #define CNL_DPP_PRE(i)                                                                                    \
   const double lv = CNL_DPP_DIV(w_, dpiv);                                                                \
   npos += dpiv > eig_tol;                                                                                 \
@@ -441,7 +448,7 @@ __device__ __forceinline__ void eliminate16_dpp(int P_prob_doubles, int P_u2_pea
   const int top = f - 1;
   { const double* Fs_ = Fs; (void)Fs_; }
 #undef CNL_DPP_DECL
-#define CNL_DPP_DECL(a) double R##a = Fs[a * 16];
+#define CNL_DPP_DECL(a) double R##a = Fs[(a * (a + 1)) / 2];
   CNL_DPP_ROWS(CNL_DPP_DECL)
   int npos = 0, nzer = 0;
   const double one_ = 1.0;
@@ -899,21 +906,21 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       wsync();
       // plain right-hand-side entries (positions (row, 0); padding entries sit in other columns and are skipped)
       if (nasmv < nasm) {
-        const int pos = rec[aoff + nasm + nasmv + l];
-        if ((pos & 15) == 0) __hip_atomic_fetch_add(&cvec[pos >> 4], prh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const int pos = rec[aoff + nasm + nasmv + l], prow = tri_row(pos);
+        if (pos == tri2(prow) && pos < FAST_IMG_TRI) __hip_atomic_fetch_add(&cvec[prow], prh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
       for (int e = nasmv + 16 + l; e < nasm; e += 16) {
-        const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
-        if ((pos & 15) == 0) __hip_atomic_fetch_add(&cvec[pos >> 4], myrhs[src - P.nnz], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const int src = rec[aoff + e], pos = rec[aoff + nasm + e], prow = tri_row(pos);
+        if (pos == tri2(prow) && pos < FAST_IMG_TRI) __hip_atomic_fetch_add(&cvec[prow], myrhs[src - P.nnz], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
       // products that land in column 0
       {
         const int* pw = rec + raw_off + nraw + l;
         for (int e = 0; e < nprod; e += 16) {
-          const int w = pw[e];
-          if ((w & 15) == 0) {
+          const int w = pw[e], pos = w & 255, prow = tri_row(pos);
+          if (pos == tri2(prow) && pos < FAST_IMG_TRI) {
             const double v = jraw[(w >> 8) & 127] * jraw[(w >> 15) & 127] * jraw[(w >> 22) & 127];
-            __hip_atomic_fetch_add(&cvec[(w & 255) >> 4], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(&cvec[prow], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           }
         }
       }
@@ -924,7 +931,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
           const int cv4 = rec[co + (lane & 3)];
           const int cu = HDRW(cv4, C_UOFF), tuc = HDRW(cv4, C_TUC), cfl = HDRW(cv4, C_FLAGS);
           if (tri2(l) < tuc) {
-            const int prow = rec[co + C_HDR + tri2(l)] >> 4;
+            const int prow = tri_row(rec[co + C_HDR + tri2(l)]);
             const double u = cfl ? mygs[cu + l] : myU[cu + l];
             __hip_atomic_fetch_add(&cvec[prow], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           }
@@ -1066,11 +1073,12 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       const long long lptr = (long long)HDRW(hv, R_LPTR_LO) | ((long long)HDRW(hv, R_LPTR_HI) << 31);
       const int f = 1 + nupd + npiv;
       const bool uglob = flags & RF_U_GLOBAL;
-      // (1) zero the strided staging image (all 16 rows of 16: no loop, no predicate)
+      // (1) zero the staging image (packed triangle + padding slots = 152 doubles = 76 pairs: no loop; the fifth round covers 12)
       {
         double2* z2 = reinterpret_cast<double2*>(myFs) + l;
 #pragma unroll
-        for (int j = 0; j < 8; j++) z2[16 * j] = make_double2(0.0, 0.0);
+        for (int j = 0; j < 4; j++) z2[16 * j] = make_double2(0.0, 0.0);
+        if (l < FAST_IMG_DOUBLES / 2 - 64) z2[64] = make_double2(0.0, 0.0);
       }
       wsync();
       // (2) extend-add the children's update matrices: needs nothing from global memory, so the stores of the
@@ -1168,7 +1176,10 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         // products -J_ra J_rb / d_r of the condensed residual rows: one packed word each, pos | ia<<8 | ib<<15 | id<<22
         // (PB rounds in flight: the LDS round trips of a round are dependent, those of different rounds are not)
         wsync();
-        constexpr int PB = 8;
+#ifndef CNL_PB
+#define CNL_PB 8
+#endif
+        constexpr int PB = CNL_PB;
         const int* pw = rec + raw_off + nraw + l;
         for (int e = 0; e < nprod; e += 16 * PB) {
           int w[PB];

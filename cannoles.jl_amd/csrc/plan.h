@@ -125,6 +125,10 @@ enum {
 };
 enum { RF_U_GLOBAL = 1, RF_FS_GLOBAL = 2 };
 enum { C_UOFF = 0, C_TUC, C_FLAGS, C_PAD, C_HDR = 4 };
+// LDS image of a fast front (order <= 16): the packed lower triangle, (a, b) -> a(a+1)/2 + b, 136 doubles, followed by 16
+// slots that only the padding entries of the assembly lists add to.  (Round 1 used a 16 x 16 strided image; the triangle
+// brings the LDS need of a wavefront from 16.8 to 12.7 KB: twelve wavefronts per CU instead of nine.)
+enum { FAST_IMG_TRI = 136, FAST_IMG_DOUBLES = 152 };
 enum { B_NPIV = 0, B_NUPD, B_RECLEN, B_XOFF, B_PXOFF, B_LPTR_LO, B_LPTR_HI, B_CLS, B_HDR = 8 };
 enum { B_PX_NONE = -1, B_PX_GLOBAL = -2 };  // B_PXOFF: no parent / parent solved by another task: the update rows name solution components
 

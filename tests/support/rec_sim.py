@@ -11,6 +11,7 @@ import numpy as np
 (R_NPIV, R_NUPD, R_RECLEN, R_NASM, R_NCHILD, R_UOFF, R_FLAGS, R_FSOFF, R_LPTR_LO, R_LPTR_HI, R_NASMV, R_ASM_OFF,
  R_CHILD_OFF, R_NPROD, R_NRAW, R_NRD) = range(16)
 R_HDR = 16
+FAST_IMG_TRI, FAST_IMG_DOUBLES = 136, 152   # plan.h
 RF_U_GLOBAL, RF_FS_GLOBAL = 1, 2
 B_NPIV, B_NUPD, B_RECLEN, B_XOFF, B_PXOFF, B_LPTR_LO, B_LPTR_HI, B_CLS = range(8)
 B_HDR = 8
@@ -51,8 +52,8 @@ class RecSim:
             f = 1 + nupd + npiv
             strided = cls == 16 and not (flags & RF_FS_GLOBAL)
             self.stats["strided" if strided else "packed"] += 1
-            img = np.zeros(max(256, tri(f) + 16) if strided else tri(f) + 16)
-            pos_of = (lambda a, b: a * 16 + b) if strided else (lambda a, b: tri(a) + b)
+            img = np.zeros(FAST_IMG_DOUBLES if strided else tri(f) + 16)   # fast fronts: packed triangle + padding slots (plan.h)
+            pos_of = lambda a, b: tri(a) + b
             r = rec[off:off + int(H[R_RECLEN])]
             # plain entries: matrix values first, right-hand side last; every group padded to rounds of 16
             assert nasmv % 16 == 0 and nasm % 16 == 0 and nasmv <= nasm
@@ -189,8 +190,8 @@ class StagedSim(RecSim):
                     nrd = int(H[R_NRD]) & 0xffff
                     f = 1 + nupd + npiv
                     strided = cls == 16 and not (flags & RF_FS_GLOBAL)
-                    img = np.zeros(max(256, tri(f) + 16) if strided else tri(f) + 16)
-                    pos_of = (lambda a, b: a * 16 + b) if strided else (lambda a, b: tri(a) + b)
+                    img = np.zeros(FAST_IMG_DOUBLES if strided else tri(f) + 16)   # fast fronts: packed triangle + padding slots (plan.h)
+                    pos_of = lambda a, b: tri(a) + b
                     r = rec[off:off + int(H[R_RECLEN])]
                     for e in range(nasm):
                         img[int(r[aoff + nasm + e])] += src_val(int(r[aoff + e]))
