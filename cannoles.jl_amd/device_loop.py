@@ -264,9 +264,13 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
     xt_e, rt_e, lamt_e, dlam_e = Z(B, n), Z(B, m), Z(B, P), Z(B, P)
     phi = lambda F_, c_, l_, et: 0.5 * (F_ * F_).sum(dim=1) - ((l_ * c_).sum(dim=1) if p else 0.0) + (et * (c_ * c_).sum(dim=1) / 2 if p else 0.0)
     steps = 0
-    while bool((status == UNKNOWN).any()) and steps < max_steps:
-        steps += 1
+    # host synchronisations per global step: one for the branch flags below, one for (rejected, small-residual) further down,
+    # and one per round of backtracking when a line search runs
+    while steps < max_steps:
         act = status == UNKNOWN
+        if not bool(act.any()):
+            break
+        steps += 1
         # ---- start of an outer iteration, src/CaNNOLeS.jl:612-626
         so = act & phase0
         combined = W(so, normdual + normprimal, combined)
@@ -278,7 +282,8 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
         # ---- Newton step (skipped on the iteration right after a rejected extrapolation), :627-652
         need = act & (inner != 1)
         brk = t.zeros(B, dtype=t.bool, device=dev)
-        if bool(need.any()):
+        any_need, any_ext, any_ls = t.stack([need.any(), (act & (inner == 0)).any(), (act & (inner > 0)).any()]).tolist()
+        if any_need:
             prepare(vals_cur, fam.hess_vals(x, r), Jv, Jcv, delta)
             ro_tmp = rho_old.clone()
             hipldl.newton_system_dev(L, ptr(vals_cur), ptr(rhs_cur), ptr(d_new), ptr(ro_tmp), ptr(rho_new), ptr(nf_new), ptr(ok_new), params, st)
@@ -292,13 +297,13 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
         dx = d[:, :n]
         ext, lsm = act & (inner == 0), act & (inner > 0)
         # ---- extrapolation step, :654-668
-        if bool(ext.any()):
+        if any_ext:   # (a superset test: problems that broke above are masked out by `ext`)
             epsk = W(ext, t.maximum(t.minimum(1e3 * delta, 99 * epsk / 100), 9 * epsk / 10), epsk)
             hipldl.trial_point_dev(L, ptr(x), ptr(r), ptr(lam) if p else 0, ptr(d), 1e4, ptr(xt_e), ptr(rt_e), ptr(lamt_e) if p else 0,
                                    ptr(dlam_e) if p else 0, st)
             xt, rt, lamt = W(ext, xt_e, xt), W(ext, rt_e, rt), W(ext, lamt_e, lamt)
         # ---- Armijo line search on the merit function, :1054-1112
-        if bool(lsm.any()):
+        if any_ls:
             lam_ls = lam - cx / delta[:, None] if p else lam
             prepare(vals_cur, None, Jv, Jcv, delta)
             g, _, _ = resid_vectors(vals_cur, Fx, lam_ls, Fx, cx)      # dual part: Jx'Fx - Jc'(lam - c/delta)
@@ -335,22 +340,25 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
         lam = W(acc_lam, lamt, lam)
         rhs_cur = W(act, rhs_t, rhs_cur)
         rej = act & ~good
-        if bool(rej.any()):   # dual at (x, r, lam) again; primal keeps the trial's value, as in the reference (:742-747)
-            prepare(vals_cur, None, Jv, Jcv, delta)
-            rhs_r, _, _ = resid_vectors(vals_cur, r, lam, Fx, cx)
-            rhs_cur = t.cat([W(rej, rhs_r[:, :n], rhs_cur[:, :n]), rhs_cur[:, n:]], dim=1)
+        delta_next = delta
         if p:
             dr_ = act & (inner > 0) & (ndh <= 0.99 * normdual + epsk / 2) & (nph > 0.99 * normprimal + epsk / 2)
-            delta = W(dr_, t.clamp(delta / 10, min=dmin), delta)
+            delta_next = W(dr_, t.clamp(delta / 10, min=dmin), delta)
         inner = inner + act.to(t.int64)
         tired = inner > max_inner
-        # ---- end of the inner loop -> end of the outer iteration, :765-800
+        # ---- end of the inner loop -> end of the outer iteration, :765-800 (tests first: one synchronisation for both branches)
         done_in = (act & (good | tired)) | brk
         normdual, normprimal = W(done_in, ndh, normdual), W(done_in, nph, normprimal)
         first_order = t.maximum(normdual / dual_scaling(lam), normprimal) <= epstol
         small_residual = (2 * t.sqrt(fx) <= epsF) & (cnorm2(cx) <= epsc)
         chk = done_in & small_residual & ~first_order
-        if bool(chk.any()):
+        any_rej, any_chk = t.stack([rej.any(), chk.any()]).tolist()
+        if any_rej:   # dual at (x, r, lam) again; primal keeps the trial's value, as in the reference (:742-747)
+            prepare(vals_cur, None, Jv, Jcv, delta)
+            rhs_r, _, _ = resid_vectors(vals_cur, r, lam, Fx, cx)
+            rhs_cur = t.cat([W(rej, rhs_r[:, :n], rhs_cur[:, :n]), rhs_cur[:, n:]], dim=1)
+        delta = delta_next
+        if any_chk:
             lam, rhs_cur, normdual, normprimal, r = small_res_check(chk, lam, rhs_cur, normdual, normprimal, r)
             first_order = t.maximum(normdual / dual_scaling(lam), normprimal) <= epstol
         it = it + done_in.to(t.int32)
