@@ -872,17 +872,26 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       const bool bottom = nsub[s] <= cap;
       if (bottom) {
         stage[s] = 0;
-        if (sparent[s] < 0 || nsub[sparent[s]] > cap) ts.push_back({0, fdesc[s], s + 1, 0, 0, sparent[s] < 0 ? 1 : 0});
+        if (sparent[s] < 0 || nsub[sparent[s]] > cap) ts.push_back({0, fdesc[s], s + 1, 0, 0, sparent[s] < 0 ? 1 : 0, -1, 0});
       } else {
         int32_t st = 0;
         for (int32_t c : skids[s]) st = std::max(st, stage[c]);
         stage[s] = st + 1;
-        ts.push_back({stage[s], s, s + 1, 0, 0, sparent[s] < 0 ? 1 : 0});
+        ts.push_back({stage[s], s, s + 1, 0, 0, sparent[s] < 0 ? 1 : 0, -1, 0});
       }
     }
     if (ts.size() > 1) {
       std::stable_sort(ts.begin(), ts.end(), [](const Task& x, const Task& y) { return x.stage < y.stage; });
       P.tasks = ts;
+      {  // dependencies between tasks (the dataflow execution waits on them instead of on a launch per stage)
+        ivec task_of(ns, -1);
+        for (size_t k = 0; k < P.tasks.size(); k++) for (int32_t f = P.tasks[k].f0; f < P.tasks[k].f1; f++) task_of[f] = (int32_t)k;
+        for (Task& t : P.tasks) {
+          const int32_t pf = sparent[t.f1 - 1];
+          t.parent = pf >= 0 ? task_of[pf] : -1;
+          if (t.parent >= 0) P.tasks[t.parent].nchild++;
+        }
+      }
       for (const Task& t : P.tasks) { task_first[t.f0] = 1; task_root[t.f1 - 1] = 1; }
       const int32_t nst = P.tasks.back().stage + 1;
       P.stage_ptr.assign(nst + 1, 0);

@@ -43,6 +43,8 @@ struct cnl_handle {
   bool staged = false;    // newton_system: first attempt stage by stage (tasks of the elimination tree on different wavefronts)
   const int32_t* d_tasks = nullptr;
   int* d_gcnt = nullptr;
+  int* d_dep = nullptr;   // dataflow counters of the staged execution (nullptr: one launch per stage)
+  int ntasks = 0;
   std::vector<int32_t> stage_ptr;
   bool v2_solve = false;  // cnl_solve runs on the register-front kernel too (direct records, every front of the fast class)
   cnl::DevPlan2 dp2{};
@@ -211,9 +213,17 @@ int setup_v2(cnl_handle* h) {
   h->staged = false;
   if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && !(getenv("CNL_NO_STAGED") && atoi(getenv("CNL_NO_STAGED")))) {
     std::vector<int32_t> tk;
-    for (const cnl::Task& t : P.tasks) { tk.push_back(t.rec_off); tk.push_back(t.f1 - t.f0); tk.push_back(t.brec_off); tk.push_back(t.is_root); }
+    for (const cnl::Task& t : P.tasks) { tk.push_back(t.rec_off); tk.push_back(t.f1 - t.f0); tk.push_back(t.brec_off); tk.push_back(t.is_root); tk.push_back(t.parent); tk.push_back(t.nchild); }
     if ((rc = upload(h, tk, &h->d_tasks))) return rc;
     if ((rc = dalloc(h, &h->d_gcnt, (size_t)h->batch * 2))) return rc;
+    // dataflow execution: per (task, group of four problems) a count of finished children (forward) and a done flag (backward)
+    h->ntasks = (int)P.tasks.size();
+    // (measured: 0.159 against 0.168 ms for one system; with more groups of problems the waiting wavefronts crowd out the
+    //  working ones — 82 k against 367 k systems/s at B = 256 — so only the smallest batches run this way; env CNL_DATAFLOW_MAX)
+    int64_t dfmax = 4;
+    if (const char* e = getenv("CNL_DATAFLOW_MAX")) dfmax = atoll(e);
+    if (h->batch <= dfmax && !(getenv("CNL_NO_DATAFLOW") && atoi(getenv("CNL_NO_DATAFLOW"))))
+      if ((rc = dalloc(h, &h->d_dep, 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4)))) return rc;
     h->stage_ptr = P.stage_ptr;
     h->staged = true;
   }
@@ -243,7 +253,7 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 // one staged pass over the tasks of a latency plan (first attempt of newton_system, try_to_factorize, or solve_ldl!)
 int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch; a.L = h->d_L; a.scratch = h->d_gs;
-  a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0;
+  a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0; a.dep = h->d_dep;
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
   hipError_t e = cnl::launch_newton2_staged(h->dp2, h->wpb2, h->lds2, a, h->stage_ptr.data(), (int)h->stage_ptr.size() - 1, stream);
   if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("staged launch: ") + hipGetErrorString(e));
@@ -597,7 +607,7 @@ int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* 
   else if (s == "asm_src") { src = P.asm_src.data(); n = (int64_t)P.asm_src.size(); }
   else if (s == "child_idx") { src = P.child_idx.data(); n = (int64_t)P.child_idx.size(); }
   else if (s == "rel_idx") { src = P.rel_idx.data(); n = (int64_t)P.rel_idx.size(); }
-  else if (s == "tasks") { src = reinterpret_cast<const int32_t*>(P.tasks.data()); n = (int64_t)P.tasks.size() * 6; }  // struct Task, csrc/plan.h
+  else if (s == "tasks") { src = reinterpret_cast<const int32_t*>(P.tasks.data()); n = (int64_t)P.tasks.size() * 8; }  // struct Task, csrc/plan.h
   else if (s == "stage_ptr") { src = P.stage_ptr.data(); n = (int64_t)P.stage_ptr.size(); }
   else if (s == "rec") { src = P.rec.data(); n = P.v2_ok ? (int64_t)P.rec.size() : 0; }     // record streams of the
   else if (s == "brec") { src = P.brec.data(); n = P.v2_ok ? (int64_t)P.brec.size() : 0; }  // register-front kernel

@@ -92,13 +92,16 @@ struct LaunchArgs {
   double params[9];      // ParamCaNNOLeS; params[0] = eig_tol also for FACTOR
   const int* extra_pos;  // [batch] optional: inertia counts of pivots eliminated outside the kernel (condensed r nodes)
   const int* extra_zer;
-  // staged execution (latency plans, kernels2.hip STAGED): one launch per stage and phase
-  const int32_t* tasks;  // device: 4 words per task {record offset, fronts, backward record offset, 1 if a root of the forest}
+  // staged execution (latency plans, kernels2.hip STAGED): one launch per phase when `dep` is given (a task waits for its
+  // children resp. its parent on device counters), else one launch per stage and phase
+  const int32_t* tasks;  // device: 6 words per task {record offset, fronts, backward record offset, 1 if a root of the forest,
+                         //                            parent task or -1, number of child tasks}
   int task0, ntasks;     // tasks of this launch
   int phase;             // 0: forward (assembly + elimination) of the tasks, 1: backward sweep of the tasks
   int nquads;            // groups of four problems
   int* gcnt;             // [batch][2] pivot counts summed over the tasks
   int skip_done;         // classic launch behind a staged attempt: problems with success[b] == 1 are left alone
+  int* dep;              // [2][tasks][nquads] dataflow counters (zeroed per call): children done (forward), task done (backward)
 };
 
 // returns hipSuccess or the launch error

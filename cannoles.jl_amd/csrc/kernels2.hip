@@ -767,6 +767,22 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
   }
 
 // ==========================================================================================
+// dataflow execution of a staged plan: wait until *p >= target (bounded: a broken dependency must not hang the device), then
+// make the producer's global stores visible; signal = all stores of this wavefront first, then the counter
+__device__ __forceinline__ void spin_until(const int* p, int target) {
+  for (int it = 0; it < (1 << 22); it++) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void task_done(int* counter, int lane) {
+  if (!counter) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Two wavefronts per SIMD (256 VGPRs).  A wavefront alone on its SIMD walks a front in 11.2 k cycles and issues instructions
 // 68 % of that time; two share a SIMD at 16.3 k cycles per front.  A 168-register variant with THREE per SIMD (the triangle
 // image makes twelve wavefronts fit the LDS of a CU) was built and measured: 12 288 problems in 11.6 ms against 8 192 in
@@ -791,12 +807,31 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   int widx = blockIdx.x * WPB + wave;
   // STAGED: the wave runs ONE task (a subtree of the elimination tree, or a front above the cut) of one group of problems
   int t_rec = 0, t_nfr = P.nsuper, t_brec = 0, t_root = 1;
+  int* dep_signal = nullptr;  // dataflow execution: the counter this wavefront bumps when its task is done
   if constexpr (STAGED) {
-    const int task = widx / A.nquads;
+    int task = widx / A.nquads;
     if (task >= A.ntasks) return;
     widx -= task * A.nquads;
-    const int32_t* tk = as_global(A.tasks) + 4 * (A.task0 + task);
+    // Dataflow execution (A.dep): ONE launch per phase covers every task.  Workgroups are dispatched in index order, tasks
+    // are sorted by stage, so a task's children (forward) have smaller indices; the backward launch runs the indices in
+    // reverse, parents first.  A wavefront waits on a device counter for the tasks it depends on: the lowest unfinished
+    // index is always resident and free to run, whatever the size of the grid.
+    if (A.dep && A.phase == 1) task = A.ntasks - 1 - task;
+    const int tix = A.task0 + task;
+    const int32_t* tk = as_global(A.tasks) + 6 * tix;
     t_rec = rfl(tk[0]); t_nfr = rfl(tk[1]); t_brec = rfl(tk[2]); t_root = rfl(tk[3]);
+    if (A.dep) {
+      const int t_parent = rfl(tk[4]), t_nchild = rfl(tk[5]);
+      int* depf = as_global(A.dep);
+      int* depb = depf + A.ntasks * A.nquads;
+      if (A.phase == 0) {
+        if (t_nchild > 0) spin_until(depf + tix * A.nquads + widx, t_nchild);
+        if (t_parent >= 0) dep_signal = depf + t_parent * A.nquads + widx;
+      } else {
+        if (t_parent >= 0) spin_until(depb + t_parent * A.nquads + widx, 1);
+        dep_signal = depb + tix * A.nquads + widx;
+      }
+    }
   }
   const int nfr = t_nfr;
   const int prob0 = widx * 4;
@@ -1009,7 +1044,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     (void)roff;
     success = valid;
     gsync();  // the z column is read back through global memory by the backward sweep
-    if constexpr (STAGED) return;  // the backward sweep of the tasks comes in launches of its own
+    if constexpr (STAGED) { task_done(dep_signal, lane); return; }  // the backward sweep of the tasks comes in a launch of its own
   }
 
   STAMP_DECL
@@ -1258,6 +1293,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         if (tpos) atomicAdd(as_global(A.gcnt) + prob * 2, tpos);
         if (tzer) atomicAdd(as_global(A.gcnt) + prob * 2 + 1, tzer);
       }
+      task_done(dep_signal, lane);
       return;
     }
     const bool ok = (CNL_ABL != 0) || (tpos == P.nvar && tzer == 0);
@@ -1591,6 +1627,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   if (lane == 0 && A.npos) for (int k = 0; k < 8; k++) A.npos[(blockIdx.x * WPB + wave) * 8 + k] = (long long)st_acc[k];
 #endif
   if constexpr (STAGED) {
+    if (A.phase == 1) task_done(dep_signal, lane);  // the children of this task may read its solution components now
     // first attempt only: rho = 0, rho_old untouched; problems that failed are handed to the classic launch that follows
     if (valid && l == 0 && t_root && A.mode == MODE_NEWTON) { A.rho[prob] = 0.0; A.nfact[prob] = 1; A.success[prob] = success ? 1 : 0; }
   } else if (valid && l == 0 && A.mode == MODE_NEWTON) {
@@ -1635,13 +1672,24 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
     if (e != hipSuccess) return e;
   }
   // newton: forward + backward; factorize: forward only, then the decision; solve: forward substitution + backward
-  for (int pass = 0; pass < (a.mode == MODE_FACTOR ? 1 : 2); pass++)
-    for (int q = 0; q < nstages; q++) {
-      const int st = pass == 0 ? q : nstages - 1 - q;  // forward: children first; backward: parents first
-      a.phase = pass; a.task0 = stage_ptr[st]; a.ntasks = stage_ptr[st + 1] - stage_ptr[st];
-      const long long waves = (long long)a.ntasks * a.nquads;
+  const int npass = a.mode == MODE_FACTOR ? 1 : 2;
+  if (a.dep) {  // dataflow: one launch per phase over all tasks
+    const int ntasks = stage_ptr[nstages];
+    e = hipMemsetAsync(a.dep, 0, 2 * (size_t)ntasks * (size_t)a.nquads * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    for (int pass = 0; pass < npass; pass++) {
+      a.phase = pass; a.task0 = 0; a.ntasks = ntasks;
+      const long long waves = (long long)ntasks * a.nquads;
       hipLaunchKernelGGL(newton2_kernel_t<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
     }
+  } else
+    for (int pass = 0; pass < npass; pass++)
+      for (int q = 0; q < nstages; q++) {
+        const int st = pass == 0 ? q : nstages - 1 - q;  // forward: children first; backward: parents first
+        a.phase = pass; a.task0 = stage_ptr[st]; a.ntasks = stage_ptr[st + 1] - stage_ptr[st];
+        const long long waves = (long long)a.ntasks * a.nquads;
+        hipLaunchKernelGGL(newton2_kernel_t<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
+      }
   if (a.mode == MODE_FACTOR)
     hipLaunchKernelGGL(staged_decide_kernel, dim3((a.batch + 255) / 256), dim3(256), 0, stream, a.gcnt, P.nvar, a.batch, a.success, a.npos, a.nzero);
   return hipGetLastError();

@@ -52,6 +52,7 @@ struct Options {
 // one wavefront; tasks of a stage are independent, a task's children belong to earlier stages.
 struct Task {
   int32_t stage, f0, f1, rec_off, brec_off, is_root;
+  int32_t parent, nchild;  // task of the parent front of this task's root (-1: none); number of tasks whose parent this is
 };
 
 struct Plan {

@@ -82,8 +82,9 @@ int cnl_plan_info(const cnl_plan* plan, int64_t info[16]);
  * "fronts" (16 int32 per front, struct FrontHdr in csrc/plan.h), "seg_ptr", "asm_pos", "asm_src",
  * "child_idx", "rel_idx".  Condensation lists (csrc/condense.h): "c_ptr", "c_a", "c_b", "c_d", "orig_of",
  * "r_orig", "r_dsrc", "r_ptr", "r_jsrc", "r_jx".  Record streams of the register-front kernel (csrc/plan.h; empty when that
- * kernel does not serve the plan): "rec", "brec".  Staged plans: "tasks" (6 int32 per task, struct Task in csrc/plan.h: stage,
- * first front, end front, record offset, backward record offset, 1 if a root), "stage_ptr".  With out == NULL only *count is set.
+ * kernel does not serve the plan): "rec", "brec".  Staged plans: "tasks" (8 int32 per task, struct Task in csrc/plan.h: stage,
+ * first front, end front, record offset, backward record offset, 1 if a root, parent task or -1, number of child tasks),
+ * "stage_ptr".  With out == NULL only *count is set.
  * Used by the tests' plan simulator and to hand the ordering to the oracle.                          */
 int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* count);
 const char* cnl_plan_order_name(const cnl_plan* plan);

@@ -150,11 +150,13 @@ class StagedSim(RecSim):
     every task with an empty LDS stack of its own, task roots handing their update matrix over through the global scratch
     and reading the parent's solution from d.  Update matrices are stored like the kernel stores them — rows of 16 lanes,
     ascending, so that up to 15 doubles past the matrix are clobbered (NaN here) — which is what makes overlapping slots
-    visible.  `order` permutes the tasks of a stage (they must be independent)."""
+    visible.  `reverse` runs the tasks of a stage in the other order (they must be independent); `dataflow` runs the tasks in a
+    depth-first order of the task tree given by the parent fields (children before their parent, whatever their stage),
+    which is what the single-launch execution with dependency counters relies on."""
 
     def __init__(self, plan, nnz_src, n_rhs):
         super().__init__(plan, nnz_src, n_rhs)
-        self.tasks = plan.array("tasks").astype(np.int64).reshape(-1, 6)
+        self.tasks = plan.array("tasks").astype(np.int64).reshape(-1, 8)   # struct Task (csrc/plan.h)
         self.stage_ptr = plan.array("stage_ptr").astype(np.int64)
         assert len(self.tasks) > 1, "not a staged plan"
 
@@ -164,7 +166,29 @@ class StagedSim(RecSim):
             row[:a + 1] = F[a, :a + 1]
             mem[uoff + tri(a): uoff + tri(a) + 16] = row
 
-    def run(self, vals, rhs, eig_tol, n_out, reverse=False, gs_doubles=None, lds_doubles=4096):
+    def dataflow_order(self):
+        """tasks in depth-first post-order of the parent links; checks the child counts"""
+        nt = len(self.tasks)
+        kids = [[] for _ in range(nt)]
+        for t in range(nt):
+            par = int(self.tasks[t][6])
+            if par >= 0:
+                assert int(self.tasks[par][0]) > int(self.tasks[t][0]), "a parent task must belong to a later stage"
+                kids[par].append(t)
+        for t in range(nt):
+            assert len(kids[t]) == int(self.tasks[t][7])
+        order, stack = [], [(t, False) for t in range(nt - 1, -1, -1) if int(self.tasks[t][6]) < 0]
+        while stack:
+            t, done = stack.pop()
+            if done:
+                order.append(t)
+            else:
+                stack.append((t, True))
+                stack.extend((c, False) for c in kids[t])
+        assert sorted(order) == list(range(nt))
+        return order
+
+    def run(self, vals, rhs, eig_tol, n_out, reverse=False, gs_doubles=None, lds_doubles=4096, dataflow=False):
         rec, br = self.rec, self.brec
         src_val = lambda s: vals[s] if s < self.nnz else rhs[s - self.nnz]
         L = np.zeros(self.lsize + 64)
@@ -173,11 +197,17 @@ class StagedSim(RecSim):
         nst = len(self.stage_ptr) - 1
         covered = np.zeros(self.ns, bool)
         # ---- forward, children first
-        for st in range(nst):
-            tl = list(range(int(self.stage_ptr[st]), int(self.stage_ptr[st + 1])))
-            for t in (reversed(tl) if reverse else tl):
-                stage, f0, f1, off, boff, is_root = (int(v) for v in self.tasks[t])
-                assert stage == st
+        if dataflow:
+            fwd_lists = [self.dataflow_order()]
+        else:
+            fwd_lists = []
+            for st in range(nst):
+                tl = list(range(int(self.stage_ptr[st]), int(self.stage_ptr[st + 1])))
+                assert all(int(self.tasks[t][0]) == st for t in tl)
+                fwd_lists.append(list(reversed(tl)) if reverse else tl)
+        for tl in fwd_lists:
+            for t in tl:
+                stage, f0, f1, off, boff, is_root = (int(v) for v in self.tasks[t][:6])
                 lds = np.full(lds_doubles, np.nan)
                 for s in range(f0, f1):
                     assert not covered[s]
@@ -244,10 +274,9 @@ class StagedSim(RecSim):
         assert covered.all(), "fronts outside every task"
         # ---- backward, parents first
         d = np.full(n_out, np.nan)
-        for st in range(nst - 1, -1, -1):
-            tl = list(range(int(self.stage_ptr[st]), int(self.stage_ptr[st + 1])))
-            for t in (reversed(tl) if reverse else tl):
-                stage, f0, f1, off, boff, is_root = (int(v) for v in self.tasks[t])
+        for tl in reversed(fwd_lists):
+            for t in reversed(tl):
+                stage, f0, f1, off, boff, is_root = (int(v) for v in self.tasks[t][:6])
                 xs = {}
                 for _ in range(f1 - f0):
                     H = br[boff:boff + B_HDR]

@@ -177,13 +177,14 @@ def test_record_streams_reproduce_the_oracle(shape, monkeypatch):
 def test_staged_plans_reproduce_the_oracle(shape):
     """Latency plans (what cnl_create builds for small batches: bushy order, elimination tree cut into tasks) executed by
     tests/support/rec_sim.py::StagedSim the way the STAGED kernel runs them — every task on its own LDS stack, task roots
-    through the global scratch, tasks of a stage in either order — must reproduce the oracle's inertia and solution."""
+    through the global scratch, tasks of a stage in either order, or all tasks in a depth-first order of the parent links (the
+    dataflow execution) — must reproduce the oracle's inertia and solution."""
     from tests.support.rec_sim import StagedSim
     n, p, hw, batch = shape
     s = syn.band_structure(n, p, hw=hw)
     rows, cols = s.kkt_pattern()
     plan = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=batch)
-    tasks = plan.array("tasks").reshape(-1, 6)
+    tasks = plan.array("tasks").reshape(-1, 8)
     assert len(tasks) > 1 and plan.array("stage_ptr")[-1] == len(tasks)
     vals, rhs = syn.band_values(s, 78)
     off = s.offsets()
@@ -194,9 +195,9 @@ def test_staged_plans_reproduce_the_oracle(shape):
     orc = O.Oracle(s.N, rows, cols, perm)
     ok, pos0, zer0 = orc.try_to_factorize(vals, s.nvar, s.nequ, s.ncon, eig_tol, return_inertia=True)
     d0 = orc.solve_ldl(rhs)
-    for reverse in (False, True):
+    for reverse, dataflow in ((False, False), (True, False), (False, True)):
         sim = StagedSim(plan, s.nnzNS, s.N)
-        d, npos, nzer = sim.run(vals, rhs, eig_tol, s.N, reverse=reverse)
+        d, npos, nzer = sim.run(vals, rhs, eig_tol, s.N, reverse=reverse, dataflow=dataflow)
         assert (npos, nzer) == (pos0, zer0)
         kept = ~np.isnan(d)
         assert kept.sum() == s.N - s.nequ
