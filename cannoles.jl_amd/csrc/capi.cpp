@@ -43,6 +43,8 @@ struct cnl_handle {
   bool staged = false;    // newton_system: first attempt stage by stage (tasks of the elimination tree on different wavefronts)
   const int32_t* d_tasks = nullptr;
   int* d_gcnt = nullptr;
+  void* pin = nullptr;    // pinned host block for the results of small host-pointer calls
+  size_t pin_bytes = 0;
   int* d_dep = nullptr;   // dataflow counters of the staged execution (nullptr: one launch per stage)
   int ntasks = 0;
   std::vector<int32_t> stage_ptr;
@@ -767,6 +769,7 @@ int cnl_destroy(cnl_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->dev_allocs) (void)hipFree(p);
+  if (h->pin) (void)hipHostFree(h->pin);
   cnl::dense_destroy(h->dense);
   cnl::dense_destroy(h->gdense);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -963,6 +966,42 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   std::memcpy(a.params, params, 9 * sizeof(double));
   if ((rc = run(h, a, h->d_vals, h->d_rhs, h->d_d, h->stream))) return rc;
   h->last_vals = h->d_vals;
+  // Small batches (the reference's own call: one system): every result goes to ONE pinned block of the handle with asynchronous
+  // copies and a single synchronisation; the caller's arrays are then filled on the host by the reference's rules (d only
+  // where the factorisation succeeded, the rho slots of vals only where the ladder wrote them).  Copies into pageable memory
+  // block one by one, and the success flags would need a round trip of their own before d may be copied.
+  if (B * (size_t)P.N * sizeof(double) <= ((size_t)1 << 20)) {
+    const size_t o_d = 0, o_tail = o_d + B * P.N * 8, o_rho = o_tail + B * P.nvar * 8, o_ro = o_rho + B * 8, o_nf = o_ro + B * 8,
+                 o_su = o_nf + B * 4, total = o_su + B * 4;
+    if (!h->pin || h->pin_bytes < total) {
+      if (h->pin) (void)hipHostFree(h->pin);
+      h->pin = nullptr;
+      HIPCHK(hipHostMalloc(&h->pin, total, hipHostMallocDefault));
+      h->pin_bytes = total;
+    }
+    char* pb = static_cast<char*>(h->pin);
+    HIPCHK(hipMemcpyAsync(pb + o_d, h->d_d, B * P.N * 8, hipMemcpyDeviceToHost, h->stream));
+    if (P.nvar > 0)
+      HIPCHK(hipMemcpy2DAsync(pb + o_tail, (size_t)P.nvar * 8, h->d_vals + (P.nnz - P.nvar), (size_t)P.nnz * 8, (size_t)P.nvar * 8, B,
+                              hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pb + o_rho, h->d_rho, B * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pb + o_ro, h->d_rho_old, B * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pb + o_nf, h->d_nfact, B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pb + o_su, h->d_success, B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::memcpy(rho, pb + o_rho, B * 8);
+    std::memcpy(rho_old_out, pb + o_ro, B * 8);
+    std::memcpy(nfact, pb + o_nf, B * 4);
+    std::memcpy(success, pb + o_su, B * 4);
+    for (size_t b = 0; b < B; b++) {
+      if (success[b]) std::memcpy(d + b * P.N, pb + o_d + b * P.N * 8, (size_t)P.N * 8);
+      // rho tail of vals (the reference mutates get_vals(LDLT)[end-nvar+1:end] on retries only, src/CaNNOLeS.jl:1031,1038); the
+      // device copy holds what the caller passed wherever the ladder did not write, so copying it back always is the same
+      if (P.nvar > 0) std::memcpy(vals + b * P.nnz + (P.nnz - P.nvar), pb + o_tail + b * P.nvar * 8, (size_t)P.nvar * 8);
+    }
+    h->factorized = true;
+    return CNL_OK;
+  }
   // the reference leaves d untouched when the factorisation fails (src/CaNNOLeS.jl:1049): copy back the rows that succeeded
   HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
