@@ -869,3 +869,52 @@ def test_f3_device_resident_lockstep_outer_loop(built, shape):
         work += one["nlinsolve"]
     assert got["nfact"].sum() > got["nlinsolve"].sum()        # the rho ladder was climbed somewhere
     assert got["steps"] < work                                 # lockstep: far fewer batched rounds than Newton systems
+
+
+@pytest.mark.parametrize("dataflow", [True, False])
+@pytest.mark.parametrize("B", [1, 3, 4])
+def test_tiny_batches_dataflow_and_per_stage_execution(built, B, dataflow, monkeypatch):
+    """Batches of at most four problems run their latency plan with ONE launch per phase, tasks waiting on device counters for
+    their children / parent (`dataflow`), larger ones with a launch per stage (forced here with CNL_NO_DATAFLOW=1): both must
+    give the oracle's (success, nfact, rho, rho_old) and solutions, with a problem that climbs the rho ladder and — for B > 1 —
+    one whose ladder runs out (its d stays untouched, its rho slots are written back), through the host-pointer call (whose
+    results come back through the pinned block of the handle) and through newton_system!'s factorize/solve siblings."""
+    hipldl, syn, O = _mods()
+    if not dataflow:
+        monkeypatch.setenv("CNL_NO_DATAFLOW", "1")
+    s = syn.band_structure(2000, 10)
+    rows, cols = s.kkt_pattern()
+    vals, rhs = syn.batch_values(s, B, cfg=5, stress="ladder")
+    off = s.offsets()
+    if B > 1:
+        vals[1, off[0]:off[1]] = np.nan   # no rho repairs it
+    p = hipldl.default_params()
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    assert L.config["kernel"] == "v2-staged"
+    v = vals.copy()
+    d = np.full((B, s.N), 7.0)
+    d, ok, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, np.zeros(B), p)
+    ok, rho, ro, nf = (np.atleast_1d(a) for a in (ok, rho, ro, nf))
+    orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
+    v0 = vals.copy()
+    d0, ok0, rho0, ro0, nf0 = O.newton_system_batch(orc, B, s.nvar, s.nequ, s.ncon, rhs, v0, np.zeros(B), p)
+    assert np.array_equal(ok, ok0) and np.array_equal(nf, nf0) and np.array_equal(rho, rho0) and np.array_equal(ro, ro0)
+    assert nf0.max() > 1
+    assert np.array_equal(v.reshape(B, -1)[:, -s.nvar:], v0.reshape(B, -1)[:, -s.nvar:])
+    d = d.reshape(B, s.N)
+    for b in range(B):
+        if ok0[b]:
+            assert backward_error(s, v0.reshape(B, -1)[b], rhs.reshape(B, -1)[b], d[b]) <= BWD_TOL
+        else:
+            assert np.array_equal(d[b], np.full(s.N, 7.0))
+    # factorize + solve on the same handle (staged as well): the solve uses this factorisation
+    good = vals.copy()
+    good[:, off[0]:off[1]] = np.nan_to_num(good[:, off[0]:off[1]], nan=1.0)
+    good[:, off[6]:off[7]] = 10.0          # a rho at which every problem factorises
+    okf = np.atleast_1d(hipldl.try_to_factorize(L, good if B > 1 else good[0], s.nvar, s.nequ, s.ncon, p[0]))
+    assert okf.all()
+    x = np.zeros((B, s.N))
+    hipldl.solve_ldl_(rhs if B > 1 else rhs[0], L.factor, x if B > 1 else x[0])
+    for b in range(B):
+        assert backward_error(s, good[b], rhs.reshape(B, -1)[b], x[b]) <= BWD_TOL
+    L.close()
