@@ -13,10 +13,12 @@ CSRC = os.path.join(ROOT, "cannoles.jl_amd", "csrc")
 
 def libpath(bits):
     """a variant is a number (CNL_ABL bits) or NAME=VALUE[,NAME=VALUE...] (arbitrary -D flags)"""
-    return os.path.join(OUTD, "libcnl_abl" + str(bits).replace("=", "-").replace(",", "_") + ".so")
+    return os.path.join(OUTD, "libcnl_abl" + str(bits).replace("=", "-").replace(",", "_").replace(":", "_").replace("+", "_") + ".so")
 
 
 def flags(bits):
+    if str(bits).startswith("RAW:"):   # raw compiler flags, '+' separated: RAW:-mllvm+-amdgpu-...=1
+        return " ".join(str(bits)[4:].split("+"))
     if "=" in str(bits):
         return " ".join("-D" + f for f in str(bits).split(","))
     return f"-DCNL_ABL={bits}"
