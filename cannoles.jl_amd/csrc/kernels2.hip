@@ -39,8 +39,14 @@ namespace cnl {
 namespace {
 
 constexpr int RN = 3;    // record prefetch: RN x dwordx4 per lane = RN*256 words
-constexpr int PVR = 6;   // raw-value prefetch of the on-the-fly condensation: PVR*16 matrix values per problem (+ 2 x 16 rhs values)
-constexpr int PVN = 8;   // value prefetch: PVN doubles per lane = PVN*16 entries per problem
+#ifndef CNL_PVR
+#define CNL_PVR 6
+#endif
+#ifndef CNL_PVN
+#define CNL_PVN 8
+#endif
+constexpr int PVR = CNL_PVR;   // raw-value prefetch of the on-the-fly condensation: PVR*16 matrix values per problem (+ 2 x 16 rhs values)
+constexpr int PVN = CNL_PVN;   // value prefetch: PVN doubles per lane = PVN*16 entries per problem
 constexpr int KB = 10;   // panel rows prefetched per front in the solve sweeps (chain-like orders: up to 10 pivots per front)
 
 __device__ __forceinline__ int tri2(int i) { return (i * (i + 1)) >> 1; }
