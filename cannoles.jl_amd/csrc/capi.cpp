@@ -480,7 +480,9 @@ int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows
 
 static int64_t staged_max_batch() {
   if (const char* e = getenv("CNL_STAGED_MAX")) return atoll(e);
-  return 4096;  // measured on MI355X (cfg3 pattern): staged 0.50 M systems/s vs 0.48 M at 4096 problems, 0.49 M vs 0.29 M at 2048
+  // measured on MI355X (cfg3 pattern, tools/cmp_staged_threshold.py): staged 442 k systems/s at every size from 1024 problems on,
+  // the single stream 342 k at 2048, 459 k at 3072, 567 k at 4096: the curves cross near 2 900 problems
+  return 2816;
 }
 
 int cnl_plan_create_for_batch(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
