@@ -112,6 +112,7 @@ struct NDWork {
   ivec level, queue;
   int32_t leaf;
   int32_t next_part = 1;
+  bool canon_leaves = false;  // leaves keep the caller's (canonical) order instead of minimum degree: chain-like inside a part
 };
 
 void bfs(NDWork& w, int32_t root, int32_t pid, ivec& order_out, int32_t& nlev) {
@@ -139,7 +140,11 @@ void nd_rec(NDWork& w, ivec nodes, ivec& out) {
     Task t = std::move(st.back()); st.pop_back();
     if (t.emit) { out.insert(out.end(), t.nodes.begin(), t.nodes.end()); continue; }
     ivec& nd = t.nodes;
-    if ((int32_t)nd.size() <= w.leaf) { min_degree(*w.g, nd, out); continue; }
+    if ((int32_t)nd.size() <= w.leaf) {
+      if (w.canon_leaves) { std::sort(nd.begin(), nd.end()); out.insert(out.end(), nd.begin(), nd.end()); }
+      else min_degree(*w.g, nd, out);
+      continue;
+    }
     int32_t pid = w.next_part++;
     for (int32_t v : nd) { w.part[v] = pid; w.level[v] = -1; }
     // connected component of the first vertex
@@ -656,16 +661,37 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       xo.insert(xo.end(), hubs.begin(), hubs.end());
       add_cand("nd" + std::to_string(leaf), xo);
     }
+    // Mid-size batches (latency plans with few wavefront slots per group of problems): a handful of LARGE parts, each kept in
+    // the canonical order — inside a part the tree is the chain of full fronts the throughput order has, the parts run as
+    // whole-subtree tasks on different wavefronts, only the separators above them are serial.
+    if (opt.latency && opt.nd_leaf <= 0 && opt.par < 64)
+      for (int div : {2, 4, 8, 16, 32}) {
+        const int32_t leaf = (int32_t)body.size() / div + 1;
+        if (leaf < 300) break;
+        NDWork w; w.g = &bg; w.part.assign(nx_, -1); w.level.assign(nx_, -1); w.leaf = leaf; w.canon_leaves = true;
+        ivec xo; xo.reserve(nx_);
+        nd_rec(w, body, xo);
+        xo.insert(xo.end(), hubs.begin(), hubs.end());
+        add_cand("ndc" + std::to_string(div), xo);
+      }
   }
   if (cands.empty()) add_cand("canonical", xs_all);
   // throughput plans minimise the total work; latency plans the critical path plus the work spread over the wavefront
   // slots a group of four problems can use (only orders the register-front kernel can run are staged)
+  // A task costs a wavefront start per phase on top of its fronts (prologue, pipeline fill, hand-over through global memory):
+  // fitted on cfg3 at 2048 problems, where 495 small tasks took 4.6 ms and 8 large ones 3.4 ms for the same model cost.
+  auto ntasks_est = [&](const Cand& c) {
+    if (c.name.rfind("ndc", 0) == 0) return 2.0 * atoi(c.name.c_str() + 3);
+    return (double)(c.sn_first.size() - 1) / 3.6;
+  };
   auto score = [&](const Cand& c) {
     if (!opt.latency) return c.cost;
-    return c.m2 ? c.cpath + c.cost / (double)std::max(1, opt.par) : 1e30 + c.cost;
+    return c.m2 ? c.cpath + (c.cost + 7.0e4 * ntasks_est(c)) / (double)std::max(1, opt.par) : 1e30 + c.cost;
   };
   size_t best = 0;
   for (size_t i = 1; i < cands.size(); i++) if (score(cands[i]) < score(cands[best])) best = i;
+  if (const char* e = getenv("CNL_FORCE_ORDER"))  // experiments: pick a candidate by name
+    for (size_t i = 0; i < cands.size(); i++) if (cands[i].name == e) best = i;
   if (getenv("CNL_VERBOSE")) {
     for (auto& c : cands)
       fprintf(stderr, "[cnl] order %-12s cost %.3e path %.3e nnzL %lld (exact %lld) fronts %zu\n", c.name.c_str(), c.cost, c.cpath,
@@ -861,6 +887,8 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     // measured (cfg3): 8 fronts per bottom task are best for a handful of problems (every task has a wavefront slot of its own),
     // 12 from 64 problems on
     int cap = opt.task_cap > 0 ? opt.task_cap : (opt.par >= 256 ? 8 : 12);
+    // orders with a few large canonical parts ("ndc"): a part is one task
+    if (opt.task_cap <= 0 && C.name.rfind("ndc", 0) == 0) cap = std::max(cap, (int)(1.5 * ns / std::max(1, atoi(C.name.c_str() + 3))));
     if (const char* e = getenv("CNL_TASK_CAP")) cap = std::max(1, atoi(e));
     ivec nsub(ns, 1), fdesc(ns), stage(ns, 0);
     for (int32_t s = 0; s < ns; s++) {

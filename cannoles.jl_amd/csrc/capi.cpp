@@ -480,9 +480,9 @@ int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows
 
 static int64_t staged_max_batch() {
   if (const char* e = getenv("CNL_STAGED_MAX")) return atoll(e);
-  // measured on MI355X (cfg3 pattern, tools/cmp_staged_threshold.py): staged 442 k systems/s at every size from 1024 problems on,
-  // the single stream 342 k at 2048, 459 k at 3072, 567 k at 4096: the curves cross near 2 900 problems
-  return 2816;
+  // measured on MI355X (cfg3 pattern, tools/cmp_staged_threshold.py): latency plans with a few large canonical parts reach
+  // 600 k systems/s at 2048 problems and 613 k at 4096 (the single stream: 342 k and 567 k); from 5120 on the single stream wins
+  return 4096;
 }
 
 int cnl_plan_create_for_batch(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -538,6 +538,11 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
       cnl::finalize_tasks(p->P);  // the records moved
     } else {
       p->P.tasks.clear();  // staged execution needs the direct records
+      if (latency) {       // a latency order without staging is only a worse order: take the throughput analysis instead
+        if (getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] latency plan without direct records: falling back to the throughput analysis\n");
+        delete p;
+        return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0);
+      }
     }
     if (getenv("CNL_VERBOSE"))
       fprintf(stderr, "[cnl] direct records: %s, rec words %zu -> %zu, longest %d -> %d\n", drc ? "not possible" : "ok", old_words,
