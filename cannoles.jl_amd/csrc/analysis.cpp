@@ -664,10 +664,10 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     // Mid-size batches (latency plans with few wavefront slots per group of problems): a handful of LARGE parts, each kept in
     // the canonical order — inside a part the tree is the chain of full fronts the throughput order has, the parts run as
     // whole-subtree tasks on different wavefronts, only the separators above them are serial.
-    if (opt.latency && opt.nd_leaf <= 0 && opt.par < 64)
-      for (int div : {2, 4, 8, 16, 32}) {
+    if (opt.latency && opt.nd_leaf <= 0 && opt.par < 512)
+      for (int div : {2, 4, 8, 16, 32, 64, 128}) {
         const int32_t leaf = (int32_t)body.size() / div + 1;
-        if (leaf < 300) break;
+        if (leaf < 64) break;
         NDWork w; w.g = &bg; w.part.assign(nx_, -1); w.level.assign(nx_, -1); w.leaf = leaf; w.canon_leaves = true;
         ivec xo; xo.reserve(nx_);
         nd_rec(w, body, xo);
