@@ -814,6 +814,11 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   // STAGED: the wave runs ONE task (a subtree of the elimination tree, or a front above the cut) of one group of problems
   int t_rec = 0, t_nfr = P.nsuper, t_brec = 0, t_root = 1;
   int* dep_signal = nullptr;  // dataflow execution: the counter this wavefront bumps when its task is done
+  // ... and the counter it waits for.  The wait is DEFERRED behind the prologue of the task (record load, value / panel
+  // prefetch: three to four dependent round trips that need nothing from other tasks): a single system is ~17 task levels
+  // deep, and the start-up latency of a task, not its fronts, is most of its critical path.
+  const int* dep_wait = nullptr;
+  int dep_target = 0;
   if constexpr (STAGED) {
     int task = widx / A.nquads;
     if (task >= A.ntasks) return;
@@ -831,10 +836,10 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       int* depf = as_global(A.dep);
       int* depb = depf + A.ntasks * A.nquads;
       if (A.phase == 0) {
-        if (t_nchild > 0) spin_until(depf + tix * A.nquads + widx, t_nchild);
+        if (t_nchild > 0) { dep_wait = depf + tix * A.nquads + widx; dep_target = t_nchild; }
         if (t_parent >= 0) dep_signal = depf + t_parent * A.nquads + widx;
       } else {
-        if (t_parent >= 0) spin_until(depb + t_parent * A.nquads + widx, 1);
+        if (t_parent >= 0) { dep_wait = depb + t_parent * A.nquads + widx; dep_target = 1; }
         dep_signal = depb + tix * A.nquads + widx;
       }
     }
@@ -916,6 +921,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       PREFETCH_ROWS(lr, lp0, HDRW(hv0, R_NUPD), HDRW(hv0, R_NPIV))
     }
     for (int s = 0; s < nfr; s++) {
+      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }  // children's update vectors are read below
       const int* rec = recw;
       const int hv = rec[lane & 15];
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM), nasmv = HDRW(hv, R_NASMV);
@@ -1092,6 +1098,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const bool fast0 = (fw0 >> 8) == 16 && !(fw0 & RF_FS_GLOBAL);
         if (!fast0) {
           // rare: large or globally staged front, handled out of line
+          if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }
           if (!(CNL_ABL & 2048)) slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, has_rhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, recw, roff, pbase0, cnt, eig_tol, rho, ovr, P.count_d != 0);
           gsync();
           roff = nxt_off;
@@ -1107,6 +1114,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       }
       bool more = true;
       while (more) {
+      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }  // children's update matrices are read below
       const int* rec = recw;
       const int hv = rec[lane & 15];
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM);
@@ -1418,6 +1426,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
           primed = true;
           deep = false;
         }
+        if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }
         // this front's panel and index words were issued two fronts ago; behind them the queue holds one store and the five
         // loads of the next front (more only makes the wait stricter); right after a restart: drain
         BSTAMP(5)
@@ -1519,6 +1528,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
 #endif
         primed = true;
       }
+      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }  // the parent's x is read below
       const int* rec = recw;
       const int hb = rec[lane & 7];
       const int npiv = HDRW(hb, B_NPIV), nupd = HDRW(hb, B_NUPD), xoff = HDRW(hb, B_XOFF), pxoff = HDRW(hb, B_PXOFF);
