@@ -132,7 +132,7 @@ void bfs(NDWork& w, int32_t root, int32_t pid, ivec& order_out, int32_t& nlev) {
 
 void nd_rec(NDWork& w, ivec nodes, ivec& out) {
   // iterative on an explicit stack of tasks to avoid deep recursion
-  struct Task { ivec nodes; bool emit; };
+  struct Task { ivec nodes; bool emit; bool presorted = false; };
   std::vector<Task> st;
   st.push_back({std::move(nodes), false});
   ivec comp, comp2;
@@ -141,7 +141,7 @@ void nd_rec(NDWork& w, ivec nodes, ivec& out) {
     if (t.emit) { out.insert(out.end(), t.nodes.begin(), t.nodes.end()); continue; }
     ivec& nd = t.nodes;
     if ((int32_t)nd.size() <= w.leaf) {
-      if (w.canon_leaves) { std::sort(nd.begin(), nd.end()); out.insert(out.end(), nd.begin(), nd.end()); }
+      if (w.canon_leaves) { if (!t.presorted) std::sort(nd.begin(), nd.end()); out.insert(out.end(), nd.begin(), nd.end()); }
       else min_degree(*w.g, nd, out);
       continue;
     }
@@ -208,11 +208,20 @@ void nd_rec(NDWork& w, ivec nodes, ivec& out) {
     }
     for (int32_t v : nd) w.part[v] = -1;
     std::sort(S.begin(), S.end());
-    std::sort(A.begin(), A.end());
-    std::sort(B.begin(), B.end());
+    if (w.canon_leaves) {
+      // a part that becomes a leaf is eliminated FROM ITS FAR END TOWARDS THIS SEPARATOR (BFS levels of the split: A lies
+      // below the separator level, B above): the chain of fronts then never carries the separator's variables along.  In the
+      // canonical order the part on the far side of the root would start next to the separator and drag it through every
+      // front (two thirds more fronts on the band patterns).
+      std::sort(A.begin(), A.end(), [&](int32_t x, int32_t y) { return w.level[x] != w.level[y] ? w.level[x] < w.level[y] : x < y; });
+      std::sort(B.begin(), B.end(), [&](int32_t x, int32_t y) { return w.level[x] != w.level[y] ? w.level[x] > w.level[y] : x > y; });
+    } else {
+      std::sort(A.begin(), A.end());
+      std::sort(B.begin(), B.end());
+    }
     st.push_back({std::move(S), true});   // emitted last
-    st.push_back({std::move(B), false});
-    st.push_back({std::move(A), false});  // processed first
+    st.push_back({std::move(B), false, w.canon_leaves});
+    st.push_back({std::move(A), false, w.canon_leaves});  // processed first
   }
 }
 
@@ -678,15 +687,22 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
   if (cands.empty()) add_cand("canonical", xs_all);
   // throughput plans minimise the total work; latency plans the critical path plus the work spread over the wavefront
   // slots a group of four problems can use (only orders the register-front kernel can run are staged)
-  // A task costs a wavefront start per phase on top of its fronts (prologue, pipeline fill, hand-over through global memory):
-  // fitted on cfg3 at 2048 problems, where 495 small tasks took 4.6 ms and 8 large ones 3.4 ms for the same model cost.
+  // Latency score = the longer of the critical path and the work spread over the wavefront slots of a group of problems.
+  // A task costs a wavefront start per phase on top of its fronts (prologue, pipeline fill, hand-over through global memory;
+  // fitted on cfg3 at 2048 problems: 495 small tasks 4.6 ms, 8 large ones 3.4 ms for the same model work), and when the parts
+  // of all groups together are more than the machine holds at once, a last partial round costs a whole one (measured: eight
+  // parts at 1536 problems = 1.5 rounds run at 496 k systems/s, thirty-two parts = 6 rounds at 586 k).
   auto ntasks_est = [&](const Cand& c) {
     if (c.name.rfind("ndc", 0) == 0) return 2.0 * atoi(c.name.c_str() + 3);
     return (double)(c.sn_first.size() - 1) / 3.6;
   };
   auto score = [&](const Cand& c) {
     if (!opt.latency) return c.cost;
-    return c.m2 ? c.cpath + (c.cost + 7.0e4 * ntasks_est(c)) / (double)std::max(1, opt.par) : 1e30 + c.cost;
+    if (!c.m2) return 1e30 + c.cost;
+    const double par = (double)std::max(1, opt.par);
+    const double rounds = 0.5 * ntasks_est(c) / par;  // bottom tasks per slot
+    const double fill = rounds > 1.0 ? std::ceil(rounds - 1e-9) / rounds : 1.0;
+    return std::max(c.cpath, (c.cost + 3.5e4 * ntasks_est(c)) / par * fill) + 1e-3 * c.cost;
   };
   size_t best = 0;
   for (size_t i = 1; i < cands.size(); i++) if (score(cands[i]) < score(cands[best])) best = i;
