@@ -471,7 +471,7 @@ void cnl_default_params(double p[9]) {
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
-                            int64_t nequ, int64_t ncon, int latency, int par);
+                            int64_t nequ, int64_t ncon, int latency, int par, double slots = 0);
 
 int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
                     int64_t nequ, int64_t ncon) {
@@ -489,20 +489,20 @@ int cnl_plan_create_for_batch(cnl_plan** plan, int64_t N, int64_t nnz, const int
                               int64_t nequ, int64_t ncon, int64_t batch) {
   if (batch < 1) return fail(CNL_ERR_ARG, "batch out of range");
   const int nquads = (int)((batch + 3) / 4);
-  return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch <= staged_max_batch() ? 1 : 0, std::max(1, 2048 / nquads));
+  return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch <= staged_max_batch() ? 1 : 0, std::max(1, 2048 / nquads), 2048.0 / nquads);
 }
 
 // latency != 0: plan for a small batch — order chosen by the critical path, tree cut into tasks (par = wavefront slots per
 // group of four problems)
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
-                            int64_t nequ, int64_t ncon, int latency, int par) {
+                            int64_t nequ, int64_t ncon, int latency, int par, double slots) {
   if (!plan || !rows1 || !cols1) return fail(CNL_ERR_ARG, "null argument");
   cnl_plan* p = new cnl_plan();
   p->N = N; p->nnz = nnz; p->nvar = nvar; p->nequ = nequ; p->ncon = ncon;
   p->latency = latency != 0;
   std::string msg;
   cnl::Options opt;
-  opt.latency = latency; opt.par = std::max(1, par);
+  opt.latency = latency; opt.par = std::max(1, par); opt.slots = slots;
   int rc = cnl::build_condensation(p->C, N, nnz, rows1, cols1, nvar, nequ, ncon, msg);
   if (!rc) {
     if (p->C.active)
@@ -541,7 +541,7 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
       if (latency) {       // a latency order without staging is only a worse order: take the throughput analysis instead
         if (getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] latency plan without direct records: falling back to the throughput analysis\n");
         delete p;
-        return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0);
+        return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0, 0);
       }
     }
     if (getenv("CNL_VERBOSE"))

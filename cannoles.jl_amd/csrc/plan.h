@@ -45,6 +45,7 @@ struct Options {
   // problems (the throughput term of the score), task_cap = largest number of fronts of a bottom task.
   int latency = 0;
   int par = 256;
+  double slots = 0;  // the same as a fraction (wavefront slots per group of four problems; 0: use par)
   int task_cap = 0;
 };
 
