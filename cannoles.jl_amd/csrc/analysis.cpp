@@ -213,8 +213,12 @@ void nd_rec(NDWork& w, ivec nodes, ivec& out) {
       // below the separator level, B above): the chain of fronts then never carries the separator's variables along.  In the
       // canonical order the part on the far side of the root would start next to the separator and drag it through every
       // front (two thirds more fronts on the band patterns).
-      std::sort(A.begin(), A.end(), [&](int32_t x, int32_t y) { return w.level[x] != w.level[y] ? w.level[x] < w.level[y] : x < y; });
-      std::sort(B.begin(), B.end(), [&](int32_t x, int32_t y) { return w.level[x] != w.level[y] ? w.level[x] > w.level[y] : x > y; });
+      // (inside a level: in the direction of travel, judged by the distance of the labels from the root's — any tie-break is
+      //  valid, this one keeps a band's chain monotone)
+      const int32_t root = comp[0];
+      auto dist = [&](int32_t v) { return v > root ? v - root : root - v; };
+      std::sort(A.begin(), A.end(), [&](int32_t x, int32_t y) { return w.level[x] != w.level[y] ? w.level[x] < w.level[y] : dist(x) < dist(y); });
+      std::sort(B.begin(), B.end(), [&](int32_t x, int32_t y) { return w.level[x] != w.level[y] ? w.level[x] > w.level[y] : dist(x) > dist(y); });
     } else {
       std::sort(A.begin(), A.end());
       std::sort(B.begin(), B.end());
