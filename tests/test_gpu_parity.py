@@ -606,15 +606,17 @@ def test_fixtures_f2_f3_through_the_hip_path(built):
     L.close()
 
 
-def test_headline_pattern_large_batch_sample_vs_oracle(built):
+@pytest.mark.parametrize("B,kernel,order", [(4608, "v2", "canonical"), (3584, "v2-staged", "ndc2"), (1536, "v2-staged", "ndc")])
+def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order):
     """The headline shape (cfg3 pattern, n = nequ = 1e4, ncon = 50) at a batch the throughput kernel serves (B = 4608 > the
-    staged threshold), the whole batch through cnl_newton_system_dev, a random sample of 32 problems against the oracle."""
+    staged threshold), at one the bidirectional chain serves (two large parts eliminated towards the separator, B = 3584) and
+    at one with many large parts (B = 1536): the whole batch through cnl_newton_system_dev, a random sample of 32 problems
+    against the oracle."""
     import torch
     hipldl, syn, O = _mods()
     import bench as BM
     s = syn.band_structure(10000, 50)
     rows, cols = s.kkt_pattern()
-    B = 4608
     dev = torch.device("cuda", 0)
     vals = torch.empty((B, s.nnzNS), dtype=torch.float64, device=dev)
     rhs = torch.empty((B, s.N), dtype=torch.float64, device=dev)
@@ -628,7 +630,7 @@ def test_headline_pattern_large_batch_sample_vs_oracle(built):
             host[int(b)] = (vh[b - b0].copy(), rh[b - b0].copy())
     p = hipldl.default_params()
     L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
-    assert L.config["kernel"] == "v2" and L.info["order"].startswith("canonical")
+    assert L.config["kernel"] == kernel and L.info["order"].startswith(order)
     d = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
     ro = torch.zeros(B, dtype=torch.float64, device=dev)
     rho = torch.ones(B, dtype=torch.float64, device=dev)
