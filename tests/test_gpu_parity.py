@@ -920,3 +920,37 @@ def test_tiny_batches_dataflow_and_per_stage_execution(built, B, dataflow, monke
     for b in range(B):
         assert backward_error(s, good[b], rhs.reshape(B, -1)[b], x[b]) <= BWD_TOL
     L.close()
+
+
+@pytest.mark.parametrize("B,order", [(256, "ndc"), (3200, "ndc2")])
+def test_two_call_sequence_on_large_part_plans(built, B, order):
+    """try_to_factorize + solve_ldl! (src/solver_types.jl:69-98) on the plans mid-size batches get — a few large parts as
+    tasks, the bidirectional chain with two — through the device entry points; a sample of problems against the oracle."""
+    import torch
+    hipldl, syn, O = _mods()
+    import bench as BM
+    s = syn.band_structure(10000, 50)
+    rows, cols = s.kkt_pattern()
+    vh, rh = BM.band_batch(s, 64, seed=4100)
+    reps = (B + 63) // 64
+    dev = torch.device("cuda", 0)
+    vals = torch.from_numpy(np.tile(vh, (reps, 1))[:B]).to(dev)
+    rhs = torch.from_numpy(np.tile(rh, (reps, 1))[:B]).to(dev)
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    assert L.config["kernel"] == "v2-staged" and L.info["order"].startswith(order)
+    lib = hipldl.lib()
+    ok = torch.zeros(B, dtype=torch.int32, device=dev)
+    d = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
+    hipldl._check(lib.cnl_factorize_dev(L._h, vals.data_ptr(), 2.220446049250313e-16, ok.data_ptr(), 0))
+    hipldl._check(lib.cnl_solve_dev(L._h, rhs.data_ptr(), d.data_ptr(), 0))
+    torch.cuda.synchronize()
+    assert bool((ok == 1).all())
+    orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
+    for b in (0, 17, 63, B - 1):
+        k = b % 64
+        assert orc.try_to_factorize(vh[k], s.nvar, s.nequ, s.ncon, 2.220446049250313e-16)
+        d0 = orc.solve_ldl(rh[k])
+        got = d[b].cpu().numpy()
+        assert np.abs(got - d0).max() <= FWD_TOL * np.abs(d0).max()
+        assert backward_error(s, vh[k], rh[k], got) <= BWD_TOL
+    L.close()
