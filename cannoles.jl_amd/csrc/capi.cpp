@@ -220,9 +220,10 @@ int setup_v2(cnl_handle* h) {
     if ((rc = dalloc(h, &h->d_gcnt, (size_t)h->batch * 2))) return rc;
     // dataflow execution: per (task, group of four problems) a count of finished children (forward) and a done flag (backward)
     h->ntasks = (int)P.tasks.size();
-    // (measured: 0.159 against 0.168 ms for one system; with more groups of problems the waiting wavefronts crowd out the
-    //  working ones — 82 k against 367 k systems/s at B = 256 — so only the smallest batches run this way; env CNL_DATAFLOW_MAX)
-    int64_t dfmax = 4;
+    // (measured, tools/sweep_dataflow.py: one system 0.132 against 0.165 ms, eight 0.177 against 0.193 ms; with more groups of
+    //  problems the waiting wavefronts crowd out the working ones — sixteen 0.233 against 0.196 ms, 256: 82 k against 367 k
+    //  systems/s — so only the smallest batches run this way; env CNL_DATAFLOW_MAX)
+    int64_t dfmax = 8;
     if (const char* e = getenv("CNL_DATAFLOW_MAX")) dfmax = atoll(e);
     if (h->batch <= dfmax && !(getenv("CNL_NO_DATAFLOW") && atoi(getenv("CNL_NO_DATAFLOW"))))
       if ((rc = dalloc(h, &h->d_dep, 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4)))) return rc;

@@ -874,9 +874,9 @@ def test_f3_device_resident_lockstep_outer_loop(built, shape):
 
 
 @pytest.mark.parametrize("dataflow", [True, False])
-@pytest.mark.parametrize("B", [1, 3, 4])
+@pytest.mark.parametrize("B", [1, 3, 7])
 def test_tiny_batches_dataflow_and_per_stage_execution(built, B, dataflow, monkeypatch):
-    """Batches of at most four problems run their latency plan with ONE launch per phase, tasks waiting on device counters for
+    """Batches of at most eight problems run their latency plan with ONE launch per phase, tasks waiting on device counters for
     their children / parent (`dataflow`), larger ones with a launch per stage (forced here with CNL_NO_DATAFLOW=1): both must
     give the oracle's (success, nfact, rho, rho_old) and solutions, with a problem that climbs the rho ladder and — for B > 1 —
     one whose ladder runs out (its d stays untouched, its rho slots are written back), through the host-pointer call (whose
