@@ -220,12 +220,13 @@ int setup_v2(cnl_handle* h) {
     if ((rc = dalloc(h, &h->d_gcnt, (size_t)h->batch * 2))) return rc;
     // dataflow execution: per (task, group of four problems) a count of finished children (forward) and a done flag (backward)
     h->ntasks = (int)P.tasks.size();
-    // (measured, tools/sweep_dataflow.py: one system 0.132 against 0.165 ms, eight 0.177 against 0.193 ms; with more groups of
-    //  problems the waiting wavefronts crowd out the working ones — sixteen 0.233 against 0.196 ms, 256: 82 k against 367 k
-    //  systems/s — so only the smallest batches run this way; env CNL_DATAFLOW_MAX)
-    int64_t dfmax = 8;
-    if (const char* e = getenv("CNL_DATAFLOW_MAX")) dfmax = atoll(e);
-    if (h->batch <= dfmax && !(getenv("CNL_NO_DATAFLOW") && atoi(getenv("CNL_NO_DATAFLOW"))))
+    // (measured, tools/sweep_dataflow.py: one system 0.132 against 0.165 ms, eight 0.177 against 0.193 ms; cfg4's pattern with
+    //  29 tasks: 32 problems 0.110 against 0.131 ms.  With more wavefronts than about half the machine's slots the waiting ones
+    //  crowd out the working ones — cfg3, 501 tasks: sixteen problems 0.233 against 0.196 ms, 256: 82 k against 367 k systems/s —
+    //  so the rule is tasks x groups of problems <= 1024; env CNL_DATAFLOW_WAVES)
+    int64_t dfwaves = 1024;
+    if (const char* e = getenv("CNL_DATAFLOW_WAVES")) dfwaves = atoll(e);
+    if ((int64_t)h->ntasks * ((h->batch + 3) / 4) <= dfwaves && !(getenv("CNL_NO_DATAFLOW") && atoi(getenv("CNL_NO_DATAFLOW"))))
       if ((rc = dalloc(h, &h->d_dep, 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4)))) return rc;
     h->stage_ptr = P.stage_ptr;
     h->staged = true;
