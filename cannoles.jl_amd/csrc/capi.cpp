@@ -47,6 +47,7 @@ struct cnl_handle {
   size_t pin_bytes = 0;
   int* d_dep = nullptr;   // dataflow counters of the staged execution (nullptr: one launch per stage)
   int ntasks = 0;
+  int df_waves = 1024;
   std::vector<int32_t> stage_ptr;
   bool v2_solve = false;  // cnl_solve runs on the register-front kernel too (direct records, every front of the fast class)
   cnl::DevPlan2 dp2{};
@@ -223,10 +224,10 @@ int setup_v2(cnl_handle* h) {
     // (measured, tools/sweep_dataflow.py: one system 0.132 against 0.165 ms, eight 0.177 against 0.193 ms; cfg4's pattern with
     //  29 tasks: 32 problems 0.110 against 0.131 ms.  With more wavefronts than about half the machine's slots the waiting ones
     //  crowd out the working ones — cfg3, 501 tasks: sixteen problems 0.233 against 0.196 ms, 256: 82 k against 367 k systems/s —
-    //  so the rule is tasks x groups of problems <= 1024; env CNL_DATAFLOW_WAVES)
-    int64_t dfwaves = 1024;
-    if (const char* e = getenv("CNL_DATAFLOW_WAVES")) dfwaves = atoll(e);
-    if ((int64_t)h->ntasks * ((h->batch + 3) / 4) <= dfwaves && !(getenv("CNL_NO_DATAFLOW") && atoi(getenv("CNL_NO_DATAFLOW"))))
+    //  so only the top stages whose tasks x groups of problems number at most 1024 run that way; env CNL_DATAFLOW_WAVES)
+    h->df_waves = 1024;
+    if (const char* e = getenv("CNL_DATAFLOW_WAVES")) h->df_waves = atoi(e);
+    if (!(getenv("CNL_NO_DATAFLOW") && atoi(getenv("CNL_NO_DATAFLOW"))))
       if ((rc = dalloc(h, &h->d_dep, 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4)))) return rc;
     h->stage_ptr = P.stage_ptr;
     h->staged = true;
@@ -257,7 +258,7 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 // one staged pass over the tasks of a latency plan (first attempt of newton_system, try_to_factorize, or solve_ldl!)
 int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch; a.L = h->d_L; a.scratch = h->d_gs;
-  a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0; a.dep = h->d_dep;
+  a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0; a.dep = h->d_dep; a.df_waves = h->df_waves;
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
   hipError_t e = cnl::launch_newton2_staged(h->dp2, h->wpb2, h->lds2, a, h->stage_ptr.data(), (int)h->stage_ptr.size() - 1, stream);
   if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("staged launch: ") + hipGetErrorString(e));

@@ -101,6 +101,10 @@ struct LaunchArgs {
   int nquads;            // groups of four problems
   int* gcnt;             // [batch][2] pivot counts summed over the tasks
   int skip_done;         // classic launch behind a staged attempt: problems with success[b] == 1 are left alone
+  int ntasks_all;        // tasks of the plan (the counters of the backward phase follow those of the forward phase)
+  int df_live;           // 1: this launch spans several stages (tasks wait on the counters; signals are released); 0: one stage,
+                         //    its dependencies are complete by launch order (no wait, plain counter bump)
+  int df_waves;          // the top stages of the tree whose wavefronts together number at most this run as ONE launch per phase
   int* dep;              // [2][tasks][nquads] dataflow counters (zeroed per call): children done (forward), task done (backward)
 };
 

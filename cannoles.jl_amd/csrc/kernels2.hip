@@ -782,9 +782,9 @@ __device__ __forceinline__ void spin_until(const int* p, int target) {
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
-__device__ __forceinline__ void task_done(int* counter, int lane) {
+__device__ __forceinline__ void task_done(int* counter, int lane, bool release = true) {
   if (!counter) return;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -834,12 +834,12 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     if (A.dep) {
       const int t_parent = rfl(tk[4]), t_nchild = rfl(tk[5]);
       int* depf = as_global(A.dep);
-      int* depb = depf + A.ntasks * A.nquads;
+      int* depb = depf + A.ntasks_all * A.nquads;
       if (A.phase == 0) {
-        if (t_nchild > 0) { dep_wait = depf + tix * A.nquads + widx; dep_target = t_nchild; }
+        if (t_nchild > 0 && A.df_live) { dep_wait = depf + tix * A.nquads + widx; dep_target = t_nchild; }
         if (t_parent >= 0) dep_signal = depf + t_parent * A.nquads + widx;
       } else {
-        if (t_parent >= 0) { dep_wait = depb + t_parent * A.nquads + widx; dep_target = 1; }
+        if (t_parent >= 0 && A.df_live) { dep_wait = depb + t_parent * A.nquads + widx; dep_target = 1; }
         dep_signal = depb + tix * A.nquads + widx;
       }
     }
@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     (void)roff;
     success = valid;
     gsync();  // the z column is read back through global memory by the backward sweep
-    if constexpr (STAGED) { task_done(dep_signal, lane); return; }  // the backward sweep of the tasks comes in a launch of its own
+    if constexpr (STAGED) { task_done(dep_signal, lane, A.df_live != 0); return; }  // the backward sweep of the tasks comes in a launch of its own
   }
 
   STAMP_DECL
@@ -1307,7 +1307,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         if (tpos) atomicAdd(as_global(A.gcnt) + prob * 2, tpos);
         if (tzer) atomicAdd(as_global(A.gcnt) + prob * 2 + 1, tzer);
       }
-      task_done(dep_signal, lane);
+      task_done(dep_signal, lane, A.df_live != 0);
       return;
     }
     const bool ok = (CNL_ABL != 0) || (tpos == P.nvar && tzer == 0);
@@ -1643,7 +1643,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   if (lane == 0 && A.npos) for (int k = 0; k < 8; k++) A.npos[(blockIdx.x * WPB + wave) * 8 + k] = (long long)st_acc[k];
 #endif
   if constexpr (STAGED) {
-    if (A.phase == 1) task_done(dep_signal, lane);  // the children of this task may read its solution components now
+    if (A.phase == 1) task_done(dep_signal, lane, A.df_live != 0);  // the children of this task may read its solution components now
     // first attempt only: rho = 0, rho_old untouched; problems that failed are handed to the classic launch that follows
     if (valid && l == 0 && t_root && A.mode == MODE_NEWTON) { A.rho[prob] = 0.0; A.nfact[prob] = 1; A.success[prob] = success ? 1 : 0; }
   } else if (valid && l == 0 && A.mode == MODE_NEWTON) {
@@ -1689,23 +1689,34 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
   }
   // newton: forward + backward; factorize: forward only, then the decision; solve: forward substitution + backward
   const int npass = a.mode == MODE_FACTOR ? 1 : 2;
-  if (a.dep) {  // dataflow: one launch per phase over all tasks
-    const int ntasks = stage_ptr[nstages];
-    e = hipMemsetAsync(a.dep, 0, 2 * (size_t)ntasks * (size_t)a.nquads * sizeof(int), stream);
+  // Stages [0, s_df) run one launch per stage; the stages from s_df on — the top of the tree, whose wavefronts together are
+  // few (at most df_waves) — run as ONE launch per phase in which a task waits for its children resp. its parent on device
+  // counters.  Every launch bumps the counters, so that the top launch finds the lower stages' tasks done; s_df = 0 is the pure
+  // dataflow execution of the smallest batches, s_df = nstages one launch per stage.
+  const int ntasks_all = stage_ptr[nstages];
+  int s_df = nstages;
+  if (a.dep) {
+    while (s_df > 0 && (long long)(ntasks_all - stage_ptr[s_df - 1]) * a.nquads <= (long long)a.df_waves) s_df--;
+    // Measured: a mixed execution (lower stages one launch each, the top of the tree as one launch) is NOT faster than a launch
+    // per stage — cfg3 64 problems 0.255 against 0.241 ms, cfg4 256 problems 1.51 M against 1.66 M systems/s: the fences of the
+    // top launch cost what the saved launch boundaries gain.  So: all of the tree in one launch per phase, or none of it.
+    if (s_df != 0) s_df = nstages;
+    e = hipMemsetAsync(a.dep, 0, 2 * (size_t)ntasks_all * (size_t)a.nquads * sizeof(int), stream);
     if (e != hipSuccess) return e;
-    for (int pass = 0; pass < npass; pass++) {
-      a.phase = pass; a.task0 = 0; a.ntasks = ntasks;
-      const long long waves = (long long)ntasks * a.nquads;
-      hipLaunchKernelGGL(newton2_kernel_t<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
-    }
-  } else
-    for (int pass = 0; pass < npass; pass++)
-      for (int q = 0; q < nstages; q++) {
-        const int st = pass == 0 ? q : nstages - 1 - q;  // forward: children first; backward: parents first
-        a.phase = pass; a.task0 = stage_ptr[st]; a.ntasks = stage_ptr[st + 1] - stage_ptr[st];
-        const long long waves = (long long)a.ntasks * a.nquads;
-        hipLaunchKernelGGL(newton2_kernel_t<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
-      }
+  }
+  a.ntasks_all = ntasks_all;
+  auto launch_range = [&](int pass, int t0, int t1, int live = 0) {
+    a.phase = pass; a.task0 = t0; a.ntasks = t1 - t0; a.df_live = live;
+    const long long waves = (long long)a.ntasks * a.nquads;
+    if (waves > 0) hipLaunchKernelGGL(newton2_kernel_t<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
+  };
+  // forward: children first
+  for (int q = 0; q < s_df; q++) launch_range(0, stage_ptr[q], stage_ptr[q + 1]);
+  if (s_df < nstages) launch_range(0, stage_ptr[s_df], ntasks_all, 1);
+  if (npass == 2) {  // backward: parents first
+    if (s_df < nstages) launch_range(1, stage_ptr[s_df], ntasks_all, 1);
+    for (int q = s_df - 1; q >= 0; q--) launch_range(1, stage_ptr[q], stage_ptr[q + 1]);
+  }
   if (a.mode == MODE_FACTOR)
     hipLaunchKernelGGL(staged_decide_kernel, dim3((a.batch + 255) / 256), dim3(256), 0, stream, a.gcnt, P.nvar, a.batch, a.success, a.npos, a.nzero);
   return hipGetLastError();
