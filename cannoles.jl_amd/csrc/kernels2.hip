@@ -780,11 +780,17 @@ __device__ __forceinline__ void spin_until(const int* p, int target) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
     __builtin_amdgcn_s_sleep(4);
   }
+#ifndef CNL_DF_NOFENCE   // (timing probe: -DCNL_DF_NOFENCE drops both fences; results are then not guaranteed)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
 }
 __device__ __forceinline__ void task_done(int* counter, int lane, bool release = true) {
   if (!counter) return;
+#ifndef CNL_DF_NOFENCE
   if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+  if (release) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
