@@ -954,3 +954,16 @@ def test_two_call_sequence_on_large_part_plans(built, B, order):
         assert np.abs(got - d0).max() <= FWD_TOL * np.abs(d0).max()
         assert backward_error(s, vh[k], rh[k], got) <= BWD_TOL
     L.close()
+
+
+@pytest.mark.parametrize("B", [96, 640])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_structures_mid_size_batches(built, seed, B):
+    """Irregular sparsity at batch sizes where the latency analysis also offers its large-part orders: whatever plan and
+    kernel serve it, every problem must reproduce the oracle (decisions and solutions)."""
+    hipldl, syn, O = _mods()
+    s = syn.random_structure(90 + 10 * seed, 130, 6 if seed % 2 else 0, 0.03, seed)
+    v8, r8 = syn.batch_values(s, 8, cfg=seed, gen=syn.random_values)
+    reps = (B + 7) // 8
+    vals, rhs = np.tile(v8, (reps, 1))[:B].copy(), np.tile(r8, (reps, 1))[:B].copy()
+    run_case(s, vals, rhs)
