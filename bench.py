@@ -252,7 +252,7 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
     BASELINE config 2 on the dense backend, and the vectors either side of the system (row f1)."""
     # ---- small batches of the same pattern: handles planned for latency (staged execution of the elimination tree)
     sb = {}
-    for bs in (256, 1):
+    for bs in (4096, 1024, 256, 1):   # two large parts (the bidirectional chain), many large parts, and the bushy tree
         if bs > B:
             continue
         p2 = DeviceProblem(torch, hipldl, s, rows, cols, vals[:bs], rhs[:bs], bs, local_rank, stream)
