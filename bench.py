@@ -30,6 +30,7 @@ HBM_MEASURED_GBPS = 6290.0  # float4 copy rate measured on MI355X (same guide)
 FP64_MFMA_SPEC_TFLOPS = 78.6       # datasheet fp64 matrix peak
 FP64_MFMA_MEASURED_TFLOPS = 47.8   # v_mfma_f64_16x16x4_f64 loop, 4 waves/SIMD x 8 accumulators (profiles/r02_microbench.json)
 CANONICAL_NNZL_CFG3 = 346209  # nnz(L) of the order "r, x natural, lambda" at n=1e4, p=50
+CANONICAL_NNZL_CFG4 = 14529   # the same order at n=1e3, p=10 (BASELINE config 4 / 5)
 TRAFFIC_FILE = "r02_traffic.json"
 
 
@@ -69,10 +70,21 @@ def backward_error(s, rows, cols, vals, rhs, d):
     return float(np.abs(res).max() / (abs(Ks).sum(axis=1).max() * np.abs(d).max() + np.abs(rhs).max()))
 
 
+def parse_options(hipldl, text):
+    """--opt key=value[,key=value] -> cnl_options (None: the library's own choices)"""
+    if not text:
+        return None
+    kw = {}
+    for item in text.split(","):
+        k, v = item.split("=", 1)
+        kw[k] = v if k == "force_order" else int(v)
+    return hipldl.Options(**kw)
+
+
 class DeviceProblem:
     """device-resident buffers + handle for `B` problems of one pattern, and a timed loop over cnl_newton_system_dev"""
 
-    def __init__(self, torch, hipldl, s, rows, cols, vals, rhs, B, device_index, stream):
+    def __init__(self, torch, hipldl, s, rows, cols, vals, rhs, B, device_index, stream, options=None):
         self.torch, self.hipldl, self.s, self.B = torch, hipldl, s, B
         dev = vals.device
         self.vals, self.rhs = vals, rhs
@@ -82,7 +94,7 @@ class DeviceProblem:
         self.nfact = torch.zeros(B, dtype=torch.int32, device=dev)
         self.succ = torch.zeros(B, dtype=torch.int32, device=dev)
         self.params = hipldl.default_params()
-        self.L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, device=device_index)
+        self.L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, device=device_index, options=options)
         self.stream = stream
 
     def step(self):
@@ -124,6 +136,7 @@ def main():
     ap.add_argument("--ncon", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="problems timed on the CPU oracle (-1 auto, 0 off)")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch, PCIe-inclusive, cfg2 and f1 blocks")
+    ap.add_argument("--opt", default="", help="cnl_options fields for the headline handle, key=value[,key=value] (measurement tools; default: the library's own choices)")
     args = ap.parse_args()
 
     import torch
@@ -166,7 +179,7 @@ def main():
             rhs[b0:b0 + nb].copy_(torch.from_numpy(rh))
             if b0 == 0:
                 host_chunk["vals"], host_chunk["rhs"] = vh, rh
-        return DeviceProblem(torch, hipldl, s, rows, cols, vals, rhs, nloc, local_rank, stream)
+        return DeviceProblem(torch, hipldl, s, rows, cols, vals, rhs, nloc, local_rank, stream, options=parse_options(hipldl, args.opt))
 
     # the per-rank driver shared with the CPU (gloo) test: shard, warm-up, barrier + synchronize on both sides of exactly
     # `steps` steps, max over ranks, job-wide counts
@@ -336,6 +349,18 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
                                           "frac": by_rv * B / (ms_rv * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                      "trial_point": {"ms": ms_tp, "bytes_per_system": by_tp, "GBps": by_tp * B / (ms_tp * 1e-3) / 1e9,
                                      "frac": by_tp * B / (ms_tp * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+    # ---- BASELINE config 4 (n = nequ = 1000, ncon = 10; the config the 1/2/4/8 scaling is defined on) and config 5 (its
+    # pattern with the rho ladder climbed to nfact = 6), each on its own algorithmic bytes
+    try:
+        out["cfg4"], out["cfg5"] = cfg45_blocks(torch, hipldl, syn, dev, local_rank, stream)
+    except Exception as e:
+        out["cfg4"] = {"error": str(e)}
+    # ---- the reference's literal call pattern: ONE system per call through host arrays (src/CaNNOLeS.jl:633), and the
+    # two-call sequence try_to_factorize + solve_ldl! (src/solver_types.jl:69-98)
+    try:
+        out["call_pattern_single_system"] = call_pattern_block(torch, hipldl, s, rows, cols, vals_h, rhs_h, dev, local_rank, stream, prob.params)
+    except Exception as e:
+        out["call_pattern_single_system"] = {"error": str(e)}
     # ---- row f3: whole outer loops (src/CaNNOLeS.jl:418-864) of a closed-form family, device-resident and in lockstep
     from cannoles_jl_amd import device_loop as DL
     Bf = 2048
@@ -348,6 +373,142 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
     out["aux_f3"] = {"workload": "band family n=300 p=4 (cfg4 pattern), B=2048 complete solves in lockstep", "problems_per_s": Bf / dt,
                      "global_steps": got["steps"], "ms_per_step": 1e3 * dt / got["steps"], "newton_systems": int(got["nlinsolve"].sum()),
                      "factorisations": int(got["nfact"].sum()), "first_order": int(sum(st == "first_order" for st in got["status"]))}
+
+
+def cfg45_blocks(torch, hipldl, syn, dev, local_rank, stream):
+    s4 = syn.band_structure(1000, 10, name="cfg4")
+    r4, c4 = s4.kkt_pattern()
+    blk4 = {"workload": "BASELINE config 4 item: n = nequ = 1000, ncon = 10, band Jacobians"}
+    for bs in (256, 4096):
+        vh, rh = band_batch(s4, bs, seed=4000)
+        p4 = DeviceProblem(torch, hipldl, s4, r4, c4, torch.from_numpy(vh).to(dev), torch.from_numpy(rh).to(dev), bs, local_rank, stream)
+        ms = p4.timed(30, 3)
+        p4.L.set_timing(True)
+        km = []
+        with torch.cuda.stream(stream):
+            for _ in range(4):
+                p4.step()
+                km.append(p4.L.last_kernel_ms())
+        p4.L.set_timing(False)
+        info = p4.L.info
+        nnzl = min(info["nnzL_exact"], CANONICAL_NNZL_CFG4)
+        b_alg = 12 * s4.nnzNS + 24 * s4.N + 32 * nnzl
+        dh = p4.d[:1].cpu().numpy()
+        gbps = b_alg * bs / (ms * 1e-3) / 1e9
+        blk4[f"B{bs}"] = {"systems_per_s": bs / (ms * 1e-3), "ms_per_call": ms, "kernel_ms": float(np.mean(km[1:])), "bytes_per_system": b_alg,
+                          "nnzL_star": nnzl, "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "frac_of_measured_copy_rate": gbps / HBM_MEASURED_GBPS,
+                          "working_set_MB": bs * 8 * (s4.nnzNS + 2 * s4.N + info["lsize"]) / 1e6,
+                          "resident_in_infinity_cache": bs * 8 * (s4.nnzNS + 2 * s4.N + info["lsize"]) <= 256 << 20,
+                          "ordering": info["order"], "fronts": info["nsuper"], "kernel": p4.L.config["kernel"],
+                          "all_success": bool((p4.succ == 1).all().item()), "backward_error": backward_error(s4, r4, c4, vh[0], rh[0], dh[0])}
+        p4.close()
+    # config 5: the same pattern, every problem climbs the ladder to rho = 605.5 (fixture F3: nfact = 6)
+    blk5 = {"workload": "BASELINE config 5: config 4's pattern, H_F = -10 on 10 % of the variables, |J| <= 1: nfact = 6 per system"}
+    v8 = np.stack([syn.band_values(s4, 5000 + b, stress="ladder")[0] for b in range(8)])
+    r8 = np.stack([syn.band_values(s4, 5000 + b, stress="ladder")[1] for b in range(8)])
+    for bs in (256, 4096):
+        vh, rh = np.tile(v8, (bs // 8, 1)), np.tile(r8, (bs // 8, 1))
+        p5 = DeviceProblem(torch, hipldl, s4, r4, c4, torch.from_numpy(vh).to(dev), torch.from_numpy(rh).to(dev), bs, local_rank, stream)
+        vals0 = p5.vals.clone()
+
+        def step5():
+            p5.vals.copy_(vals0)   # the ladder leaves its rho in the rho slots: restore them (device copy, inside the timed region)
+            p5.step()
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                step5()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(10):
+                step5()
+            e1.record(stream)
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        nf = p5.nfact.cpu().numpy()
+        info = p5.L.info
+        nnzl = min(info["nnzL_exact"], CANONICAL_NNZL_CFG4)
+        nfm = float(nf.mean())
+        b_alg = nfm * (12 * s4.nnzNS + 16 * nnzl) + 16 * nnzl + 24 * s4.N   # factor terms x nfact + the solve terms
+        v_end = p5.vals[:1].cpu().numpy()
+        dh = p5.d[:1].cpu().numpy()
+        gbps = b_alg * bs / (ms * 1e-3) / 1e9
+        blk5[f"B{bs}"] = {"systems_per_s": bs / (ms * 1e-3), "factorisations_per_s": bs * nfm / (ms * 1e-3), "ms_per_call": ms, "nfact_mean": nfm,
+                          "nfact_min": int(nf.min()), "nfact_max": int(nf.max()), "bytes_per_system": b_alg, "achieved_GBps": gbps,
+                          "frac": gbps / HBM_PEAK_GBPS, "kernel": p5.L.config["kernel"], "all_success": bool((p5.succ == 1).all().item()),
+                          "rho_final": float(p5.rho[0].item()), "backward_error_with_final_rho": backward_error(s4, r4, c4, v_end[0], rh[0], dh[0]),
+                          "note": "the timed step includes a device copy that restores the rho slots (0.1 MB per system)"}
+        p5.close()
+    return blk4, blk5
+
+
+def call_pattern_block(torch, hipldl, s, rows, cols, vals_h, rhs_h, dev, local_rank, stream, params):
+    """One system per call, as `newton_system!` is called by the reference (host arrays), and the two-call sequence; wall-clock
+    medians over repeated calls on one handle of batch 1."""
+    L1 = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=1, device=local_rank)
+    v1, r1 = vals_h[0].copy(), rhs_h[0].copy()
+    d1 = np.zeros(s.N)
+
+    def med(fn, reps=30):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts) * 1e3)
+
+    res = {"entry": "host pointers, pageable numpy arrays, batch 1, cfg3 pattern"}
+    res["newton_system_ms"] = med(lambda: hipldl.newton_system_(d1, s.nvar, s.nequ, s.ncon, r1, v1, L1, 0.0, params))
+    res["try_to_factorize_ms"] = med(lambda: hipldl.try_to_factorize(L1, v1, s.nvar, s.nequ, s.ncon, params[0]))
+    res["solve_ldl_ms"] = med(lambda: hipldl.solve_ldl_(r1, L1.factor, d1))
+    res["two_call_total_ms"] = res["try_to_factorize_ms"] + res["solve_ldl_ms"]
+    # device-resident twins of the same three calls (HIP events)
+    tv, tr = torch.from_numpy(v1[None].copy()).to(dev), torch.from_numpy(r1[None].copy()).to(dev)
+    td = torch.zeros((1, s.N), dtype=torch.float64, device=dev)
+    su = torch.zeros(1, dtype=torch.int32, device=dev)
+    ro, rho = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    nf = torch.zeros(1, dtype=torch.int32, device=dev)
+    sh = stream.cuda_stream
+
+    def ev(fn, reps=40):
+        with torch.cuda.stream(stream):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                fn()
+            e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    lib = hipldl.lib()
+    res["dev_newton_system_ms"] = ev(lambda: hipldl.newton_system_dev(L1, tv.data_ptr(), tr.data_ptr(), td.data_ptr(), ro.data_ptr(), rho.data_ptr(),
+                                                                      nf.data_ptr(), su.data_ptr(), params, sh))
+    res["dev_try_to_factorize_ms"] = ev(lambda: hipldl._check(lib.cnl_factorize_dev(L1._h, tv.data_ptr(), float(params[0]), su.data_ptr(), sh)))
+    res["dev_solve_ldl_ms"] = ev(lambda: hipldl._check(lib.cnl_solve_dev(L1._h, tr.data_ptr(), td.data_ptr(), sh)))
+    L1.close()
+    return res
+
+
+def oracle_split(O, s, rows, cols, perm64, vals_h, rhs_h, params, nsys):
+    """assemble (set_vals!) / factorize + inertia / solve split of the restated reference path on one host core"""
+    orc = O.Oracle(s.N, rows, cols, perm64)
+    t_set = t_fac = t_sol = 0.0
+    for b in range(nsys):
+        t0 = time.perf_counter()
+        orc.set_vals(vals_h[b])
+        t1 = time.perf_counter()
+        orc.try_to_factorize(vals_h[b], s.nvar, s.nequ, s.ncon, params[0])   # = set_vals! + ldl_factorize! + inertia
+        t2 = time.perf_counter()
+        orc.solve_ldl(rhs_h[b])
+        t3 = time.perf_counter()
+        t_set += t1 - t0
+        t_fac += max(0.0, (t2 - t1) - (t1 - t0))
+        t_sol += t3 - t2
+    tot = t_set + t_fac + t_sol
+    return {"systems": nsys, "systems_per_s": nsys / tot, "ms_per_system": 1e3 * tot / nsys, "assemble_ms": 1e3 * t_set / nsys,
+            "factorize_ms": 1e3 * t_fac / nsys, "solve_ms": 1e3 * t_sol / nsys, "cores": 1, "nnzL": orc.nnzL}
 
 
 def cpu_baseline(out, s, rows, cols, vals_h, rhs_h, prob, LDLT, args):
@@ -409,6 +570,27 @@ def cpu_baseline(out, s, rows, cols, vals_h, rhs_h, prob, LDLT, args):
         cb["all_cores"] = {"value": sum(done) / ta, "threads": nthr, "systems": sum(done)}
     except Exception as e:
         cb["all_cores"] = {"error": str(e)}
+    # the assemble / factorize / solve split on the headline pattern, and the same for configs 4 and 2 with the
+    # orderings the product chose for them (bounded samples; cfg2's restated up-looking factorisation takes seconds per system)
+    try:
+        import cannoles_jl_amd  # noqa: F401
+        from cannoles_jl_amd import hipldl, synthetic as syn
+        cb["split_cfg3"] = oracle_split(O, s, rows, cols, perm64, vals_h, rhs_h, params, min(8, len(vals_h)))
+        if not args.no_extras:
+            s4 = syn.band_structure(1000, 10)
+            r4, c4 = s4.kkt_pattern()
+            pl4 = hipldl.Plan(s4.N, r4, c4, s4.nvar, s4.nequ, s4.ncon, batch=256)
+            v4, rh4 = band_batch(s4, 64, seed=4000)
+            cb["cfg4"] = oracle_split(O, s4, r4, c4, pl4.array("perm").astype(np.int64), v4, rh4, params, 64)
+            s2 = syn.dense_structure(1000, 2000)
+            r2, c2 = s2.kkt_pattern()
+            pl2 = hipldl.Plan(s2.N, r2, c2, s2.nvar, s2.nequ, s2.ncon, batch=1)
+            v2, rh2 = syn.dense_values(s2, 2002)
+            cb["cfg2"] = oracle_split(O, s2, r2, c2, pl2.array("perm").astype(np.int64), v2[None], rh2[None], params, 1)
+        cb["note"] = ("all_cores / cores = %.1f x one core on %d logical cores: the host leg is memory-bound (every thread streams its own "
+                      "factor through the shared memory system), not compute-bound" % (cb.get("all_cores", {}).get("value", 0) / cb["value"], os.cpu_count()))
+    except Exception as e:
+        cb["split_error"] = str(e)
     out["cpu_baseline"] = cb
 
 

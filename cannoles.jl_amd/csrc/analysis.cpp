@@ -359,10 +359,8 @@ struct SNode {
 // ===========================================================================
 int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
                int64_t nvar, int64_t nequ, int64_t ncon, const Options& opt_in, std::string& msg) {
-  Options opt = opt_in;
-  if (const char* e = getenv("CNL_ORDER")) opt.order_mode = atoi(e);
-  if (const char* e = getenv("CNL_ND_LEAF")) opt.nd_leaf = atoi(e);
-  if (const char* e = getenv("CNL_RELAX")) opt.relax = atoi(e);
+  const Options& opt = opt_in;
+  const bool verbose = opt.verbose != 0 || getenv("CNL_VERBOSE") != nullptr;  // logging only: never changes a decision
   if (N64 <= 0 || nvar < 0 || nequ < 0 || ncon < 0 || nvar + nequ + ncon != N64) { msg = "bad dimensions: N != nvar+nequ+ncon"; return 2; }
   if (N64 + nnz >= (int64_t)1 << 30) { msg = "problem too large for 32-bit plan indices"; return 2; }
   if (nnz < nvar) { msg = "nnz < nvar: the last nvar COO entries must be the rho slots"; return 2; }
@@ -518,7 +516,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     // kernel selection: the register-front kernel needs every front of order <= 64
     int64_t fund_fmax = 0;
     for (int32_t s = 0; s < ns; s++) fund_fmax = std::max<int64_t>(fund_fmax, 1 + sn[s].nupd + sn[s].np());
-    const bool m2 = fund_fmax <= 64 && !getenv("CNL_NO_V2");
+    const bool m2 = fund_fmax <= 64 && opt.register_front;
     const int64_t fcap = m2 ? 64 : ((int64_t)1 << 40);
     auto fcost = [&](int64_t np_, int64_t nu_, int64_t ind_) { return m2 ? front_cost2(np_, nu_, ind_) : front_cost(np_, nu_, ind_); };
     auto ecost = [&](int64_t nu_) { return m2 ? extend_cost2(nu_) : extend_cost(nu_); };
@@ -624,7 +622,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
   };
 
   std::vector<Cand> cands;
-  const bool try_early = !stageC.empty() && !(getenv("CNL_NO_EARLY") && atoi(getenv("CNL_NO_EARLY")));
+  const bool try_early = !stageC.empty() && opt.early;
   auto add_cand = [&](const std::string& name, const ivec& xorder) {
     {
       Cand c; c.name = name;
@@ -713,9 +711,9 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
   };
   size_t best = 0;
   for (size_t i = 1; i < cands.size(); i++) if (score(cands[i]) < score(cands[best])) best = i;
-  if (const char* e = getenv("CNL_FORCE_ORDER"))  // experiments: pick a candidate by name
-    for (size_t i = 0; i < cands.size(); i++) if (cands[i].name == e) best = i;
-  if (getenv("CNL_VERBOSE")) {
+  if (!opt.force_order.empty())  // experiments: pick a candidate by name
+    for (size_t i = 0; i < cands.size(); i++) if (cands[i].name == opt.force_order) best = i;
+  if (verbose) {
     for (auto& c : cands)
       fprintf(stderr, "[cnl] order %-12s cost %.3e path %.3e nnzL %lld (exact %lld) fronts %zu\n", c.name.c_str(), c.cost, c.cpath,
               (long long)c.nnzL, (long long)c.nnzL_exact, c.sn_first.size() - 1);
@@ -900,8 +898,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
   }
 
   // ---- v2 streams (register-front kernel) ---------------------------------------------
-  P.v2_ok = opt.with_rhs_row && P.fmax <= 64;
-  if (const char* e = getenv("CNL_NO_V2")) if (atoi(e)) P.v2_ok = false;
+  P.v2_ok = opt.with_rhs_row && P.fmax <= 64 && opt.register_front;
   // ---- tasks of the staged execution: maximal subtrees of at most task_cap fronts at the bottom (postorder makes a
   //      subtree a contiguous range of fronts), every front above the cut on its own; stage = 1 + latest child stage
   ivec task_first(ns, 0), task_root(ns, 0);
@@ -912,7 +909,6 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     int cap = opt.task_cap > 0 ? opt.task_cap : (opt.par >= 256 ? 8 : 12);
     // orders with a few large canonical parts ("ndc"): a part is one task
     if (opt.task_cap <= 0 && C.name.rfind("ndc", 0) == 0) cap = std::max(cap, (int)(1.5 * ns / std::max(1, atoi(C.name.c_str() + 3))));
-    if (const char* e = getenv("CNL_TASK_CAP")) cap = std::max(1, atoi(e));
     ivec nsub(ns, 1), fdesc(ns), stage(ns, 0);
     for (int32_t s = 0; s < ns; s++) {
       fdesc[s] = s;
@@ -948,15 +944,14 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       P.stage_ptr.assign(nst + 1, 0);
       for (const Task& t : P.tasks) P.stage_ptr[t.stage + 1]++;
       for (int32_t q = 0; q < nst; q++) P.stage_ptr[q + 1] += P.stage_ptr[q];
-      if (getenv("CNL_VERBOSE"))
+      if (verbose)
         fprintf(stderr, "[cnl] staged: %zu tasks in %d stages (cap %d fronts), first stage %d tasks\n", P.tasks.size(), nst, cap, P.stage_ptr[1]);
     }
   }
   const bool staged = !P.tasks.empty();
   if (P.v2_ok) {
-    const int64_t ubig_thr = getenv("CNL_UBIG") ? tri(atoi(getenv("CNL_UBIG"))) : tri(17);  // update matrices above this size live in global scratch
-    int32_t wait_thr = 2;
-    if (const char* e = getenv("CNL_WAIT_THR")) wait_thr = atoi(e);
+    const int64_t ubig_thr = tri(opt.ubig > 0 ? opt.ubig : 17);  // update matrices above this size live in global scratch
+    const int32_t wait_thr = opt.wait_thr >= 0 ? opt.wait_thr : 2;
     ivec uoff2(ns, 0), uglob(ns, 0), fsglob(ns, 0), fsoff2(ns, 0), cls(ns, 16);
     int64_t spL = 0, spG = 0, peakL = 0, peakG = 0, fsmax = 0;
     for (int32_t s = 0; s < ns; s++) {

@@ -7,6 +7,10 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +33,8 @@ struct cnl_plan {
   bool latency = false;  // ordered and cut into tasks for small batches (staged execution, csrc/plan.h)
   cnl::DensePlan D;  // dense residual block (BASELINE config 2): served by the dense backend, csrc/dense.h
   std::vector<int32_t> gpos;  // non-empty: the condensed system may be treated as ONE dense matrix (position of every K2 slot)
+  cnl_options opt{};          // the options the plan was built with (the handle reads its execution switches from here)
+  std::atomic<int> refs{1};   // handles of a cnl_multi share one analysis (read-only after creation)
 };
 
 struct cnl_handle {
@@ -46,6 +52,7 @@ struct cnl_handle {
   void* pin = nullptr;    // pinned host block for the results of small host-pointer calls
   size_t pin_bytes = 0;
   int* d_dep = nullptr;   // dataflow counters of the staged execution (nullptr: one launch per stage)
+  int* d_status = nullptr;  // [1] dataflow waits that gave up (sticky; kernels2.hip spin_until)
   int ntasks = 0;
   int df_waves = 1024;
   std::vector<int32_t> stage_ptr;
@@ -67,6 +74,8 @@ struct cnl_handle {
   int32_t *d_nfact = nullptr, *d_success = nullptr;
   int64_t *d_npos = nullptr, *d_nzero = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t pipe_stream[3] = {nullptr, nullptr, nullptr};  // chunked host-pointer calls: two compute streams, one for the results
+  std::vector<hipEvent_t> pipe_ev;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
   float last_ms = 0.f;
@@ -153,9 +162,10 @@ int choose_config(cnl_handle* h) {
     tpp = P.fmax <= 96 ? 64 : (P.fmax <= 400 ? 256 : 1024);
     ppb = tpp == 64 ? 4 : 1;
   }
-  if (const char* e = getenv("CNL_TPP")) tpp = atoi(e);
-  if (const char* e = getenv("CNL_PPB")) ppb = atoi(e);
-  if (const char* e = getenv("CNL_LDS")) ldsw = atoi(e);
+  const cnl_options& o = h->plan->opt;
+  if (o.v1_tpp > 0) tpp = o.v1_tpp;
+  if (o.v1_ppb > 0) ppb = o.v1_ppb;
+  if (o.v1_lds >= 0) ldsw = o.v1_lds;
   c.tpp = tpp; c.ppb = ppb; c.lds_work = ldsw;
   c.lds_bytes = hdr + (ldsw ? (size_t)ppb * per : 0);
   if (c.lds_bytes > maxlds) return fail(CNL_ERR_DIM, "kernel configuration exceeds LDS");
@@ -165,8 +175,8 @@ int choose_config(cnl_handle* h) {
 int setup_v2(cnl_handle* h) {
   const cnl::Plan& P = h->plan->P;
   h->use_v2 = false;
-  if (!P.v2_ok) return CNL_OK;
-  if (const char* e = getenv("CNL_FORCE_V1")) if (atoi(e)) return CNL_OK;
+  const cnl_options& o = h->plan->opt;
+  if (!P.v2_ok || !o.register_front) return CNL_OK;
   cnl::DevPlan2& d = h->dp2;
   // streams are over-read by the prefetcher: pad with zeros
   std::vector<int32_t> rec(P.rec), brec(P.brec);
@@ -182,13 +192,12 @@ int setup_v2(cnl_handle* h) {
   d.recwords = std::max(d.reccap, 2 * d.breccap);
   d.u2_peak = P.u2_peak;
   d.jraw_off = (int32_t)((P.u2_peak + std::max<int64_t>(P.fs2_max, 64) + 1) & ~(int64_t)1);
-  // backward sweep: the x stack, then three buffers of 160 doubles (panel + index words; kernels2.hip, CNL_GLDS_BACK)
-  d.bpanel_off = (int32_t)((P.bwd_peak + 2 + 1) & ~(int64_t)1);
-  int64_t prob = std::max<int64_t>((int64_t)d.jraw_off + (P.rec_direct ? 128 : 0), (int64_t)d.bpanel_off + cnl::newton2_backward_lds_doubles());
+  d.bpanel_off = (int32_t)((P.bwd_peak + 2 + 1) & ~(int64_t)1);  // end of the backward sweep's x stack
+  int64_t prob = std::max<int64_t>((int64_t)d.jraw_off + (P.rec_direct ? 128 : 0), (int64_t)d.bpanel_off);
   // per-problem areas 32 banks apart modulo 64 (prob_doubles = 16 mod 32): the 16 lanes of two neighbouring problems
   // then touch disjoint LDS banks when they read the same row of their images (env CNL_LDS_PAD=0 disables)
   prob = (prob + 1) & ~(int64_t)1;
-  if (!(getenv("CNL_LDS_PAD") && !atoi(getenv("CNL_LDS_PAD")))) while (prob % 32 != 16) prob += 2;
+  if (o.lds_pad) while (prob % 32 != 16) prob += 2;
   d.prob_doubles = (int32_t)prob;
   d.gs_doubles = P.gs_doubles + 64;
   d.lsize = h->dp.lsize;  // padded stride, see cnl_create
@@ -207,14 +216,16 @@ int setup_v2(cnl_handle* h) {
   if (wave_bytes + 512 > maxlds) return CNL_OK;  // does not fit: stay on v1
   // waves per workgroup: small workgroups give the dispatcher freedom; 2 keeps the launch grid moderate
   int wpb = 1;
-  if (const char* e = getenv("CNL_WPB")) wpb = std::max(1, std::min(4, atoi(e)));
+  if (o.waves_per_block > 0) wpb = std::max(1, std::min(4, o.waves_per_block));
   while (wpb > 1 && wpb * wave_bytes + 512 > maxlds) wpb--;
   h->wpb2 = wpb;
   h->lds2 = wpb * wave_bytes + 512;
   if ((rc = dalloc(h, &h->d_gs, (size_t)h->batch * (size_t)d.gs_doubles))) return rc;
   h->use_v2 = true;
   h->staged = false;
-  if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && !(getenv("CNL_NO_STAGED") && atoi(getenv("CNL_NO_STAGED")))) {
+  if ((rc = dalloc(h, &h->d_status, 1))) return rc;
+  if (hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess) return fail(CNL_ERR_HIP, "hipMemset failed");
+  if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && o.staged) {
     std::vector<int32_t> tk;
     for (const cnl::Task& t : P.tasks) { tk.push_back(t.rec_off); tk.push_back(t.f1 - t.f0); tk.push_back(t.brec_off); tk.push_back(t.is_root); tk.push_back(t.parent); tk.push_back(t.nchild); }
     if ((rc = upload(h, tk, &h->d_tasks))) return rc;
@@ -225,14 +236,25 @@ int setup_v2(cnl_handle* h) {
     //  29 tasks: 32 problems 0.110 against 0.131 ms.  With more wavefronts than about half the machine's slots the waiting ones
     //  crowd out the working ones — cfg3, 501 tasks: sixteen problems 0.233 against 0.196 ms, 256: 82 k against 367 k systems/s —
     //  so only the top stages whose tasks x groups of problems number at most 1024 run that way; env CNL_DATAFLOW_WAVES)
-    h->df_waves = 1024;
-    if (const char* e = getenv("CNL_DATAFLOW_WAVES")) h->df_waves = atoi(e);
-    if (!(getenv("CNL_NO_DATAFLOW") && atoi(getenv("CNL_NO_DATAFLOW"))))
-      if ((rc = dalloc(h, &h->d_dep, 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4)))) return rc;
+    h->df_waves = o.dataflow_waves > 0 ? o.dataflow_waves : 1024;
+    {
+      // a wavefront that waits occupies its slot: never more waiting wavefronts than the device holds at once (the scheme
+      // relies on the lowest unfinished workgroup being resident; kernels2.hip).  Slots: two wavefronts per SIMD by the
+      // register budget of the kernel, and what the LDS of a CU holds.
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) {
+        const size_t per_wg = (size_t)wpb * wave_bytes + 512;
+        const long long by_lds = (long long)(std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : maxlds, 160 * 1024) / per_wg) * wpb;
+        const long long resident = (long long)prop.multiProcessorCount * std::max<long long>(1, std::min<long long>(8, by_lds));
+        h->df_waves = (int)std::min<long long>(h->df_waves, resident);
+      }
+    }
+    if (o.dataflow)
+      if ((rc = dalloc(h, &h->d_dep, 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4) + 2))) return rc;  // + the per-call status words
     h->stage_ptr = P.stage_ptr;
     h->staged = true;
   }
-  h->v2_solve = P.rec_direct && P.d_outer && P.ncls[1] == 0 && P.ncls[2] == 0 && !(getenv("CNL_V1_SOLVE") && atoi(getenv("CNL_V1_SOLVE")));
+  h->v2_solve = P.rec_direct && P.d_outer && P.ncls[1] == 0 && P.ncls[2] == 0 && !o.v1_solve;
   return CNL_OK;
 }
 
@@ -259,10 +281,27 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch; a.L = h->d_L; a.scratch = h->d_gs;
   a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0; a.dep = h->d_dep; a.df_waves = h->df_waves;
+  a.status_total = h->d_status;
+  a.status_call = h->d_dep ? h->d_dep + 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4) : nullptr;
+  a.spin_limit = h->plan->opt.dataflow_spin_limit > 0 ? h->plan->opt.dataflow_spin_limit : (1 << 22);
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
   hipError_t e = cnl::launch_newton2_staged(h->dp2, h->wpb2, h->lds2, a, h->stage_ptr.data(), (int)h->stage_ptr.size() - 1, stream);
   if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("staged launch: ") + hipGetErrorString(e));
   return CNL_OK;
+}
+
+// Behind a staged try_to_factorize / solve_ldl! that ran in dataflow fashion: the sequential execution of the same call, which
+// exits at once unless a dataflow wait of the attempt gave up (kernels2.hip, spin_until).  newton_system has its classic launch
+// anyway (the rho ladder of the problems that failed the first attempt).
+int launch_redo(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
+  if (!a.status_call) return CNL_OK;  // one launch per stage: nothing waits, nothing can time out
+  const bool tm = h->timing;
+  h->timing = false;
+  a.only_if_status = 1;
+  const int rc = launch(h, a, stream);
+  a.only_if_status = 0;
+  h->timing = tm;
+  return rc;
 }
 
 // One call of the path on device-resident data: [condense ->] multifrontal kernel [-> expand].
@@ -360,6 +399,7 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
       a.vals = d_vals; a.extra_pos = count_d ? nullptr : h->d_xpos; a.extra_zer = count_d ? nullptr : h->d_xzer;
       if (h->staged) {  // try_to_factorize stage by stage (the elimination tree's tasks on different wavefronts)
         if ((rc = launch_staged(h, a, stream))) return rc;
+        if ((rc = launch_redo(h, a, stream))) return rc;
         if (h->timing) HIPCHK(hipEventRecord(h->ev1, stream));
       } else if ((rc = launch(h, a, stream))) return rc;
       h->last_vals = d_vals;
@@ -386,6 +426,7 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
       a.vals = const_cast<double*>(h->last_vals); a.rhs = d_rhs; a.d = d_d;
       if (h->staged) {  // solve_ldl! stage by stage: forward substitution of the tasks, then their backward sweeps
         if ((rc = launch_staged(h, a, stream))) return rc;
+        if ((rc = launch_redo(h, a, stream))) return rc;
         if (h->timing) HIPCHK(hipEventRecord(h->ev1, stream));
       } else if ((rc = launch(h, a, stream))) return rc;
       e = cnl::launch_expand(h->dc, const_cast<double*>(h->last_vals), d_rhs, nullptr, h->d_cbuf, d_d, nullptr, 0, B, stream);
@@ -408,6 +449,35 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
   }
   return CNL_OK;
 }
+
+// run() on problems [b0, b0 + nb) of the handle: the base pointer of every per-problem device array of the handle is moved to
+// problem b0 and the batch set to nb for the lifetime of the view (b0 a multiple of 4: a wavefront serves four problems).
+// Dataflow counters are per handle, not per view: views run one launch per stage.
+struct SubBatch {
+  cnl_handle* h;
+  int64_t batch;
+  double *L, *gs, *scratch, *cbuf, *d2;
+  int *xpos, *xzer, *gcnt, *dep;
+  SubBatch(cnl_handle* h_, int64_t b0, int64_t nb) : h(h_) {
+    batch = h->batch; L = h->d_L; gs = h->d_gs; scratch = h->d_scratch; cbuf = h->d_cbuf; d2 = h->d_d2;
+    xpos = h->d_xpos; xzer = h->d_xzer; gcnt = h->d_gcnt; dep = h->d_dep;
+    const cnl::Cond& C = h->plan->C;
+    h->batch = nb;
+    h->d_L += b0 * h->dp.lsize;
+    if (h->d_gs) h->d_gs += b0 * h->dp2.gs_doubles;
+    if (h->d_scratch) h->d_scratch += b0 * (int64_t)h->dp.work_doubles;
+    if (h->d_cbuf) h->d_cbuf += b0 * C.cstride;
+    if (h->d_d2) h->d_d2 += b0 * C.N2;
+    if (h->d_xpos) h->d_xpos += b0;
+    if (h->d_xzer) h->d_xzer += b0;
+    if (h->d_gcnt) h->d_gcnt += 2 * b0;
+    h->d_dep = nullptr;
+  }
+  ~SubBatch() {
+    h->batch = batch; h->d_L = L; h->d_gs = gs; h->d_scratch = scratch; h->d_cbuf = cbuf; h->d_d2 = d2;
+    h->d_xpos = xpos; h->d_xzer = xzer; h->d_gcnt = gcnt; h->d_dep = dep;
+  }
+};
 
 int ensure_staging(cnl_handle* h) {
   if (h->d_vals) return CNL_OK;
@@ -432,30 +502,67 @@ struct cnl_multi {
   std::vector<int64_t> start, count;
   std::vector<int> device;
   int64_t N = 0, nnz = 0, batch = 0;
+  // one persistent host thread per shard (created with the handle, bound to the shard's device once): the host-pointer
+  // calls hand each of them a job and wait; no thread is created or joined per call
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::function<int(size_t)> job;
+  uint64_t generation = 0;
+  size_t pending = 0;
+  bool stop = false;
+  std::vector<int> rc;
+  std::vector<std::string> msg;
 };
 
 namespace {
-// runs f(i) for every shard on its own host thread; the first failure (in shard order) becomes the caller's error
+void multi_worker(cnl_multi* m, size_t i) {
+  (void)hipSetDevice(m->device[i]);  // the thread's current device for its whole life
+  uint64_t seen = 0;
+  for (;;) {
+    std::function<int(size_t)> f;
+    {
+      std::unique_lock<std::mutex> lk(m->mu);
+      m->cv_job.wait(lk, [&] { return m->stop || m->generation != seen; });
+      if (m->stop) return;
+      seen = m->generation;
+      f = m->job;
+    }
+    const int r = f(i);
+    {
+      std::lock_guard<std::mutex> lk(m->mu);
+      m->rc[i] = r;
+      if (r) m->msg[i] = g_err;  // thread-local in the worker: carry it over
+      if (--m->pending == 0) m->cv_done.notify_all();
+    }
+  }
+}
+
+// runs f(i) for every shard on the shard's worker thread; the first failure (in shard order) becomes the caller's error
 template <class F>
 int multi_run(cnl_multi* m, F f) {
   const size_t n = m->h.size();
-  std::vector<int> rc(n, CNL_OK);
-  std::vector<std::string> msg(n);
-  std::vector<std::thread> th;
+  {
+    std::unique_lock<std::mutex> lk(m->mu);
+    m->job = f;
+    m->rc.assign(n, CNL_OK);
+    m->msg.assign(n, std::string());
+    m->pending = n;
+    m->generation++;
+    m->cv_job.notify_all();
+    m->cv_done.wait(lk, [&] { return m->pending == 0; });
+    m->job = nullptr;
+  }
   for (size_t i = 0; i < n; i++)
-    th.emplace_back([&, i]() {
-      rc[i] = f(i);
-      if (rc[i]) msg[i] = g_err;  // thread-local in the worker: carry it over
-    });
-  for (auto& t : th) t.join();
-  for (size_t i = 0; i < n; i++)
-    if (rc[i]) return fail(rc[i], "shard " + std::to_string(i) + " (device " + std::to_string(m->device[i]) + "): " + msg[i]);
+    if (m->rc[i]) return fail(m->rc[i], "shard " + std::to_string(i) + " (device " + std::to_string(m->device[i]) + "): " + m->msg[i]);
   return CNL_OK;
 }
 }  // namespace
 
 
 extern "C" {
+
+static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* rows1, const int64_t* cols1, int64_t batch, int device);
 
 const char* cnl_last_error(void) { return g_err.c_str(); }
 int32_t cnl_version(void) { return 100; }
@@ -467,46 +574,83 @@ void cnl_default_params(double p[9]) {
   p[2] = 1.0 / 3.0;
   p[3] = 8.0;
   p[4] = std::min(100.0, 8.0 * 16.0);
-  p[5] = std::cbrt(eps);
+  p[5] = std::pow(eps, 1.0 / 3.0);  // the reference writes eps^T(1/3): pow with the exponent 0.333..., NOT cbrt (2.5 ulp apart)
   p[6] = std::pow(eps, -2.0);
   p[7] = std::sqrt(eps);
   p[8] = std::pow(eps, 0.25);
 }
 
+void cnl_options_init(cnl_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->struct_size = (int32_t)sizeof(cnl_options);
+  o->plan_kind = CNL_PLAN_AUTO;
+  // measured on MI355X (cfg3 pattern, tools/cmp_staged_threshold.py): latency plans with a few large canonical parts reach
+  // 600 k systems/s at 2048 problems and 613 k at 4096 (the single stream: 342 k and 567 k); from 5120 on the single stream wins
+  o->staged_max_batch = 4096;
+  o->order_mode = -1; o->nd_leaf = 0; o->relax = -1; o->task_cap = 0;
+  o->multipliers_early = 1; o->condense = 1; o->direct_records = 1; o->register_front = 1; o->dense_backend = 1; o->general_dense = 1;
+  o->staged = 1; o->dataflow = 1; o->dataflow_waves = 1024; o->dataflow_spin_limit = 1 << 22;
+  o->waves_per_block = 0; o->v1_tpp = -1; o->v1_ppb = -1; o->v1_lds = -1; o->v1_solve = 0; o->lds_pad = 1;
+  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1;
+}
+
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
-                            int64_t nequ, int64_t ncon, int latency, int par, double slots = 0);
+                            int64_t nequ, int64_t ncon, int latency, int par, double slots, const cnl_options& o);
+
+// options as given, or the defaults; rejects a struct of another ABI revision
+static int resolve_options(const cnl_options* in, cnl_options& out) {
+  cnl_options_init(&out);
+  if (!in) return CNL_OK;
+  if (in->struct_size != (int32_t)sizeof(cnl_options)) return fail(CNL_ERR_ARG, "cnl_options.struct_size does not match this library (use cnl_options_init)");
+  out = *in;
+  out.force_order[sizeof(out.force_order) - 1] = 0;
+  return CNL_OK;
+}
+
+int cnl_plan_create_ex(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                       int64_t nequ, int64_t ncon, int64_t batch, const cnl_options* opt) {
+  cnl_options o;
+  int rc = resolve_options(opt, o);
+  if (rc) return rc;
+  int latency = 0;
+  if (o.plan_kind == CNL_PLAN_LATENCY) latency = 1;
+  else if (o.plan_kind == CNL_PLAN_AUTO) latency = batch >= 1 && batch <= (o.staged_max_batch > 0 ? o.staged_max_batch : 4096);
+  else if (o.plan_kind != CNL_PLAN_THROUGHPUT) return fail(CNL_ERR_ARG, "unknown plan_kind");
+  if (!latency) return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0, 0, o);
+  if (batch < 1) return fail(CNL_ERR_ARG, "a latency plan needs the batch size");
+  const int nquads = (int)((batch + 3) / 4);
+  return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 1, std::max(1, 2048 / nquads), 2048.0 / nquads, o);
+}
 
 int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
                     int64_t nequ, int64_t ncon) {
-  return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0);
-}
-
-static int64_t staged_max_batch() {
-  if (const char* e = getenv("CNL_STAGED_MAX")) return atoll(e);
-  // measured on MI355X (cfg3 pattern, tools/cmp_staged_threshold.py): latency plans with a few large canonical parts reach
-  // 600 k systems/s at 2048 problems and 613 k at 4096 (the single stream: 342 k and 567 k); from 5120 on the single stream wins
-  return 4096;
+  return cnl_plan_create_ex(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, nullptr);
 }
 
 int cnl_plan_create_for_batch(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
                               int64_t nequ, int64_t ncon, int64_t batch) {
   if (batch < 1) return fail(CNL_ERR_ARG, "batch out of range");
-  const int nquads = (int)((batch + 3) / 4);
-  return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch <= staged_max_batch() ? 1 : 0, std::max(1, 2048 / nquads), 2048.0 / nquads);
+  return cnl_plan_create_ex(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch, nullptr);
 }
 
 // latency != 0: plan for a small batch — order chosen by the critical path, tree cut into tasks (par = wavefront slots per
 // group of four problems)
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
-                            int64_t nequ, int64_t ncon, int latency, int par, double slots) {
+                            int64_t nequ, int64_t ncon, int latency, int par, double slots, const cnl_options& o) {
   if (!plan || !rows1 || !cols1) return fail(CNL_ERR_ARG, "null argument");
   cnl_plan* p = new cnl_plan();
   p->N = N; p->nnz = nnz; p->nvar = nvar; p->nequ = nequ; p->ncon = ncon;
   p->latency = latency != 0;
+  p->opt = o;
+  const bool verbose = o.verbose != 0 || getenv("CNL_VERBOSE") != nullptr;  // logging only
   std::string msg;
   cnl::Options opt;
   opt.latency = latency; opt.par = std::max(1, par); opt.slots = slots;
-  int rc = cnl::build_condensation(p->C, N, nnz, rows1, cols1, nvar, nequ, ncon, msg);
+  opt.order_mode = o.order_mode; opt.nd_leaf = o.nd_leaf; opt.relax = o.relax; opt.task_cap = o.task_cap;
+  opt.early = o.multipliers_early; opt.register_front = o.register_front; opt.ubig = o.ubig; opt.wait_thr = o.wait_thr;
+  opt.verbose = verbose ? 1 : 0; opt.force_order = o.force_order;
+  int rc = cnl::build_condensation(p->C, N, nnz, rows1, cols1, nvar, nequ, ncon, msg, o.condense != 0);
   if (!rc) {
     if (p->C.active)
       rc = cnl::build_plan(p->P, p->C.N2, p->C.ncs + nvar, p->C.rows2.data(), p->C.cols2.data(), nvar, p->C.nequ2, ncon, opt, msg);
@@ -520,7 +664,7 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
   }
   // register-front kernel on a condensed system: rewrite the assembly lists against the ORIGINAL arrays, so
   // that the kernel condenses on the fly and the separate condense pass disappears (CNL_NO_DIRECT=1 keeps it)
-  if (p->C.active && p->P.v2_ok && !(getenv("CNL_NO_DIRECT") && atoi(getenv("CNL_NO_DIRECT")))) {
+  if (p->C.active && p->P.v2_ok && o.direct_records) {
     cnl::DirectLists D{p->C.c_ptr.data(), p->C.c_a.data(), p->C.c_b.data(), p->C.c_d.data(), (int32_t)nnz, (int32_t)N};
     const int32_t old_len = p->P.rec_maxlen;
     const size_t old_words = p->P.rec.size();
@@ -541,22 +685,28 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
       cnl::finalize_tasks(p->P);  // the records moved
     } else {
       p->P.tasks.clear();  // staged execution needs the direct records
-      if (latency) {       // a latency order without staging is only a worse order: take the throughput analysis instead
-        if (getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] latency plan without direct records: falling back to the throughput analysis\n");
-        delete p;
-        return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0, 0);
-      }
     }
-    if (getenv("CNL_VERBOSE"))
+    if (verbose)
       fprintf(stderr, "[cnl] direct records: %s, rec words %zu -> %zu, longest %d -> %d\n", drc ? "not possible" : "ok", old_words,
               p->P.rec.size(), old_len, p->P.rec_maxlen);
   }
-  if (!(getenv("CNL_NO_DENSE") && atoi(getenv("CNL_NO_DENSE")))) cnl::detect_dense(p->D, N, nnz, rows1, cols1, nvar, nequ, ncon);
+  // A latency order that cannot run staged (setup_v2's conditions: tasks, direct records, solution components in the caller's
+  // numbering, every condensed pivot counted by a front) would run on the single sequential stream, where it is only a worse
+  // order — more total work, chosen for a critical path nothing exploits: take the throughput analysis instead.
+  if (latency && p->opt.plan_kind != CNL_PLAN_LATENCY) {
+    const bool stageable = o.staged && !p->P.tasks.empty() && p->P.v2_ok && p->P.rec_direct && p->P.d_outer &&
+                           p->P.d_owned == (int64_t)p->C.r_dsrc.size();
+    if (!stageable) {
+      if (verbose) fprintf(stderr, "[cnl] latency plan cannot be staged: falling back to the throughput analysis\n");
+      delete p;
+      return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0, 0, o);
+    }
+  }
+  if (o.dense_backend) cnl::detect_dense(p->D, N, nnz, rows1, cols1, nvar, nequ, ncon);
   // Irregular sparsity: when the fill makes fronts larger than the register-front kernel takes and the condensed system is of
   // moderate order, one dense LDL^T of the whole condensed matrix beats the general multifrontal kernel by far
   // (csrc/dense.h; chosen at handle creation for small batches; CNL_NO_GDENSE=1 disables)
-  if (p->C.active && !p->D.active && !p->P.v2_ok && p->C.N2 >= 96 && p->C.N2 <= 4096 &&
-      !(getenv("CNL_NO_GDENSE") && atoi(getenv("CNL_NO_GDENSE")))) {
+  if (p->C.active && !p->D.active && !p->P.v2_ok && p->C.N2 >= 96 && p->C.N2 <= 4096 && o.general_dense) {
     p->gpos.resize(p->C.ncs);
     for (int64_t s2 = 0; s2 < p->C.ncs; s2++) p->gpos[s2] = (int32_t)((p->C.rows2[s2] - 1) + p->C.N2 * (p->C.cols2[s2] - 1));
   }
@@ -573,7 +723,9 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
   return CNL_OK;
 }
 
-void cnl_plan_destroy(cnl_plan* plan) { delete plan; }
+void cnl_plan_destroy(cnl_plan* plan) {
+  if (plan && plan->refs.fetch_sub(1) == 1) delete plan;
+}
 
 int cnl_plan_info(const cnl_plan* plan, int64_t info[16]) {
   if (!plan || !info) return fail(CNL_ERR_ARG, "null argument");
@@ -634,6 +786,11 @@ int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* 
 
 int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
                int64_t nequ, int64_t ncon, int64_t batch, int device) {
+  return cnl_create_ex(hout, N, nnz, rows1, cols1, nvar, nequ, ncon, batch, device, nullptr);
+}
+
+int cnl_create_ex(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                  int64_t nequ, int64_t ncon, int64_t batch, int device, const cnl_options* opt) {
   if (!hout) return fail(CNL_ERR_ARG, "null handle pointer");
   *hout = nullptr;
   if (batch < 1 || batch > (1 << 24)) return fail(CNL_ERR_ARG, "batch out of range");
@@ -645,8 +802,15 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   if (device < 0 || device >= ndev) return fail(CNL_ERR_ARG, "device index out of range");
   cnl_plan* plan = nullptr;
   // small batches cannot fill the chip with one wavefront per four problems: plan for latency (bushy order, tasks)
-  int rc = cnl_plan_create_for_batch(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch);
+  int rc = cnl_plan_create_ex(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch, opt);
   if (rc) return rc;
+  return create_from_plan(hout, plan, rows1, cols1, batch, device);
+}
+
+// device state for `batch` problems of an analysed pattern; takes ownership of `plan` (freed with the handle, or here on failure)
+static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* rows1, const int64_t* cols1, int64_t batch, int device) {
+  const int64_t N = plan->N, nnz = plan->nnz, nvar = plan->nvar, nequ = plan->nequ, ncon = plan->ncon;
+  int rc = CNL_OK;
   cnl_handle* h = new cnl_handle();
   h->plan = plan; h->device = device; h->batch = batch;
   auto bail = [&](int code) { cnl_destroy(h); return code; };
@@ -712,14 +876,14 @@ int cnl_create(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, 
   if ((rc = setup_v2(h))) return bail(rc);
   if (h->plan->D.active) {
     std::string derr;
-    int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr);
+    int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_syrk_wgs);
     if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
   } else if (!h->plan->gpos.empty() && !h->use_v2 && batch <= 16) {
     std::string derr;
     const cnl::Cond& C2 = h->plan->C;
     h->gops.ns = (int32_t)C2.N2; h->gops.nv = (int32_t)nvar; h->gops.nslots = (int32_t)C2.ncs; h->gops.cstride = C2.cstride;
     if ((rc = upload(h, h->plan->gpos, &h->gops.d_pos))) return bail(rc);
-    int drc = cnl::dense_create_general(&h->gdense, (int32_t)C2.N2, (int32_t)nvar, (int32_t)C2.ncs, h->gops.d_pos, batch, derr);
+    int drc = cnl::dense_create_general(&h->gdense, (int32_t)C2.N2, (int32_t)nvar, (int32_t)C2.ncs, h->gops.d_pos, batch, derr, h->plan->opt.dense_graph != 0);
     if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
   }
   {
@@ -782,6 +946,8 @@ int cnl_destroy(cnl_handle* h) {
   if (h->pin) (void)hipHostFree(h->pin);
   cnl::dense_destroy(h->dense);
   cnl::dense_destroy(h->gdense);
+  for (hipEvent_t e : h->pipe_ev) (void)hipEventDestroy(e);
+  for (hipStream_t st : h->pipe_stream) if (st) (void)hipStreamDestroy(st);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -791,6 +957,18 @@ int cnl_destroy(cnl_handle* h) {
 }
 
 const cnl_plan* cnl_get_plan(const cnl_handle* h) { return h ? h->plan : nullptr; }
+
+int cnl_dataflow_timeouts(cnl_handle* h, int64_t* count) {
+  if (!h || !count) return fail(CNL_ERR_ARG, "null argument");
+  *count = 0;
+  if (!h->d_status) return CNL_OK;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  int v = 0;
+  HIPCHK(hipMemcpy(&v, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  *count = v;
+  return CNL_OK;
+}
 
 int cnl_prepare_newton_system_dev(cnl_handle* h, int64_t nnzhF, int64_t nnzhc, int64_t nnzjF, int64_t nnzjc, const double* d_hF,
                                   const double* d_hc, const double* d_Jx, const double* d_Jcx, const double* d_delta, double* d_vals,
@@ -954,6 +1132,106 @@ int cnl_solve(cnl_handle* h, const double* rhs, double* d) {
   return CNL_OK;
 }
 
+// Large host-pointer batches, chunk by chunk: the call is bound by the host link (1.1 MB per system go up, 0.25 MB come back),
+// which is full duplex — while chunk c + 1 goes up (calling thread, alternating between two streams) chunk c is computed and the
+// results of chunk c - 1 come down (a helper thread of the call, third stream).  Copies between pageable host memory and the
+// device block their host thread, hence the second thread; the compute of a chunk hides behind the upload of the next.
+static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rhs, double* d, const double* rho_old, const double params[9],
+                                   double* rho, double* rho_old_out, int32_t* nfact, int32_t* success, size_t chunk) {
+  const cnl_plan& P = *h->plan;
+  const size_t B = (size_t)h->batch;
+  const size_t nchunks = (B + chunk - 1) / chunk;
+  for (hipStream_t& st : h->pipe_stream) if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  while (h->pipe_ev.size() < nchunks) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->pipe_ev.push_back(e);
+  }
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t posted = 0;
+  bool abort_ = false;
+  int wrc = CNL_OK;
+  std::string wmsg;
+  const int device = h->device;
+  std::thread down([&]() {
+    (void)hipSetDevice(device);
+    hipStream_t st = h->pipe_stream[2];
+    auto chk = [&](hipError_t e, const char* what) {
+      if (e != hipSuccess && wrc == CNL_OK) { wrc = CNL_ERR_HIP; wmsg = std::string(what) + ": " + hipGetErrorString(e); }
+      return e == hipSuccess;
+    };
+    for (size_t c = 0; c < nchunks; c++) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return posted > c || abort_; });
+        if (posted <= c) return;
+      }
+      const size_t b0 = c * chunk, nb = std::min(chunk, B - b0);
+      if (!chk(hipEventSynchronize(h->pipe_ev[c]), "hipEventSynchronize")) continue;
+      if (!chk(hipMemcpyAsync(success + b0, h->d_success + b0, nb * sizeof(int32_t), hipMemcpyDeviceToHost, st), "copy success")) continue;
+      if (!chk(hipStreamSynchronize(st), "hipStreamSynchronize")) continue;
+      // the reference leaves d untouched when the factorisation fails (src/CaNNOLeS.jl:1049): maximal runs of successes
+      size_t q0 = 0;
+      while (q0 < nb) {
+        while (q0 < nb && !success[b0 + q0]) q0++;
+        size_t q1 = q0;
+        while (q1 < nb && success[b0 + q1]) q1++;
+        if (q1 > q0) chk(hipMemcpyAsync(d + (b0 + q0) * P.N, h->d_d + (b0 + q0) * P.N, (q1 - q0) * P.N * sizeof(double), hipMemcpyDeviceToHost, st), "copy d");
+        q0 = q1;
+      }
+      chk(hipMemcpyAsync(rho + b0, h->d_rho + b0, nb * sizeof(double), hipMemcpyDeviceToHost, st), "copy rho");
+      chk(hipMemcpyAsync(rho_old_out + b0, h->d_rho_old + b0, nb * sizeof(double), hipMemcpyDeviceToHost, st), "copy rho_old");
+      chk(hipMemcpyAsync(nfact + b0, h->d_nfact + b0, nb * sizeof(int32_t), hipMemcpyDeviceToHost, st), "copy nfact");
+      if (P.nvar > 0)
+        chk(hipMemcpy2DAsync(vals + b0 * P.nnz + (P.nnz - P.nvar), (size_t)P.nnz * sizeof(double), h->d_vals + b0 * P.nnz + (P.nnz - P.nvar),
+                             (size_t)P.nnz * sizeof(double), (size_t)P.nvar * sizeof(double), nb, hipMemcpyDeviceToHost, st), "copy rho slots");
+      chk(hipStreamSynchronize(st), "hipStreamSynchronize");
+    }
+  });
+  int rc = CNL_OK;
+  for (size_t c = 0; c < nchunks && rc == CNL_OK; c++) {
+    const size_t b0 = c * chunk, nb = std::min(chunk, B - b0);
+    hipStream_t st = h->pipe_stream[c & 1];
+    hipError_t e = hipMemcpyAsync(h->d_vals + b0 * P.nnz, vals + b0 * P.nnz, nb * P.nnz * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->d_rhs + b0 * P.N, rhs + b0 * P.N, nb * P.N * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = rho_old ? hipMemcpyAsync(h->d_rho_old + b0, rho_old + b0, nb * sizeof(double), hipMemcpyHostToDevice, st)
+                                     : hipMemsetAsync(h->d_rho_old + b0, 0, nb * sizeof(double), st);
+    if (e != hipSuccess) { rc = fail(CNL_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); break; }
+    {
+      SubBatch view(h, (int64_t)b0, (int64_t)nb);
+      cnl::LaunchArgs a{};
+      a.mode = cnl::MODE_NEWTON;
+      a.rho_old = h->d_rho_old + b0; a.rho = h->d_rho + b0; a.nfact = h->d_nfact + b0; a.success = h->d_success + b0;
+      std::memcpy(a.params, params, 9 * sizeof(double));
+      const bool tm = h->timing;
+      h->timing = false;
+      rc = run(h, a, h->d_vals + b0 * P.nnz, h->d_rhs + b0 * P.N, h->d_d + b0 * P.N, st);
+      h->timing = tm;
+    }
+    if (rc == CNL_OK && hipEventRecord(h->pipe_ev[c], st) != hipSuccess) rc = fail(CNL_ERR_HIP, "hipEventRecord failed");
+    if (rc == CNL_OK) {
+      std::lock_guard<std::mutex> lk(mu);
+      posted = c + 1;
+      cv.notify_all();
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (rc != CNL_OK) abort_ = true;
+    cv.notify_all();
+  }
+  const std::string keep = g_err;
+  down.join();
+  (void)hipStreamSynchronize(h->pipe_stream[0]);
+  (void)hipStreamSynchronize(h->pipe_stream[1]);
+  if (rc != CNL_OK) return fail(rc, keep);
+  if (wrc != CNL_OK) return fail(wrc, "download: " + wmsg);
+  h->last_vals = h->d_vals;
+  h->factorized = true;
+  return CNL_OK;
+}
+
 int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d, const double* rho_old, const double params[9],
                       double* rho, double* rho_old_out, int32_t* nfact, int32_t* success) {
   if (!h || !vals || !rhs || !d || !params || !rho || !rho_old_out || !nfact || !success) return fail(CNL_ERR_ARG, "null argument");
@@ -962,6 +1240,13 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   if (rc) return rc;
   const cnl_plan& P = *h->plan;
   const size_t B = (size_t)h->batch;
+  if (!h->dense && !h->gdense && !h->timing && B >= 32 && B * (size_t)(P.nnz + P.N) * sizeof(double) >= ((size_t)96 << 20)) {
+    // eight chunks or more, each a multiple of four problems and at least 16 MB of upload
+    size_t chunk = std::max<size_t>(16, ((B / 8) + 3) & ~(size_t)3);
+    const size_t per = (size_t)(P.nnz + P.N) * sizeof(double);
+    while (chunk * per < ((size_t)16 << 20) && chunk < B) chunk += 4;
+    if (chunk < B) return newton_system_pipelined(h, vals, rhs, d, rho_old, params, rho, rho_old_out, nfact, success, chunk);
+  }
   HIPCHK(hipMemcpyAsync(h->d_vals, vals, B * P.nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_rhs, rhs, B * P.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (rho_old) HIPCHK(hipMemcpyAsync(h->d_rho_old, rho_old, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1042,9 +1327,20 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
 //      device, no collective — the devices never exchange data --------------------------------------------------------------
 int cnl_multi_create(cnl_multi** mout, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
                      int64_t ncon, int64_t batch, const int* devices, int ndev) {
+  return cnl_multi_create_ex(mout, N, nnz, rows1, cols1, nvar, nequ, ncon, batch, devices, ndev, nullptr);
+}
+
+int cnl_multi_create_ex(cnl_multi** mout, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
+                        int64_t ncon, int64_t batch, const int* devices, int ndev, const cnl_options* opt) {
   if (!mout || !devices) return fail(CNL_ERR_ARG, "null argument");
   *mout = nullptr;
   if (ndev < 1 || ndev > 64 || batch < 1) return fail(CNL_ERR_ARG, "need 1 <= ndev <= 64 and batch >= 1");
+  cnl_options o;
+  int rc = resolve_options(opt, o);
+  if (rc) return rc;
+  int navail = 0;
+  if (hipGetDeviceCount(&navail) != hipSuccess || navail == 0) return fail(CNL_ERR_HIP, "no HIP device available (this backend has no CPU fallback)");
+  for (int i = 0; i < ndev; i++) if (devices[i] < 0 || devices[i] >= navail) return fail(CNL_ERR_ARG, "device index out of range");
   cnl_multi* m = new cnl_multi();
   m->N = N; m->nnz = nnz; m->batch = batch;
   const int64_t base = batch / ndev, rem = batch % ndev;
@@ -1055,22 +1351,47 @@ int cnl_multi_create(cnl_multi** mout, int64_t N, int64_t nnz, const int64_t* ro
     m->count.push_back(cnt);
     m->device.push_back(devices[i]);
   }
-  for (size_t i = 0; i < m->count.size(); i++) {
+  // The symbolic analysis runs ONCE ("done once on host and broadcast"): the plan is reference-counted, every
+  // shard's handle uploads its own copy of the index data to its device.  Shard sizes differ by at most one problem; the
+  // plan depends on the batch only through the plan kind and the wavefront slots per group of problems, so the first shard's
+  // plan serves all shards of the same kind (a second analysis only when the sizes straddle staged_max_batch).
+  cnl_plan* shared[2] = {nullptr, nullptr};
+  auto kind_of = [&](int64_t cnt) { return o.plan_kind == CNL_PLAN_LATENCY || (o.plan_kind == CNL_PLAN_AUTO && cnt <= (o.staged_max_batch > 0 ? o.staged_max_batch : 4096)) ? 1 : 0; };
+  for (size_t i = 0; i < m->count.size() && !rc; i++) {
+    cnl_plan* plan = nullptr;
+    if (o.multi_share_plan) {
+      const int k = kind_of(m->count[i]);
+      if (!shared[k]) rc = cnl_plan_create_ex(&shared[k], N, nnz, rows1, cols1, nvar, nequ, ncon, m->count[i], &o);
+      if (!rc) { plan = shared[k]; plan->refs.fetch_add(1); }
+    } else {
+      rc = cnl_plan_create_ex(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon, m->count[i], &o);
+    }
     cnl_handle* h = nullptr;
-    const int rc = cnl_create(&h, N, nnz, rows1, cols1, nvar, nequ, ncon, m->count[i], m->device[i]);
+    if (!rc) rc = create_from_plan(&h, plan, rows1, cols1, m->count[i], m->device[i]);  // owns one reference, also when it fails
     if (rc) {
       const std::string keep = g_err;
+      for (cnl_plan* p : shared) cnl_plan_destroy(p);
       cnl_multi_destroy(m);
       return fail(rc, "shard " + std::to_string(i) + ": " + keep);
     }
     m->h.push_back(h);
   }
+  for (cnl_plan* p : shared) cnl_plan_destroy(p);  // the handles keep theirs
+  m->rc.assign(m->h.size(), CNL_OK);
+  m->msg.assign(m->h.size(), std::string());
+  for (size_t i = 0; i < m->h.size(); i++) m->workers.emplace_back(multi_worker, m, i);
   *mout = m;
   return CNL_OK;
 }
 
 int cnl_multi_destroy(cnl_multi* m) {
   if (!m) return CNL_OK;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->stop = true;
+    m->cv_job.notify_all();
+  }
+  for (auto& t : m->workers) t.join();
   for (cnl_handle* h : m->h) cnl_destroy(h);
   delete m;
   return CNL_OK;
@@ -1111,6 +1432,52 @@ int cnl_multi_newton_system(cnl_multi* m, double* vals, const double* rhs, doubl
     return cnl_newton_system(m->h[i], vals + s * m->nnz, rhs + s * m->N, d + s * m->N, rho_old ? rho_old + s : nullptr, params, rho + s,
                              rho_old_out + s, nfact + s, success + s);
   });
+}
+
+// ---- device-pointer twins: shard i's arrays live on shard i's device (problem-major, count[i] problems).  The calls only
+//      ENQUEUE (from the calling thread, one shard after the other) and return; cnl_multi_synchronize waits for all shards.
+//      streams[i] == NULL (or streams == NULL): the shard handle's own stream.
+static hipStream_t shard_stream(cnl_multi* m, size_t i, void* const* streams) {
+  return streams && streams[i] ? (hipStream_t)streams[i] : m->h[i]->stream;
+}
+
+int cnl_multi_factorize_dev(cnl_multi* m, const double* const* d_vals, double eig_tol, int32_t* const* d_success, void* const* streams) {
+  if (!m || !d_vals || !d_success) return fail(CNL_ERR_ARG, "null argument");
+  for (size_t i = 0; i < m->h.size(); i++) {
+    const int rc = cnl_factorize_dev(m->h[i], d_vals[i], eig_tol, d_success[i], shard_stream(m, i, streams));
+    if (rc) return fail(rc, "shard " + std::to_string(i) + ": " + g_err);
+  }
+  return CNL_OK;
+}
+
+int cnl_multi_solve_dev(cnl_multi* m, const double* const* d_rhs, double* const* d_d, void* const* streams) {
+  if (!m || !d_rhs || !d_d) return fail(CNL_ERR_ARG, "null argument");
+  for (size_t i = 0; i < m->h.size(); i++) {
+    const int rc = cnl_solve_dev(m->h[i], d_rhs[i], d_d[i], shard_stream(m, i, streams));
+    if (rc) return fail(rc, "shard " + std::to_string(i) + ": " + g_err);
+  }
+  return CNL_OK;
+}
+
+int cnl_multi_newton_system_dev(cnl_multi* m, double* const* d_vals, const double* const* d_rhs, double* const* d_d,
+                                double* const* d_rho_old, double* const* d_rho, int32_t* const* d_nfact, int32_t* const* d_success,
+                                const double params[9], void* const* streams) {
+  if (!m || !d_vals || !d_rhs || !d_d || !d_rho_old || !d_rho || !d_nfact || !d_success || !params) return fail(CNL_ERR_ARG, "null argument");
+  for (size_t i = 0; i < m->h.size(); i++) {
+    const int rc = cnl_newton_system_dev(m->h[i], d_vals[i], d_rhs[i], d_d[i], d_rho_old[i], d_rho[i], d_nfact[i], d_success[i], params,
+                                         shard_stream(m, i, streams));
+    if (rc) return fail(rc, "shard " + std::to_string(i) + ": " + g_err);
+  }
+  return CNL_OK;
+}
+
+int cnl_multi_synchronize(cnl_multi* m, void* const* streams) {
+  if (!m) return fail(CNL_ERR_ARG, "null argument");
+  for (size_t i = 0; i < m->h.size(); i++) {
+    HIPCHK(hipSetDevice(m->device[i]));
+    HIPCHK(hipStreamSynchronize(shard_stream(m, i, streams)));
+  }
+  return CNL_OK;
 }
 
 }  // extern "C"

@@ -9,10 +9,10 @@
 namespace cnl {
 
 int build_condensation(Cond& C, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
-                       int64_t nequ, int64_t ncon, std::string& msg) {
+                       int64_t nequ, int64_t ncon, std::string& msg, bool enable) {
   C = Cond();
   C.N = N; C.nnz = nnz; C.nvar = nvar; C.nequ = nequ; C.ncon = ncon;
-  if (getenv("CNL_NO_CONDENSE") && atoi(getenv("CNL_NO_CONDENSE"))) return 0;
+  if (!enable) return 0;
   if (N <= 0 || nvar < 0 || nequ < 0 || ncon < 0 || nvar + nequ + ncon != N || nnz < nvar) return 0;  // build_plan reports it
   if (nequ == 0) return 0;
   if (N + nnz >= ((int64_t)1 << 29)) return 0;

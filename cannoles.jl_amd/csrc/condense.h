@@ -58,6 +58,6 @@ struct Cond {
 // Decides which residual nodes are condensed and builds the contribution lists.
 // Returns 0 or an error code; when nothing can be condensed `active` stays false.
 int build_condensation(Cond& C, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
-                       int64_t nequ, int64_t ncon, std::string& msg);
+                       int64_t nequ, int64_t ncon, std::string& msg, bool enable = true);
 
 }  // namespace cnl

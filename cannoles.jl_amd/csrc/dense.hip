@@ -876,6 +876,7 @@ struct DenseState {
   std::vector<GraphEntry> graphs;
   hipStream_t cap = nullptr;
   bool use_graph = true;
+  int misses = 0;  // consecutive calls whose argument set was not cached (a caller that hands over fresh buffers every step)
 };
 
 bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
@@ -944,7 +945,6 @@ int upload_(DenseState* st, const T** p, const std::vector<T>& v, std::string& e
 // sizes, tile lists and buffers common to both forms
 int setup_common(DenseState* st, int ns, int nv, int64_t batch, std::string& err) {
   DnDev& d = st->d;
-  if (const char* e = getenv("CNL_NO_GRAPH")) if (atoi(e)) st->use_graph = false;
 #ifdef DN_STAMPS
   st->use_graph = false;
 #endif
@@ -971,9 +971,10 @@ int setup_common(DenseState* st, int ns, int nv, int64_t batch, std::string& err
 
 }  // namespace
 
-int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::string& err) {
+int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::string& err, bool use_graph, int syrk_wgs) {
   DenseState* st = new DenseState();
   st->batch = batch;
+  st->use_graph = use_graph;
   *out = st;
   DnDev& d = st->d;
   d.n = P.n; d.m = P.m; d.p = P.p; d.nnz = P.nnz;
@@ -989,7 +990,7 @@ int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::strin
   {
     const long long nch = d.mp / KT, units = (long long)batch * d.ntl * nch;
     int nwg = 512;
-    if (const char* e = getenv("CNL_DENSE_SYRK_WGS")) nwg = std::max(1, atoi(e));
+    if (syrk_wgs > 0) nwg = syrk_wgs;
     nwg = (int)std::min<long long>(nwg, units);
     std::vector<int> wg(nwg + 1, 0), pb, ptl, pc0, pc1;
     for (int w = 0; w < nwg; w++) {
@@ -1054,9 +1055,11 @@ int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::strin
   return 0;
 }
 
-int dense_create_general(DenseState** out, int32_t ns, int32_t nv, int32_t nslots, const int32_t* d_pos, int64_t batch, std::string& err) {
+int dense_create_general(DenseState** out, int32_t ns, int32_t nv, int32_t nslots, const int32_t* d_pos, int64_t batch, std::string& err,
+                         bool use_graph) {
   DenseState* st = new DenseState();
   st->batch = batch;
+  st->use_graph = use_graph;
   st->general = true;
   *out = st;
   DnDev& d = st->d;
@@ -1119,9 +1122,14 @@ int run_cached(DenseState* st, const GraphKey& key, hipStream_t stream, std::str
   if (!st->use_graph) return enqueue(stream);
   for (auto& g : st->graphs)
     if (g.key == key) {
+      st->misses = 0;
       DCHK(hipGraphLaunch(g.exec, stream));
       return 0;
     }
+  // Capture + instantiation cost far more than the launches they replace: a caller whose pointers change with every call
+  // (fresh device buffers per step) would pay them each time.  After a few misses in a row such a handle stays on plain
+  // launches (a hit resets the count, so alternating between a few fixed argument sets keeps its graphs).
+  if (++st->misses > 4) return enqueue(stream);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return enqueue(stream);  // the caller captures
   if (!st->cap && hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking) != hipSuccess) { st->use_graph = false; return enqueue(stream); }
@@ -1143,6 +1151,9 @@ int run_cached(DenseState* st, const GraphKey& key, hipStream_t stream, std::str
     return enqueue(stream);
   }
   if (st->graphs.size() >= 8) {
+    // the evicted graph may still be running on whatever stream its last caller used (the _dev calls are asynchronous):
+    // drain the device first (rare: the ninth distinct argument set of a handle)
+    (void)hipDeviceSynchronize();
     (void)hipGraphExecDestroy(st->graphs.front().exec);
     (void)hipGraphDestroy(st->graphs.front().graph);
     st->graphs.erase(st->graphs.begin());

@@ -106,12 +106,18 @@ struct LaunchArgs {
                          //    its dependencies are complete by launch order (no wait, plain counter bump)
   int df_waves;          // the top stages of the tree whose wavefronts together number at most this run as ONE launch per phase
   int* dep;              // [2][tasks][nquads] dataflow counters (zeroed per call): children done (forward), task done (backward)
+  // A dataflow wait that gives up after spin_limit polls bumps both counters: status_total is sticky (cnl_dataflow_timeouts),
+  // status_call is zeroed with `dep` at the start of every staged call and makes the classic launch behind the staged attempt
+  // redo the whole batch sequentially (only_if_status: that launch exits at once when the attempt had no timeout)
+  int* status_total;
+  int* status_call;
+  int spin_limit;
+  int only_if_status;
 };
 
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream);
-int newton2_backward_lds_doubles();  // per-problem LDS the backward sweep needs behind the x stack (0 unless built with CNL_GLDS_BACK)
 // one attempt at the rho given in vals, stage by stage (stage_ptr: host array of nstages + 1 task offsets)
 hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, LaunchArgs a, const int32_t* stage_ptr, int nstages, hipStream_t stream);
 hipError_t launch_condense(const DevCond& C, const double* vals, const double* rhs, double* cbuf, int slot_begin, int slot_end,

@@ -256,92 +256,8 @@ struct Ctx2 {
     }                                                                                                                  \
   }
 
-// the rare large classes are real calls so that their register needs do not leak into the hot path
-// The hot class (order <= 16, strided LDS image) spelled out by hand: per pivot, the pivot d, the first
-// multiplier and ALL row pairs are read back from LDS in one batch right after the row is published, ahead
-// of the division, so one LDS round trip (instead of two) and the division sit on the dependent chain.
-__device__ __forceinline__ void eliminate16(int P_prob_doubles, int P_u2_peak, long long P_gs_doubles, long long P_lsize, double* cL_,
-                                            double* cgs_, int cbatch, int lane, int prob0, int pass, int f, int nupd,
-                                            long long lptr, int uoff, int fsoff, bool uglob, double* pbase0, int* cnt,
-                                            double eig_tol, unsigned long long* st_ = nullptr) {
-  ESTAMP0
-  double* Lg = as_global(cL_);
-  double* gsg = as_global(cgs_);
-  const int gp = lane >> 4;
-  const int b = lane & 15;
-  const int prob = prob0 + gp;
-  const bool valid = prob < cbatch;
-  int pc32_ = valid ? prob : prob0;
-  // opaque: the per-lane factor base would otherwise be hoisted out of the fronts loop and kept alive (or spilled)
-  asm volatile("" : "+v"(pc32_));
-  const long long pclamp = pc32_;
-  double* pb = pbase0 + gp * P_prob_doubles;
-  const double* Fs = pb + P_u2_peak;
-  // factor rows: wave-uniform base + 32-bit byte offset (the 4 problems of a wave span < 4 GB)
-  const int prob0u = __builtin_amdgcn_readfirstlane(prob0);
-  char* L_wb = reinterpret_cast<char*>(Lg + (long long)prob0u * P_lsize + lptr);
-  const int tu = tri2(1 + nupd);
-  const unsigned lofs = ((valid ? (unsigned)gp : 0u) * (unsigned)P_lsize + (unsigned)b - (unsigned)tu) * 8u;
-  const int top = f - 1;
-  const double* Fss = Fs + (top - 15) * 16 + b;
-  double* lb = pb + P_u2_peak;  // the LDS staging area is dead once the rows are in registers
-  (void)pass; (void)fsoff;
-  CNL_ALL16(CNL_DECL)
-  CNL_ALL16(CNL_LOADS)
-  ESTAMP(7)
-  int npos = 0, nzer = 0;
-  for (int i = top; i > nupd; i--) {
-    const double w = r0;
-    {
-      int li_ = i - b;
-      li_ = li_ >= 0 ? li_ : 17;  // lanes b > i park their value in an unused slot
-      lb[li_] = w;
-    }
-    const double2* lb2 = reinterpret_cast<const double2*>(lb);
-    const double2 p0 = lb2[0], p2 = lb2[1], p4 = lb2[2], p6 = lb2[3], p8 = lb2[4];  // (d, w_{i-1}), (w_{i-2}, w_{i-3}), ...
-    double2 p10 = p8, p12 = p8, p14 = p8;
-    const bool hi = i > 9;  // rows i-10 .. i-15 exist only in large fronts (wave-uniform)
-    if (hi) { p10 = lb2[5]; p12 = lb2[6]; p14 = lb2[7]; }
-    const double dpiv = p0.x;
-    const double lv = fast_div(w, dpiv);
-    npos += dpiv > eig_tol;
-    nzer += fabs(dpiv) <= eig_tol;
-    if (valid && b <= i && !(CNL_ABL & 64))
-      *reinterpret_cast<double*>(L_wb + (lofs + ((unsigned)tri2(i) << 3))) = (b == i) ? dpiv : lv;
-    if (!(CNL_ABL & 32)) {
-      // F(a, b) -= w_a * lv for the remaining rows; register r<k> holds row i-k, the update shifts it to r<k-1>
-      r0 = fma(-p0.y, lv, r1);
-      r1 = fma(-p2.x, lv, r2);
-      r2 = fma(-p2.y, lv, r3);
-      r3 = fma(-p4.x, lv, r4);
-      r4 = fma(-p4.y, lv, r5);
-      r5 = fma(-p6.x, lv, r6);
-      r6 = fma(-p6.y, lv, r7);
-      r7 = fma(-p8.x, lv, r8);
-      r8 = fma(-p8.y, lv, r9);
-      if (hi) {
-        r9 = fma(-p10.x, lv, r10);
-        r10 = fma(-p10.y, lv, r11);
-        r11 = fma(-p12.x, lv, r12);
-        r12 = fma(-p12.y, lv, r13);
-        r13 = fma(-p14.x, lv, r14);
-        r14 = fma(-p14.y, lv, r15);
-      }
-    }
-  }
-  ESTAMP(5)
-  if (b == 0) { cnt[gp * 2] += npos; cnt[gp * 2 + 1] += nzer; }
-  if (uglob) {
-    if (valid) {
-      double* Ug = gsg + pclamp * P_gs_doubles + uoff;
-      CNL_REV16(CNL_USTG)
-    }
-  } else if (!(CNL_ABL & 128)) {
-    double* Ul = pb + uoff;
-    CNL_REV16(CNL_USTL)
-  }
-}
-// The hot class again, without the LDS round trip per pivot (CNL_DPP_ELIM=0 keeps the version above).  Rows are absolute
+// The rare large classes are real calls (CNL_DEFINE_ELIM, LDS form) so that their register needs do not leak into the hot path.
+// The hot class (order <= 16) without an LDS round trip per pivot.  Rows are absolute
 // (R<a> = row a of the front, lane b = column b).  A problem is 16 lanes = one DPP row, so "the value of lane a for every
 // lane of the problem" is the DPP row broadcast of the fp64 FMA:
 //     pivot i:  d = w[lane i],  l_b = w_b / d,   R<a>[b] += w[lane a] * (-l_b)   for a < i
@@ -349,74 +265,10 @@ __device__ __forceinline__ void eliminate16(int P_prob_doubles, int P_u2_peak, l
 // One instruction per row update, no publish / read-back through LDS (the LDS pipe is the busiest unit of this kernel)
 // and a shorter dependent chain per pivot (broadcast -> division -> update).  Lane numbers are immediates, hence one
 // block per pivot position (elim_dpp.inc), entered by wave-uniform branches.
-#ifndef CNL_DPP_ELIM
-#define CNL_DPP_ELIM 1
-#endif
-// Row-per-lane backward sweep through the same broadcast (one FMA per position on the chain instead of a product and a
-// four-step lane reduction per pivot): correct, but MEASURED SLOWER — 886k against 944k systems/s at B = 8192: every lane then
-// loads 16 entries of its own row (16 row segments per instruction) instead of 10 coalesced panel rows, and the vector-memory
-// path is already half busy.  Kept behind -DCNL_DPP_BACK=1.
-#ifndef CNL_DPP_BACK
-#define CNL_DPP_BACK 0
-#endif
-// Round 2, second experiment: the backward sweep of the fast fronts rebuilt around that chain (-DCNL_GLDS_BACK=1):
-//  * the 8 header words of a front through the SCALAR cache (s_load from the record stream, constant address space), three
-//    fronts ahead, straight into SGPRs; the index words by LDS-DMA: no LDS copy of the record;
-//  * the panel of a front is a CONTIGUOUS piece of the factor storage (packed rows nupd+1 .. f-1), so the whole wave copies
-//    it as it lies into LDS with `global_load_lds_dwordx4` (one instruction per problem: 64 lanes x 16 bytes, no register
-//    staging, TWO fronts ahead into three buffers) and every pivot lane reads ITS OWN row from LDS (immediate offsets);
-//  * the dependent chain is one DPP-broadcast FMA per position, with the accumulator itself as the broadcast source.
-// Parity-green (the whole -m gpu suite), and MEASURED NO FASTER: 921k against 947k systems/s at B = 8192, 0.180 against
-// 0.171 ms at B = 1.  In-kernel stamps: the chain fell from 1150 to 350 cycles per front and wave and the header wait went
-// away, yet the sweep stayed at ~3800 cycles per front: at B = 8192 it streams the 9.5 GB of the factor in 1.9 ms = 5 TB/s,
-// i.e. it sits on the HBM read rate of this access pattern (address translation is not it: 12 k UTCL1 misses in 965 M
-// requests), whatever the per-wave latency chain looks like.  What shortens it is fewer bytes of L, not this.
-#ifndef CNL_GLDS_BACK
-#define CNL_GLDS_BACK 0
-#endif
-#define CNL_BPANEL_SLOT 152   // doubles per panel: 135 (f = 16, no update rows) + the 16-entry over-read of a row
-#define CNL_BPANEL_BUF 160    // doubles per buffer: the panel and 16 index words
-#define CNL_BPANEL_NBUF 3
-typedef __attribute__((address_space(3))) void* cnl_lds_ptr;
-typedef const __attribute__((address_space(4))) int* cnl_const_ptr;
-// 16 bytes per lane from base + off (8-byte alignment is enough, measured) to LDS byte address lds_addr + lane * 16 (wave-uniform
-// SGPR value).  The compiler does not count this load: the consumer waits with an explicit s_waitcnt vmcnt(0).
-__device__ __forceinline__ void glds16(const char* base, unsigned off, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_addr) : "memory");
-}
-// same, 4 bytes per lane
-__device__ __forceinline__ void glds4(const char* base, unsigned off, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ unsigned lds_byte_address(const void* p) {
-  return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(cnl_lds_ptr)p);
-}
-struct BHdr { int w[8]; };
-// header of the backward record at word offset woff (wave-uniform) through the scalar cache
-__device__ __forceinline__ BHdr load_bhdr(const int* stream, int woff) {
-  cnl_const_ptr p = (cnl_const_ptr)(stream) + __builtin_amdgcn_readfirstlane(woff);
-  BHdr h;
-#pragma unroll
-  for (int k = 0; k < 8; k++) h.w[k] = p[k];
-  return h;
-}
-// w / d through the raw reciprocal (2^-25 on gfx950) and ONE residual correction of the quotient: relative error ~2^-50, four
-// dependent fp64 operations on the per-pivot chain instead of the six of fast_div (-DCNL_DPP_QUICKDIV=1; off by default)
-__device__ __forceinline__ double quick_div(double w, double d) {
-  const double r = __builtin_amdgcn_rcp(d);
-  const double q = w * r;
-  const double res = fma(-d, q, w);
-  return fma(res, r, q);
-}
-#if defined(CNL_DPP_QUICKDIV) && CNL_DPP_QUICKDIV  // measured: no gain (943k vs 947k systems/s): the division is not the critical resource
-#define CNL_DPP_DIV quick_div
-#else
+// (Round-2 experiments on this kernel that were measured and NOT kept — a row-per-lane backward sweep through the DPP broadcast,
+// a backward sweep fed by global_load_lds_dwordx4 with headers through the scalar cache, a four-operation division chain — are
+// recorded in DESIGN.md section 4; their code lives in the git history, not here.)
 #define CNL_DPP_DIV fast_div
-#endif
 #include "elim_dpp.inc"
 #define CNL_DPPF(X, W, NL, A) \
   asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #A " row_mask:0xf bank_mask:0xf" : "+v"(X) : "v"(W), "v"(NL));
@@ -443,7 +295,7 @@ __device__ __forceinline__ void eliminate16_dpp(int P_prob_doubles, int P_u2_pea
   const int prob = prob0 + gp;
   const bool valid = prob < cbatch;
   int pc32_ = valid ? prob : prob0;
-  asm volatile("" : "+v"(pc32_));  // opaque: see eliminate16
+  asm volatile("" : "+v"(pc32_));  // opaque: the per-lane factor base must not be hoisted out of the fronts loop and kept alive (or spilled)
   const long long pclamp = pc32_;
   double* pb = pbase0 + gp * P_prob_doubles;
   const double* Fs = pb + P_u2_peak + b;
@@ -691,43 +543,6 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     }                                                                                  \
   }
 
-// Backward sweep, row-per-lane form: lane l takes the first 16 entries of ITS OWN panel row (local row l of the front:
-// z_l in column 0, then l_l1 .. l_l,l-1); lanes without a row (update rows, lanes past the front) and entries at or past
-// the diagonal read as zero.  Same addressing as above; entries no lane of the front needs (j >= f - 1) are not loaded.
-#define PREFETCH_LROWS(DST, LPTR, NUPD, NPIV)                                                    \
-  {                                                                                              \
-    const int nu_ = (NUPD), f_ = 1 + nu_ + (NPIV);                                               \
-    const bool has_ = l > nu_ && l < f_;                                                         \
-    const char* rb_ = L_wb + ((long long)(LPTR) << 3);                                           \
-    const unsigned ro_ = gofs_l0 + (has_ ? (unsigned)(tri2(l) - tri2(1 + nu_)) << 3 : 0u);       \
-    _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                                          \
-      double2 v_ = make_double2(0.0, 0.0);                                                       \
-      if (j < f_ - 1) v_ = *reinterpret_cast<const double2*>(rb_ + (ro_ + 8u * j));   /* 16-byte piece of the row */ \
-      DST[j] = (has_ && j < l) ? v_.x : 0.0;                                                     \
-      DST[j + 1] = (has_ && j + 1 < l) ? v_.y : 0.0;                                             \
-    }                                                                                            \
-  }
-
-// Panel of a front -> LDS buffer BUF of every problem of the wave (see CNL_GLDS_BACK): problem q is copied by all 64 lanes.
-#define GLDS_PANEL(LPTR, NUPD, NPIV, BUF)                                                                      \
-  {                                                                                                            \
-    const int pbytes_ = __builtin_amdgcn_readfirstlane((tri2(1 + (NUPD) + (NPIV)) - tri2(1 + (NUPD))) << 3);   \
-    const char* rb_ = L_wb + ((long long)(LPTR) << 3);                                                         \
-    const unsigned lo_ = (unsigned)lane * 16u;                                                                 \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                         \
-      const unsigned qo_ = (prob0 + q_ < A.batch ? (unsigned)q_ : 0u) * (unsigned)P.lsize * 8u;                \
-      const unsigned dst_ = lds_panel0 + (unsigned)(q_ * P.prob_doubles + (BUF) * CNL_BPANEL_BUF) * 8u;        \
-      if ((int)lo_ < pbytes_) glds16(rb_, qo_ + lo_, dst_);                                                    \
-    }                                                                                                          \
-    if (pbytes_ > 1024) { /* only a front of order 16 without update rows */                                   \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                       \
-        const unsigned qo_ = (prob0 + q_ < A.batch ? (unsigned)q_ : 0u) * (unsigned)P.lsize * 8u;              \
-        const unsigned dst_ = lds_panel0 + (unsigned)(q_ * P.prob_doubles + (BUF) * CNL_BPANEL_BUF) * 8u;      \
-        if ((int)lo_ + 1024 < pbytes_) glds16(rb_, qo_ + 1024u + lo_, dst_ + 1024u);                           \
-      }                                                                                                        \
-    }                                                                                                          \
-  }
-
 // Value prefetch of the NEXT front.  The lists of a record hold the entries that read the matrix values first and
 // the entries that read the right-hand side last, so every round of 16 gathers from one array: the address is a
 // wave-uniform base (SGPR pair) plus a 32-bit per-lane byte offset.  All source indices are read from the LDS
@@ -773,12 +588,21 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
   }
 
 // ==========================================================================================
-// dataflow execution of a staged plan: wait until *p >= target (bounded: a broken dependency must not hang the device), then
-// make the producer's global stores visible; signal = all stores of this wavefront first, then the counter
-__device__ __forceinline__ void spin_until(const int* p, int target) {
-  for (int it = 0; it < (1 << 22); it++) {
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+// dataflow execution of a staged plan: wait until *p >= target, then make the producer's global stores visible; signal = all
+// stores of this wavefront first, then the counter.  The wait is bounded (a broken dependency — workgroups not dispatched in
+// index order, a time-sliced device — must not hang the device): a wait that gives up is COUNTED in status_total / status_call,
+// and the classic launch that follows every staged attempt then redoes the whole batch sequentially, so a timeout costs time,
+// never a wrong result.  Once one wait of the call has given up the others stop waiting at once.
+__device__ __forceinline__ void spin_until(const int* p, int target, int limit, int* status_total, int* status_call) {
+  bool ok = false;
+  for (int it = 0; it < limit; it++) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
+    if ((it & 255) == 255 && __hip_atomic_load(status_call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
     __builtin_amdgcn_s_sleep(4);
+  }
+  if (!ok && (threadIdx.x & 63) == 0) {
+    __hip_atomic_fetch_add(status_total, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(status_call, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #ifndef CNL_DF_NOFENCE   // (timing probe: -DCNL_DF_NOFENCE drops both fences; results are then not guaranteed)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -855,8 +679,12 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   if (prob0 >= A.batch) return;
   const int prob = prob0 + g;
   bool valid_ = prob < A.batch;
-  if (!STAGED && A.skip_done) {  // behind a staged attempt: only the problems that failed it are processed
-    if (valid_ && as_global(A.success)[prob] == 1) valid_ = false;
+  if (!STAGED && (A.skip_done || A.only_if_status)) {
+    // behind a staged attempt: only the problems that failed it are processed — all of them when a dataflow wait of the
+    // attempt gave up (its results are then not to be trusted)
+    const bool redo_all = A.status_call && __hip_atomic_load(as_global(A.status_call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (A.only_if_status && !redo_all) return;
+    if (A.skip_done && !redo_all && valid_ && as_global(A.success)[prob] == 1) valid_ = false;
     if (!__any(valid_)) return;
   }
   const bool valid = valid_;
@@ -888,7 +716,6 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   const unsigned gofs_r = (gsel * (unsigned)(has_rhs ? P.rstride : P.vstride) - (unsigned)P.nnz) * 8u;  // rhs sources are nnz + index
   const char* L_wb = reinterpret_cast<const char*>(A.L + (long long)prob0u * P.lsize);
   const unsigned gofs_l = (gsel * (unsigned)P.lsize + (unsigned)l) * 8u;
-  const unsigned gofs_l0 = gsel * (unsigned)P.lsize * 8u;
 
   // per-problem ladder state, replicated over the 16 lanes of the group
   double rho = 0.0, wrote = 0.0;
@@ -927,7 +754,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       PREFETCH_ROWS(lr, lp0, HDRW(hv0, R_NUPD), HDRW(hv0, R_NPIV))
     }
     for (int s = 0; s < nfr; s++) {
-      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }  // children's update vectors are read below
+      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }  // children's update vectors are read below
       const int* rec = recw;
       const int hv = rec[lane & 15];
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM), nasmv = HDRW(hv, R_NASMV);
@@ -936,7 +763,6 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       const int nprod = HDRW(hv, R_NPROD) & 0xffff, nraw = HDRW(hv, R_NRAW), nrdw = HDRW(hv, R_NRD);
       const int nrd = nrdw & 0xffff, nrawv = nrdw >> 16;
       const long long lptr = (long long)HDRW(hv, R_LPTR_LO) | ((long long)HDRW(hv, R_LPTR_HI) << 31);
-      const int f = 1 + nupd + npiv;
       const bool uglob = flags & RF_U_GLOBAL;
       double* cvec = myFs;  // c_a = entry (a, 0) of the front, a = 0 .. f-1 (a = 0 unused)
       cvec[l] = 0.0;
@@ -1104,7 +930,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const bool fast0 = (fw0 >> 8) == 16 && !(fw0 & RF_FS_GLOBAL);
         if (!fast0) {
           // rare: large or globally staged front, handled out of line
-          if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }
+          if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }
           if (!(CNL_ABL & 2048)) slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, has_rhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, recw, roff, pbase0, cnt, eig_tol, rho, ovr, P.count_d != 0);
           gsync();
           roff = nxt_off;
@@ -1120,11 +946,11 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       }
       bool more = true;
       while (more) {
-      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }  // children's update matrices are read below
+      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }  // children's update matrices are read below
       const int* rec = recw;
       const int hv = rec[lane & 15];
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM);
-      const int nchild = HDRW(hv, R_NCHILD), uoff = HDRW(hv, R_UOFF), flags = HDRW(hv, R_FLAGS), fsoff = HDRW(hv, R_FSOFF);
+      const int nchild = HDRW(hv, R_NCHILD), uoff = HDRW(hv, R_UOFF), flags = HDRW(hv, R_FLAGS);
       const int nasmv = HDRW(hv, R_NASMV), aoff = HDRW(hv, R_ASM_OFF), coff = HDRW(hv, R_CHILD_OFF);
       const int nprodw = HDRW(hv, R_NPROD), nraw = HDRW(hv, R_NRAW), nrdw = HDRW(hv, R_NRD);
       const int nprod = nprodw & 0xffff, nrd = nrdw & 0xffff, nrawv = nrdw >> 16;
@@ -1290,13 +1116,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       }
       STAMP(1)
       // (5) eliminate in registers, store L rows and the update matrix
-#if defined(CNL_STAMPS) && !CNL_DPP_ELIM
-      eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol, st_acc);
-#elif CNL_DPP_ELIM
       if (!(CNL_ABL & 1024)) eliminate16_dpp(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol);
-#else
-      if (!(CNL_ABL & 1024)) eliminate16(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, 0, f, nupd, lptr, uoff, fsoff, uglob, pbase0, cnt, eig_tol);
-#endif
       STAMP(3)
       if (uglob) gsync(); else wsync();
       roff = nroff;
@@ -1363,157 +1183,9 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     const double* myL = A.L + pclamp * P.lsize;
     double* mydout = A.d + pclamp * P.dstride;
     double* xs = myU;  // the x stack reuses the per-problem LDS area
-#if CNL_GLDS_BACK
-    {
-      // Every asynchronous load of this loop is an LDS-DMA the compiler does not count (panels, index words): the waits are
-      // explicit.  Prefetch distance: TWO fronts (three LDS buffers) — at one front the sweep ran at the concurrency limit of
-      // HBM (4 KB per wave in flight x 2048 waves x ~2 us), not at its bandwidth.
-      const int* bw = P.brec;
-      const unsigned lds_panel0 = lds_byte_address(pbase0 + P.bpanel_off);   // buffers of the wave's first problem
-      const char* bwc = reinterpret_cast<const char*>(bw);
-      // buffer k of a problem: [panel: CNL_BPANEL_SLOT doubles | 16 index words (first problem's copy only)]
-#define GLDS_FRONT(HH, BOFF, BUF)                                                                                  \
-      {                                                                                                            \
-        const long long lp_ = (long long)HH.w[B_LPTR_LO] | ((long long)HH.w[B_LPTR_HI] << 31);                     \
-        if (!(CNL_ABL & 16384)) GLDS_PANEL(lp_, HH.w[B_NUPD], HH.w[B_NPIV], BUF)                                   \
-        if (lane < 16 && !(CNL_ABL & 262144)) glds4(bwc, (unsigned)((BOFF) + B_HDR + lane) * 4u, lds_panel0 + (unsigned)((BUF) * CNL_BPANEL_BUF + CNL_BPANEL_SLOT) * 8u); \
-      }
-      int boff = t_brec;
-      BHdr H = load_bhdr(bw, boff);
-      int boff1 = boff + H.w[B_RECLEN];
-      BHdr H1 = load_bhdr(bw, boff1);   // the stream is zero-padded: reading records past the end is harmless
-      int boff2 = boff1 + H1.w[B_RECLEN];
-      BHdr H2 = load_bhdr(bw, boff2);
-      bool primed = false, deep = false;
-      int b0 = 0, b1 = 1, b2 = 2;       // LDS buffers of fronts s, s+1, s+2
-      // the scattered store of a front's pivots is issued behind the NEXT front's drain: stores count in vmcnt on gfx9, a
-      // store issued right before the drain would put a full memory round trip on every front's critical path
-      double dpend = 0.0;
-      int ipend = -1;
-      int s = 0;
-      while (s < nfr) {
-        const int npiv = H.w[B_NPIV], nupd = H.w[B_NUPD], xoff = H.w[B_XOFF], pxoff = H.w[B_PXOFF], cls = H.w[B_CLS];
-        const long long lptr = (long long)H.w[B_LPTR_LO] | ((long long)H.w[B_LPTR_HI] << 31);
-        const int f = 1 + nupd + npiv;
-        const int boff3 = boff2 + H2.w[B_RECLEN];
-        if (cls != 16) {
-          // rare large front: its record goes to LDS for the out-of-line sweep, then the pipeline restarts
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (ipend >= 0) mydout[ipend] = dpend;
-          ipend = -1;
-          const int len = H.w[B_RECLEN];
-          for (int w4 = lane; w4 * 4 < len; w4 += 64) reinterpret_cast<int4*>(recbuf)[w4] = bstream[(boff >> 2) + w4];
-          wsync();
-          const int* rec = recbuf;
-          if (CNL_ABL & 4096) {
-          } else if (cls == 32) {
-            for (int pass = 0; pass < 2; pass++) {
-              if (prob0 + pass * 2 >= A.batch) break;
-              back_front_call<32>(P.prob_doubles, P.lsize, P.dstride, A.L, A.d, A.batch, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);
-            }
-          } else {
-            for (int pass = 0; pass < 4; pass++) {
-              if (prob0 + pass >= A.batch) break;
-              back_front_call<64>(P.prob_doubles, P.lsize, P.dstride, A.L, A.d, A.batch, lane, prob0, pass, rec, f, nupd, npiv, lptr, xoff, pxoff, pbase0, okflag);
-            }
-          }
-          wsync();
-          boff = boff1; boff1 = boff2; boff2 = boff3;
-          H = H1; H1 = H2;
-          H2 = load_bhdr(bw, boff2);
-          s++;
-          primed = false;
-          continue;
-        }
-        const bool next_fast = s + 1 < nfr && H1.w[B_CLS] == 16;
-        if (!primed) {
-          GLDS_FRONT(H, boff, b0)
-          if (next_fast) GLDS_FRONT(H1, boff1, b1)
-          primed = true;
-          deep = false;
-        }
-        if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }
-        // this front's panel and index words were issued two fronts ago; behind them the queue holds one store and the five
-        // loads of the next front (more only makes the wait stricter); right after a restart: drain
-        BSTAMP(5)
-        if (deep) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        BSTAMP(0)
-        if (ipend >= 0 && !(CNL_ABL & 65536)) mydout[ipend] = dpend;
-        // the front after the next: panel and index words; the header after that
-        deep = false;
-        if (next_fast && s + 2 < nfr && H2.w[B_CLS] == 16) {
-          GLDS_FRONT(H2, boff2, b2)
-          deep = true;
-        }
-        const BHdr H3 = load_bhdr(bw, boff3);
-        BSTAMP(1)
-        const int idx = (CNL_ABL & 262144) ? l : reinterpret_cast<const int*>(pbase0 + P.bpanel_off + b0 * CNL_BPANEL_BUF + CNL_BPANEL_SLOT)[l];
-        // x of the update rows from the parent's vector; lane 0 (right-hand-side column, z in the panel) holds -1 (see below)
-        double xb = l == 0 ? -1.0 : 0.0;
-        if (pxoff >= 0 && l >= 1 && l <= nupd && !(CNL_ABL & 131072)) xb = xs[pxoff + idx];
-        if (pxoff == B_PX_GLOBAL && l >= 1 && l <= nupd) {  // the parent was solved by another task: x = -d of the named components
-          xb = -__hip_atomic_load(mydout + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // this lane's row of the panel.  Lanes without a pivot row read row 0; entries at or past the diagonal are whatever
-        // follows in the buffer: a lane's sum is final before they are added and is not used afterwards.
-        double lr[16];
-        {
-          const bool has_ = l > nupd && l < f;
-          const double* prow_ = myU + P.bpanel_off + b0 * CNL_BPANEL_BUF + (has_ ? tri2(l) - tri2(1 + nupd) : 0);
-#pragma unroll
-          for (int j = 0; j < 16; j++) lr[j] = (CNL_ABL & 32768) ? 1.0 : prow_[j];
-        }
-        wsync();
-#if defined(CNL_STAMPS) && CNL_STAMPS == 2
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-        BSTAMP(2)
-        {
-          // s_l = sum_j L(l, j) x_j over the columns j < l, one DPP-broadcast FMA per position.  Update rows: x_j comes from
-          // lane j of xb.  Pivots: x_j = -s_j, so the accumulator itself is the broadcast source and the row entry enters
-          // negated (nlr, formed off the chain): the dependent chain per pivot is ONE instruction (+ the DPP read hazard).
-          // The solution of pivot J is captured when its sum is final (later steps add over-read entries to that lane).
-          double s_ = 0.0, xcap = 0.0;
-#define CNL_BSTEP(J)                                                                                                    \
-          if (J < f && !(CNL_ABL & 8192)) {                                                                                \
-            if (J <= nupd) {                                                                                               \
-              asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(s_) : "v"(xb), "v"(lr[J])); \
-            } else {                                                                                                       \
-              const double nlr_ = -lr[J];                                                                                  \
-              xcap = (l == J) ? s_ : xcap;                                                                                 \
-              asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(s_) : "v"(nlr_)); \
-            }                                                                                                              \
-          }
-          CNL_BSTEP(0) CNL_BSTEP(1) CNL_BSTEP(2) CNL_BSTEP(3) CNL_BSTEP(4) CNL_BSTEP(5) CNL_BSTEP(6) CNL_BSTEP(7)
-          CNL_BSTEP(8) CNL_BSTEP(9) CNL_BSTEP(10) CNL_BSTEP(11) CNL_BSTEP(12) CNL_BSTEP(13) CNL_BSTEP(14) CNL_BSTEP(15)
-#undef CNL_BSTEP
-          if (l > nupd && l < f) xb = -xcap;
-        }
-        BSTAMP(3)
-        // d = -x of the pivots: one scattered store per front (the index word names the solution component of every pivot)
-        ipend = (okme && l > nupd && l < f) ? idx : -1;
-        dpend = -xb;
-        if (l >= 1 && l < f && !(CNL_ABL & 131072)) xs[xoff + l] = xb;
-        wsync();
-        boff = boff1; boff1 = boff2; boff2 = boff3;
-        H = H1; H1 = H2; H2 = H3;
-        { const int t_ = b0; b0 = b1; b1 = b2; b2 = t_; }
-        s++;
-        BSTAMP(4)
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (ipend >= 0) mydout[ipend] = dpend;
-#undef GLDS_FRONT
-    }
-#else
     int boff = t_brec, nxt = 0;
     int4 Rb;
-#if CNL_DPP_BACK
-    double lr[16];     // this lane's panel row of the CURRENT front, prefetched one front ahead
-#else
     double lr[KB];     // panel rows of the CURRENT front (first KB pivots), prefetched one front ahead
-#endif
     bool primed = false;
     int s = 0;
     while (s < nfr) {
@@ -1527,14 +1199,10 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const int hb0 = recw[lane & 7];
         const int nupd0 = HDRW(hb0, B_NUPD), npiv0 = HDRW(hb0, B_NPIV);
         const long long lp0 = (long long)HDRW(hb0, B_LPTR_LO) | ((long long)HDRW(hb0, B_LPTR_HI) << 31);
-#if CNL_DPP_BACK
-        PREFETCH_LROWS(lr, lp0, nupd0, npiv0)
-#else
         PREFETCH_ROWS(lr, lp0, nupd0, npiv0)
-#endif
         primed = true;
       }
-      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target); dep_wait = nullptr; }  // the parent's x is read below
+      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }  // the parent's x is read below
       const int* rec = recw;
       const int hb = rec[lane & 7];
       const int npiv = HDRW(hb, B_NPIV), nupd = HDRW(hb, B_NUPD), xoff = HDRW(hb, B_XOFF), pxoff = HDRW(hb, B_PXOFF);
@@ -1562,11 +1230,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         continue;
       }
       // next record into the other buffer, then prefetch the record after it and the next front's panel rows
-#if CNL_DPP_BACK
-      double lrn[16];
-#else
       double lrn[KB];
-#endif
       int nboff = nxt;
       if (s + 1 < nfr) {
         int* nrec = recbuf + ((s + 1) & 1) * P.breccap;
@@ -1582,14 +1246,10 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const int nn = nxt + nlen;
         Rb = bstream[(nn >> 2) + lane];
         nxt = nn;
-#if CNL_DPP_BACK
-        PREFETCH_LROWS(lrn, lp1, nupd1, npiv1)
-#else
         PREFETCH_ROWS(lrn, lp1, nupd1, npiv1)
-#endif
       } else {
 #pragma unroll
-        for (int k = 0; k < (CNL_DPP_BACK ? 16 : KB); k++) lrn[k] = lr[k];
+        for (int k = 0; k < KB; k++) lrn[k] = lr[k];
       }
       // x of the update rows from the parent's vector (in place when this front reuses the parent's slot).
       // Lane l keeps x of local row l; rows not known yet hold 0, so the dot product of a pivot row needs no lane
@@ -1601,24 +1261,6 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       if (pxoff == B_PX_GLOBAL && l >= 1 && l <= nupd)  // the parent was solved by another task: x = -d of the named components
         xb = -__hip_atomic_load(mydout + rec[B_HDR + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       wsync();
-#if CNL_DPP_BACK
-      // Row-per-lane sweep: lane l accumulates s_l = sum_j L(l, j) x_j over the columns j < l of its row as the x_j become
-      // known — x_j is fetched from lane j with the DPP row broadcast of the fp64 FMA (a problem is one DPP row).  Column 0
-      // holds z and lane 0 holds -1, so s_l = -x_l once every column is in; position j turns lane j's sum into x_j first when
-      // j is a pivot.  One FMA per position on the dependent chain, instead of a product and a four-step lane reduction
-      // per pivot.  Positions are immediates: the sixteen steps are spelled out, skipped by wave-uniform tests.
-      {
-        double s_ = 0.0;
-#define CNL_BSTEP(J)                                                                                                    \
-        if (J < f) {                                                                                                     \
-          if (J > nupd) xb = (l == J) ? -s_ : xb;                                                                        \
-          asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "+v"(s_) : "v"(xb), "v"(lr[J])); \
-        }
-        CNL_BSTEP(0) CNL_BSTEP(1) CNL_BSTEP(2) CNL_BSTEP(3) CNL_BSTEP(4) CNL_BSTEP(5) CNL_BSTEP(6) CNL_BSTEP(7)
-        CNL_BSTEP(8) CNL_BSTEP(9) CNL_BSTEP(10) CNL_BSTEP(11) CNL_BSTEP(12) CNL_BSTEP(13) CNL_BSTEP(14) CNL_BSTEP(15)
-#undef CNL_BSTEP
-      }
-#else
 #pragma unroll
       for (int k = 0; k < KB; k++) {
         if (k < npiv) {
@@ -1632,17 +1274,15 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const double sum = gsum<16>(lv * xb);
         if (l == i) xb = -sum;
       }
-#endif
       // d = -x of the pivots: one scattered store per front (rec holds the original index of every pivot)
       if (okme && l > nupd && l < f) mydout[rec[B_HDR + l]] = -xb;
       if (l >= 1 && l < f) xs[xoff + l] = xb;
       wsync();
 #pragma unroll
-      for (int k = 0; k < (CNL_DPP_BACK ? 16 : KB); k++) lr[k] = lrn[k];
+      for (int k = 0; k < KB; k++) lr[k] = lrn[k];
       boff = nboff;
       s++;
     }
-#endif
   }
 #ifdef CNL_STAMPS
   STAMP(6)
@@ -1659,8 +1299,6 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     A.success[prob] = success ? 1 : 0;
   }
 }
-
-int newton2_backward_lds_doubles() { return CNL_GLDS_BACK ? CNL_BPANEL_NBUF * CNL_BPANEL_BUF : 0; }
 
 hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream) {
   if (wpb < 1 || wpb > 4) return hipErrorInvalidConfiguration;
@@ -1707,7 +1345,8 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
     // per stage — cfg3 64 problems 0.255 against 0.241 ms, cfg4 256 problems 1.51 M against 1.66 M systems/s: the fences of the
     // top launch cost what the saved launch boundaries gain.  So: all of the tree in one launch per phase, or none of it.
     if (s_df != 0) s_df = nstages;
-    e = hipMemsetAsync(a.dep, 0, 2 * (size_t)ntasks_all * (size_t)a.nquads * sizeof(int), stream);
+    // the two words behind the counters are the per-call status (see spin_until)
+    e = hipMemsetAsync(a.dep, 0, (2 * (size_t)ntasks_all * (size_t)a.nquads + 2) * sizeof(int), stream);
     if (e != hipSuccess) return e;
   }
   a.ntasks_all = ntasks_all;

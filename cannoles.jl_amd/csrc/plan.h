@@ -47,6 +47,14 @@ struct Options {
   int par = 256;
   double slots = 0;  // the same as a fraction (wavefront slots per group of four problems; 0: use par)
   int task_cap = 0;
+  // the rest mirrors cnl_options (include/cannoles_hip.h): explicit switches instead of environment variables, so that the
+  // numerical path of a handle depends on its arguments only
+  int early = 1;           // consider the "+early" candidates (a multiplier right behind the last variable it touches)
+  int register_front = 1;  // allow the register-front kernel (record streams) when every front has order <= 64
+  int ubig = 17;           // update matrices of order above this live in the global scratch
+  int wait_thr = 2;        // update matrices that wait for more than this many fronts go to the global scratch
+  int verbose = 0;
+  std::string force_order; // pick an ordering candidate by name (experiments)
 };
 
 // One task of the staged execution: fronts [f0, f1) (a complete subtree, or a single front above the cut) processed by

@@ -29,6 +29,7 @@ _lib = None
 # symbols declared in include/cannoles_hip.h (checked by the CPU test-suite)
 ABI_SYMBOLS = [
     "cnl_last_error", "cnl_version", "cnl_default_params",
+    "cnl_options_init", "cnl_plan_create_ex", "cnl_create_ex", "cnl_dataflow_timeouts",
     "cnl_plan_create", "cnl_plan_create_for_batch", "cnl_plan_destroy", "cnl_plan_info", "cnl_plan_get", "cnl_plan_order_name",
     "cnl_create", "cnl_destroy", "cnl_get_plan",
     "cnl_factorize", "cnl_solve", "cnl_newton_system",
@@ -36,8 +37,45 @@ ABI_SYMBOLS = [
     "cnl_set_timing", "cnl_last_kernel_ms", "cnl_get_config",
     "cnl_residual_vectors_dev", "cnl_trial_point_dev", "cnl_prepare_newton_system_dev",
     "cnl_cgls_multipliers_dev",
+    "cnl_multi_create_ex", "cnl_multi_factorize_dev", "cnl_multi_solve_dev", "cnl_multi_newton_system_dev", "cnl_multi_synchronize",
     "cnl_multi_create", "cnl_multi_destroy", "cnl_multi_shards", "cnl_multi_factorize", "cnl_multi_solve", "cnl_multi_newton_system",
 ]
+
+
+PLAN_AUTO, PLAN_THROUGHPUT, PLAN_LATENCY = 0, 1, 2
+
+
+class cnl_options(C.Structure):
+    """struct cnl_options of include/cannoles_hip.h (field order and types must match)"""
+    _fields_ = [("struct_size", C.c_int32), ("plan_kind", C.c_int32), ("staged_max_batch", C.c_int64)] + [
+        (k, C.c_int32) for k in (
+            "order_mode", "nd_leaf", "relax", "task_cap", "multipliers_early", "condense", "direct_records", "register_front",
+            "dense_backend", "general_dense", "staged", "dataflow", "dataflow_waves", "dataflow_spin_limit", "waves_per_block",
+            "v1_tpp", "v1_ppb", "v1_lds", "v1_solve", "lds_pad", "ubig", "wait_thr", "dense_graph", "dense_syrk_wgs", "verbose",
+            "multi_share_plan")] + [("force_order", C.c_char * 32)]
+
+
+def Options(**kw):
+    """cnl_options with the library's defaults (cnl_options_init), then the given fields: explicit arguments instead of
+    environment variables — e.g. Options(plan_kind=PLAN_THROUGHPUT), Options(dataflow=0), Options(force_order="nd32+early")."""
+    o = cnl_options()
+    lib().cnl_options_init(C.byref(o))
+    assert o.struct_size == C.sizeof(cnl_options), "cnl_options layout differs from the library's"
+    for k, v in kw.items():
+        if k == "force_order":
+            v = v.encode() if isinstance(v, str) else v
+        if not hasattr(o, k):
+            raise AttributeError(f"cnl_options has no field {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+def _optref(options):
+    if options is None:
+        return None
+    if isinstance(options, dict):
+        options = Options(**options)
+    return C.byref(options)
 
 
 class CnlError(RuntimeError):
@@ -61,6 +99,11 @@ def lib():
         L.cnl_default_params.argtypes = [vp]
         L.cnl_plan_create.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64]
         L.cnl_plan_create_for_batch.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64, i64]
+        L.cnl_options_init.argtypes = [vp]
+        L.cnl_options_init.restype = None
+        L.cnl_plan_create_ex.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64, i64, vp]
+        L.cnl_create_ex.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64, i64, C.c_int, vp]
+        L.cnl_dataflow_timeouts.argtypes = [vp, C.POINTER(i64)]
         L.cnl_plan_destroy.argtypes = [vp]
         L.cnl_plan_destroy.restype = None
         L.cnl_plan_info.argtypes = [vp, _i64p]
@@ -82,6 +125,11 @@ def lib():
         L.cnl_prepare_newton_system_dev.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
         L.cnl_cgls_multipliers_dev.argtypes = [vp, vp, vp, vp, vp, dbl, dbl, i64, C.c_int, vp, vp]
         L.cnl_multi_create.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64, i64, vp, C.c_int]
+        L.cnl_multi_create_ex.argtypes = [C.POINTER(vp), i64, i64, _i64p, _i64p, i64, i64, i64, i64, vp, C.c_int, vp]
+        L.cnl_multi_factorize_dev.argtypes = [vp, vp, dbl, vp, vp]
+        L.cnl_multi_solve_dev.argtypes = [vp, vp, vp, vp]
+        L.cnl_multi_newton_system_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cnl_multi_synchronize.argtypes = [vp, vp]
         L.cnl_multi_destroy.argtypes = [vp]
         L.cnl_multi_shards.argtypes = [vp, C.POINTER(i64), vp, vp, vp]
         L.cnl_multi_factorize.argtypes = [vp, vp, dbl, vp, vp, vp]
@@ -142,10 +190,13 @@ class Plan:
     """Host-only symbolic analysis (what `ldl_analyze` is to the reference).
     Needs no GPU; used by the CPU test-suite and for sizing."""
 
-    def __init__(self, N, rows, cols, nvar, nequ, ncon, batch=None):
+    def __init__(self, N, rows, cols, nvar, nequ, ncon, batch=None, options=None):
         self.rows, self.cols = _i64(rows), _i64(cols)
         p = C.c_void_p()
-        if batch is None:  # the large-batch analysis
+        if options is not None:   # explicit options (batch None: the large-batch analysis unless the options say otherwise)
+            _check(lib().cnl_plan_create_ex(C.byref(p), int(N), len(self.rows), self.rows, self.cols, int(nvar), int(nequ), int(ncon),
+                                            int(batch or 0), _optref(options)))
+        elif batch is None:  # the large-batch analysis
             _check(lib().cnl_plan_create(C.byref(p), int(N), len(self.rows), self.rows, self.cols, int(nvar), int(nequ), int(ncon)))
         else:              # what cnl_create(batch) runs
             _check(lib().cnl_plan_create_for_batch(C.byref(p), int(N), len(self.rows), self.rows, self.cols, int(nvar), int(nequ),
@@ -174,7 +225,7 @@ class HIPLDLStruct:
     (src/solver_types.jl:45-65).  `batch > 1` is the batched twin: one shared
     pattern, problem-major values `vals[b, :]`."""
 
-    def __init__(self, N, rows, cols, vals, nvar=None, nequ=None, ncon=None, batch=1, device=0):
+    def __init__(self, N, rows, cols, vals, nvar=None, nequ=None, ncon=None, batch=1, device=0, options=None):
         self.N = int(N)
         self.rows, self.cols = _i64(rows), _i64(cols)
         self.nnz = len(self.rows)
@@ -185,8 +236,12 @@ class HIPLDLStruct:
         # `vals` is aliased, not copied: the driver mutates the array returned by get_vals
         self.vals = vals if vals is not None else np.ones((self.batch, self.nnz) if self.batch > 1 else self.nnz)
         h = C.c_void_p()
-        _check(lib().cnl_create(C.byref(h), self.N, self.nnz, self.rows, self.cols, self.nvar, self.nequ, self.ncon,
-                                self.batch, int(device)))
+        if options is None:
+            _check(lib().cnl_create(C.byref(h), self.N, self.nnz, self.rows, self.cols, self.nvar, self.nequ, self.ncon,
+                                    self.batch, int(device)))
+        else:
+            _check(lib().cnl_create_ex(C.byref(h), self.N, self.nnz, self.rows, self.cols, self.nvar, self.nequ, self.ncon,
+                                       self.batch, int(device), _optref(options)))
         self._h = h
         self.factor = _Factor(self)
         self.info = _plan_info(lib().cnl_get_plan(h))
@@ -211,6 +266,11 @@ class HIPLDLStruct:
 
     def set_timing(self, on=True):
         _check(lib().cnl_set_timing(self._h, 1 if on else 0))
+
+    def dataflow_timeouts(self):
+        n = C.c_int64(0)
+        _check(lib().cnl_dataflow_timeouts(self._h, C.byref(n)))
+        return int(n.value)
 
     def last_kernel_ms(self):
         ms = C.c_float(0)
@@ -324,14 +384,14 @@ class MultiHIPLDLStruct:
     """One solver object over several devices (cnl_multi_*): the batch is cut into contiguous balanced shards, one handle and
     one host thread per device, no collective.  Same call surface as a batched HIPLDLStruct for the host-pointer calls."""
 
-    def __init__(self, N, rows, cols, nvar, nequ, ncon, batch, devices):
+    def __init__(self, N, rows, cols, nvar, nequ, ncon, batch, devices, options=None):
         self.N, self.nvar, self.nequ, self.ncon, self.batch = int(N), int(nvar), int(nequ), int(ncon), int(batch)
         self.rows, self.cols = _i64(rows), _i64(cols)
         self.nnz = len(self.rows)
         dv = np.ascontiguousarray(devices, dtype=np.int32)
         m = C.c_void_p()
-        _check(lib().cnl_multi_create(C.byref(m), self.N, self.nnz, self.rows, self.cols, self.nvar, self.nequ, self.ncon, self.batch,
-                                      dv.ctypes.data, len(dv)))
+        _check(lib().cnl_multi_create_ex(C.byref(m), self.N, self.nnz, self.rows, self.cols, self.nvar, self.nequ, self.ncon, self.batch,
+                                         dv.ctypes.data, len(dv), _optref(options)))
         self._m = m
         n = C.c_int64(0)
         _check(lib().cnl_multi_shards(m, C.byref(n), None, None, None))
@@ -370,3 +430,27 @@ class MultiHIPLDLStruct:
         _check(lib().cnl_multi_newton_system(self._m, vals.ctypes.data, rhs.ctypes.data, d.ctypes.data, ro.ctypes.data, params.ctypes.data,
                                              rho.ctypes.data, ro_out.ctypes.data, nfact.ctypes.data, succ.ctypes.data))
         return d, succ.astype(bool), rho, ro_out, nfact.astype(np.int64)
+
+    # ---- device-resident twins: one list entry per shard (data_ptr of that shard's array on its device) ----
+    @staticmethod
+    def _ptrs(ptrs):
+        return (C.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+
+    def newton_system_dev(self, vals_ptrs, rhs_ptrs, d_ptrs, rho_old_ptrs, rho_ptrs, nfact_ptrs, success_ptrs, params, streams=None):
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        st = self._ptrs(streams) if streams is not None else None
+        _check(lib().cnl_multi_newton_system_dev(self._m, self._ptrs(vals_ptrs), self._ptrs(rhs_ptrs), self._ptrs(d_ptrs),
+                                                 self._ptrs(rho_old_ptrs), self._ptrs(rho_ptrs), self._ptrs(nfact_ptrs),
+                                                 self._ptrs(success_ptrs), params.ctypes.data, st))
+
+    def factorize_dev(self, vals_ptrs, eig_tol, success_ptrs, streams=None):
+        st = self._ptrs(streams) if streams is not None else None
+        _check(lib().cnl_multi_factorize_dev(self._m, self._ptrs(vals_ptrs), float(eig_tol), self._ptrs(success_ptrs), st))
+
+    def solve_dev(self, rhs_ptrs, d_ptrs, streams=None):
+        st = self._ptrs(streams) if streams is not None else None
+        _check(lib().cnl_multi_solve_dev(self._m, self._ptrs(rhs_ptrs), self._ptrs(d_ptrs), st))
+
+    def synchronize(self, streams=None):
+        st = self._ptrs(streams) if streams is not None else None
+        _check(lib().cnl_multi_synchronize(self._m, st))

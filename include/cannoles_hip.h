@@ -59,6 +59,49 @@ int32_t cnl_version(void);
  * [eig_tol, delta_min, kappa_dec, kappa_inc, kappa_largeinc, rho0, rho_max, rho_min, gamma_A] */
 void cnl_default_params(double params[9]);
 
+/* ---- options ----------------------------------------------------------------------------------------------------------
+ * Everything that selects a plan or an execution is an ARGUMENT: the library reads no environment variable that changes what it
+ * computes (CNL_VERBOSE only adds log lines on stderr).  cnl_options_init fills the defaults — the choices cnl_create makes by
+ * itself; the `_ex` entry points take a modified copy.  Used by tests and measurement tools to force a plan kind or an execution
+ * the automatic choice would not pick for that batch; a drop-in caller never needs it (the reference has no counterpart:
+ * `ldl_analyze` takes no options, src/solver_types.jl:63).                                                                       */
+#define CNL_PLAN_AUTO 0        /* by batch size: latency plan up to staged_max_batch problems, throughput plan above           */
+#define CNL_PLAN_THROUGHPUT 1  /* least total work, one sequential record stream per four problems                             */
+#define CNL_PLAN_LATENCY 2     /* bushy elimination tree cut into tasks (staged execution)                                      */
+typedef struct cnl_options {
+  int32_t struct_size;         /* sizeof(cnl_options), set by cnl_options_init (ABI evolution)                                  */
+  int32_t plan_kind;           /* CNL_PLAN_*                                                                                    */
+  int64_t staged_max_batch;    /* CNL_PLAN_AUTO: largest batch planned for latency (default 4096)                              */
+  int32_t order_mode;          /* -1 auto (cost model over all candidates), 0 canonical, 1 nested dissection, 2 minimum degree  */
+  int32_t nd_leaf;             /* nested-dissection leaf size, 0 = sweep                                                        */
+  int32_t relax;               /* relaxed-amalgamation budget (explicit zeros per merged column), -1 = default                  */
+  int32_t task_cap;            /* fronts per bottom task of a latency plan, 0 = default                                         */
+  int32_t multipliers_early;   /* 1: candidates with every multiplier right behind the last variable it touches are considered  */
+  int32_t condense;            /* 1: static condensation of the -I block                                                        */
+  int32_t direct_records;      /* 1: the register-front kernel condenses on the fly (no separate condense pass)                 */
+  int32_t register_front;      /* 1: the register-front kernel may serve the plan (fronts of order <= 64)                       */
+  int32_t dense_backend;       /* 1: dense residual blocks go to the dense backend                                              */
+  int32_t general_dense;       /* 1: small batches of irregular plans with fronts > 64 are factorised as ONE dense matrix       */
+  int32_t staged;              /* 1: latency plans run their first attempt stage by stage                                       */
+  int32_t dataflow;            /* 1: smallest batches run all tasks in one launch per phase, waiting on device counters         */
+  int32_t dataflow_waves;      /* at most this many wavefronts run in dataflow fashion (default 1024; clamped to what the device
+                                  holds at once)                                                                                */
+  int32_t dataflow_spin_limit; /* polls before a dataflow wait gives up (default 1 << 22).  A wait that gives up is counted
+                                  (cnl_dataflow_timeouts) and the call falls back to the sequential execution for the batch      */
+  int32_t waves_per_block;     /* register-front kernel: wavefronts per workgroup, 0 = default (1)                              */
+  int32_t v1_tpp, v1_ppb, v1_lds; /* general kernel: threads per problem, problems per workgroup, work area in LDS; -1 = auto   */
+  int32_t v1_solve;            /* 1: cnl_solve always runs on the general kernel                                                */
+  int32_t lds_pad;             /* 1: per-problem LDS areas 32 banks apart                                                       */
+  int32_t ubig;                /* update matrices of order above this live in global scratch (default 17)                       */
+  int32_t wait_thr;            /* ... and those that wait for more than this many fronts (default 2)                            */
+  int32_t dense_graph;         /* 1: the dense backend replays its launch sequence as a hipGraph                                */
+  int32_t dense_syrk_wgs;      /* workgroups of the J'WJ kernel, 0 = default                                                    */
+  int32_t verbose;             /* 1: log plan decisions on stderr                                                               */
+  int32_t multi_share_plan;    /* 1: cnl_multi_create analyses the pattern once for all shards of equal plan kind               */
+  char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
+} cnl_options;
+void cnl_options_init(cnl_options* opt);
+
 /* ---- symbolic analysis (host only; replaces `ldl_analyze`, ------------------
  *      src/solver_types.jl:61-65: sparse()+triu()+ldl_analyze) ---------------- */
 int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
@@ -68,6 +111,9 @@ int cnl_plan_create(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows
  * the least total work (one sequential record stream per four problems).  cnl_plan_create is the large-batch analysis.      */
 int cnl_plan_create_for_batch(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
                               int64_t nvar, int64_t nequ, int64_t ncon, int64_t batch);
+/* the same with explicit options (opt == NULL: defaults).  batch <= 0 with CNL_PLAN_AUTO means the large-batch analysis. */
+int cnl_plan_create_ex(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
+                       int64_t nvar, int64_t nequ, int64_t ncon, int64_t batch, const cnl_options* opt);
 void cnl_plan_destroy(cnl_plan* plan);
 /* info[0]=N [1]=nnz [2]=unique nnz(K) [3]=nsuper [4]=nnz(L) stored (strictly lower, with relaxed zeros)
  * [5]=nnz(L) of the ordering without relaxation [6]=factor storage doubles/problem [7]=largest front order
@@ -93,7 +139,14 @@ const char* cnl_plan_order_name(const cnl_plan* plan);
  *      src/solver_types.jl:45-51,61-65; called at src/CaNNOLeS.jl:327) --------- */
 int cnl_create(cnl_handle** h, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
                int64_t nvar, int64_t nequ, int64_t ncon, int64_t batch, int device);
+/* cnl_create with explicit options (opt == NULL: defaults = cnl_create) */
+int cnl_create_ex(cnl_handle** h, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1,
+                  int64_t nvar, int64_t nequ, int64_t ncon, int64_t batch, int device, const cnl_options* opt);
 int cnl_destroy(cnl_handle* h);
+/* Number of dataflow waits that gave up since the handle was created (see cnl_options.dataflow_spin_limit).  Every such call
+ * was redone by the sequential execution, so results are right; a non-zero count says the device did not run the workgroups
+ * of a launch concurrently / in index order (time-slicing, a debugger).  Synchronises the handle's last call.                 */
+int cnl_dataflow_timeouts(cnl_handle* h, int64_t* count);
 const cnl_plan* cnl_get_plan(const cnl_handle* h);
 
 /* try_to_factorize(LDLT, vals, nvar, nequ, ncon, eig_tol) — src/solver_types.jl:79-98.
@@ -167,6 +220,9 @@ int cnl_trial_point_dev(cnl_handle* h, const double* d_x, const double* d_r, con
 typedef struct cnl_multi cnl_multi;
 int cnl_multi_create(cnl_multi** m, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
                      int64_t ncon, int64_t batch, const int* devices, int ndev);
+/* the same with explicit options (opt == NULL: defaults).  The pattern is analysed ONCE for all shards (cnl_options.multi_share_plan). */
+int cnl_multi_create_ex(cnl_multi** m, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
+                        int64_t ncon, int64_t batch, const int* devices, int ndev, const cnl_options* opt);
 int cnl_multi_destroy(cnl_multi* m);
 /* shards actually created: *nshards, and (optional arrays of that length) first problem, problems, device index */
 int cnl_multi_shards(const cnl_multi* m, int64_t* nshards, int64_t* start, int64_t* count, int32_t* device);
@@ -174,6 +230,16 @@ int cnl_multi_factorize(cnl_multi* m, const double* vals, double eig_tol, int32_
 int cnl_multi_solve(cnl_multi* m, const double* rhs, double* d);
 int cnl_multi_newton_system(cnl_multi* m, double* vals, const double* rhs, double* d, const double* rho_old, const double params[9],
                             double* rho, double* rho_old_out, int32_t* nfact, int32_t* success);
+
+/* Device-resident twins: entry i of every pointer array is shard i's device array on shard i's device (problem-major,
+ * count[i] problems; cnl_multi_shards).  The calls enqueue every shard's work on streams[i] (NULL: the shard handle's own
+ * stream) from the calling thread and return; nothing crosses PCIe or xGMI.  cnl_multi_synchronize waits for all shards.   */
+int cnl_multi_factorize_dev(cnl_multi* m, const double* const* d_vals, double eig_tol, int32_t* const* d_success, void* const* streams);
+int cnl_multi_solve_dev(cnl_multi* m, const double* const* d_rhs, double* const* d_d, void* const* streams);
+int cnl_multi_newton_system_dev(cnl_multi* m, double* const* d_vals, const double* const* d_rhs, double* const* d_d,
+                                double* const* d_rho_old, double* const* d_rho, int32_t* const* d_nfact, int32_t* const* d_success,
+                                const double params[9], void* const* streams);
+int cnl_multi_synchronize(cnl_multi* m, void* const* streams);
 
 /* Device time, in milliseconds, of the multifrontal kernel (the dominant kernel) of the last call,
  * measured with HIP events on the call's stream.  Enabling timing makes every call synchronise on

@@ -53,7 +53,7 @@ void cnlo_default_params(double *p) {
   p[2] = 1.0 / 3.0;           /* kappa_dec = 1//3           */
   p[3] = 8.0;                 /* kappa_inc = 8              */
   p[4] = fmin(100.0, 8 * 16); /* kappa_largeinc = min(100, sizeof(T)*16) */
-  p[5] = cbrt(eps);           /* rho0      = eps^(1/3)      */
+  p[5] = pow(eps, 1.0 / 3.0); /* rho0      = eps^T(1/3): pow with exponent 0.333..., not cbrt (src/CaNNOLeS.jl:56) */
   p[6] = pow(eps, -2.0);      /* rho_max   = eps^-2         */
   p[7] = sqrt(eps);           /* rho_min   = sqrt(eps)      */
   p[8] = pow(eps, 0.25);      /* gamma_A   = eps^(1/4)      */

@@ -17,7 +17,7 @@ import json
 import os
 from fractions import Fraction as Fr
 
-rho0 = 6.0554544523933395e-06  # eps^(1/3), src/CaNNOLeS.jl:56
+rho0 = 6.055454452393343e-06  # eps^T(1/3) = pow(eps, 0.3333333333333333), src/CaNNOLeS.jl:56 (not cbrt: 6.0554544523933395e-06)
 
 
 def solve_exact(K, b):

@@ -22,7 +22,8 @@ def test_params_defaults(params):
     """ParamCaNNOLeS(Float64), src/CaNNOLeS.jl:48-62 (values listed in SURVEY.md §8 a12)"""
     exp = [2.220446049250313e-16, 1.4901161193847656e-8, 1 / 3, 8.0, 100.0, 6.055454452393343e-6, 2.028240960365167e31,
            1.4901161193847656e-8, 1.220703125e-4]
-    assert np.allclose(params, exp, rtol=1e-15)
+    # bit for bit: rounds 1-2 compared with rtol 1e-15 and let cbrt(eps) (2.5 ulp from the reference's eps^(1/3)) through
+    assert [float(v) for v in params] == exp
 
 
 def test_pattern_builder_matches_reference_layout():

@@ -15,9 +15,9 @@ from tests.support.plan_sim import PlanSim
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def check_structure(s, vals, rhs, params, rho_old=0.0, fwd_tol=1e-9, expect=None):
+def check_structure(s, vals, rhs, params, rho_old=0.0, fwd_tol=1e-9, expect=None, options=None):
     rows, cols = s.kkt_pattern()
-    pl = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon)
+    pl = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, options=options)
     perm = pl.array("perm").astype(np.int64)
     assert sorted(perm.tolist()) == list(range(s.N))
     sim = PlanSim(pl)
@@ -46,6 +46,32 @@ def test_abi_exports_every_declared_symbol(built):
 
 def test_default_params_match_reference(built, params):
     assert np.array_equal(hipldl.default_params(), params)
+
+
+def test_options_are_arguments_not_environment(built, monkeypatch):
+    """cnl_options (include/cannoles_hip.h) replaces the environment switches of earlier rounds: a struct of another ABI
+    revision is refused, the defaults are the choices cnl_create makes by itself, and the old environment variables no longer
+    change the plan (the numerical path of a handle depends on its arguments only)."""
+    o = hipldl.Options()
+    assert (o.plan_kind, o.staged_max_batch, o.multipliers_early, o.dataflow_waves, o.dataflow_spin_limit) == (0, 4096, 1, 1024, 1 << 22)
+    s = syn.band_structure(400, 8)
+    rows, cols = s.kkt_pattern()
+    bad = hipldl.Options()
+    bad.struct_size = 8
+    with pytest.raises(hipldl.CnlError) as e:
+        hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=4, options=bad)
+    assert e.value.code == 1
+    base = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=64)
+    for k, v in (("CNL_NO_EARLY", "1"), ("CNL_STAGED_MAX", "0"), ("CNL_NO_CONDENSE", "1"), ("CNL_NO_V2", "1"), ("CNL_FORCE_ORDER", "canonical"),
+                 ("CNL_ORDER", "0"), ("CNL_TASK_CAP", "1")):
+        monkeypatch.setenv(k, v)
+    again = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=64)
+    assert again.info == base.info and np.array_equal(again.array("rec"), base.array("rec")) and np.array_equal(again.array("tasks"), base.array("tasks"))
+    forced = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=64, options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT))
+    assert len(forced.array("tasks")) == 0 and len(base.array("tasks")) > 0
+    # the large-batch analysis and an explicit throughput plan are the same thing
+    big = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon)
+    assert forced.info == big.info
 
 
 def test_no_device_is_a_loud_error(built):
@@ -111,15 +137,13 @@ def test_gauss_newton_and_dense(built, params):
     check_structure(s, vals, rhs, params)
 
 
-def test_without_condensation_and_v1_only(built, params, monkeypatch):
+def test_without_condensation_and_v1_only(built, params):
     """the residual-block condensation and the register-front streams are optional layers: the plain plan agrees"""
     s = syn.band_structure(300, 6)
     vals, rhs = syn.band_values(s, 4001)
-    monkeypatch.setenv("CNL_NO_CONDENSE", "1")
-    pl = check_structure(s, vals, rhs, params)
+    pl = check_structure(s, vals, rhs, params, options=hipldl.Options(condense=0))
     assert pl.info["ncond"] == 0
-    monkeypatch.setenv("CNL_NO_V2", "1")
-    pl = check_structure(s, vals, rhs, params)
+    pl = check_structure(s, vals, rhs, params, options=hipldl.Options(condense=0, register_front=0))
     assert pl.info["v2"] is None
 
 
@@ -134,7 +158,7 @@ def test_cfg3_plan_quality(built):
 
 # ---- record streams of the register-front kernel, interpreted on the CPU -----------------------------------------
 @pytest.mark.parametrize("shape", [(200, 4, 2), (600, 6, 1), (600, 6, 3), (400, 0, 2), (1000, 50, 2)])
-def test_record_streams_reproduce_the_oracle(shape, monkeypatch):
+def test_record_streams_reproduce_the_oracle(shape):
     """tests/support/rec_sim.py executes the forward / backward record streams (direct records: plain entries, raw
     values, products, extend-add tables, L panels, solution indices in the caller's numbering) for one problem and
     must reproduce the oracle's inertia and solution."""
@@ -143,11 +167,11 @@ def test_record_streams_reproduce_the_oracle(shape, monkeypatch):
     from oracle import oracle as O
     from tests.support.rec_sim import RecSim
     n, p, hw = shape
-    if p == 50:
-        monkeypatch.setenv("CNL_NO_EARLY", "1")  # multipliers last: keeps the large (packed, two-word-product) fronts in play
+    # multipliers last: keeps the large (packed, two-word-product) fronts in play
+    opts = hipldl.Options(multipliers_early=0) if p == 50 else None
     s = syn.band_structure(n, p, hw=hw)
     rows, cols = s.kkt_pattern()
-    plan = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon)
+    plan = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, options=opts)
     assert plan.info["v2"] is not None and plan.info["ncond"] == s.nequ
     vals, rhs = syn.band_values(s, 77)
     off = s.offsets()

@@ -7,8 +7,8 @@ s = syn.band_structure(n, p)
 rows, cols = s.kkt_pattern()
 vals, rhs = syn.batch_values(s, B, cfg=4)
 prm = hipldl.default_params()
-def run():
-    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+def run(options=None):
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=options)
     d = np.zeros((B, s.N))
     d, ok, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, np.zeros(B), prm)
     cfg = L.config; info = L.info
@@ -16,8 +16,7 @@ def run():
     L.close()
     return d.reshape(B, s.N), np.atleast_1d(ok), np.atleast_1d(nf), cfg, info, perm, tk
 d1, ok1, nf1, cfg1, info1, perm1, tk1 = run()
-os.environ["CNL_NO_STAGED"] = "1"
-d0, ok0, nf0, cfg0, info0, perm0, tk0 = run()
+d0, ok0, nf0, cfg0, info0, perm0, tk0 = run(hipldl.Options(staged=0))
 print(cfg1["kernel"], cfg0["kernel"], info1["order"], info1["nsuper"], "tasks", len(tk1))
 print("ok", ok1.all(), ok0.all(), "nfact", nf1.max(), nf0.max())
 for b in range(B):

@@ -6,6 +6,7 @@ set -u
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
+mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 args="--steps 6 --warmup 2 --cpu-sample 0 --no-extras $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o p -- python3 $root/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-extras $* > $out/${tag}_stats.log 2>&1

@@ -3,8 +3,7 @@ import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for order in ("nd32+early", "nd64+early", "nd96+early"):
     for cap in (3, 4, 6, 8, 12):
-        e = dict(os.environ, CNL_TASK_CAP=str(cap), CNL_FORCE_ORDER=order)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "1", "--steps", "60", "--cpu-sample", "0", "--no-extras"], env=e, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "1", "--steps", "60", "--cpu-sample", "0", "--no-extras", "--opt", f"task_cap={cap},force_order={order}"], capture_output=True, text=True)
         try:
             j = json.loads(out.stdout.strip().splitlines()[-1])
             print(order, "cap", cap, "ms/step %.4f" % j["ms_per_step"], j["config"]["fronts"], flush=True)

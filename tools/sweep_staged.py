@@ -1,8 +1,7 @@
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-def run(B, env):
-    e = dict(os.environ); e.update(env)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(B), "--steps", "20", "--cpu-sample", "0"], env=e, capture_output=True, text=True)
+def run(B, opt):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(B), "--steps", "20", "--cpu-sample", "0", "--no-extras", "--opt", opt], capture_output=True, text=True)
     try:
         j = json.loads(out.stdout.strip().splitlines()[-1])
         return j["value"], j["ms_per_step"], j["config"]["ordering"], j["config"]["fronts"], j["config"]["kernel"]["kernel"]
@@ -10,7 +9,7 @@ def run(B, env):
         return ("ERR", out.stderr[-300:])
 for B in (1, 64, 256):
     for cap in (8, 12, 20, 32, 48):
-        print(B, "cap", cap, run(B, {"CNL_TASK_CAP": str(cap)}), flush=True)
+        print(B, "cap", cap, run(B, f"task_cap={cap}"), flush=True)
 for B in (512, 1024, 2048, 4096):
-    print(B, "staged", run(B, {"CNL_STAGED_MAX": "100000"}), flush=True)
-    print(B, "classic", run(B, {"CNL_STAGED_MAX": "0"}), flush=True)
+    print(B, "staged", run(B, "plan_kind=2"), flush=True)
+    print(B, "classic", run(B, "plan_kind=1"), flush=True)
