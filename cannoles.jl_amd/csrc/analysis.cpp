@@ -12,6 +12,7 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1060,6 +1061,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
   int64_t st_raw = 0, st_prod = 0, st_asm = 0, st_rawmax = 0, st_prodmax = 0, st_asmmax = 0;
   // every condensed residual pivot d_r is "owned" by the first front that stages it: that front counts it in the inertia
   std::unordered_map<int32_t, char> d_claimed;
+  P.rows_fronts = 0; P.listprod_fronts = 0;
   for (int32_t s = 0; s < ns; s++) {
     const FrontHdr& F = P.fronts[s];
     size_t r0 = rec.size();
@@ -1121,6 +1123,96 @@ int write_forward_records(Plan& P, const DirectLists* D) {
       for (size_t i = 0; i < prs.size(); i++) q[i] = prs[key[i].second];
       prs.swap(q);
     }
+    // ---- row form (plan.h, RF_ROWS): products grouped by residual row, operands in registers --------------------------
+    ivec rowsec;
+    int32_t rows_own = 0, rows_n = 0;
+    // The row form costs the same seven gathers and twenty atomic rounds whatever the front holds; the list form costs per
+    // round of sixteen products (measured on cfg3's chain fronts, 208 products: 1.47 ms of the kernel as lists, 0.62 ms as
+    // rows).  Fronts with fewer than five rounds of products — the small fronts of the bushy latency orders — keep the lists.
+    if (D && strided && prs.size() >= 72 && P.row_products) {
+      struct Row { int32_t d; ivec m; int32_t r = -1; std::vector<std::array<int32_t, 3>> pr; };  // pr: (operand a, operand b, pos)
+      std::vector<Row> rows;
+      std::unordered_map<int32_t, int32_t> row_of;
+      bool ok = true;
+      for (auto& p_ : prs) {
+        if (p_.d >= nnz_thr) { ok = false; break; }
+        auto it = row_of.find(p_.d);
+        if (it == row_of.end()) { it = row_of.emplace(p_.d, (int32_t)rows.size()).first; rows.push_back(Row()); rows.back().d = p_.d; }
+        rows[it->second].pr.push_back({p_.a, p_.b, p_.pos});
+      }
+      if (rows.size() > 16) ok = false;
+      for (auto& R : rows) {
+        if (!ok) break;
+        for (auto& q : R.pr)
+          for (int k = 0; k < 2; k++) {
+            const int32_t src = q[k];
+            if (src == R.d) { ok = false; break; }
+            if (src >= nnz_thr) { if (R.r >= 0 && R.r != src) ok = false; R.r = src; }
+            else if (std::find(R.m.begin(), R.m.end(), src) == R.m.end()) R.m.push_back(src);
+          }
+        if ((int)R.m.size() > ROWS_KM) ok = false;
+        std::sort(R.m.begin(), R.m.end());
+      }
+      // pivots must not be operands of other rows either (the old form refuses that too)
+      if (ok) for (auto& R : rows) for (int32_t m : R.m) if (row_of.count(m)) ok = false;
+      if (ok) {
+        // rows whose pivot no earlier front has staged come first: this front counts them in the inertia
+        std::vector<Row> own, rest;
+        for (auto& R : rows) (d_claimed.count(R.d) ? rest : own).push_back(R);
+        auto byd = [](const Row& x, const Row& y) { return x.d < y.d; };
+        std::sort(own.begin(), own.end(), byd);
+        std::sort(rest.begin(), rest.end(), byd);
+        rows_own = (int32_t)own.size();
+        rows = own;
+        rows.insert(rows.end(), rest.begin(), rest.end());
+        rows_n = (int32_t)rows.size();
+        rowsec.assign(ROWS_WORDS, 0);
+        const int32_t dummy = rows[0].d;
+        for (int32_t l = 0; l < 16; l++) {
+          rowsec[l] = dummy;
+          for (int q = 0; q < ROWS_KM; q++) rowsec[16 * (1 + q) + l] = dummy;
+          rowsec[16 * (1 + ROWS_KM) + l] = nnz_thr;  // right-hand side entry 0
+        }
+        std::vector<uint8_t> posb(16 * ROWS_PW * 4);
+        for (int32_t l = 0; l < 16; l++) for (int k = 0; k < ROWS_PW * 4; k++) posb[(size_t)l * ROWS_PW * 4 + k] = (uint8_t)(FAST_IMG_TRI + l);
+        for (int32_t l = 0; l < rows_n && ok; l++) {
+          const Row& R = rows[l];
+          rowsec[l] = R.d;
+          for (size_t q = 0; q < R.m.size(); q++) rowsec[16 * (1 + q) + l] = R.m[q];
+          if (R.r >= 0) rowsec[16 * (1 + ROWS_KM) + l] = R.r;
+          std::vector<char> used(ROWS_NPAIR, 0);
+          for (auto& q : R.pr) {
+            int32_t a = q[0], b = q[1];
+            int k;
+            if (a >= nnz_thr || b >= nnz_thr) {
+              if (a >= nnz_thr && b >= nnz_thr) { ok = false; break; }
+              const int32_t m = a >= nnz_thr ? b : a;
+              const int iq = (int)(std::find(R.m.begin(), R.m.end(), m) - R.m.begin());
+              k = ROWS_KM * (ROWS_KM + 1) / 2 + iq;
+            } else {
+              int ia = (int)(std::find(R.m.begin(), R.m.end(), a) - R.m.begin()), ib = (int)(std::find(R.m.begin(), R.m.end(), b) - R.m.begin());
+              if (ia < ib) std::swap(ia, ib);
+              k = ia * (ia + 1) / 2 + ib;
+            }
+            if (used[k] || q[2] >= FAST_IMG_TRI) { ok = false; break; }  // one slot per operand pair
+            used[k] = 1;
+            posb[(size_t)l * ROWS_PW * 4 + k] = (uint8_t)q[2];
+          }
+        }
+        if (ok) {
+          for (int32_t l = 0; l < 16; l++)
+            for (int g = 0; g < ROWS_PW; g++) {
+              const uint8_t* pb_ = &posb[(size_t)l * ROWS_PW * 4 + 4 * g];
+              rowsec[16 * (2 + ROWS_KM + g) + l] = (int32_t)((uint32_t)pb_[0] | ((uint32_t)pb_[1] << 8) | ((uint32_t)pb_[2] << 16) | ((uint32_t)pb_[3] << 24));
+            }
+          for (int32_t l = 0; l < rows_own; l++) d_claimed[rows[l].d] = 1;
+        } else {
+          rowsec.clear();
+        }
+      }
+    }
+    const bool rowform = !rowsec.empty();
+    if (rowform) prs.clear();
     // raw sources of the products: pivots d first, then the other operands
     ivec raw; int32_t nrd = 0;
     std::unordered_map<int32_t, int32_t> rawidx;
@@ -1176,6 +1268,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
       if (prs.empty()) prod.clear();
     }
     if (prs.empty()) raw.clear();
+    if (rowform) { raw = rowsec; nrd = rows_n; nrd_own = rows_own; }
     int32_t asm_off = (int32_t)(rec.size() - r0);
     rec.insert(rec.end(), asrc.begin(), asrc.end());
     rec.insert(rec.end(), apos.begin(), apos.end());
@@ -1196,11 +1289,13 @@ int write_forward_records(Plan& P, const DirectLists* D) {
     int32_t* H = rec.data() + r0;
     H[R_NPIV] = F.npiv; H[R_NUPD] = F.nupd; H[R_RECLEN] = (int32_t)(rec.size() - r0); H[R_NASM] = (int32_t)asrc.size();
     H[R_NCHILD] = F.child_end - F.child_begin; H[R_UOFF] = uoff2[s];
-    H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0) | (cls[s] << 8); H[R_FSOFF] = fsoff2[s];
+    H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0) | (rowform ? RF_ROWS : 0) | (cls[s] << 8); H[R_FSOFF] = fsoff2[s];
+    P.rows_fronts += rowform ? 1 : 0;
+    P.listprod_fronts += (!rowform && !prod.empty() && strided) ? 1 : 0;
     H[R_LPTR_LO] = F.lptr_lo; H[R_LPTR_HI] = F.lptr_hi; H[R_NASMV] = nasmv; H[R_ASM_OFF] = asm_off; H[R_CHILD_OFF] = child_off;
     const int32_t nprod_ = (int32_t)(strided ? prod.size() : prod.size() / 2);
     if (nprod_ >= 65536) return why("more than 65535 products in one front");
-    H[R_NPROD] = nprod_ | (nrd_own << 16); H[R_NRAW] = (int32_t)raw.size(); H[R_NRD] = nrd | (nrawv << 16);
+    H[R_NPROD] = nprod_ | (nrd_own << 16); H[R_NRAW] = (int32_t)raw.size(); H[R_NRD] = nrd | ((rowform ? 0 : nrawv) << 16);
     st_raw += H[R_NRAW]; st_prod += nprod_; st_asm += H[R_NASM];
     st_rawmax = std::max<int64_t>(st_rawmax, H[R_NRAW]); st_prodmax = std::max<int64_t>(st_prodmax, nprod_);
     st_asmmax = std::max<int64_t>(st_asmmax, H[R_NASM]);

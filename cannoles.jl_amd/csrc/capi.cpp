@@ -193,7 +193,8 @@ int setup_v2(cnl_handle* h) {
   d.u2_peak = P.u2_peak;
   d.jraw_off = (int32_t)((P.u2_peak + std::max<int64_t>(P.fs2_max, 64) + 1) & ~(int64_t)1);
   d.bpanel_off = (int32_t)((P.bwd_peak + 2 + 1) & ~(int64_t)1);  // end of the backward sweep's x stack
-  int64_t prob = std::max<int64_t>((int64_t)d.jraw_off + (P.rec_direct ? 128 : 0), (int64_t)d.bpanel_off);
+  // the raw-value area (128 doubles per problem) is needed only by fast fronts whose products come as lists (plan.h: RF_ROWS)
+  int64_t prob = std::max<int64_t>((int64_t)d.jraw_off + (P.rec_direct && P.listprod_fronts > 0 ? 128 : 0), (int64_t)d.bpanel_off);
   // per-problem areas 32 banks apart modulo 64 (prob_doubles = 16 mod 32): the 16 lanes of two neighbouring problems
   // then touch disjoint LDS banks when they read the same row of their images (env CNL_LDS_PAD=0 disables)
   prob = (prob + 1) & ~(int64_t)1;
@@ -592,7 +593,7 @@ void cnl_options_init(cnl_options* o) {
   o->multipliers_early = 1; o->condense = 1; o->direct_records = 1; o->register_front = 1; o->dense_backend = 1; o->general_dense = 1;
   o->staged = 1; o->dataflow = 1; o->dataflow_waves = 1024; o->dataflow_spin_limit = 1 << 22;
   o->waves_per_block = 0; o->v1_tpp = -1; o->v1_ppb = -1; o->v1_lds = -1; o->v1_solve = 0; o->lds_pad = 1;
-  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1;
+  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -668,6 +669,7 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
     cnl::DirectLists D{p->C.c_ptr.data(), p->C.c_a.data(), p->C.c_b.data(), p->C.c_d.data(), (int32_t)nnz, (int32_t)N};
     const int32_t old_len = p->P.rec_maxlen;
     const size_t old_words = p->P.rec.size();
+    p->P.row_products = o.row_products != 0;
     int drc = cnl::write_forward_records(p->P, &D);
     if (!drc) {
       // the backward records name the solution component of every pivot: switch them to the caller's numbering, so
@@ -1147,9 +1149,9 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
     HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     h->pipe_ev.push_back(e);
   }
-  std::mutex mu;
+  std::mutex mu;        // posted[], abort_, and the handle view (SubBatch mutates the handle: one enqueue at a time)
   std::condition_variable cv;
-  size_t posted = 0;
+  std::vector<char> posted(nchunks, 0);
   bool abort_ = false;
   int wrc = CNL_OK;
   std::string wmsg;
@@ -1164,8 +1166,8 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
     for (size_t c = 0; c < nchunks; c++) {
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return posted > c || abort_; });
-        if (posted <= c) return;
+        cv.wait(lk, [&] { return posted[c] || abort_; });
+        if (!posted[c]) return;
       }
       const size_t b0 = c * chunk, nb = std::min(chunk, B - b0);
       if (!chk(hipEventSynchronize(h->pipe_ev[c]), "hipEventSynchronize")) continue;
@@ -1189,43 +1191,52 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
       chk(hipStreamSynchronize(st), "hipStreamSynchronize");
     }
   });
-  int rc = CNL_OK;
-  for (size_t c = 0; c < nchunks && rc == CNL_OK; c++) {
-    const size_t b0 = c * chunk, nb = std::min(chunk, B - b0);
-    hipStream_t st = h->pipe_stream[c & 1];
-    hipError_t e = hipMemcpyAsync(h->d_vals + b0 * P.nnz, vals + b0 * P.nnz, nb * P.nnz * sizeof(double), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(h->d_rhs + b0 * P.N, rhs + b0 * P.N, nb * P.N * sizeof(double), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = rho_old ? hipMemcpyAsync(h->d_rho_old + b0, rho_old + b0, nb * sizeof(double), hipMemcpyHostToDevice, st)
-                                     : hipMemsetAsync(h->d_rho_old + b0, 0, nb * sizeof(double), st);
-    if (e != hipSuccess) { rc = fail(CNL_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); break; }
-    {
-      SubBatch view(h, (int64_t)b0, (int64_t)nb);
-      cnl::LaunchArgs a{};
-      a.mode = cnl::MODE_NEWTON;
-      a.rho_old = h->d_rho_old + b0; a.rho = h->d_rho + b0; a.nfact = h->d_nfact + b0; a.success = h->d_success + b0;
-      std::memcpy(a.params, params, 9 * sizeof(double));
-      const bool tm = h->timing;
-      h->timing = false;
-      rc = run(h, a, h->d_vals + b0 * P.nnz, h->d_rhs + b0 * P.N, h->d_d + b0 * P.N, st);
-      h->timing = tm;
-    }
-    if (rc == CNL_OK && hipEventRecord(h->pipe_ev[c], st) != hipSuccess) rc = fail(CNL_ERR_HIP, "hipEventRecord failed");
-    if (rc == CNL_OK) {
+  // two uploaders (the calling thread and a helper) take alternate chunks, each on a stream of its own: a copy out of pageable
+  // memory keeps a host thread busy (the runtime pins or stages the pages), and one thread alone does not fill the link
+  int urc[2] = {CNL_OK, CNL_OK};
+  std::string umsg[2];
+  auto uploader = [&](int u) {
+    if (u) (void)hipSetDevice(device);
+    hipStream_t st = h->pipe_stream[u];
+    for (size_t c = (size_t)u; c < nchunks; c += 2) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (abort_) return;
+      }
+      const size_t b0 = c * chunk, nb = std::min(chunk, B - b0);
+      hipError_t e = hipMemcpyAsync(h->d_vals + b0 * P.nnz, vals + b0 * P.nnz, nb * P.nnz * sizeof(double), hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(h->d_rhs + b0 * P.N, rhs + b0 * P.N, nb * P.N * sizeof(double), hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = rho_old ? hipMemcpyAsync(h->d_rho_old + b0, rho_old + b0, nb * sizeof(double), hipMemcpyHostToDevice, st)
+                                       : hipMemsetAsync(h->d_rho_old + b0, 0, nb * sizeof(double), st);
+      int r = CNL_OK;
+      std::string m;
+      if (e != hipSuccess) { r = CNL_ERR_HIP; m = std::string("upload: ") + hipGetErrorString(e); }
       std::lock_guard<std::mutex> lk(mu);
-      posted = c + 1;
+      if (r == CNL_OK) {
+        SubBatch view(h, (int64_t)b0, (int64_t)nb);
+        cnl::LaunchArgs a{};
+        a.mode = cnl::MODE_NEWTON;
+        a.rho_old = h->d_rho_old + b0; a.rho = h->d_rho + b0; a.nfact = h->d_nfact + b0; a.success = h->d_success + b0;
+        std::memcpy(a.params, params, 9 * sizeof(double));
+        r = run(h, a, h->d_vals + b0 * P.nnz, h->d_rhs + b0 * P.N, h->d_d + b0 * P.N, st);
+        if (r) m = g_err;
+        if (r == CNL_OK && hipEventRecord(h->pipe_ev[c], st) != hipSuccess) { r = CNL_ERR_HIP; m = "hipEventRecord failed"; }
+      }
+      if (r != CNL_OK) { urc[u] = r; umsg[u] = m; abort_ = true; cv.notify_all(); return; }
+      posted[c] = 1;
       cv.notify_all();
     }
-  }
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (rc != CNL_OK) abort_ = true;
-    cv.notify_all();
-  }
-  const std::string keep = g_err;
+  };
+  const bool tm = h->timing;
+  h->timing = false;
+  std::thread up1(uploader, 1);
+  uploader(0);
+  up1.join();
+  h->timing = tm;
   down.join();
   (void)hipStreamSynchronize(h->pipe_stream[0]);
   (void)hipStreamSynchronize(h->pipe_stream[1]);
-  if (rc != CNL_OK) return fail(rc, keep);
+  for (int u = 0; u < 2; u++) if (urc[u] != CNL_OK) return fail(urc[u], umsg[u]);
   if (wrc != CNL_OK) return fail(wrc, "download: " + wmsg);
   h->last_vals = h->d_vals;
   h->factorized = true;

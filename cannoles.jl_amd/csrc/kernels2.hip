@@ -269,7 +269,57 @@ struct Ctx2 {
 // a backward sweep fed by global_load_lds_dwordx4 with headers through the scalar cache, a four-operation division chain — are
 // recorded in DESIGN.md section 4; their code lives in the git history, not here.)
 #define CNL_DPP_DIV fast_div
+#ifndef CNL_PIV_BITMASK
+#define CNL_PIV_BITMASK 1
+#endif
+#if CNL_PIV_BITMASK
+#define CNL_PIV_GUARD(i) (pm_ & (1u << (i)))
+#else
+#define CNL_PIV_GUARD(i) ((i) <= top && (i) > nupd)
+#endif
+#ifndef CNL_LANE_OPAQUE
+#define CNL_LANE_OPAQUE 1
+#endif
+#if CNL_LANE_OPAQUE
+#define CNL_LANE_FENCE asm volatile("" : "+v"(bm_));
+#else
+#define CNL_LANE_FENCE
+#endif
 #include "elim_dpp.inc"
+// L rows one front late.  Stores and loads return out of order with respect to each other, so a wait for ANY load is a
+// vmcnt(0) while stores are in flight: with the ten row stores of a front issued during its elimination, the first use of the
+// next front's prefetched values waited for those stores' round trips (ablation, round 3: no L stores = -0.7 ms of 8.0).  The
+// rows of front s are therefore kept in registers and stored in step (4) of front s + 1, BEFORE that step's gathers are
+// issued: by the time anything waits on those gathers, the stores are a whole front old.
+// That pays where two wavefronts share a SIMD (large batches: 7.79 -> 7.38 ms at 8192 problems).  A wavefront that runs
+// alone (the staged execution of small batches) loses by it — one system 0.1205 -> 0.133 ms, 256 problems 462 k -> 436 k
+// systems/s: its waits are short anyway and the burst of ten stores sits in front of the next gathers — so the kernel is
+// compiled both ways (template parameter LATE) and the launcher chooses by the wavefronts in flight.
+#define CNL_LPEND_LIST(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+struct LPend {
+#define CNL_LP_MEMBER(i) double v##i;
+  CNL_LPEND_LIST(CNL_LP_MEMBER)
+#undef CNL_LP_MEMBER
+  unsigned pm;     // pivot positions whose rows are pending (0: nothing)
+  unsigned lofs;   // per-lane byte offset into the factor of the wave's first problem
+  long long lptr;  // factor offset (doubles) of the front
+};
+#define CNL_LROW_OUT(i)                                                                                                              \
+  if constexpr (LATE) LP.v##i = (bm_ == i) ? dpiv : lv;                                                                              \
+  else if (bm_ <= i && !(CNL_ABL & 64)) *reinterpret_cast<double*>(L_wb + (lofs + ((unsigned)tri2(i) << 3))) = (bm_ == i) ? dpiv : lv;
+__device__ __forceinline__ void flush_lrows(LPend& LP, char* L_wb0, int bm_) {
+  if (LP.pm == 0) return;
+  char* L_wb = L_wb0 + (LP.lptr << 3);
+  const unsigned lofs = LP.lofs;
+#define CNL_LP_FLUSH(i)                                                                                                   \
+  if (LP.pm & (1u << i)) {                                                                                                \
+    asm volatile("" : "+v"(bm_));                                                                                         \
+    if (bm_ <= i && !(CNL_ABL & 64)) *reinterpret_cast<double*>(L_wb + (lofs + ((unsigned)tri2(i) << 3))) = LP.v##i;      \
+  }
+  CNL_LPEND_LIST(CNL_LP_FLUSH)
+#undef CNL_LP_FLUSH
+  LP.pm = 0;
+}
 #define CNL_DPPF(X, W, NL, A) \
   asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #A " row_mask:0xf bank_mask:0xf" : "+v"(X) : "v"(W), "v"(NL));
 // first DPP read of a row the previous pivot's updates wrote: hipcc pads no hazards inside asm (VALU write -> DPP read: 2 wait states)
@@ -280,14 +330,18 @@ struct Ctx2 {
   const double lv = CNL_DPP_DIV(w_, dpiv);                                                                \
   npos += dpiv > eig_tol;                                                                                 \
   nzer += fabs(dpiv) <= eig_tol;                                                                          \
-  if (valid && b <= i && !(CNL_ABL & 64)) *reinterpret_cast<double*>(L_wb + (lofs + ((unsigned)tri2(i) << 3))) = (b == i) ? dpiv : lv; \
+  /* the lane number is made opaque per pivot: the sixteen (b <= i) and sixteen (b == i) lane masks would otherwise be hoisted  */ \
+  /* out of the fronts loop into 64 SGPRs, spilled to VGPR lanes and fetched back with two v_readlane each (round 2 ISA)       */ \
+  CNL_LANE_FENCE                                                                                          \
+  CNL_LROW_OUT(i)                                                                                         \
   const double nl_ = (CNL_ABL & 32) ? 0.0 : -lv;
 #define CNL_DPP_POST(i)
 #define CNL_DPP_USTG(a) if (a <= nupd) Ug[tri2(a) + b] = R##a;
 #define CNL_DPP_USTL(a) if (a <= nupd) Ul[tri2(a) + b] = R##a;
+template <bool LATE>
 __device__ __forceinline__ void eliminate16_dpp(int P_prob_doubles, int P_u2_peak, long long P_gs_doubles, long long P_lsize, double* cL_,
                                                 double* cgs_, int cbatch, int lane, int prob0, int f, int nupd, long long lptr, int uoff,
-                                                bool uglob, double* pbase0, int* cnt, double eig_tol) {
+                                                bool uglob, double* pbase0, int* cnt, double eig_tol, LPend& LP) {
   double* Lg = as_global(cL_);
   double* gsg = as_global(cgs_);
   const int gp = lane >> 4;
@@ -310,7 +364,12 @@ __device__ __forceinline__ void eliminate16_dpp(int P_prob_doubles, int P_u2_pea
   CNL_DPP_ROWS(CNL_DPP_DECL)
   int npos = 0, nzer = 0;
   const double one_ = 1.0;
+  // bit I set <=> I is a pivot position (nupd < I <= top), wave-uniform
+  int bm_ = valid ? b : 64;  // column of this lane; lanes of problems past the batch never store
+  const unsigned pm_ = __builtin_amdgcn_readfirstlane(((2u << top) - 1u) & ~((2u << nupd) - 1u));
   CNL_DPP_PIVOTS(CNL_DPP_PRE, CNL_DPP_POST)
+  if constexpr (LATE) { LP.pm = pm_; LP.lofs = lofs; LP.lptr = lptr; }
+  (void)L_wb;
   if (b == 0) { cnt[gp * 2] += npos; cnt[gp * 2 + 1] += nzer; }
   // update matrix: rows 0 .. nupd in ascending order with all lanes active (see CNL_USTG)
   if (uglob) {
@@ -587,6 +646,22 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     if (nv_ + 16 < nr_) prr[1] = GATHER_R(src_[PVR + 1]); else prr[1] = 0.0;           \
   }
 
+// Row form of the condensation products (plan.h, RF_ROWS): lane l takes residual row l of the front.  Seven gathers without a
+// guard: the row's pivot (kept in pvr[ROWS_KM]), its ROWS_KM Jacobian operands (pvr[0 ..]) and its right-hand-side entry.
+static_assert(PVR == ROWS_KM + 1, "the raw-value prefetch registers double as the row operands");
+#define PREFETCH_ROWFORM(RECP, ROFF)                                                   \
+  {                                                                                    \
+    const int* sp_ = (RECP) + (ROFF) + l;                                              \
+    int src_[ROWS_KM + 2];                                                             \
+    _Pragma("unroll") for (int j = 0; j < ROWS_KM + 2; j++) src_[j] = sp_[j * 16];     \
+    pvr[ROWS_KM] = GATHER_V(src_[0]);                                                  \
+    _Pragma("unroll") for (int j = 0; j < ROWS_KM; j++) pvr[j] = GATHER_V(src_[1 + j]); \
+    prr[0] = GATHER_R(src_[ROWS_KM + 1]);                                              \
+    prr[1] = 0.0;                                                                      \
+  }
+// image position of pair K (compile-time) out of the lane's position words
+#define ROW_POS(PW, K) (((unsigned)(PW)[(K) >> 2] >> (8 * ((K) & 3))) & 255u)
+
 // ==========================================================================================
 // dataflow execution of a staged plan: wait until *p >= target, then make the producer's global stores visible; signal = all
 // stores of this wavefront first, then the counter.  The wait is bounded (a broken dependency — workgroups not dispatched in
@@ -626,7 +701,7 @@ __device__ __forceinline__ void task_done(int* counter, int lane, bool release =
 #ifndef CNL_WAVES_PER_SIMD
 #define CNL_WAVES_PER_SIMD 2
 #endif
-template <bool STAGED>
+template <bool STAGED, bool LATE>
 __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(const DevPlan2 Pin, const LaunchArgs Ain) {
   DevPlan2 P = Pin;
   P.rec = as_global(Pin.rec); P.brec = as_global(Pin.brec);
@@ -709,10 +784,18 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   const int xpos = A.extra_pos ? A.extra_pos[pclamp] : 0, xzer = A.extra_zer ? A.extra_zer[pclamp] : 0;
   // gathers: wave-uniform bases of the first problem of the wave + 32-bit byte offsets (4 problems span < 4 GB)
   const int prob0u = __builtin_amdgcn_readfirstlane(prob0);
+#ifdef CNL_DBG_VSTRIDE0   // timing probe (results wrong): every problem gathers problem 0's values — what do the gathers cost when they hit in cache?
+  const char* vals_wb = reinterpret_cast<const char*>(A.vals);
+#else
   const char* vals_wb = reinterpret_cast<const char*>(A.vals + (long long)prob0u * P.vstride);
+#endif
   const char* rhs_wb = has_rhs ? reinterpret_cast<const char*>(A.rhs + (long long)prob0u * P.rstride) : vals_wb;
   const unsigned gsel = valid ? (unsigned)g : 0u;
+#ifdef CNL_DBG_VSTRIDE0
+  const unsigned gofs_v = 0u;
+#else
   const unsigned gofs_v = gsel * (unsigned)P.vstride * 8u;
+#endif
   const unsigned gofs_r = (gsel * (unsigned)(has_rhs ? P.rstride : P.vstride) - (unsigned)P.nnz) * 8u;  // rhs sources are nnz + index
   const char* L_wb = reinterpret_cast<const char*>(A.L + (long long)prob0u * P.lsize);
   const unsigned gofs_l = (gsel * (unsigned)P.lsize + (unsigned)l) * 8u;
@@ -749,7 +832,8 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       const int hv0 = recw[lane & 15];
       const int nasm0 = HDRW(hv0, R_NASM), aoff0 = HDRW(hv0, R_ASM_OFF);
       PREFETCH_RHS_ROUND(recw, aoff0, HDRW(hv0, R_NASMV), nasm0)
-      PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRD) >> 16, HDRW(hv0, R_NRAW))
+      if (HDRW(hv0, R_FLAGS) & RF_ROWS) PREFETCH_ROWFORM(recw, aoff0 + 2 * nasm0)
+      else PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRD) >> 16, HDRW(hv0, R_NRAW))
       const long long lp0 = (long long)HDRW(hv0, R_LPTR_LO) | ((long long)HDRW(hv0, R_LPTR_HI) << 31);
       PREFETCH_ROWS(lr, lp0, HDRW(hv0, R_NUPD), HDRW(hv0, R_NPIV))
     }
@@ -767,7 +851,8 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       double* cvec = myFs;  // c_a = entry (a, 0) of the front, a = 0 .. f-1 (a = 0 unused)
       cvec[l] = 0.0;
       const int raw_off = aoff + 2 * nasm;
-      if (nraw > 0) {
+      const bool rowform = flags & RF_ROWS;
+      if (nraw > 0 && !rowform) {
 #pragma unroll
         for (int j = 0; j < PVR; j++)
           if (j * 16 < nrawv) {
@@ -796,8 +881,19 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const int src = rec[aoff + e], pos = rec[aoff + nasm + e], prow = tri_row(pos);
         if (pos == tri2(prow) && pos < FAST_IMG_TRI) __hip_atomic_fetch_add(&cvec[prow], myrhs[src - P.nnz], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
-      // products that land in column 0
-      {
+      // products that land in column 0: in the row form the pairs (right-hand side, Jacobian operand q)
+      if (rowform) {
+        const int* rw = rec + raw_off + l;
+        int pw_[ROWS_PW];
+#pragma unroll
+        for (int g = 0; g < ROWS_PW; g++) pw_[g] = rw[(2 + ROWS_KM + g) * 16];
+        const double tr = prr[0] * fast_div(-1.0, pvr[ROWS_KM]);
+#pragma unroll
+        for (int q = 0; q < ROWS_KM; q++) {
+          const int pos = (int)ROW_POS(pw_, ROWS_KM * (ROWS_KM + 1) / 2 + q), prow = tri_row(pos);
+          if (pos == tri2(prow) && pos < FAST_IMG_TRI) __hip_atomic_fetch_add(&cvec[prow], tr * pvr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      } else {
         const int* pw = rec + raw_off + nraw + l;
         for (int e = 0; e < nprod; e += 16) {
           const int w = pw[e], pos = w & 255, prow = tri_row(pos);
@@ -834,6 +930,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const int aoff1 = __builtin_amdgcn_readlane(R0.w, 2);
         const int nraw1 = __builtin_amdgcn_readlane(R0.z, 3);
         const int nrawv1 = __builtin_amdgcn_readlane(R0.w, 3) >> 16;
+        const int nflags1 = __builtin_amdgcn_readlane(R0.z, 1);
         const int npiv1 = __builtin_amdgcn_readlane(R0.x, 0), nupd1 = __builtin_amdgcn_readlane(R0.y, 0);
         const long long lp1 = (long long)__builtin_amdgcn_readlane(R0.x, 2) | ((long long)__builtin_amdgcn_readlane(R0.y, 2) << 31);
         static_assert(R_NPIV == 0 && R_NUPD == 1 && R_LPTR_LO == 8 && R_LPTR_HI == 9, "record header layout");
@@ -849,7 +946,8 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         R1 = rstream[(nn_off >> 2) + lane + 64];
         R2 = rstream[(nn_off >> 2) + lane + 128];
         PREFETCH_RHS_ROUND(nrec, aoff1, nasmv1, nasm1)
-        PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nrawv1, nraw1)
+        if (nflags1 & RF_ROWS) PREFETCH_ROWFORM(nrec, aoff1 + 2 * nasm1)
+        else PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nrawv1, nraw1)
         PREFETCH_ROWS(lrn, lp1, nupd1, npiv1)
         nxt_off = nn_off;
       } else {
@@ -910,6 +1008,9 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     int roff = t_rec;  // word offset of the current record
     int nxt_off = 0;   // word offset of the next record
     int s = 0;
+    LPend LP;          // L rows of the front just eliminated, stored one front late (flush_lrows)
+    LP.pm = 0; LP.lofs = 0; LP.lptr = 0;
+    const int lp_bm = valid ? l : 64;
     // Outer loop: (re)start the pipeline at front s, then either hand a rare large front to the out-of-line path
     // or run the inner loop over a stretch of fast fronts.  The inner loop contains NO call: values that live
     // across a call are spilled, and every reload from scratch (a VMEM access) waits for all outstanding
@@ -942,7 +1043,8 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         R2 = rstream[(nxt_off >> 2) + lane + 128];
         const int nasm0 = HDRW(hv0, R_NASM), aoff0 = HDRW(hv0, R_ASM_OFF);
         PREFETCH_VALUES(recw, aoff0, HDRW(hv0, R_NASMV), nasm0)
-        PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRD) >> 16, HDRW(hv0, R_NRAW))
+        if (fw0 & RF_ROWS) PREFETCH_ROWFORM(recw, aoff0 + 2 * nasm0)
+        else PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRD) >> 16, HDRW(hv0, R_NRAW))
       }
       bool more = true;
       while (more) {
@@ -997,7 +1099,8 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       }
       // (3) assemble the prefetched values (then any overflow)
       const int raw_off = aoff + 2 * nasm;
-      if (nraw > 0 && !(CNL_ABL & 4)) {
+      const bool rowform = flags & RF_ROWS;
+      if (nraw > 0 && !rowform && !(CNL_ABL & 4)) {
         // on-the-fly condensation: raw values to LDS, matrix values first (the first nrd are the residual pivots
         // d_r: keep -1/d_r), then the right-hand-side operands (a missing right-hand side reads as zero)
 #pragma unroll
@@ -1057,6 +1160,32 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const int src = rec[aoff + e], pos = rec[aoff + nasm + e];
         __hip_atomic_fetch_add(&myFs[pos], myrhs ? myrhs[src - P.nnz] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
+      if (rowform && !(CNL_ABL & 1)) {
+        // row form: lane l = residual row l.  w = -1/d_r once, then (J_p w) J_q to the position byte of pair (p, q); lanes
+        // without a row multiply dummy operands into the padding slots.  The pivots this front owns are counted here
+        // (src/solver_types.jl:90-95).
+        const int* rw = rec + raw_off + l;
+        int pw_[ROWS_PW];
+#pragma unroll
+        for (int g = 0; g < ROWS_PW; g++) pw_[g] = rw[(2 + ROWS_KM + g) * 16];
+        const double dv = pvr[ROWS_KM];
+        const bool own = l < nrd_own;
+        rpos += own && dv > eig_tol;
+        rzer += own && fabs(dv) <= eig_tol;
+        const double w = fast_div(-1.0, dv);
+        double t_[ROWS_KM];
+#pragma unroll
+        for (int q = 0; q < ROWS_KM; q++) t_[q] = pvr[q] * w;
+        const double tr = (has_rhs ? prr[0] : 0.0) * w;
+#pragma unroll
+        for (int p_ = 0; p_ < ROWS_KM; p_++)
+#pragma unroll
+          for (int q = 0; q <= p_; q++)
+            __hip_atomic_fetch_add(&myFs[ROW_POS(pw_, p_ * (p_ + 1) / 2 + q)], t_[p_] * pvr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+        for (int q = 0; q < ROWS_KM; q++)
+          __hip_atomic_fetch_add(&myFs[ROW_POS(pw_, ROWS_KM * (ROWS_KM + 1) / 2 + q)], tr * pvr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
       if (nprod > 0 && !(CNL_ABL & 1)) {
         // products -J_ra J_rb / d_r of the condensed residual rows: one packed word each, pos | ia<<8 | ib<<15 | id<<22
         // (PB rounds in flight: the LDS round trips of a round are dependent, those of different rounds are not)
@@ -1102,6 +1231,9 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         wsync();
         for (int w4 = RN * 64 + lane; w4 * 4 < clen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = rstream[(nxt_off >> 2) + w4];
         wsync();
+        // the previous front's L rows: behind the last use of a prefetched register (a wait for it would wait for these
+        // stores), ahead of this step's loads (whoever waits for those finds the stores a whole elimination old)
+        flush_lrows(LP, const_cast<char*>(L_wb), lp_bm);
         const int nn_off = nxt_off + nlen;
         R0 = rstream[(nn_off >> 2) + lane];
         R1 = rstream[(nn_off >> 2) + lane + 64];
@@ -1109,20 +1241,23 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const bool nfast = (nflags1 >> 8) == 16 && !(nflags1 & RF_FS_GLOBAL);
         if (!(CNL_ABL & 8)) {
         PREFETCH_VALUES(nrec, aoff1, nfast ? nasmv1 : 0, nfast ? nasm1 : 0)
-        PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nfast ? nrawv1 : 0, nfast ? nraw1 : 0)
+        if (nfast && (nflags1 & RF_ROWS)) PREFETCH_ROWFORM(nrec, aoff1 + 2 * nasm1)
+        else PREFETCH_RAW(nrec, aoff1 + 2 * nasm1, nfast ? nrawv1 : 0, nfast ? nraw1 : 0)
         }
         nxt_off = nn_off;
         more = nfast;  // a large front ends the stretch: the outer loop takes over
       }
+      else flush_lrows(LP, const_cast<char*>(L_wb), lp_bm);
       STAMP(1)
       // (5) eliminate in registers, store L rows and the update matrix
-      if (!(CNL_ABL & 1024)) eliminate16_dpp(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol);
+      if (!(CNL_ABL & 1024)) eliminate16_dpp<LATE>(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol, LP);
       STAMP(3)
       if (uglob) gsync(); else wsync();
       roff = nroff;
       s++;
       STAMP(4)
       }
+      flush_lrows(LP, const_cast<char*>(L_wb), lp_bm);  // end of a stretch of fast fronts: nothing stays pending
     }
     // ---------------- inertia test and rho ladder (src/solver_types.jl:90-97, src/CaNNOLeS.jl:1023-1047) ----
     wsync();
@@ -1187,6 +1322,11 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     int4 Rb;
     double lr[KB];     // panel rows of the CURRENT front (first KB pivots), prefetched one front ahead
     bool primed = false;
+    // the scattered store of a front's solution components is issued one front late, right before the NEXT front's prefetch
+    // loads: a wait for any load is a vmcnt(0) while a store is in flight (see LPend), and a store issued at the end of front s
+    // put its whole round trip on the critical path of front s + 1
+    int ipend = -1;
+    double dpend = 0.0;
     int s = 0;
     while (s < nfr) {
       int* recw = recbuf + (s & 1) * P.breccap;
@@ -1211,6 +1351,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       const int f = 1 + nupd + npiv;
       if (cls != 16) {
         // rare large front: out of line, then restart the pipeline
+        if (ipend >= 0) { mydout[ipend] = dpend; ipend = -1; }
         if (CNL_ABL & 4096) {
         } else if (cls == 32) {
           for (int pass = 0; pass < 2; pass++) {
@@ -1243,6 +1384,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         wsync();
         for (int w4 = 64 + lane; w4 * 4 < nlen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = bstream[(nxt >> 2) + w4];
         wsync();
+        if (ipend >= 0) { mydout[ipend] = dpend; ipend = -1; }   // the previous front's solution components (see above)
         const int nn = nxt + nlen;
         Rb = bstream[(nn >> 2) + lane];
         nxt = nn;
@@ -1275,7 +1417,9 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         if (l == i) xb = -sum;
       }
       // d = -x of the pivots: one scattered store per front (rec holds the original index of every pivot)
-      if (okme && l > nupd && l < f) mydout[rec[B_HDR + l]] = -xb;
+      if (ipend >= 0) mydout[ipend] = dpend;   // (only behind the last prefetch: the front before this one had no successor to carry it)
+      ipend = (okme && l > nupd && l < f) ? rec[B_HDR + l] : -1;
+      dpend = -xb;
       if (l >= 1 && l < f) xs[xoff + l] = xb;
       wsync();
 #pragma unroll
@@ -1283,6 +1427,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       boff = nboff;
       s++;
     }
+    if (ipend >= 0) mydout[ipend] = dpend;
   }
 #ifdef CNL_STAMPS
   STAMP(6)
@@ -1305,9 +1450,12 @@ hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const La
   const int waves = (a.batch + 3) / 4;
   const int grid = (waves + wpb - 1) / wpb;
   // per device and cheap: set on every launch (a process may drive several devices)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(newton2_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  // L rows one front late (LPend) where wavefronts share their SIMDs: from about one wavefront per SIMD on
+  const bool late = waves >= 1024;
+  auto kern = late ? newton2_kernel_t<false, true> : newton2_kernel_t<false, false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(newton2_kernel_t<false>, dim3(grid), dim3(64 * wpb), lds_bytes, stream, P, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), lds_bytes, stream, P, a);
   return hipGetLastError();
 }
 
@@ -1324,9 +1472,16 @@ __global__ void __launch_bounds__(256) staged_decide_kernel(const int* __restric
 
 hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, LaunchArgs a, const int32_t* stage_ptr, int nstages, hipStream_t stream) {
   if (wpb < 1 || wpb > 4) return hipErrorInvalidConfiguration;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(newton2_kernel_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) return e;
   a.nquads = (a.batch + 3) / 4;
+  // the bidirectional chain of mid-size batches (two large tasks per group of problems) fills the SIMDs like the single stream
+  // does: L rows one front late there, immediate stores for the bushy trees of small batches (see LPend)
+  // (measured: 4096 problems in two tasks of 500 fronts 881 k -> 958 k systems/s; 256 problems in 32 tasks of 58 fronts
+  //  462 k -> 436 k: short tasks lose — their L rows would mostly be flushed at the task's end, in front of the hand-over)
+  const int ntask0 = stage_ptr[1] - stage_ptr[0];
+  const bool late = (long long)a.nquads * ntask0 >= 1536 && P.nsuper >= 128 * ntask0;
+  auto kern = late ? newton2_kernel_t<true, true> : newton2_kernel_t<true, false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
   if (a.mode != MODE_SOLVE) {
     e = hipMemsetAsync(a.gcnt, 0, (size_t)a.batch * 2 * sizeof(int), stream);
     if (e != hipSuccess) return e;
@@ -1353,7 +1508,7 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
   auto launch_range = [&](int pass, int t0, int t1, int live = 0) {
     a.phase = pass; a.task0 = t0; a.ntasks = t1 - t0; a.df_live = live;
     const long long waves = (long long)a.ntasks * a.nquads;
-    if (waves > 0) hipLaunchKernelGGL(newton2_kernel_t<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
+    if (waves > 0) hipLaunchKernelGGL(kern, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
   };
   // forward: children first
   for (int q = 0; q < s_df; q++) launch_range(0, stage_ptr[q], stage_ptr[q + 1]);

@@ -109,6 +109,8 @@ struct Plan {
   // products of the condensed residual rows, so the multifrontal kernel condenses on the fly
   bool rec_direct = false;
   int64_t d_owned = 0;   // number of condensed residual pivots staged (and counted) by the direct records
+  bool row_products = true;   // direct records of fast fronts may use the row form (RF_ROWS)
+  int32_t rows_fronts = 0, listprod_fronts = 0;  // fast fronts in row form / with product lists
   bool d_outer = false;  // backward records name solution components in the caller's numbering (set with rec_direct)
   int32_t nnz_outer = 0, n_outer = 0;  // outer (reference) nnz and N when rec_direct
   // staged execution (empty: the plan runs as one sequential stream per group of four problems)
@@ -133,7 +135,19 @@ enum {
   R_NPIV = 0, R_NUPD, R_RECLEN, R_NASM, R_NCHILD, R_UOFF, R_FLAGS, R_FSOFF, R_LPTR_LO, R_LPTR_HI, R_NASMV,
   R_ASM_OFF, R_CHILD_OFF, R_NPROD, R_NRAW, R_NRD, R_HDR = 16
 };
-enum { RF_U_GLOBAL = 1, RF_FS_GLOBAL = 2 };
+enum { RF_U_GLOBAL = 1, RF_FS_GLOBAL = 2, RF_ROWS = 4 };
+// RF_ROWS (fast fronts with direct records): the products of the on-the-fly condensation are organised PER RESIDUAL ROW instead
+// of as a list of (position, three raw-value indices) words.  Lane l of a problem takes residual row l of the front (at most 16):
+// it gathers the row's pivot d_r, up to ROWS_KM Jacobian entries and its right-hand-side entry into registers, forms
+// w = -1/d_r once and adds  (J_p w) J_q  to the position of pair (p, q) — no LDS staging of raw values, no index decode.
+// The section replaces the raw-value list of the record (R_NRAW = ROWS_WORDS words, R_NPROD = 0 products):
+//   [16 pivot sources][ROWS_KM x 16 Jacobian sources][16 right-hand-side sources (>= nnz)]
+//   [ROWS_PW x 16 position words: byte k & 3 of word k >> 2 = image position of pair k]
+// pair k: (p, q), q <= p < ROWS_KM at p (p + 1) / 2 + q, then (rhs, q) at ROWS_KM (ROWS_KM + 1) / 2 + q.  Absent operands read
+// a valid dummy source and their pairs go to the padding slots FAST_IMG_TRI + lane.  Rows whose pivot this front owns come first
+// (their number is the high half of R_NPROD, as before); R_NRD holds the number of rows.
+enum { ROWS_KM = 5, ROWS_NPAIR = ROWS_KM * (ROWS_KM + 1) / 2 + ROWS_KM, ROWS_PW = (ROWS_NPAIR + 3) / 4,
+       ROWS_WORDS = 16 * (1 + ROWS_KM + 1 + ROWS_PW) };
 enum { C_UOFF = 0, C_TUC, C_FLAGS, C_PAD, C_HDR = 4 };
 // LDS image of a fast front (order <= 16): the packed lower triangle, (a, b) -> a(a+1)/2 + b, 136 doubles, followed by 16
 // slots that only the padding entries of the assembly lists add to.  (Round 1 used a 16 x 16 strided image; the triangle

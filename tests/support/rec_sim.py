@@ -12,7 +12,11 @@ import numpy as np
  R_CHILD_OFF, R_NPROD, R_NRAW, R_NRD) = range(16)
 R_HDR = 16
 FAST_IMG_TRI, FAST_IMG_DOUBLES = 136, 152   # plan.h
-RF_U_GLOBAL, RF_FS_GLOBAL = 1, 2
+RF_U_GLOBAL, RF_FS_GLOBAL, RF_ROWS = 1, 2, 4
+ROWS_KM = 5                                   # plan.h: row form of the condensation products
+ROWS_NPAIR = ROWS_KM * (ROWS_KM + 1) // 2 + ROWS_KM
+ROWS_PW = (ROWS_NPAIR + 3) // 4
+ROWS_WORDS = 16 * (1 + ROWS_KM + 1 + ROWS_PW)
 B_NPIV, B_NUPD, B_RECLEN, B_XOFF, B_PXOFF, B_LPTR_LO, B_LPTR_HI, B_CLS = range(8)
 B_HDR = 8
 
@@ -64,6 +68,9 @@ class RecSim:
             self.stats["plain"] += nasm
             # raw values and products
             raw_off = aoff + 2 * nasm
+            if flags & RF_ROWS:
+                self._row_products(r, raw_off, nraw, nprod, nrd, nrd_own, img, src_val, eig_tol)
+                nraw = nprod = nrd = nrd_own = nrawv = 0
             assert nrawv % 16 == 0 and nraw % 16 == 0
             jraw = np.array([src_val(int(r[raw_off + t])) for t in range(nraw)])
             for t in range(nraw):
@@ -118,6 +125,41 @@ class RecSim:
             off += int(H[R_RECLEN])
         assert all(len(u) == 1 for u in U.values()), "update matrices left on the stack"
         return L, int(npos), int(nzer)
+
+    def _row_products(self, r, raw_off, nraw, nprod, nrows, nown, img, src_val, eig_tol):
+        """RF_ROWS (plan.h): lane l = residual row l; (J_p w) J_q with w = -1/d_r goes to the position byte of pair (p, q)"""
+        assert nraw == ROWS_WORDS and nprod == 0 and nown <= nrows <= 16
+        self.stats["rowform"] = self.stats.get("rowform", 0) + 1
+        for l in range(16):
+            dsrc = int(r[raw_off + l])
+            assert dsrc < self.nnz
+            dv = src_val(dsrc)
+            if l < nown:
+                self.owned += 1
+                self.own_pos += int(dv > eig_tol)
+                self.own_zer += int(abs(dv) <= eig_tol)
+            w = -1.0 / dv
+            J = [src_val(int(r[raw_off + 16 * (1 + q) + l])) for q in range(ROWS_KM)]
+            for q in range(ROWS_KM):
+                assert int(r[raw_off + 16 * (1 + q) + l]) < self.nnz
+            rs = int(r[raw_off + 16 * (1 + ROWS_KM) + l])
+            assert rs >= self.nnz
+            rh = src_val(rs)
+            words = [int(r[raw_off + 16 * (2 + ROWS_KM + g) + l]) & 0xffffffff for g in range(ROWS_PW)]
+            pos = lambda k: (words[k >> 2] >> (8 * (k & 3))) & 255
+            k = 0
+            for p in range(ROWS_KM):
+                for q in range(p + 1):
+                    if l >= nrows:
+                        assert pos(k) >= FAST_IMG_TRI
+                    img[pos(k)] += (J[p] * w) * J[q]
+                    self.stats["products"] += pos(k) < FAST_IMG_TRI
+                    k += 1
+            for q in range(ROWS_KM):
+                img[pos(k)] += (rh * w) * J[q]
+                self.stats["products"] += pos(k) < FAST_IMG_TRI
+                k += 1
+        self.stats["raw"] += nraw
 
     def backward(self, L, n_out):
         """d = -x from the factor storage (z = D^-1 L^-1 b sits in column 0 of the panels)."""
@@ -226,6 +268,13 @@ class StagedSim(RecSim):
                     for e in range(nasm):
                         img[int(r[aoff + nasm + e])] += src_val(int(r[aoff + e]))
                     raw_off = aoff + 2 * nasm
+                    if flags & RF_ROWS:
+                        self.stats = getattr(self, "stats", None) or dict(plain=0, products=0, raw=0, strided=0, packed=0)
+                        self.owned = self.own_pos = self.own_zer = 0
+                        self._row_products(r, raw_off, nraw, nprod, nrd, nrd_own, img, src_val, eig_tol)
+                        npos += self.own_pos
+                        nzer += self.own_zer
+                        nraw = nprod = nrd = nrd_own = 0
                     jraw = np.array([src_val(int(r[raw_off + q])) for q in range(nraw)])
                     npos += int((jraw[:nrd_own] > eig_tol).sum())
                     nzer += int((np.abs(jraw[:nrd_own]) <= eig_tol).sum())
