@@ -35,6 +35,7 @@ struct cnl_plan {
   std::vector<int32_t> gpos;  // non-empty: the condensed system may be treated as ONE dense matrix (position of every K2 slot)
   cnl_options opt{};          // the options the plan was built with (the handle reads its execution switches from here)
   std::atomic<int> refs{1};   // handles of a cnl_multi share one analysis (read-only after creation)
+  bool split_mode = false;    // bidirectional-chain plan for a batch between one and two wavefronts per SIMD (capi.cpp, run_split)
 };
 
 struct cnl_handle {
@@ -74,6 +75,10 @@ struct cnl_handle {
   int32_t *d_nfact = nullptr, *d_success = nullptr;
   int64_t *d_npos = nullptr, *d_nzero = nullptr;
   hipStream_t stream = nullptr;
+  int64_t split_staged = 0;   // > 0: problems [0, split_staged) run staged, the rest single-stream, concurrently (run_split)
+  bool in_split = false;
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t pipe_stream[3] = {nullptr, nullptr, nullptr};  // chunked host-pointer calls: two compute streams, one for the results
   std::vector<hipEvent_t> pipe_ev;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -291,6 +296,92 @@ int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   return CNL_OK;
 }
 
+// run() on problems [b0, b0 + nb) of the handle: the base pointer of every per-problem device array of the handle is moved to
+// problem b0 and the batch set to nb for the lifetime of the view (b0 a multiple of 4: a wavefront serves four problems).
+// Dataflow counters are per handle, not per view: views run one launch per stage.
+struct SubBatch {
+  cnl_handle* h;
+  int64_t batch;
+  double *L, *gs, *scratch, *cbuf, *d2;
+  int *xpos, *xzer, *gcnt, *dep;
+  const double* last_vals;
+  bool staged;
+  SubBatch(cnl_handle* h_, int64_t b0, int64_t nb, bool allow_staged = true) : h(h_) {
+    last_vals = h->last_vals; staged = h->staged;
+    if (h->last_vals) h->last_vals += b0 * h->plan->nnz;
+    if (!allow_staged) h->staged = false;
+    batch = h->batch; L = h->d_L; gs = h->d_gs; scratch = h->d_scratch; cbuf = h->d_cbuf; d2 = h->d_d2;
+    xpos = h->d_xpos; xzer = h->d_xzer; gcnt = h->d_gcnt; dep = h->d_dep;
+    const cnl::Cond& C = h->plan->C;
+    h->batch = nb;
+    h->d_L += b0 * h->dp.lsize;
+    if (h->d_gs) h->d_gs += b0 * h->dp2.gs_doubles;
+    if (h->d_scratch) h->d_scratch += b0 * (int64_t)h->dp.work_doubles;
+    if (h->d_cbuf) h->d_cbuf += b0 * C.cstride;
+    if (h->d_d2) h->d_d2 += b0 * C.N2;
+    if (h->d_xpos) h->d_xpos += b0;
+    if (h->d_xzer) h->d_xzer += b0;
+    if (h->d_gcnt) h->d_gcnt += 2 * b0;
+    h->d_dep = nullptr;
+  }
+  ~SubBatch() {
+    h->batch = batch; h->d_L = L; h->d_gs = gs; h->d_scratch = scratch; h->d_cbuf = cbuf; h->d_d2 = d2;
+    h->d_xpos = xpos; h->d_xzer = xzer; h->d_gcnt = gcnt; h->d_dep = dep;
+    h->last_vals = last_vals; h->staged = staged;
+  }
+};
+
+int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, double* d_d, hipStream_t stream);
+
+// Batches between one and two wavefronts per SIMD (4096 .. 8192 problems of cfg3's size): the single stream gives a group of
+// four problems ONE wavefront for 1000 fronts, the bidirectional chain TWO for 500 each, and the machine holds 2048 wavefronts.
+// With x groups on the chain and y on the stream, 2 x + y = 2048 fills every slot whatever the batch: the chain part runs staged
+// on the caller's stream, the rest single-stream on a second stream of the handle, forked and joined with events (no host
+// synchronisation).  Both parts use the SAME plan — the chain order has the throughput order's fronts, and the classic launch
+// runs any plan's records from end to end (it already does behind every staged attempt).
+int run_split(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, double* d_d, hipStream_t stream) {
+  if (!h->aux_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
+  const int64_t nA = h->split_staged, nB = h->batch - nA, nnz = h->plan->nnz, N = h->plan->N;
+  const bool tm = h->timing;
+  if (tm) HIPCHK(hipEventRecord(h->ev0, stream));
+  h->timing = false;
+  h->in_split = true;
+  HIPCHK(hipEventRecord(h->ev_fork, stream));
+  HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+  int rc;
+  {
+    SubBatch view(h, nA, nB, false);
+    cnl::LaunchArgs b = a;
+    if (b.rho_old) b.rho_old += nA;
+    if (b.rho) b.rho += nA;
+    if (b.nfact) b.nfact += nA;
+    if (b.success) b.success += nA;
+    if (b.npos) b.npos += nA;
+    if (b.nzero) b.nzero += nA;
+    rc = run(h, b, d_vals ? d_vals + nA * nnz : nullptr, d_rhs ? d_rhs + nA * N : nullptr, d_d ? d_d + nA * N : nullptr, h->aux_stream);
+  }
+  if (rc == CNL_OK) {
+    SubBatch view(h, 0, nA, true);
+    rc = run(h, a, d_vals, d_rhs, d_d, stream);
+  }
+  h->in_split = false;
+  h->timing = tm;
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
+  HIPCHK(hipStreamWaitEvent(stream, h->ev_join, 0));
+  if (a.mode == cnl::MODE_FACTOR) h->last_vals = d_vals;
+  if (tm) {
+    HIPCHK(hipEventRecord(h->ev1, stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  }
+  return CNL_OK;
+}
+
 // Behind a staged try_to_factorize / solve_ldl! that ran in dataflow fashion: the sequential execution of the same call, which
 // exits at once unless a dataflow wait of the attempt gave up (kernels2.hip, spin_until).  newton_system has its classic launch
 // anyway (the rho ladder of the problems that failed the first attempt).
@@ -309,6 +400,7 @@ int launch_redo(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, double* d_d, hipStream_t stream) {
   const cnl::Cond& C = h->plan->C;
   int rc = CNL_OK;
+  if (h->split_staged > 0 && !h->in_split && h->staged && h->split_staged < h->batch) return run_split(h, a, d_vals, d_rhs, d_d, stream);
   if (h->dense) {
     // dense residual block: J'WJ + tiled dense LDL^T on the fp64 matrix cores (csrc/dense.hip); asynchronous, the rho ladder
     // is decided on the device
@@ -451,35 +543,6 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
   return CNL_OK;
 }
 
-// run() on problems [b0, b0 + nb) of the handle: the base pointer of every per-problem device array of the handle is moved to
-// problem b0 and the batch set to nb for the lifetime of the view (b0 a multiple of 4: a wavefront serves four problems).
-// Dataflow counters are per handle, not per view: views run one launch per stage.
-struct SubBatch {
-  cnl_handle* h;
-  int64_t batch;
-  double *L, *gs, *scratch, *cbuf, *d2;
-  int *xpos, *xzer, *gcnt, *dep;
-  SubBatch(cnl_handle* h_, int64_t b0, int64_t nb) : h(h_) {
-    batch = h->batch; L = h->d_L; gs = h->d_gs; scratch = h->d_scratch; cbuf = h->d_cbuf; d2 = h->d_d2;
-    xpos = h->d_xpos; xzer = h->d_xzer; gcnt = h->d_gcnt; dep = h->d_dep;
-    const cnl::Cond& C = h->plan->C;
-    h->batch = nb;
-    h->d_L += b0 * h->dp.lsize;
-    if (h->d_gs) h->d_gs += b0 * h->dp2.gs_doubles;
-    if (h->d_scratch) h->d_scratch += b0 * (int64_t)h->dp.work_doubles;
-    if (h->d_cbuf) h->d_cbuf += b0 * C.cstride;
-    if (h->d_d2) h->d_d2 += b0 * C.N2;
-    if (h->d_xpos) h->d_xpos += b0;
-    if (h->d_xzer) h->d_xzer += b0;
-    if (h->d_gcnt) h->d_gcnt += 2 * b0;
-    h->d_dep = nullptr;
-  }
-  ~SubBatch() {
-    h->batch = batch; h->d_L = L; h->d_gs = gs; h->d_scratch = scratch; h->d_cbuf = cbuf; h->d_d2 = d2;
-    h->d_xpos = xpos; h->d_xzer = xzer; h->d_gcnt = gcnt; h->d_dep = dep;
-  }
-};
-
 int ensure_staging(cnl_handle* h) {
   if (h->d_vals) return CNL_OK;
   const cnl_plan& P = *h->plan;
@@ -593,7 +656,7 @@ void cnl_options_init(cnl_options* o) {
   o->multipliers_early = 1; o->condense = 1; o->direct_records = 1; o->register_front = 1; o->dense_backend = 1; o->general_dense = 1;
   o->staged = 1; o->dataflow = 1; o->dataflow_waves = 1024; o->dataflow_spin_limit = 1 << 22;
   o->waves_per_block = 0; o->v1_tpp = -1; o->v1_ppb = -1; o->v1_lds = -1; o->v1_solve = 0; o->lds_pad = 1;
-  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1;
+  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -618,7 +681,32 @@ int cnl_plan_create_ex(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* r
   if (o.plan_kind == CNL_PLAN_LATENCY) latency = 1;
   else if (o.plan_kind == CNL_PLAN_AUTO) latency = batch >= 1 && batch <= (o.staged_max_batch > 0 ? o.staged_max_batch : 4096);
   else if (o.plan_kind != CNL_PLAN_THROUGHPUT) return fail(CNL_ERR_ARG, "unknown plan_kind");
-  if (!latency) return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0, 0, o);
+  if (!latency) {
+    rc = plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 0, 0, 0, o);
+    // Between one and two wavefronts per SIMD the single stream leaves wavefront slots idle (686 k systems/s at 5120 problems of
+    // cfg3's pattern between 958 k at 4096 and 964 k at 8192): when the bidirectional chain is available at the throughput
+    // order's cost, the handle runs part of the batch on it and the rest single-stream, concurrently (run_split).
+    const int64_t smb = o.staged_max_batch > 0 ? o.staged_max_batch : 4096;
+    if (rc == CNL_OK && o.plan_kind == CNL_PLAN_AUTO && o.split_batch && batch > smb && batch <= 2 * smb - smb / 8 && o.force_order[0] == 0) {
+      cnl_options o2 = o;
+      std::snprintf(o2.force_order, sizeof(o2.force_order), "ndc2+early");
+      cnl_plan* alt = nullptr;
+      const int nq = (int)((smb + 3) / 4);
+      if (plan_create_impl(&alt, N, nnz, rows1, cols1, nvar, nequ, ncon, 1, std::max(1, 2048 / nq), 2048.0 / nq, o2) == CNL_OK) {
+        const bool same_work = alt->latency && alt->P.order_name == "ndc2+early" && alt->P.tasks.size() >= 2 &&
+                               alt->P.cost <= 1.05 * (*plan)->P.cost && alt->P.nsuper <= (*plan)->P.nsuper + 8;
+        if (same_work) {
+          alt->split_mode = true;
+          std::memset(alt->opt.force_order, 0, sizeof(alt->opt.force_order));
+          cnl_plan_destroy(*plan);
+          *plan = alt;
+        } else {
+          cnl_plan_destroy(alt);
+        }
+      }
+    }
+    return rc;
+  }
   if (batch < 1) return fail(CNL_ERR_ARG, "a latency plan needs the batch size");
   const int nquads = (int)((batch + 3) / 4);
   return plan_create_impl(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, 1, std::max(1, 2048 / nquads), 2048.0 / nquads, o);
@@ -876,6 +964,12 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
   }
   if ((rc = choose_config(h))) return bail(rc);
   if ((rc = setup_v2(h))) return bail(rc);
+  if (plan->split_mode && h->staged) {
+    // x groups of four problems on the chain (two wavefronts each), the rest on the single stream: 2 x + y = 2048 slots
+    const int64_t nquads = (batch + 3) / 4, x = std::max<int64_t>(0, 2048 - nquads);
+    h->split_staged = std::min<int64_t>(batch, 4 * x);
+    if (h->split_staged == 0) h->staged = false;  // the whole batch on the single stream
+  }
   if (h->plan->D.active) {
     std::string derr;
     int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_syrk_wgs);
@@ -948,6 +1042,9 @@ int cnl_destroy(cnl_handle* h) {
   if (h->pin) (void)hipHostFree(h->pin);
   cnl::dense_destroy(h->dense);
   cnl::dense_destroy(h->gdense);
+  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   for (hipEvent_t e : h->pipe_ev) (void)hipEventDestroy(e);
   for (hipStream_t st : h->pipe_stream) if (st) (void)hipStreamDestroy(st);
   if (h->ev0) (void)hipEventDestroy(h->ev0);

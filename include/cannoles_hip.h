@@ -99,7 +99,8 @@ typedef struct cnl_options {
   int32_t verbose;             /* 1: log plan decisions on stderr                                                               */
   int32_t multi_share_plan;    /* 1: cnl_multi_create analyses the pattern once for all shards of equal plan kind               */
   int32_t row_products;        /* 1: condensation products of small fronts organised per residual row (csrc/plan.h, RF_ROWS)    */
-  int32_t reserved_;           /* keeps the struct a multiple of 8 bytes                                                        */
+  int32_t split_batch;         /* 1: batches between one and two wavefronts per SIMD run partly on the bidirectional chain,
+                                  partly single-stream, concurrently (csrc/capi.cpp, run_split)                                 */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);

@@ -609,12 +609,15 @@ def test_fixtures_f2_f3_through_the_hip_path(built):
     L.close()
 
 
-@pytest.mark.parametrize("B,kernel,order", [(4608, "v2", "canonical"), (3584, "v2-staged", "ndc2"), (1536, "v2-staged", "ndc")])
-def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order):
-    """The headline shape (cfg3 pattern, n = nequ = 1e4, ncon = 50) at a batch the throughput kernel serves (B = 4608 > the
-    staged threshold), at one the bidirectional chain serves (two large parts eliminated towards the separator, B = 3584) and
-    at one with many large parts (B = 1536): the whole batch through cnl_newton_system_dev, a random sample of 32 problems
-    against the oracle."""
+@pytest.mark.parametrize("B,kernel,order,forced", [(4608, "v2", "canonical", True), (4608, "v2-staged", "ndc2", False),
+                                                   (3584, "v2-staged", "ndc2", False), (1536, "v2-staged", "ndc", False)])
+def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, forced):
+    """The headline shape (cfg3 pattern, n = nequ = 1e4, ncon = 50): on the throughput kernel (single stream, forced here with
+    cnl_options.plan_kind: it is what cnl_create picks from 7681 problems on), at a batch between one and two wavefronts per SIMD
+    (B = 4608: 3584 problems on the bidirectional chain and 1024 on the single stream, CONCURRENTLY on two streams —
+    csrc/capi.cpp, run_split), at one the bidirectional chain serves alone (B = 3584) and at one with many large parts
+    (B = 1536): the whole batch through cnl_newton_system_dev, a random sample of 32 problems against the oracle; in the
+    split batch one problem of each part also climbs the rho ladder."""
     import torch
     hipldl, syn, O = _mods()
     import bench as BM
@@ -632,7 +635,17 @@ def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order):
         for b in pick[(pick >= b0) & (pick < b0 + 512)]:
             host[int(b)] = (vh[b - b0].copy(), rh[b - b0].copy())
     p = hipldl.default_params()
-    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    split = B == 4608 and not forced
+    if split:   # one problem in the chain part and one in the single-stream part need rho > 0
+        off = s.offsets()
+        hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
+        dg = torch.from_numpy(off[0] + np.nonzero(hF_r == hF_c)[0][:400]).to(dev)
+        for b in (int(pick[0]), int(pick[-1])):
+            vals[b, dg] = -30.0
+            host[b][0][dg.cpu().numpy()] = -30.0
+        assert pick[0] < 3584 <= pick[-1]
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B,
+                            options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT) if forced else None)
     assert L.config["kernel"] == kernel and L.info["order"].startswith(order)
     d = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
     ro = torch.zeros(B, dtype=torch.float64, device=dev)
@@ -641,15 +654,22 @@ def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order):
     ok = torch.zeros(B, dtype=torch.int32, device=dev)
     hipldl.newton_system_dev(L, vals.data_ptr(), rhs.data_ptr(), d.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), ok.data_ptr(), p, 0)
     torch.cuda.synchronize()
-    assert bool((ok == 1).all()) and bool((nf == 1).all()) and bool((rho == 0).all())
+    nfh, rhoh = nf.cpu().numpy(), rho.cpu().numpy()
+    assert bool((ok == 1).all())
+    if not split:
+        assert (nfh == 1).all() and (rhoh == 0).all()
     orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
     dh = d[torch.from_numpy(pick).to(dev)].cpu().numpy()
+    vend = vals[torch.from_numpy(pick).to(dev)].cpu().numpy()
     for k, b in enumerate(pick):
         v0, r0 = host[int(b)]
-        d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, r0, v0.copy(), 0.0, p)
-        assert ok0 and nf0 == 1
+        vv = v0.copy()
+        d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, r0, vv, 0.0, O.default_params())
+        assert ok0 and (nf0, rho0) == (int(nfh[b]), float(rhoh[b]))
+        assert (nf0 > 1) == (split and k in (0, 31))
+        assert np.array_equal(vend[k, -s.nvar:], vv[-s.nvar:])
         assert np.abs(dh[k] - d0).max() <= FWD_TOL * np.abs(d0).max()
-        assert backward_error(s, v0, r0, dh[k]) <= BWD_TOL
+        assert backward_error(s, vv, r0, dh[k]) <= BWD_TOL
     L.close()
 
 
@@ -818,6 +838,42 @@ def test_dataflow_timeout_is_counted_and_recovered(built, B):
     hipldl.newton_system_(np.zeros((B, s.N)), s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L2, np.zeros(B), p)
     assert L2.dataflow_timeouts() == 0
     L2.close()
+
+
+def test_split_batch_factorize_then_solve(built):
+    """try_to_factorize + solve_ldl! (src/solver_types.jl:69-98) on a batch between one and two wavefronts per SIMD: the handle
+    runs 4 x (2048 - groups) problems on the bidirectional chain and the rest single-stream, concurrently (run_split); both
+    parts must give the oracle's inertia decisions and solutions, and solve_ldl! must find each part's own factor."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(600, 6)
+    rows, cols = s.kkt_pattern()
+    B = 5000
+    v8, r8 = syn.batch_values(s, 8, cfg=3)
+    rng = np.random.default_rng(3)
+    vals = np.tile(v8, (B // 8, 1)) * (1.0 + 1e-3 * rng.standard_normal((B, 1)))
+    rhs = np.tile(r8, (B // 8, 1)) + 1e-3 * np.arange(B)[:, None]
+    off = s.offsets()
+    vals[:, off[4]:off[5]] = -1.0
+    bad = [7, 4999]
+    hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
+    dg = off[0] + np.nonzero(hF_r == hF_c)[0]
+    for b in bad:
+        vals[b, dg[:50]] = -40.0        # wrong inertia at rho = 0
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    assert L.config["kernel"] == "v2-staged" and L.info["order"].startswith("ndc2")
+    p = hipldl.default_params()
+    ok, npos, nzer = hipldl.try_to_factorize(L, vals, s.nvar, s.nequ, s.ncon, p[0], return_inertia=True)
+    assert ok.sum() == B - 2 and not ok[7] and not ok[4999]
+    orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
+    d = np.zeros((B, s.N))
+    hipldl.solve_ldl_(rhs, L.factor, d)
+    for b in (0, 7, 2500, 4095, 4096, 4500, 4999):
+        ob, np0, nz0 = orc.try_to_factorize(vals[b], s.nvar, s.nequ, s.ncon, p[0], return_inertia=True)
+        assert bool(ok[b]) == ob and (int(npos[b]), int(nzer[b])) == (np0, nz0)
+        if ob:
+            d0 = orc.solve_ldl(rhs[b])
+            assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+    L.close()
 
 
 def test_host_pointer_call_pipelined_in_chunks(built):
