@@ -50,12 +50,14 @@ struct DnDev {
   int n, m, p, mp, npj, Tn;  // residual-block form: variables, residual rows (0: general condensed system), constraints, padded sizes
   int nnz;                   // COO entries per problem of the caller's vals
   int ks, ntl, nlt;          // K splits of J'WJ, lower tiles of the variable block, lower tiles of S
+  int Tm, nml;               // 128 x 128 macro tiles per side of the variable block, lower macro tiles (dn_syrk2)
   int npos_ok;               // success <=> #positive pivots == npos_ok and no zero pivot
   const int *jslot, *dslot;  // gather lists
   const int *lI, *lJ;        // lower tiles of S: tile -> (I, J)
   const int *ht_ptr, *hu_loc, *hu_ptr, *hslot;  // H entries per lower tile: unique positions, their COO entries in COO order
   const int* gpos;           // general path: position i + ns j of every slot
   int nslots;
+  double *Jw;                // diag(w) J: the A operand of J'WJ (dn_gather writes it next to J)
   double *Jd, *w, *slab, *S0, *S, *G, *Wn, *dv, *rsh, *y, *x, *jxp;  // Wn: [batch][T] tiles -L(J, k) d_k of the current column
   double *part1, *part2, *partA, *partB;  // [batch][T * T][64] partial tile products of the solve (summed in a fixed order)
   // J'WJ work partition: workgroup -> pieces, piece = (problem, lower tile, rows [ch0, ch1) in chunks of KT); pieces of a tile
@@ -80,15 +82,17 @@ __global__ void __launch_bounds__(256) dn_gather(DnDev D, const double* __restri
   const int b = blockIdx.y;
   const double* v = vals + (size_t)b * D.nnz;
   double* Jd = D.Jd + (size_t)b * D.mp * D.npj;
+  double* Jw = D.Jw + (size_t)b * D.mp * D.npj;
   double* w = D.w + (size_t)b * D.mp;
   const long long tot = (long long)D.m * D.n;
   int np = 0, nz = 0;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < tot; t += (long long)gridDim.x * 256) {
     const int i = (int)(t % D.m), j = (int)(t / D.m);
-    Jd[(size_t)i + (size_t)D.mp * j] = v[D.jslot[t]];
+    const double jv = v[D.jslot[t]], dvv = v[D.dslot[i]], wi = -1.0 / dvv;
+    Jd[(size_t)i + (size_t)D.mp * j] = jv;
+    Jw[(size_t)i + (size_t)D.mp * j] = jv * wi;
     if (j == 0) {
-      const double dvv = v[D.dslot[i]];
-      w[i] = -1.0 / dvv;
+      w[i] = wi;
       np += dvv > eig_tol;
       nz += fabs(dvv) <= eig_tol;
     }
@@ -98,75 +102,87 @@ __global__ void __launch_bounds__(256) dn_gather(DnDev D, const double* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// slab[ks][tile (I, J)] = sum over the rows of split ks of  J(:, I)' diag(w) J(:, J)   (64 x 64, lower tiles I >= J).
+// slab[piece] = sum over the rows of the piece of  J(:, I)' diag(w) J(:, J)   (lower tiles I >= J).
 // C' = C^T is what the matrix core produces here (D'[c][r]): the 16 lanes that share a register then hold 16 consecutive
 // rows r of one column c, so the tile is written in 128-byte runs.  A operand: rows m of the J columns scaled by w,
-// B operand: the I columns; both staged through LDS 32 rows of J at a time as [column][row] with a stride of 34 doubles
-// (conflict-free for the 16 x 4 operand fetch).  4 waves, 32 x 32 of the tile each, 2 x 2 accumulators.
-constexpr int KT = 32, LDK = 34;
-__global__ void __launch_bounds__(256) dn_syrk(DnDev D) {
-  __shared__ double tA[64 * LDK], tB[64 * LDK];
+// B operand: the I columns; both staged through LDS as [column][row] with a stride of LDK doubles (conflict-free for the
+// 16 x 4 operand fetch).  Rounds 1-2 used one 64 x 64 tile per workgroup (4 waves, 32 x 32 each, 2 x 2 accumulators):
+// a 64 x 64 tile per workgroup streams 32 KB of J per 32-row chunk for
+// 131 k FMAs (8 flop per byte: at the matrix cores' rate that is ~6 TB/s out of L2 / Infinity Cache — the kernel ran at 27 % of
+// the MFMA rate); a 128 x 128 tile halves the operand traffic per flop and every LDS operand read feeds two matrix
+// instructions instead of one.  4 waves, a 64 x 64 quadrant each (4 x 4 accumulators = 16 independent chains), operands of the
+// next chunk prefetched into registers while this one is multiplied.  A piece of work = (problem, lower macro tile, row
+// chunks); its partial product is stored as the four 64 x 64 tiles dn_assemble sums.
+// Chunks of 16 rows: the prefetch registers of a 32-row chunk (96) next to the 128 accumulator registers pushed the kernel to
+// 360 VGPRs = one wavefront per SIMD, nothing to hide the barriers behind (670 us for 8 problems against 641 us before).
+constexpr int MT = 128, KT = 16, LDK = 18;
+__global__ void __launch_bounds__(256, 2) dn_syrk2(DnDev D) {
+  extern __shared__ double sm_syrk[];
+  double* tA = sm_syrk;
+  double* tB = sm_syrk + MT * LDK;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, lg = lane >> 4;
-#ifdef DN_SYRK_COLLANE
-  const int col = lane, part = wave;  // conflict-free 16-byte LDS writes (8 consecutive columns -> 32 distinct banks), 64-byte global pieces
-#else
-  const int col = t >> 2, part = t & 3;
-#endif
-  const int cq = (wave >> 1) * 32, rq = (wave & 1) * 32;
-  // the (problem, tile, row chunk) space is cut into equal shares, one per workgroup (a share spans at most a few tiles):
-  // every CU gets the same number of matrix-core instructions, whatever the number of tiles
+  const int col = t >> 1, part = t & 1;          // staging: thread = (column of the macro tile, 8-row half of the chunk)
+  const int wc = (wave >> 1) * 64, wr = (wave & 1) * 64;  // this wave's quadrant: A-side columns wc.., B-side columns wr..
   for (int pc = D.sy_wg[blockIdx.x]; pc < D.sy_wg[blockIdx.x + 1]; pc++) {
-    const int b = D.sy_b[pc], tl = D.sy_tl[pc], ch0 = D.sy_ch0[pc], ch1 = D.sy_ch1[pc];
-    int J = 0, rem = tl;  // lower tile of the variable block, column by column
-    while (rem >= D.Tn - J) { rem -= D.Tn - J; J++; }
-    const int I = J + rem;
+    const int b = D.sy_b[pc], ml = D.sy_tl[pc], ch0 = D.sy_ch0[pc], ch1 = D.sy_ch1[pc];
+    int MJ = 0, rem = ml;  // lower macro tile, column by column
+    while (rem >= D.Tm - MJ) { rem -= D.Tm - MJ; MJ++; }
+    const int MI = MJ + rem;
     const double* Jb = D.Jd + (size_t)b * D.mp * D.npj;
-    const double* wb = D.w + (size_t)b * D.mp;
-    d4 acc[2][2];
+    const double* Jwb = D.Jw + (size_t)b * D.mp * D.npj;
+    d4 acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int c = 0; c < 2; c++) acc[a][c] = d4{0.0, 0.0, 0.0, 0.0};
-    const double* pa = Jb + (size_t)D.mp * (64 * J + col) + 8 * part;
-    const double* pb = Jb + (size_t)D.mp * (64 * I + col) + 8 * part;
-    double2 ra[4], rb[4], rw[4];
-#define DN_GLOAD(CH)                                                                  \
+      for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    const double* pa = Jwb + (size_t)D.mp * min(MT * MJ + col, D.npj - 1) + 8 * part;
+    const double* pb = Jb + (size_t)D.mp * min(MT * MI + col, D.npj - 1) + 8 * part;
+    // named scalars: as arrays these stay allocas that the backend refuses to promote under the two-waves register budget
+    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define DN_GLOAD2(CH)                                                                 \
   {                                                                                   \
-    const int m0_ = (CH) * KT;                                                        \
-    _Pragma("unroll") for (int q = 0; q < 4; q++) {                                   \
-      ra[q] = *reinterpret_cast<const double2*>(pa + m0_ + 2 * q);                    \
-      rb[q] = *reinterpret_cast<const double2*>(pb + m0_ + 2 * q);                    \
-      rw[q] = *reinterpret_cast<const double2*>(wb + m0_ + 8 * part + 2 * q);         \
-    }                                                                                 \
+    const double2* qa_ = reinterpret_cast<const double2*>(pa + (CH) * KT);            \
+    const double2* qb_ = reinterpret_cast<const double2*>(pb + (CH) * KT);            \
+    ra0 = qa_[0]; ra1 = qa_[1]; ra2 = qa_[2]; ra3 = qa_[3];                           \
+    rb0 = qb_[0]; rb1 = qb_[1]; rb2 = qb_[2]; rb3 = qb_[3];                           \
   }
-    DN_GLOAD(ch0)
+    DN_GLOAD2(ch0)
     for (int ch = ch0; ch < ch1; ch++) {
       __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        *reinterpret_cast<double2*>(&tA[col * LDK + 8 * part + 2 * q]) = make_double2(ra[q].x * rw[q].x, ra[q].y * rw[q].y);
-        *reinterpret_cast<double2*>(&tB[col * LDK + 8 * part + 2 * q]) = rb[q];
+      {
+        double2* wa_ = reinterpret_cast<double2*>(&tA[col * LDK + 8 * part]);
+        double2* wb_ = reinterpret_cast<double2*>(&tB[col * LDK + 8 * part]);
+        wa_[0] = ra0; wa_[1] = ra1; wa_[2] = ra2; wa_[3] = ra3;
+        wb_[0] = rb0; wb_[1] = rb1; wb_[2] = rb2; wb_[3] = rb3;
       }
       __syncthreads();
-      if (ch + 1 < ch1) DN_GLOAD(ch + 1)
-#pragma unroll
+      if (ch + 1 < ch1) DN_GLOAD2(ch + 1)
+#pragma unroll 2
       for (int s = 0; s < KT / 4; s++) {
-        const double a0 = tA[(cq + li) * LDK + 4 * s + lg], a1 = tA[(cq + 16 + li) * LDK + 4 * s + lg];
-        const double b0 = tB[(rq + li) * LDK + 4 * s + lg], b1 = tB[(rq + 16 + li) * LDK + 4 * s + lg];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        double a[4], bb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          a[i] = tA[(wc + 16 * i + li) * LDK + 4 * s + lg];
+          bb[i] = tB[(wr + 16 * i + li) * LDK + 4 * s + lg];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
       }
     }
-#undef DN_GLOAD
-    double* out = D.slab + (size_t)pc * TT;
+#undef DN_GLOAD2
+    // quadrant (wr, wc) of the macro tile = 64 x 64 tile (2 MI + (wave & 1), 2 MJ + (wave >> 1)); the upper one of a diagonal
+    // macro tile is not needed
+    if (!(MI == MJ && (wave & 1) == 0 && (wave >> 1) == 1)) {
+      double* out = D.slab + ((size_t)pc * 4 + (size_t)((wave & 1) * 2 + (wave >> 1))) * TT;
 #pragma unroll
-    for (int bc = 0; bc < 2; bc++)
+      for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int br = 0; br < 2; br++)
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) out[(rq + 16 * br + li) + 64 * (cq + 16 * bc + lg + 4 * reg)] = acc[bc][br][reg];
+          for (int reg = 0; reg < 4; reg++) out[(16 * j + li) + 64 * (16 * i + lg + 4 * reg)] = acc[i][j][reg];
+    }
   }
 }
 
@@ -190,14 +206,15 @@ __global__ void __launch_bounds__(256) dn_assemble(DnDev D, const double* __rest
   const double* v = vals + (size_t)b * D.nnz;
   double* rsh = D.rsh + (size_t)b * D.nsp;
   const bool has_slab = D.m > 0 && I < D.Tn;
-  const int tl = J * D.Tn - (J * (J - 1)) / 2 + (I - J);
+  const int MI = I >> 1, MJ = J >> 1, sub = (I & 1) * 2 + (J & 1);   // pieces come per 128 x 128 macro tile, four tiles each
+  const int ml = MJ * D.Tm - (MJ * (MJ - 1)) / 2 + (MI - MJ);
   int p0 = 0, p1 = 0;
-  if (has_slab) { p0 = D.sy_tp[b * D.ntl + tl]; p1 = D.sy_tp[b * D.ntl + tl + 1]; }
+  if (has_slab) { p0 = D.sy_tp[b * D.nml + ml]; p1 = D.sy_tp[b * D.nml + ml + 1]; }
   double2 s2[8];
 #pragma unroll
   for (int q = 0; q < 8; q++) s2[q] = make_double2(0.0, 0.0);
   for (int pc = p0; pc < p1; pc++) {
-    const double2* sp = reinterpret_cast<const double2*>(D.slab + (size_t)pc * TT) + t;
+    const double2* sp = reinterpret_cast<const double2*>(D.slab + ((size_t)pc * 4 + sub) * TT) + t;
     double2 g[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) g[q] = sp[256 * q];
@@ -421,9 +438,9 @@ __device__ __forceinline__ void row_tile_ptrs(const DnDev& D, int b, int k, int 
   }
 }
 
-__global__ void __launch_bounds__(256) dn_panel(DnDev D, int k, double eig_tol) {
+__global__ void __launch_bounds__(256) dn_panel(DnDev D, int k, double eig_tol, int b0) {
   __shared__ PanelLds P;
-  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef DN_STAMPS
   const long long st0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -508,8 +525,8 @@ __device__ __forceinline__ void trailing_tile(const DnDev& D, int b, int k, int 
 }
 
 // one workgroup = one 32 x 32 quadrant of a trailing tile (4 waves, a 16 x 16 block each)
-__global__ void __launch_bounds__(256) dn_update(DnDev D, int k) {
-  const int b = blockIdx.y;
+__global__ void __launch_bounds__(256) dn_update(DnDev D, int k, int b0) {
+  const int b = b0 + blockIdx.y;
   const double *At, *Bt; double* Ct; bool czero;
   trailing_tile(D, b, k, blockIdx.x >> 2, At, Bt, Ct, czero);
   const int q = blockIdx.x & 3, wave = threadIdx.x >> 6;
@@ -988,7 +1005,8 @@ int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::strin
   std::vector<int> sy_tp;
   int npieces = 0;
   {
-    const long long nch = d.mp / KT, units = (long long)batch * d.ntl * nch;
+    d.Tm = (d.Tn + 1) / 2; d.nml = d.Tm * (d.Tm + 1) / 2;
+    const long long nch = d.mp / KT, units = (long long)batch * d.nml * nch;
     int nwg = 512;
     if (syrk_wgs > 0) nwg = syrk_wgs;
     nwg = (int)std::min<long long>(nwg, units);
@@ -998,14 +1016,14 @@ int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::strin
       const long long u1 = units * (w + 1) / nwg;
       while (u < u1) {
         const long long tile = u / nch, c0 = u % nch, c1 = std::min(nch, c0 + (u1 - u));
-        pb.push_back((int)(tile / d.ntl)); ptl.push_back((int)(tile % d.ntl)); pc0.push_back((int)c0); pc1.push_back((int)c1);
+        pb.push_back((int)(tile / d.nml)); ptl.push_back((int)(tile % d.nml)); pc0.push_back((int)c0); pc1.push_back((int)c1);
         u += c1 - c0;
       }
       wg[w + 1] = (int)pb.size();
     }
     npieces = (int)pb.size();
-    sy_tp.assign((size_t)batch * d.ntl + 1, 0);
-    for (int q = 0; q < npieces; q++) sy_tp[(size_t)pb[q] * d.ntl + ptl[q] + 1]++;
+    sy_tp.assign((size_t)batch * d.nml + 1, 0);
+    for (int q = 0; q < npieces; q++) sy_tp[(size_t)pb[q] * d.nml + ptl[q] + 1]++;
     for (size_t q = 0; q + 1 < sy_tp.size(); q++) sy_tp[q + 1] += sy_tp[q];  // pieces are generated in (problem, tile, chunk) order
     d.ks = nwg;
     if ((rc = upload_(st, &d.sy_wg, wg, err))) return rc;
@@ -1049,8 +1067,13 @@ int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::strin
   if ((rc = upload_(st, &d.dslot, P.dslot, err))) return rc;
   const size_t B = (size_t)batch;
   if ((rc = dalloc_(st, &d.Jd, B * d.mp * d.npj, err, true))) return rc;
+  if ((rc = dalloc_(st, &d.Jw, B * d.mp * d.npj, err, true))) return rc;
   if ((rc = dalloc_(st, &d.w, B * d.mp, err, true))) return rc;
-  if ((rc = dalloc_(st, &d.slab, (size_t)npieces * TT, err))) return rc;
+  if ((rc = dalloc_(st, &d.slab, (size_t)npieces * 4 * TT, err))) return rc;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(dn_syrk2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * MT * LDK * sizeof(double))) != hipSuccess) {
+    err = "hipFuncSetAttribute(dn_syrk2) failed";
+    return 4;
+  }
   if ((rc = dalloc_(st, &d.jxp, B * (d.npj / 32) * d.mp, err))) return rc;
   return 0;
 }
@@ -1085,10 +1108,13 @@ namespace {
 int enqueue_factor(DenseState* st, double eig_tol, hipStream_t stream, std::string& err) {
   const DnDev& d = st->d;
   const int B = (int)st->batch;
+  // (Round 3: the factorisations of different problems as parallel branches — streams forked and joined with events, parallel
+  //  branches of the graph — so that one problem's latency-bound panel overlaps the others' updates: measured at 8 problems
+  //  1.109 ms in lockstep, 1.090 with two branches, 1.175 with four, 1.45 with eight.  Not kept.)
   for (int k = 0; k < d.T; k++) {
-    hipLaunchKernelGGL(dn_panel, dim3((d.T + 2) / 3, B), dim3(256), 0, stream, d, k, eig_tol);
+    hipLaunchKernelGGL(dn_panel, dim3((d.T + 2) / 3, B), dim3(256), 0, stream, d, k, eig_tol, 0);
     const int nt = d.T - 1 - k, ntr = nt * (nt + 1) / 2 + (k + 1) * nt;
-    if (ntr > 0) hipLaunchKernelGGL(dn_update, dim3(4 * ntr, B), dim3(256), 0, stream, d, k);
+    if (ntr > 0) hipLaunchKernelGGL(dn_update, dim3(4 * ntr, B), dim3(256), 0, stream, d, k, 0);
   }
   DCHK(hipGetLastError());
   return 0;
@@ -1209,7 +1235,7 @@ int dense_enqueue(DenseState* st, int mode, double* vals, const double* rhs, dou
   int rc;
   if (mode != 2) {
     hipLaunchKernelGGL(dn_gather, dim3(std::min(2048, blocks((long long)d.m * d.n)), B), dim3(256), 0, stream, d, vals, eig_tol);
-    hipLaunchKernelGGL(dn_syrk, dim3(d.ks), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(dn_syrk2, dim3(d.ks), dim3(256), 2 * MT * LDK * sizeof(double), stream, d);
     hipLaunchKernelGGL(dn_assemble, dim3(d.nlt, B), dim3(256), 0, stream, d, vals);
     if ((rc = enqueue_factor(st, eig_tol, stream, err))) return rc;
     if (mode == 0)

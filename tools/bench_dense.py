@@ -11,6 +11,7 @@ def main():
     ap.add_argument("--m", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--opt", default="", help="cnl_options fields, key=value[,key=value]")
     args = ap.parse_args()
     import torch
     import cannoles_jl_amd  # noqa
@@ -26,7 +27,8 @@ def main():
     ro = torch.zeros(B, dtype=torch.float64, device=dev); rho = torch.zeros_like(ro)
     nf = torch.zeros(B, dtype=torch.int32, device=dev); ok = torch.zeros(B, dtype=torch.int32, device=dev)
     p = hipldl.default_params()
-    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    opts = hipldl.Options(**{k: int(v) for k, v in (kv.split("=") for kv in args.opt.split(","))}) if args.opt else None
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=opts)
     st = torch.cuda.Stream(device=dev)
     def step():
         hipldl.newton_system_dev(L, vals.data_ptr(), rhs.data_ptr(), d.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), ok.data_ptr(), p, st.cuda_stream)
