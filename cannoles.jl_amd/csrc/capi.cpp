@@ -974,7 +974,10 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     std::string derr;
     int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_syrk_wgs);
     if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
-  } else if (!h->plan->gpos.empty() && !h->use_v2 && batch <= 16) {
+  } else if (!h->plan->gpos.empty() && !h->use_v2 &&
+             // S0, S and G in 64 x 64 tiles per problem: small batches always, larger ones while the tiles stay below 8 GB
+             // (round 2 stopped at 16 problems; batches of small irregular systems then fell to the general kernel)
+             (batch <= 16 || (double)batch * 3.0 * 32768.0 * std::pow(std::ceil((double)h->plan->C.N2 / 64.0), 2) <= 8e9)) {
     std::string derr;
     const cnl::Cond& C2 = h->plan->C;
     h->gops.ns = (int32_t)C2.N2; h->gops.nv = (int32_t)nvar; h->gops.nslots = (int32_t)C2.ncs; h->gops.cstride = C2.cstride;
