@@ -6,11 +6,43 @@
 batched handle) or, in the tests, the CPU oracle.  The model object provides residual / jac_residual /
 hess_coord_residual / cons / jac / hess_coord_cons and the structure arrays (h_rows, h_cols, jF_rows, jF_cols,
 jc_rows, jc_cols, 1-based), like an NLPModels model does.  The Krylov CGLS call of the reference (min-norm
-least-squares multipliers, :512-518) is replaced by numpy's lstsq, which returns the same minimiser.  Logging,
+least-squares multipliers, :512-518) is the same CGLS recurrence in numpy (`cgls` below).  Logging,
 timing and callback plumbing are not restated.
 """
 import numpy as np
 
+
+
+def cgls(A, b, atol=None, rtol=None, itmax=0):
+    """CGLS for min ||A x - b|| started at 0 — the recurrence of Krylov.jl's `cgls` (the reference's multiplier estimate,
+    src/CaNNOLeS.jl:512-518, 880-882): stop when ||A' res|| <= atol + rtol ||A' b|| (defaults sqrt(eps)) or after m + n
+    steps.  Same recurrence as csrc/kernels_aux.hip (cnl_cgls_multipliers_dev), which the device-resident loop uses."""
+    eps = np.finfo(np.float64).eps
+    atol = np.sqrt(eps) if atol is None else atol
+    rtol = np.sqrt(eps) if rtol is None else rtol
+    m, n = A.shape
+    x = np.zeros(n)
+    res = np.asarray(b, float).copy()
+    s = A.T @ res
+    pdir = s.copy()
+    gamma = float(s @ s)
+    tol = atol + rtol * np.sqrt(gamma)
+    itmax = m + n if itmax <= 0 else itmax
+    it = 0
+    while it < itmax and np.sqrt(gamma) > tol:
+        q = A @ pdir
+        delta = float(q @ q)
+        if delta == 0.0:
+            break
+        alpha = gamma / delta
+        x += alpha * pdir
+        res -= alpha * q
+        s = A.T @ res
+        gnext = float(s @ s)
+        pdir = s + (gnext / gamma) * pdir
+        gamma = gnext
+        it += 1
+    return x
 
 def solve(nls, make_solver, newton_system, params, method="Newton", x=None, lam=None, max_iter=-1, max_eval=100000,
           max_inner=10000, atol=None, rtol=None, Fatol=None, Frtol=None, always_accept_extrapolation=False,
@@ -57,8 +89,8 @@ def solve(nls, make_solver, newton_system, params, method="Newton", x=None, lam=
     r = Fx.copy()
     Jxtr = Jx.T @ r
 
-    def ls_multipliers(rhs_vec):  # krylov_solve!(cgls, Jcx', Jxtr): min || Jcx' lam - rhs ||, min-norm
-        return np.linalg.lstsq(Jcx.T, rhs_vec, rcond=None)[0] if p else np.zeros(0)
+    def ls_multipliers(rhs_vec):  # krylov_solve!(cgls_workspace, Jcx', Jxtr): min || Jcx' lam - rhs || (src/CaNNOLeS.jl:512-518)
+        return cgls(Jcx.T, rhs_vec) if p else np.zeros(0)
 
     lam = ls_multipliers(Jxtr)
     if p and np.linalg.norm(lam) == 0:
