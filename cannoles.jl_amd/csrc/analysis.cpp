@@ -1129,7 +1129,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
     // The row form costs the same seven gathers and twenty atomic rounds whatever the front holds; the list form costs per
     // round of sixteen products (measured on cfg3's chain fronts, 208 products: 1.47 ms of the kernel as lists, 0.62 ms as
     // rows).  Fronts with fewer than five rounds of products — the small fronts of the bushy latency orders — keep the lists.
-    if (D && strided && prs.size() >= 72 && P.row_products) {
+    if (D && strided && (int64_t)prs.size() >= P.row_min_products && P.row_products) {
       struct Row { int32_t d; ivec m; int32_t r = -1; std::vector<std::array<int32_t, 3>> pr; };  // pr: (operand a, operand b, pos)
       std::vector<Row> rows;
       std::unordered_map<int32_t, int32_t> row_of;

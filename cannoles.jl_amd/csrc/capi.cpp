@@ -58,6 +58,7 @@ struct cnl_handle {
   int df_waves = 1024;
   std::vector<int32_t> stage_ptr;
   bool v2_solve = false;  // cnl_solve runs on the register-front kernel too (direct records, every front of the fast class)
+  bool lean = false;      // every front of the fast class with row-form (or no) products: the kernels' LEAN instantiation serves it
   cnl::DevPlan2 dp2{};
   int wpb2 = 1;
   size_t lds2 = 0;
@@ -261,11 +262,13 @@ int setup_v2(cnl_handle* h) {
     h->staged = true;
   }
   h->v2_solve = P.rec_direct && P.d_outer && P.ncls[1] == 0 && P.ncls[2] == 0 && !o.v1_solve;
+  h->lean = o.lean_kernel && P.rec_direct && P.d_outer && d.count_d && P.ncls[1] == 0 && P.ncls[2] == 0 && P.listprod_fronts == 0;
   return CNL_OK;
 }
 
 int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch;
+  a.lean = h->lean ? 1 : 0;
   a.L = h->d_L;
   a.scratch = h->d_scratch;
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));  // events bracket the multifrontal kernel only
@@ -287,6 +290,7 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch; a.L = h->d_L; a.scratch = h->d_gs;
   a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0; a.dep = h->d_dep; a.df_waves = h->df_waves;
+  a.lean = h->lean ? 1 : 0;
   a.status_total = h->d_status;
   a.status_call = h->d_dep ? h->d_dep + 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4) : nullptr;
   a.spin_limit = h->plan->opt.dataflow_spin_limit > 0 ? h->plan->opt.dataflow_spin_limit : (1 << 22);
@@ -656,7 +660,7 @@ void cnl_options_init(cnl_options* o) {
   o->multipliers_early = 1; o->condense = 1; o->direct_records = 1; o->register_front = 1; o->dense_backend = 1; o->general_dense = 1;
   o->staged = 1; o->dataflow = 1; o->dataflow_waves = 1024; o->dataflow_spin_limit = 1 << 22;
   o->waves_per_block = 0; o->v1_tpp = -1; o->v1_ppb = -1; o->v1_lds = -1; o->v1_solve = 0; o->lds_pad = 1;
-  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1;
+  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -758,7 +762,19 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
     const int32_t old_len = p->P.rec_maxlen;
     const size_t old_words = p->P.rec.size();
     p->P.row_products = o.row_products != 0;
+    p->P.row_min_products = 72;
     int drc = cnl::write_forward_records(p->P, &D);
+    // A plan whose fronts are ALL row-form runs the kernels' lean instantiation (10 % faster on chain-like orders), which is
+    // worth more than the few rounds a handful of small fronts save with product lists: when the list fronts are few, give
+    // them the row form as well.
+    if (!drc && o.row_products && o.lean_kernel && p->P.listprod_fronts > 0 && 8 * p->P.listprod_fronts <= p->P.rows_fronts) {
+      p->P.row_min_products = 1;
+      drc = cnl::write_forward_records(p->P, &D);
+      if (!drc && p->P.listprod_fronts > 0) {  // some front cannot take the row form: the lists' threshold again
+        p->P.row_min_products = 72;
+        drc = cnl::write_forward_records(p->P, &D);
+      }
+    }
     if (!drc) {
       // the backward records name the solution component of every pivot: switch them to the caller's numbering, so
       // that the kernel writes the kept components straight into `d` (no reduced solution vector, no copy pass)
@@ -1145,6 +1161,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   cfg[0] = h->cfg.tpp; cfg[1] = h->cfg.ppb; cfg[2] = (int64_t)h->cfg.lds_bytes; cfg[3] = h->cfg.lds_work;
   cfg[4] = (h->batch + h->cfg.ppb - 1) / h->cfg.ppb;
   cfg[5] = (h->dense || h->gdense) ? 3 : (h->use_v2 ? (h->staged ? 4 : 2) : 1);
+  if (h->lean && !h->dense && !h->gdense) cfg[5] |= 16;  // newton_system / factorize run the kernels' LEAN instantiation
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;
   return CNL_OK;

@@ -109,6 +109,7 @@ struct LaunchArgs {
   // A dataflow wait that gives up after spin_limit polls bumps both counters: status_total is sticky (cnl_dataflow_timeouts),
   // status_call is zeroed with `dep` at the start of every staged call and makes the classic launch behind the staged attempt
   // redo the whole batch sequentially (only_if_status: that launch exits at once when the attempt had no timeout)
+  int lean;              // 1: the plan qualifies for the kernels' LEAN instantiation (fast-class fronts, row-form products only)
   int* status_total;
   int* status_call;
   int spin_limit;

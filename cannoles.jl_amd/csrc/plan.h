@@ -110,6 +110,7 @@ struct Plan {
   bool rec_direct = false;
   int64_t d_owned = 0;   // number of condensed residual pivots staged (and counted) by the direct records
   bool row_products = true;   // direct records of fast fronts may use the row form (RF_ROWS)
+  int32_t row_min_products = 72;  // ... from this many products on (analysis.cpp); 1 when that makes the whole plan row-form (lean kernel)
   int32_t rows_fronts = 0, listprod_fronts = 0;  // fast fronts in row form / with product lists
   bool d_outer = false;  // backward records name solution components in the caller's numbering (set with rec_direct)
   int32_t nnz_outer = 0, n_outer = 0;  // outer (reference) nnz and N when rec_direct

@@ -52,7 +52,7 @@ class cnl_options(C.Structure):
             "order_mode", "nd_leaf", "relax", "task_cap", "multipliers_early", "condense", "direct_records", "register_front",
             "dense_backend", "general_dense", "staged", "dataflow", "dataflow_waves", "dataflow_spin_limit", "waves_per_block",
             "v1_tpp", "v1_ppb", "v1_lds", "v1_solve", "lds_pad", "ubig", "wait_thr", "dense_graph", "dense_syrk_wgs", "verbose",
-            "multi_share_plan", "row_products", "split_batch")] + [("force_order", C.c_char * 32)]
+            "multi_share_plan", "row_products", "split_batch", "lean_kernel")] + [("force_order", C.c_char * 32)]
 
 
 def Options(**kw):
@@ -248,7 +248,8 @@ class HIPLDLStruct:
         cfg = np.zeros(8, np.int64)
         _check(lib().cnl_get_config(h, cfg))
         self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4]),
-                       "kernel": {2: "v2", 3: "dense", 4: "v2-staged"}.get(int(cfg[5]), "v1"), "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7])}
+                       "kernel": {2: "v2", 3: "dense", 4: "v2-staged"}.get(int(cfg[5]) & 15, "v1"), "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7]),
+                       "lean": bool(int(cfg[5]) & 16)}
 
     def plan_array(self, name):
         return _plan_array(lib().cnl_get_plan(self._h), name)
@@ -266,6 +267,12 @@ class HIPLDLStruct:
 
     def set_timing(self, on=True):
         _check(lib().cnl_set_timing(self._h, 1 if on else 0))
+
+    def uses_lean_kernel(self):
+        """True when newton_system / factorize of this handle run the kernels' LEAN instantiation (cnl_get_config, cfg[5] bit 4)"""
+        cfg = np.zeros(8, np.int64)
+        _check(lib().cnl_get_config(self._h, cfg))
+        return bool(int(cfg[5]) & 16)
 
     def dataflow_timeouts(self):
         n = C.c_int64(0)

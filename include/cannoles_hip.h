@@ -101,6 +101,7 @@ typedef struct cnl_options {
   int32_t row_products;        /* 1: condensation products of small fronts organised per residual row (csrc/plan.h, RF_ROWS)    */
   int32_t split_batch;         /* 1: batches between one and two wavefronts per SIMD run partly on the bidirectional chain,
                                   partly single-stream, concurrently (csrc/capi.cpp, run_split)                                 */
+  int32_t lean_kernel;         /* 1: plans of fast-class row-form fronts run the kernels' instantiation without the cold paths  */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);
@@ -253,7 +254,8 @@ int cnl_last_kernel_ms(cnl_handle* h, float* ms);
 /* Kernel configuration actually chosen: cfg[0]=threads per problem, [1]=problems per workgroup,
  * [2]=LDS bytes per workgroup, [3]=1 if the work stack lives in LDS else 0 (global scratch),
  * [4]=grid size (those five describe the general kernel, kernels.hip), [5]=2 if the register-front
- * kernel (kernels2.hip) serves newton_system/factorize (4: with staged execution of the first attempt), 3 dense backend, else 1, [6]=its wavefronts per workgroup,
+ * kernel (kernels2.hip) serves newton_system/factorize (4: with staged execution of the first attempt), 3 dense backend, else 1;
+ * + 16 when newton_system / factorize run the LEAN instantiation (fast-class fronts with row-form products only), [6]=its wavefronts per workgroup,
  * [7]=its LDS bytes per workgroup.                                                              */
 int cnl_get_config(const cnl_handle* h, int64_t cfg[8]);
 

@@ -840,6 +840,41 @@ def test_dataflow_timeout_is_counted_and_recovered(built, B):
     L2.close()
 
 
+@pytest.mark.parametrize("lean", [1, 0])
+@pytest.mark.parametrize("B", [5, 44])
+@pytest.mark.parametrize("shape", [(600, 6, 2), (1000, 10, 2), (400, 0, 2)])
+def test_lean_and_full_instantiations_agree_with_the_oracle(built, shape, B, lean):
+    """Plans whose fronts are all fast-class row-form fronts run the kernels' LEAN instantiation (no MODE_SOLVE section, no
+    out-of-line front classes, no product lists: csrc/kernels2.hip); cnl_options.lean_kernel = 0 keeps the full one.  Both, on
+    throughput and latency plans, with a ladder problem and a hopeless one, against the oracle; solve_ldl! (which always runs the
+    full instantiation) must find the factor the lean one stored."""
+    hipldl, syn, O = _mods()
+    n, p, hw = shape
+    s = syn.band_structure(n, p, hw=hw)
+    rows, cols = s.kkt_pattern()
+    vals, rhs = syn.batch_values(s, B, cfg=3)
+    off = s.offsets()
+    vl, rl = syn.batch_values(s, B, cfg=5, stress="ladder")
+    vals[B - 2], rhs[B - 2] = vl[B - 2], rl[B - 2]
+    vals[1, off[0]:off[1]] = np.nan
+    for kind in (hipldl.PLAN_THROUGHPUT, hipldl.PLAN_LATENCY):
+        opts = hipldl.Options(plan_kind=kind, lean_kernel=lean)
+        info, cfg = run_case(s, vals, rhs, options=opts, check_fwd=False)
+        assert lean or not cfg["lean"]
+        if kind == hipldl.PLAN_THROUGHPUT and p > 0:   # chain-like order: every front in row form
+            assert cfg["lean"] == bool(lean)
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, lean_kernel=lean))
+    prm = hipldl.default_params()
+    good = [b for b in range(B) if b not in (1, B - 2)]
+    ok = hipldl.try_to_factorize(L, vals, s.nvar, s.nequ, s.ncon, prm[0])
+    assert all(ok[b] for b in good) and not ok[1]
+    d = np.zeros((B, s.N))
+    hipldl.solve_ldl_(rhs, L.factor, d)
+    for b in good[:6]:
+        assert backward_error(s, vals[b], rhs[b], d[b]) <= BWD_TOL
+    L.close()
+
+
 def test_split_batch_factorize_then_solve(built):
     """try_to_factorize + solve_ldl! (src/solver_types.jl:69-98) on a batch between one and two wavefronts per SIMD: the handle
     runs 4 x (2048 - groups) problems on the bidirectional chain and the rest single-stream, concurrently (run_split); both
