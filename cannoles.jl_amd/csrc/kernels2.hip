@@ -1486,7 +1486,9 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
   // (measured: 4096 problems in two tasks of 500 fronts 881 k -> 958 k systems/s; 256 problems in 32 tasks of 58 fronts
   //  462 k -> 436 k: short tasks lose — their L rows would mostly be flushed at the task's end, in front of the hand-over)
   const int ntask0 = stage_ptr[1] - stage_ptr[0];
-  const bool late = (long long)a.nquads * ntask0 >= 1536 && P.nsuper >= 128 * ntask0;
+  // (3 072 problems = 1.5 wavefronts per SIMD: 925 k systems/s with immediate stores against 819 k one front late;
+  //  4 096: 938 k against 966 k — late only when the first stage fills both slots of every SIMD)
+  const bool late = (long long)a.nquads * ntask0 >= 1920 && P.nsuper >= 128 * ntask0;
   const bool lean = a.lean != 0 && a.mode != MODE_SOLVE;
   auto kern = lean ? (late ? newton2_kernel_t<true, true, true> : newton2_kernel_t<true, false, true>)
                    : (late ? newton2_kernel_t<true, true, false> : newton2_kernel_t<true, false, false>);
