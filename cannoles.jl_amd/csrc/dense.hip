@@ -534,6 +534,10 @@ __global__ void __launch_bounds__(256) dn_update(DnDev D, int k, int b0) {
   update_block(At, Bt, Ct, czero, blk, threadIdx.x & 63);
 }
 
+// (Round 3: a workgroup-per-tile variant with both operand tiles staged in LDS once — a quarter of the operand traffic out of L2 —
+//  was built for batches: 18.7 us per step at 8 problems against 18.1 us for the kernel above.  One or two workgroups of 80 KB per
+//  CU serialise their load and multiply phases; the many small independent wavefronts of this kernel overlap them.  Not kept.)
+
 // ---------------------------------------------------------------------------------------------------------------------
 // inertia rule + first rung of the ladder state.  mode 0: newton, 1: factorize
 __global__ void __launch_bounds__(256) dn_decide(DnDev D, int batch, int mode, const double* __restrict__ rho_old, int32_t* success,
