@@ -381,6 +381,15 @@ __device__ __forceinline__ void eliminate16_dpp(int P_prob_doubles, int P_u2_pea
     double* Ul = pb + uoff;
     CNL_DPP_ROWS(CNL_DPP_USTL)
   }
+  // The image is dead: zero it for the NEXT front here (LDS executes a wavefront's operations in order), so that the next front
+  // starts with its extend-add instead of five stores and a barrier.  Behind the update-matrix store: its rows are written
+  // with all sixteen lanes and may run up to 15 doubles past the top of the stack, into the image.
+  {
+    double2* z2 = reinterpret_cast<double2*>(pb + P_u2_peak) + b;
+#pragma unroll
+    for (int j = 0; j < 4; j++) z2[16 * j] = make_double2(0.0, 0.0);
+    if (b < FAST_IMG_DOUBLES / 2 - 64) z2[64] = make_double2(0.0, 0.0);
+  }
 }
 CNL_DEFINE_ELIM(eliminate16g, __attribute__((noinline)), 16, true, CNL_ALL16, CNL_REV16, CNL_STEPS16, CNL_LOAD)
 CNL_DEFINE_ELIM(eliminate32, __attribute__((noinline)), 32, false, CNL_ALL32, CNL_REV32, CNL_STEPS32, CNL_LOAD)
@@ -1053,6 +1062,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         else PREFETCH_RAW(recw, aoff0 + 2 * nasm0, HDRW(hv0, R_NRD) >> 16, HDRW(hv0, R_NRAW))
       }
       bool more = true;
+      bool img_clean = false;  // the staging image is known to be all zeros
       while (more) {
       if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }  // children's update matrices are read below
       const int* rec = recw;
@@ -1067,13 +1077,15 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       const int f = 1 + nupd + npiv;
       const bool uglob = flags & RF_U_GLOBAL;
       // (1) zero the staging image (packed triangle + padding slots = 152 doubles = 76 pairs: no loop; the fifth round covers 12)
-      {
+      //     — only at the start of a stretch of fast fronts: inside it the previous front's elimination left the image zeroed
+      if (!img_clean) {
         double2* z2 = reinterpret_cast<double2*>(myFs) + l;
 #pragma unroll
         for (int j = 0; j < 4; j++) z2[16 * j] = make_double2(0.0, 0.0);
         if (l < FAST_IMG_DOUBLES / 2 - 64) z2[64] = make_double2(0.0, 0.0);
+        wsync();
       }
-      wsync();
+      img_clean = !(CNL_ABL & 1024);
       // (2) extend-add the children's update matrices: needs nothing from global memory, so the stores of the
       //     previous front (L rows) retire behind it before the prefetched values are waited for
       {
