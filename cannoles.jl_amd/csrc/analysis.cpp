@@ -1314,4 +1314,100 @@ int write_forward_records(Plan& P, const DirectLists* D) {
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+int write_backward_rows(Plan& P, const BackRowsIn& in) {
+  const int32_t ns = P.nsuper;
+  if (!P.rec_direct || P.rec.empty() || P.brec.empty() || in.ncond <= 0) return 1;
+  // elimination position of every local row of every front (parents first: update rows are named by the parent's rows)
+  std::vector<std::array<int32_t, 17>> glob(ns);
+  for (int32_t s = ns - 1; s >= 0; s--) {
+    const FrontHdr& F = P.fronts[s];
+    const int32_t f = 1 + F.nupd + F.npiv;
+    if (f > 17) return 1;
+    glob[s].fill(-1);
+    for (int32_t i = F.nupd + 1; i < f; i++) glob[s][i] = F.first_piv + (f - 1 - i);
+    for (int32_t l = 1; l <= F.nupd; l++) {
+      if (F.parent < 0) return 1;
+      const int32_t pl = P.rel_idx[F.rel_begin + l];
+      if (pl < 1 || pl > 16) return 1;
+      glob[s][l] = glob[F.parent][pl];
+    }
+  }
+  std::unordered_map<int32_t, int32_t> row_of_d;  // pivot source -> condensed row
+  for (int32_t q = 0; q < in.ncond; q++) row_of_d[in.r_dsrc[q]] = q;
+  std::vector<ivec> sec(ns);
+  std::vector<int32_t> nown(ns, 0);
+  std::vector<char> covered(in.ncond, 0);
+  int64_t ncov = 0;
+  size_t r0 = 0;
+  for (int32_t s = 0; s < ns; s++) {
+    const int32_t* H = P.rec.data() + r0;
+    const FrontHdr& F = P.fronts[s];
+    const int32_t f = 1 + F.nupd + F.npiv;
+    const int32_t flags = H[R_FLAGS];
+    if ((flags >> 8) != 16 || (flags & RF_FS_GLOBAL)) return 1;
+    ivec& S = sec[s];
+    S.assign(BROWS_WORDS, 0);
+    for (int32_t l = 0; l < 16; l++) {
+      S[16 * (ROWS_KM + 1) + l] = P.nnz_outer;  // right-hand side entry 0
+      S[16 * (ROWS_KM + 2) + l] = 0x11111;      // operands that do not exist: local index 1 (a finite x), coefficient 0
+    }
+    int32_t rows_own = 0;
+    if (flags & RF_ROWS) {
+      rows_own = H[R_NPROD] >> 16;
+      const int32_t* rs = H + H[R_ASM_OFF] + 2 * H[R_NASM];
+      if (H[R_NRAW] != ROWS_WORDS || rows_own > 16) return 1;
+      for (int32_t l = 0; l < rows_own; l++) {
+        auto it = row_of_d.find(rs[l]);
+        if (it == row_of_d.end()) return 1;
+        const int32_t q = it->second;
+        if (covered[q]) return 1;
+        const int32_t k0 = in.r_ptr[q], k1 = in.r_ptr[q + 1];
+        if (k1 - k0 > ROWS_KM) return 1;
+        int32_t iw = ((k1 - k0) << 20) | (1 << 23) | 0x11111;
+        S[l] = in.r_dsrc[q];
+        for (int32_t k = k0; k < k1; k++) {
+          const int32_t pos = P.iperm[in.r_jx[k]];
+          int32_t li = -1;
+          for (int32_t t = 1; t < f; t++) if (glob[s][t] == pos) { li = t; break; }
+          if (li < 0) return 1;  // a column of the row outside the front that owns it
+          S[16 * (1 + (k - k0)) + l] = in.r_jsrc[k];
+          iw = (iw & ~(15 << (4 * (k - k0)))) | (li << (4 * (k - k0)));
+        }
+        S[16 * (ROWS_KM + 1) + l] = P.nnz_outer + in.r_orig[q];
+        S[16 * (ROWS_KM + 2) + l] = iw;
+        covered[q] = 1;
+        ncov++;
+      }
+    } else if ((H[R_NPROD] & 0xffff) != 0) return 1;  // products in list form: the lean kernel does not take this plan anyway
+    nown[s] = rows_own;
+    r0 += (size_t)H[R_RECLEN];
+  }
+  if (ncov != in.ncond) return 1;
+  // rebuild the backward stream (reverse post-order) with the sections
+  ivec br;
+  br.reserve(P.brec.size() + (size_t)ns * BROWS_WORDS);
+  int32_t maxlen = 0;
+  size_t b0 = 0;
+  for (int32_t s = ns - 1; s >= 0; s--) {
+    const int32_t len = P.brec[b0 + B_RECLEN];
+    const int32_t f = 1 + P.brec[b0 + B_NUPD] + P.brec[b0 + B_NPIV];
+    const int32_t roff = (B_HDR + f + 3) & ~3;
+    if (len != roff || (P.brec[b0 + B_CLS] >> 8) != 0) return 1;
+    const size_t n0 = br.size();
+    br.insert(br.end(), P.brec.begin() + b0, P.brec.begin() + b0 + len);
+    br.insert(br.end(), sec[s].begin(), sec[s].end());
+    br[n0 + B_RECLEN] = roff + BROWS_WORDS;
+    br[n0 + B_CLS] |= B_ROWS_FLAG | (nown[s] << 16);
+    maxlen = std::max(maxlen, roff + (int32_t)BROWS_WORDS);
+    b0 += (size_t)len;
+  }
+  P.brec.swap(br);
+  P.brec_maxlen = maxlen;
+  P.back_rows = true;
+  finalize_tasks(P);
+  return 0;
+}
+
 }  // namespace cnl

@@ -269,6 +269,7 @@ int setup_v2(cnl_handle* h) {
 int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch;
   a.lean = h->lean ? 1 : 0;
+  a.back_rows = (h->lean && h->plan->P.back_rows) ? 1 : 0;
   a.L = h->d_L;
   a.scratch = h->d_scratch;
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));  // events bracket the multifrontal kernel only
@@ -291,6 +292,7 @@ int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.batch = (int)h->batch; a.L = h->d_L; a.scratch = h->d_gs;
   a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0; a.dep = h->d_dep; a.df_waves = h->df_waves;
   a.lean = h->lean ? 1 : 0;
+  a.back_rows = (h->lean && h->plan->P.back_rows) ? 1 : 0;
   a.status_total = h->d_status;
   a.status_call = h->d_dep ? h->d_dep + 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4) : nullptr;
   a.spin_limit = h->plan->opt.dataflow_spin_limit > 0 ? h->plan->opt.dataflow_spin_limit : (1 << 22);
@@ -486,8 +488,11 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
         if (rc) return rc;
         if (h->timing) HIPCHK(hipEventRecord(h->ev1, stream));
       } else if ((rc = launch(h, a, stream))) return rc;
-      e = cnl::launch_expand(h->dc, d_vals, d_rhs, d_outer ? nullptr : h->d_d2, h->d_cbuf, d_d, a.success, 0, B, stream);
-      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
+      // (the lean instantiation has recovered the residual components in its backward sweep: plan.h, B_ROWS_FLAG)
+      if (!(h->lean && h->plan->P.back_rows)) {
+        e = cnl::launch_expand(h->dc, d_vals, d_rhs, d_outer ? nullptr : h->d_d2, h->d_cbuf, d_d, a.success, 0, B, stream);
+        if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
+      }
     } else if (direct && a.mode == cnl::MODE_FACTOR) {
       if (!count_d) {
         e = cnl::launch_cond_inertia(h->dc, d_vals, h->d_xpos, h->d_xzer, a.params[0], B, stream);
@@ -660,7 +665,7 @@ void cnl_options_init(cnl_options* o) {
   o->multipliers_early = 1; o->condense = 1; o->direct_records = 1; o->register_front = 1; o->dense_backend = 1; o->general_dense = 1;
   o->staged = 1; o->dataflow = 1; o->dataflow_waves = 1024; o->dataflow_spin_limit = 1 << 22;
   o->waves_per_block = 0; o->v1_tpp = -1; o->v1_ppb = -1; o->v1_lds = -1; o->v1_solve = 0; o->lds_pad = 1;
-  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1;
+  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -789,6 +794,13 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
       }
       p->P.d_outer = true;
       cnl::finalize_tasks(p->P);  // the records moved
+      // plans the lean kernel takes: the residual components of the rows a front owns are recovered in its backward step
+      if (o.lean_kernel && o.rows_in_backward && p->P.ncls[1] == 0 && p->P.ncls[2] == 0 && p->P.listprod_fronts == 0) {
+        const cnl::Cond& Cc = p->C;
+        cnl::BackRowsIn in{Cc.r_orig.data(), Cc.r_dsrc.data(), Cc.r_ptr.data(), Cc.r_jsrc.data(), Cc.r_jx.data(), (int32_t)Cc.r_orig.size()};
+        const int brc = cnl::write_backward_rows(p->P, in);
+        if (verbose) fprintf(stderr, "[cnl] backward rows: %s\n", brc ? "not possible" : "ok");
+      }
     } else {
       p->P.tasks.clear();  // staged execution needs the direct records
     }

@@ -110,6 +110,7 @@ struct LaunchArgs {
   // status_call is zeroed with `dep` at the start of every staged call and makes the classic launch behind the staged attempt
   // redo the whole batch sequentially (only_if_status: that launch exits at once when the attempt had no timeout)
   int lean;              // 1: the plan qualifies for the kernels' LEAN instantiation (fast-class fronts, row-form products only)
+  int back_rows;         // 1: (lean) the backward records carry the rows sections (plan.h, B_ROWS_FLAG): no post-pass behind the launch
   int* status_total;
   int* status_call;
   int spin_limit;

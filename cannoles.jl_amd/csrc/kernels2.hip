@@ -668,6 +668,21 @@ static_assert(PVR == ROWS_KM + 1, "the raw-value prefetch registers double as th
     prr[0] = GATHER_R(src_[ROWS_KM + 1]);                                              \
     prr[1] = 0.0;                                                                      \
   }
+// Backward rows (plan.h, B_ROWS_FLAG): lane l gathers the operands of residual row l of the front whose record is RECP — pivot,
+// ROWS_KM Jacobian entries, right-hand-side entry — one front ahead, like the panel rows.  ON == 0 (records without the
+// sections): every source reads entry 0 and the index word names no row.  Operands a row does
+// not have carry local index 1 (a finite x) and get the coefficient 0.
+#define PREFETCH_BACKROWS(DST, IXW, RSRC, RECP, ROFF, ON)                              \
+  {                                                                                    \
+    const int* sp_ = (RECP) + (ROFF) + l;                                              \
+    int src_[ROWS_KM + 3];                                                             \
+    _Pragma("unroll") for (int j = 0; j < ROWS_KM + 3; j++) src_[j] = (ON) ? sp_[j * 16] : 0; \
+    if (!(ON)) { src_[ROWS_KM + 1] = P.nnz; src_[ROWS_KM + 2] = 0x11111; }             \
+    _Pragma("unroll") for (int j = 0; j < ROWS_KM + 1; j++) DST[j] = GATHER_V(src_[j]); \
+    DST[ROWS_KM + 1] = GATHER_R(src_[ROWS_KM + 1]);                                    \
+    IXW = src_[ROWS_KM + 2];                                                           \
+    RSRC = src_[ROWS_KM + 1] - P.nnz;                                                  \
+  }
 // image position of pair K (compile-time) out of the lane's position words
 #define ROW_POS(PW, K) (((unsigned)(PW)[(K) >> 2] >> (8 * ((K) & 3))) & 255u)
 
@@ -1345,6 +1360,11 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     // put its whole round trip on the critical path of front s + 1
     int ipend = -1;
     double dpend = 0.0;
+    // (lean) operands of the residual rows the CURRENT front owns, prefetched one front ahead; their store is deferred too
+    const bool brows = CNL_LEAN && A.back_rows != 0;
+    double bpv[ROWS_KM + 2];
+    int bix = 0, brs = 0, ipend2 = -1;
+    double dpend2 = 0.0;
     int s = 0;
     while (s < nfr) {
       int* recw = recbuf + (s & 1) * P.breccap;
@@ -1357,6 +1377,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const int hb0 = recw[lane & 7];
         const int nupd0 = HDRW(hb0, B_NUPD), npiv0 = HDRW(hb0, B_NPIV);
         const long long lp0 = (long long)HDRW(hb0, B_LPTR_LO) | ((long long)HDRW(hb0, B_LPTR_HI) << 31);
+        if constexpr (CNL_LEAN) PREFETCH_BACKROWS(bpv, bix, brs, recw, (B_HDR + 1 + nupd0 + npiv0 + 3) & ~3, brows)
         PREFETCH_ROWS(lr, lp0, nupd0, npiv0)
         primed = true;
       }
@@ -1364,7 +1385,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       const int* rec = recw;
       const int hb = rec[lane & 7];
       const int npiv = HDRW(hb, B_NPIV), nupd = HDRW(hb, B_NUPD), xoff = HDRW(hb, B_XOFF), pxoff = HDRW(hb, B_PXOFF);
-      const int cls = HDRW(hb, B_CLS);
+      const int cls = HDRW(hb, B_CLS) & 255;
       const long long lptr = (long long)HDRW(hb, B_LPTR_LO) | ((long long)HDRW(hb, B_LPTR_HI) << 31);
       const int f = 1 + nupd + npiv;
       if (!CNL_LEAN && cls != 16) {
@@ -1390,6 +1411,8 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       }
       // next record into the other buffer, then prefetch the record after it and the next front's panel rows
       double lrn[KB];
+      double bpvn[ROWS_KM + 2];
+      int bixn = 0, brsn = 0;
       int nboff = nxt;
       if (s + 1 < nfr) {
         int* nrec = recbuf + ((s + 1) & 1) * P.breccap;
@@ -1403,13 +1426,19 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         for (int w4 = 64 + lane; w4 * 4 < nlen; w4 += 64) reinterpret_cast<int4*>(nrec)[w4] = bstream[(nxt >> 2) + w4];
         wsync();
         if (ipend >= 0) { mydout[ipend] = dpend; ipend = -1; }   // the previous front's solution components (see above)
+        if constexpr (CNL_LEAN) if (ipend2 >= 0) { mydout[ipend2] = dpend2; ipend2 = -1; }
         const int nn = nxt + nlen;
         Rb = bstream[(nn >> 2) + lane];
         nxt = nn;
+        if constexpr (CNL_LEAN) PREFETCH_BACKROWS(bpvn, bixn, brsn, nrec, (B_HDR + 1 + nupd1 + npiv1 + 3) & ~3, brows)
         PREFETCH_ROWS(lrn, lp1, nupd1, npiv1)
       } else {
 #pragma unroll
         for (int k = 0; k < KB; k++) lrn[k] = lr[k];
+        if constexpr (CNL_LEAN) {
+#pragma unroll
+          for (int k = 0; k < ROWS_KM + 2; k++) bpvn[k] = bpv[k];
+        }
       }
       // x of the update rows from the parent's vector (in place when this front reuses the parent's slot).
       // Lane l keeps x of local row l; rows not known yet hold 0, so the dot product of a pivot row needs no lane
@@ -1440,12 +1469,31 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       dpend = -xb;
       if (l >= 1 && l < f) xs[xoff + l] = xb;
       wsync();
+      if constexpr (CNL_LEAN) {
+        // residual components of the rows this front owns: d_r = (sum_p J_p x[l_p] - rhs_r) / d_r with x of the front's own
+        // vector (every column of an owned row is a row of this front)
+        const double* xf = xs + xoff;
+        const int nm = (bix >> 20) & 7;
+        double sacc = -bpv[ROWS_KM + 1];
+#pragma unroll
+        for (int p_ = 0; p_ < ROWS_KM; p_++) {
+          const double cf = p_ < nm ? bpv[1 + p_] : 0.0;
+          sacc = fma(cf, xf[(bix >> (4 * p_)) & 15], sacc);
+        }
+        if (ipend2 >= 0) mydout[ipend2] = dpend2;
+        ipend2 = (okme && (bix & (1 << 23))) ? brs : -1;
+        dpend2 = fast_div(sacc, bpv[0]);
+#pragma unroll
+        for (int k = 0; k < ROWS_KM + 2; k++) bpv[k] = bpvn[k];
+        bix = bixn; brs = brsn;
+      }
 #pragma unroll
       for (int k = 0; k < KB; k++) lr[k] = lrn[k];
       boff = nboff;
       s++;
     }
     if (ipend >= 0) mydout[ipend] = dpend;
+    if constexpr (CNL_LEAN) if (ipend2 >= 0) mydout[ipend2] = dpend2;
   }
 #ifdef CNL_STAMPS
   STAMP(6)

@@ -112,6 +112,7 @@ struct Plan {
   bool row_products = true;   // direct records of fast fronts may use the row form (RF_ROWS)
   int32_t row_min_products = 72;  // ... from this many products on (analysis.cpp); 1 when that makes the whole plan row-form (lean kernel)
   int32_t rows_fronts = 0, listprod_fronts = 0;  // fast fronts in row form / with product lists
+  bool back_rows = false;  // the backward records recover the condensed residual components themselves (write_backward_rows)
   bool d_outer = false;  // backward records name solution components in the caller's numbering (set with rec_direct)
   int32_t nnz_outer = 0, n_outer = 0;  // outer (reference) nnz and N when rec_direct
   // staged execution (empty: the plan runs as one sequential stream per group of four problems)
@@ -130,6 +131,11 @@ struct DirectLists {
 // (Re)writes P.rec.  D == nullptr: sources are the condensed buffer's slots.  Returns 0, or 1 when the plan
 // cannot be expressed with direct records (then P.rec is left in the indirect form).
 int write_forward_records(Plan& P, const DirectLists* D);
+// Appends the backward-rows sections to P.brec (see B_ROWS_FLAG) from the row-form forward records and the condensed rows'
+// Jacobian lists (condense.h: r_orig, r_dsrc, r_ptr, r_jsrc, r_jx; ncond rows).  Returns 0 and sets P.back_rows, or 1 (P.brec
+// untouched) when some front is not in row form or some row is not covered.
+struct BackRowsIn { const int32_t *r_orig, *r_dsrc, *r_ptr, *r_jsrc, *r_jx; int32_t ncond; };
+int write_backward_rows(Plan& P, const BackRowsIn& in);
 
 // record layouts shared by analysis.cpp (writer) and kernels2.hip (reader)
 enum {
@@ -155,6 +161,13 @@ enum { C_UOFF = 0, C_TUC, C_FLAGS, C_PAD, C_HDR = 4 };
 // brings the LDS need of a wavefront from 16.8 to 12.7 KB: twelve wavefronts per CU instead of nine.)
 enum { FAST_IMG_TRI = 136, FAST_IMG_DOUBLES = 152 };
 enum { B_NPIV = 0, B_NUPD, B_RECLEN, B_XOFF, B_PXOFF, B_LPTR_LO, B_LPTR_HI, B_CLS, B_HDR = 8 };
+// Backward rows (write_backward_rows): the residual components of the condensed rows a front OWNS are recovered inside the
+// backward sweep, right behind the front's own solution components — every column of such a row belongs to the front (the row
+// is a clique whose first column is a pivot here), so  d_r = (sum_p J_p x[l_p] - rhs_r) / d_r  needs nothing but the front's x.
+// B_CLS then carries  cls | B_ROWS_FLAG | rows << 16  and the record ends with a section of BROWS_WORDS words at
+// (B_HDR + f + 3) & ~3:  [16 pivot sources][ROWS_KM x 16 Jacobian sources][16 right-hand-side sources (>= nnz)][16 index words:
+// nibble p = local index of operand p's column, bits 20..22 = number of operands, bit 23 = the lane holds a row].
+enum { B_ROWS_FLAG = 256, BROWS_WORDS = 16 * (ROWS_KM + 3) };
 enum { B_PX_NONE = -1, B_PX_GLOBAL = -2 };  // B_PXOFF: no parent / parent solved by another task: the update rows name solution components
 
 // Builds the plan.  rows1/cols1: 1-based COO of the lower triangle, duplicates

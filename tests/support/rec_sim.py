@@ -19,6 +19,7 @@ ROWS_PW = (ROWS_NPAIR + 3) // 4
 ROWS_WORDS = 16 * (1 + ROWS_KM + 1 + ROWS_PW)
 B_NPIV, B_NUPD, B_RECLEN, B_XOFF, B_PXOFF, B_LPTR_LO, B_LPTR_HI, B_CLS = range(8)
 B_HDR = 8
+B_ROWS_FLAG, BROWS_WORDS = 256, 16 * (ROWS_KM + 3)   # plan.h: residual rows recovered by the backward records
 
 
 def tri(i):
@@ -161,7 +162,34 @@ class RecSim:
                 k += 1
         self.stats["raw"] += nraw
 
-    def backward(self, L, n_out):
+    def _back_rows(self, br, off, H, f, x, d, vals, rhs):
+        """B_ROWS_FLAG (plan.h): lane l recovers the residual component of row l the front owns from the front's own x"""
+        clsw = int(H[B_CLS])
+        if not clsw & B_ROWS_FLAG:
+            return 0
+        assert vals is not None, "the backward records recover residual components: vals / rhs needed"
+        roff = (B_HDR + f + 3) & ~3
+        assert int(H[B_RECLEN]) == roff + BROWS_WORDS
+        sec = br[off + roff: off + roff + BROWS_WORDS]
+        nrows = clsw >> 16
+        for l in range(16):
+            iw = int(sec[16 * (ROWS_KM + 2) + l])
+            assert bool(iw & (1 << 23)) == (l < nrows)
+            if l >= nrows:
+                continue
+            nm = (iw >> 20) & 7
+            dsrc, rsrc = int(sec[l]), int(sec[16 * (ROWS_KM + 1) + l])
+            assert dsrc < self.nnz <= rsrc
+            acc = -rhs[rsrc - self.nnz]
+            for p in range(nm):
+                li = (iw >> (4 * p)) & 15
+                assert 1 <= li < f
+                acc += vals[int(sec[16 * (1 + p) + l])] * x[li]
+            assert np.isnan(d[rsrc - self.nnz]), "residual component written twice"
+            d[rsrc - self.nnz] = acc / vals[dsrc]
+        return nrows
+
+    def backward(self, L, n_out, vals=None, rhs=None):
         """d = -x from the factor storage (z = D^-1 L^-1 b sits in column 0 of the panels)."""
         br = self.brec
         d = np.full(n_out, np.nan)
@@ -183,6 +211,7 @@ class RecSim:
                 d[int(idx[i])] = -x[i]
             for l in range(1, f):
                 xs[xoff + l] = x[l]
+            self._back_rows(br, off, H, f, x, d, vals, rhs)
             off += int(H[B_RECLEN])
         return d
 
@@ -347,5 +376,6 @@ class StagedSim(RecSim):
                         d[int(idx[i])] = -x[i]
                     for l in range(1, f):
                         xs[xoff + l] = x[l]
+                    self._back_rows(br, boff, H, f, x, d, vals, rhs)
                     boff += int(H[B_RECLEN])
         return d, int(npos), int(nzer)

@@ -1226,4 +1226,40 @@ def test_random_structures_mid_size_batches(built, seed, B):
     # the general kernel itself stays covered
     if B == 96:
         _, cfg1 = run_case(s, vals[:24], rhs[:24], options=hipldl.Options(general_dense=0))
-        assert cfg1["kernel"] == "v1"
+        assert cfg1["kernel"] == "v1"@pytest.mark.gpu
+@pytest.mark.parametrize("B", [5, 300])
+def test_residual_components_in_the_backward_sweep(built, B):
+    """Lean plans recover the residual components d_r inside the backward sweep (csrc/plan.h, B_ROWS_FLAG: the front that owns a
+    condensed row holds all its columns) instead of in a post-pass; cnl_options.rows_in_backward = 0 keeps the post-pass.
+    Both against the oracle, throughput and latency plans, general residual pivots d_r (not the reference's -1), a ladder problem
+    and a hopeless one whose d must stay untouched; the two executions must agree to rounding."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(600, 6)
+    rows, cols = s.kkt_pattern()
+    vals, rhs = syn.batch_values(s, B, cfg=3)
+    off = s.offsets()
+    rng = np.random.default_rng(11)
+    vals[:, off[4]:off[5]] = -rng.uniform(0.5, 2.0, (B, s.nequ))
+    vl, rl = syn.batch_values(s, B, cfg=5, stress="ladder")
+    vals[B - 2], rhs[B - 2] = vl[B - 2], rl[B - 2]
+    vals[1, off[0]:off[1]] = np.nan
+    for kind in (hipldl.PLAN_THROUGHPUT, hipldl.PLAN_LATENCY):
+        out = {}
+        for rib in (1, 0):
+            opts = hipldl.Options(plan_kind=kind, rows_in_backward=rib)
+            info, cfg = run_case(s, vals, rhs, options=opts, check_fwd=False)
+            L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=opts)
+            assert bool(L.plan_array("brec")[7] & 256) == (bool(rib) and cfg["lean"])
+            d = np.full((B, s.N), 7.0)
+            d, ok, rho, rho_old, nfact = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, np.zeros(B), hipldl.default_params())
+            assert not ok[1] and (d[1] == 7.0).all()
+            out[rib] = d
+            L.close()
+        if kind == hipldl.PLAN_THROUGHPUT:
+            assert cfg["lean"]
+        good = [b for b in range(B) if b != 1]
+        scale = np.abs(out[0][good]).max(axis=1, keepdims=True)
+        assert (np.abs(out[1][good] - out[0][good]) / scale).max() <= 1e-12
+
+
+

@@ -183,7 +183,7 @@ def test_record_streams_reproduce_the_oracle(shape):
     assert sim.stats["products"] > 0 and sim.stats["raw"] > 0
     if p == 50:
         assert sim.stats["packed"] > 0  # large fronts: packed staging, two-word products
-    d = sim.backward(L, s.N)
+    d = sim.backward(L, s.N, vals, rhs)
     perm = plan.array("perm").astype(np.int64)
     orc = O.Oracle(s.N, rows, cols, perm)
     ok, pos0, zer0 = orc.try_to_factorize(vals, s.nvar, s.nequ, s.ncon, eig_tol, return_inertia=True)
@@ -193,7 +193,14 @@ def test_record_streams_reproduce_the_oracle(shape):
     assert sim.own_pos == int((dr > eig_tol).sum()) and sim.own_zer == int((np.abs(dr) <= eig_tol).sum())  # ... which counts it
     assert npos + sim.own_pos == pos0 and nzer + sim.own_zer == zer0
     kept = ~np.isnan(d)
-    assert kept.sum() == s.N - s.nequ and not kept[s.nvar:s.nvar + s.nequ].any()
+    # plans the lean kernel takes recover the residual components in the backward records (all of them or none)
+    back_rows = bool(plan.array("brec")[7] & 256)
+    if shape in ((200, 4, 2), (600, 6, 1)):
+        assert back_rows   # (rows of more than five entries or fronts of more than 16 rows keep the product lists and the post-pass)
+    if back_rows:
+        assert kept.all()
+    else:
+        assert kept.sum() == s.N - s.nequ and not kept[s.nvar:s.nvar + s.nequ].any()
     assert np.abs(d[kept] - d0[kept]).max() <= 1e-10 * np.abs(d0).max()
 
 
@@ -226,5 +233,5 @@ def test_staged_plans_reproduce_the_oracle(shape):
         d, npos, nzer = sim.run(vals, rhs, eig_tol, s.N, reverse=reverse, dataflow=dataflow)
         assert (npos, nzer) == (pos0, zer0)
         kept = ~np.isnan(d)
-        assert kept.sum() == s.N - s.nequ
+        assert kept.sum() == (s.N if plan.array("brec")[7] & 256 else s.N - s.nequ)
         assert np.abs(d[kept] - d0[kept]).max() <= 1e-10 * np.abs(d0).max()
