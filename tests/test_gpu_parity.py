@@ -1226,7 +1226,10 @@ def test_random_structures_mid_size_batches(built, seed, B):
     # the general kernel itself stays covered
     if B == 96:
         _, cfg1 = run_case(s, vals[:24], rhs[:24], options=hipldl.Options(general_dense=0))
-        assert cfg1["kernel"] == "v1"@pytest.mark.gpu
+        assert cfg1["kernel"] == "v1"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [5, 300])
 def test_residual_components_in_the_backward_sweep(built, B):
     """Lean plans recover the residual components d_r inside the backward sweep (csrc/plan.h, B_ROWS_FLAG: the front that owns a
