@@ -247,6 +247,10 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_src,
                      "measured_hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                      "bytes_per_system": b_alg, "nnzL_star": nnzL_star, "kernel_ms": kern_ms, "kernel": "newton2_kernel",
+                     "kernel_is_whole_step": bool(LDLT.config.get("lean")) and bool(LDLT.plan_array("brec")[7] & 256),
+                     "note": "since round 3 the lean kernel recovers the residual components in its backward sweep: no post-pass, kernel_ms == step_ms; "
+                             "rounds 1-2 (and round 3 before that change) priced a kernel that left 1.2 ms of the step to a second kernel on the same algorithmic bytes "
+                             "(their step_frac is the comparable figure)",
                      "step_ms": step_ms, "step_frac": b_alg * B / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
     }
     extras = (not args.no_extras) and world == 1 and not args.strong

@@ -107,10 +107,15 @@ __device__ __forceinline__ double fast_div(double w, double d) {
   return fma(res, r, q);
 }
 
+#ifndef CNL_DPP_BC
+#define CNL_DPP_BC true
+#endif
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  // bound_ctrl: every lane of a row rotation reads a valid lane, so the destination needs no initial value (the compiler
+  // emitted a v_mov 0 in front of every DPP move otherwise: 8 of the 24 instructions of a 16-lane sum)
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, CNL_DPP_BC);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, CNL_DPP_BC);
   return __hiloint2double(hi, lo);
 }
 
@@ -601,12 +606,15 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
 // rows past the last pivot read finite data that is never used (the factor storage is zero-padded).
 // Same addressing as the forward gathers (wave-uniform base + 32-bit byte offset); rows past the last pivot are
 // not loaded.
+#ifndef CNL_DBG_LSTRIDE0   // timing probe: every problem reads problem 0's factor in the solve sweeps (cache hits; wrong results)
+#define CNL_DBG_LSTRIDE0 0
+#endif
 #define PREFETCH_ROWS(DST, LPTR, NUPD, NPIV)                                           \
   {                                                                                    \
-    const char* rb_ = L_wb + ((long long)(LPTR) << 3);                                 \
-    unsigned ro_ = gofs_l;                                                             \
+    const char* rb_ = CNL_DBG_LSTRIDE0 ? reinterpret_cast<const char*>(A.L) + ((long long)(LPTR) << 3) : L_wb + ((long long)(LPTR) << 3); \
+    unsigned ro_ = CNL_DBG_LSTRIDE0 ? (unsigned)l * 8u : gofs_l;                       \
     _Pragma("unroll") for (int k = 0; k < KB; k++) {                                   \
-      if (k < (NPIV)) DST[k] = *reinterpret_cast<const double*>(rb_ + ro_); else DST[k] = 0.0; \
+      if (k < (NPIV) && !(CNL_ABL & 16384)) DST[k] = *reinterpret_cast<const double*>(rb_ + ro_); else DST[k] = 0.0; \
       ro_ += (unsigned)((NUPD) + 2 + k) << 3;                                          \
     }                                                                                  \
   }
@@ -1361,7 +1369,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     int ipend = -1;
     double dpend = 0.0;
     // (lean) operands of the residual rows the CURRENT front owns, prefetched one front ahead; their store is deferred too
-    const bool brows = CNL_LEAN && A.back_rows != 0;
+    const bool brows = CNL_LEAN && A.back_rows != 0 && !(CNL_ABL & 32768);
     double bpv[ROWS_KM + 2];
     int bix = 0, brs = 0, ipend2 = -1;
     double dpend2 = 0.0;
@@ -1452,20 +1460,20 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       wsync();
 #pragma unroll
       for (int k = 0; k < KB; k++) {
-        if (k < npiv) {
-          const double sum = gsum<16>(lr[k] * xb);
-          if (l == nupd + 1 + k) xb = -sum;
+        if (k < npiv && !(CNL_ABL & 8192)) {
+          const double sum = gsum<16>(-lr[k] * xb);
+          if (l == nupd + 1 + k) xb = sum;
         }
       }
       for (int k0 = KB; k0 < npiv; k0++) {  // fronts with more than KB pivots: remaining rows loaded on demand
         const int i = nupd + 1 + k0;
         const double lv = myL[lptr + tri2(i) - tu + l];
-        const double sum = gsum<16>(lv * xb);
-        if (l == i) xb = -sum;
+        const double sum = gsum<16>(-lv * xb);
+        if (l == i) xb = sum;
       }
       // d = -x of the pivots: one scattered store per front (rec holds the original index of every pivot)
       if (ipend >= 0) mydout[ipend] = dpend;   // (only behind the last prefetch: the front before this one had no successor to carry it)
-      ipend = (okme && l > nupd && l < f) ? rec[B_HDR + l] : -1;
+      ipend = (okme && l > nupd && l < f && !(CNL_ABL & 65536)) ? rec[B_HDR + l] : -1;
       dpend = -xb;
       if (l >= 1 && l < f) xs[xoff + l] = xb;
       wsync();
