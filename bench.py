@@ -302,9 +302,10 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
         r2, c2 = s2.kkt_pattern()
         flop = 2000 * 1000 ** 2 + 1000 ** 3 / 3  # m n^2 + n^3 / 3
         c2blk = {"flop_per_system": flop, "peak_spec_TFLOPs": FP64_MFMA_SPEC_TFLOPS, "peak_measured_TFLOPs": FP64_MFMA_MEASURED_TFLOPS}
-        for bs in (1, 8):
-            vh = np.stack([syn.dense_values(s2, 2002 + b)[0] for b in range(bs)])
-            rh = np.stack([syn.dense_values(s2, 2002 + b)[1] for b in range(bs)])
+        gen8 = [syn.dense_values(s2, 2002 + b) for b in range(8)]
+        for bs in (1, 8, 32):   # (32: the panel steps' latency is shared by more problems; 8 distinct problems, tiled)
+            vh = np.stack([gen8[b % 8][0] for b in range(bs)])
+            rh = np.stack([gen8[b % 8][1] for b in range(bs)])
             pv, pr = torch.from_numpy(vh).to(dev), torch.from_numpy(rh).to(dev)
             p3 = DeviceProblem(torch, hipldl, s2, r2, c2, pv, pr, bs, local_rank, stream)
             ms = p3.timed(20, 3)

@@ -665,7 +665,7 @@ void cnl_options_init(cnl_options* o) {
   o->multipliers_early = 1; o->condense = 1; o->direct_records = 1; o->register_front = 1; o->dense_backend = 1; o->general_dense = 1;
   o->staged = 1; o->dataflow = 1; o->dataflow_waves = 1024; o->dataflow_spin_limit = 1 << 22;
   o->waves_per_block = 0; o->v1_tpp = -1; o->v1_ppb = -1; o->v1_lds = -1; o->v1_solve = 0; o->lds_pad = 1;
-  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1;
+  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -1000,7 +1000,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
   }
   if (h->plan->D.active) {
     std::string derr;
-    int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_syrk_wgs);
+    int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_syrk_wgs, h->plan->opt.dense_panel_blocks != 0);
     if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
   } else if (!h->plan->gpos.empty() && !h->use_v2 &&
              // S0, S and G in 64 x 64 tiles per problem: small batches always, larger ones while the tiles stay below 8 GB
@@ -1010,7 +1010,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     const cnl::Cond& C2 = h->plan->C;
     h->gops.ns = (int32_t)C2.N2; h->gops.nv = (int32_t)nvar; h->gops.nslots = (int32_t)C2.ncs; h->gops.cstride = C2.cstride;
     if ((rc = upload(h, h->plan->gpos, &h->gops.d_pos))) return bail(rc);
-    int drc = cnl::dense_create_general(&h->gdense, (int32_t)C2.N2, (int32_t)nvar, (int32_t)C2.ncs, h->gops.d_pos, batch, derr, h->plan->opt.dense_graph != 0);
+    int drc = cnl::dense_create_general(&h->gdense, (int32_t)C2.N2, (int32_t)nvar, (int32_t)C2.ncs, h->gops.d_pos, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_panel_blocks != 0);
     if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
   }
   {

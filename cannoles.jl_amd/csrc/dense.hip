@@ -474,6 +474,173 @@ __global__ void __launch_bounds__(256) dn_panel(DnDev D, int k, double eig_tol, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Panel step, round 3 (dn_panel2): both the diagonal tile and every row tile are cut into four blocks of 16 COLUMNS, one
+// wavefront each (lane = row, 16 registers).  The old kernel above gives a whole tile to one wavefront: 2016 rank-1 updates of
+// 14 cycles each = 28 k cycles of issue per tile, for the diagonal tile (which paces everything) as for the row tiles — the
+// panel step took 14.2 us.  With column blocks a wavefront applies the pivots of the blocks to its left as they are published
+// (16 updates per pivot), then runs its own 16 pivots; the pivot chain of the diagonal tile walks from block to block and is
+// free of LDS round trips: the pivot and the operands of the updates inside the block come from v_readlane (scalar
+// operands of a plain v_fmac_f64), only the blocks to the right read the published column back.
+// Workgroup = row tile rt of the tile column: waves 0 .. 3 the diagonal tile's blocks (recomputed by every workgroup, as
+// before), waves 4 .. 7 the row tile's.  Multipliers of the row tile go from block to block through LDS (Lr).
+#ifndef DN_P2_SINGLES   // pivots of the block to the left that are applied one at a time (finer hand-over): measured 0.428 ms per system
+#define DN_P2_SINGLES 0  // with 0, 0.431 with 4, 0.435 with 8 — the coarser wait keeps more loads in flight
+#endif
+#ifndef DN_P2_ABL   // timing experiments (results wrong): 1 no row tiles, 2 no earlier-block updates in the diagonal tile, 4 no in-block
+#define DN_P2_ABL 0 // bulk in the diagonal tile, 8 no earlier-block updates in the row tiles
+#endif
+struct Panel2Lds {
+  double W[TS * TS];   // [J][r]: column J of the diagonal tile at the moment pivot J is taken (undivided)
+  double Lr[TS * TS];  // [J][r]: multiplier of pivot J for row r of the row tile
+  double inv[TS + 8];  // [TS ..]: dump slots ("lane 0 stores" without a branch)
+  int pub[12];         // [0]: pivots of the diagonal tile published so far, [1]: pivots whose row-tile multipliers are in Lr; dump slots
+};
+__device__ __forceinline__ void lds_wait_ge(const int* c, int v) {
+  while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// x[c] += W[row_newbcast: c] * nl for the 16 columns of a block (c >= C0)
+template <int C0>
+__device__ __forceinline__ void blk_update(double (&x)[16], double w, double nl) {
+#define DN_B(I) if constexpr (C0 <= I) DN_FMAC_BCAST(x[I], w, nl, I);
+  DN_B(0) DN_B(1) DN_B(2) DN_B(3) DN_B(4) DN_B(5) DN_B(6) DN_B(7) DN_B(8) DN_B(9) DN_B(10) DN_B(11) DN_B(12) DN_B(13) DN_B(14) DN_B(15)
+#undef DN_B
+}
+
+// own pivot JJ (compile-time position inside the block) of a diagonal block.  Chain of a pivot: the column is final -> pivot and
+// the operand of the NEXT column's update through v_readlane (scalar operands) -> reciprocal, multiplier -> next column.  The
+// other columns of the block take their operands from the published column (one LDS read, DPP broadcast): they are needed a
+// pivot later at the earliest.  No branch inside (lane-0 stores go to dump slots otherwise).
+template <int JJ>
+__device__ __forceinline__ void diag_own(Panel2Lds& P, double (&a)[16], int q, int lane, int li, int nreal, double eig_tol, int& np, int& nz,
+                                         double d, double r1) {
+  // here: a[JJ] is final, d = its pivot (same value in every lane), r1 ~ 1 / d (rcp + one Newton step: 2^-50)
+  const int J = 16 * q + JJ;
+  const double col = a[JJ];
+  P.W[J * 64 + lane] = col;
+  np += (J < nreal) & (d > eig_tol); nz += (J < nreal) & (fabs(d) <= eig_tol);
+  const double l = col * r1;
+  const double nl = -l;
+  double dn = 1.0, r1n = 1.0;
+  if constexpr (JJ + 1 < 16) {
+    // The NEXT pivot ahead of the vector path: d' = a11 - w1 (w1 / d) is what lane J + 1 of the updated column will hold (the same
+    // two operations, bit for bit), so its reciprocal chain (rcp, Newton step) runs next to this pivot's column update instead of
+    // behind it: 5 dependent fp64 operations per pivot instead of 8 (a dependent v_fma_f64 is 32 cycles on this part).
+    const double w1 = readlane_f64(col, J + 1), a11 = readlane_f64(a[JJ + 1], J + 1);
+    const double m = w1 * r1;
+    dn = fma(-w1, m, a11);
+    const double r0n = __builtin_amdgcn_rcp(dn);
+    const double en = fma(-dn, r0n, 1.0);
+    r1n = fma(r0n, en, r0n);
+    a[JJ + 1] = fma(w1, nl, a[JJ + 1]);
+  }
+  {  // the reciprocal the other wavefronts use: one more Newton step, off the chain
+    const double e1 = fma(-d, r1, 1.0);
+    P.inv[lane == 0 ? J : TS + (lane & 7)] = fma(r1, e1, r1);
+  }
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(&P.pub[lane == 0 ? 0 : 2 + (lane & 7)], J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // LDS keeps a wave's operations in order
+  asm volatile("" ::: "memory");
+  if constexpr (JJ + 2 < 16 && !(DN_P2_ABL & 4)) {
+    const double w = P.W[J * 64 + 16 * q + li];
+    blk_update<JJ + 2>(a, w, nl);
+  }
+  if constexpr (JJ + 1 < 16) diag_own<JJ + 1>(P, a, q, lane, li, nreal, eig_tol, np, nz, dn, r1n);
+}
+
+__device__ __forceinline__ void panel2_diag_block(Panel2Lds& P, const double* __restrict__ tile, int q, int lane, int nreal, double eig_tol,
+                                                  int& np, int& nz) {
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) a[c] = tile[lane + 64 * (16 * q + c)];
+  const int li = lane & 15;
+  const int nbulk = (DN_P2_ABL & 2) ? 0 : 16 * q - DN_P2_SINGLES;
+  for (int J0 = 0; J0 < nbulk; J0 += 4) {  // four pivots per wait: their operands are in flight together
+    lds_wait_ge(&P.pub[0], J0 + 4);
+    double l[4], w[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { l[u] = P.W[(J0 + u) * 64 + lane] * P.inv[J0 + u]; w[u] = P.W[(J0 + u) * 64 + 16 * q + li]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) blk_update<0>(a, w[u], -l[u]);
+  }
+  // the last pivots of the block to the left one at a time: this wavefront's own chain starts right behind its last pivot
+  for (int J = nbulk < 0 ? 0 : nbulk; J < 16 * q && !(DN_P2_ABL & 2); J++) {
+    lds_wait_ge(&P.pub[0], J + 1);
+    const double l = P.W[J * 64 + lane] * P.inv[J];
+    const double w = P.W[J * 64 + 16 * q + li];
+    blk_update<0>(a, w, -l);
+  }
+  np = 0; nz = 0;
+  const double d0 = readlane_f64(a[0], 16 * q);
+  const double r00 = __builtin_amdgcn_rcp(d0);
+  diag_own<0>(P, a, q, lane, li, nreal, eig_tol, np, nz, d0, fma(r00, fma(-d0, r00, 1.0), r00));
+}
+
+template <int JJ>
+__device__ __forceinline__ void rows_own(Panel2Lds& P, double (&x)[16], int q, int lane, int li, double* __restrict__ wout) {
+  const int J = 16 * q + JJ;
+  if constexpr ((JJ & 3) == 0) lds_wait_ge(&P.pub[0], J + 4);
+  if (wout) wout[lane + 64 * J] = -x[JJ];  // -l d: the B operand of this column's trailing update
+  const double l = x[JJ] * P.inv[J];
+  P.Lr[J * 64 + lane] = l;
+  x[JJ] = l;
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(&P.pub[lane == 0 ? 1 : 2 + (lane & 7)], J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  if constexpr (JJ + 1 < 16) {
+    const double w = P.W[J * 64 + 16 * q + li];
+    blk_update<JJ + 1>(x, w, -l);
+    rows_own<JJ + 1>(P, x, q, lane, li, wout);
+  }
+}
+
+__device__ __forceinline__ void panel2_rows_block(Panel2Lds& P, const double* __restrict__ in, double* __restrict__ out, double* __restrict__ wout,
+                                                  bool ident, int q, int lane) {
+  double x[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c] = ident ? ((16 * q + c) == lane ? 1.0 : 0.0) : in[lane + 64 * (16 * q + c)];
+  const int li = lane & 15;
+  for (int J0 = 0; J0 < 16 * q && !(DN_P2_ABL & 8); J0 += 4) {
+    lds_wait_ge(&P.pub[1], J0 + 4);
+    double l[4], w[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { l[u] = P.Lr[(J0 + u) * 64 + lane]; w[u] = P.W[(J0 + u) * 64 + 16 * q + li]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) blk_update<0>(x, w[u], -l[u]);
+  }
+  rows_own<0>(P, x, q, lane, li, wout);
+#pragma unroll
+  for (int c = 0; c < 16; c++) out[lane + 64 * (16 * q + c)] = x[c];
+}
+
+__global__ void __launch_bounds__(512) dn_panel2(DnDev D, int k, double eig_tol) {
+  extern __shared__ double dn_p2_lds[];
+  Panel2Lds& P = *reinterpret_cast<Panel2Lds*>(dn_p2_lds);
+  const int b = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) { P.pub[0] = 0; P.pub[1] = 0; }
+  __syncthreads();
+  if (wave < 4) {
+    int np, nz;
+    panel2_diag_block(P, D.S + (size_t)b * D.T * D.T * TT + tile_off(D.T, k, k), wave, lane, min(64, D.ns - 64 * k), eig_tol, np, nz);
+    if (blockIdx.x == 0) {
+      if (lane >= 16 * wave && lane < 16 * wave + 16) D.dv[(size_t)b * D.nsp + 64 * k + lane] = P.W[lane * 64 + lane];  // own column: written by this wave
+      if (lane == 0) {
+        if (np) atomicAdd(&D.cnt[b * 4 + 0], np);
+        if (nz) atomicAdd(&D.cnt[b * 4 + 1], nz);
+      }
+    }
+  } else if (!(DN_P2_ABL & 1)) {
+    const int rt = blockIdx.x;
+    const double* in; double* out; double* wout; bool ident;
+    row_tile_ptrs(D, b, k, rt, in, out, wout, ident);
+    panel2_rows_block(P, in, out, wout, ident, wave - 4, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // C(I, J) -= L(I, k) diag(d) L(J, k)'  (tiles of S, or of the G block with G(I, k) in place of L(I, k)): rank-64 update of
 // one tile on the fp64 matrix cores.  The core produces C' (see dn_syrk); its A operand is the tile -L(J, k) d that the
 // panel step left in Wn, its B operand the L form of the row tile.  One wave per 16 x 16 block: it loads its 16 + 16
@@ -534,6 +701,11 @@ __global__ void __launch_bounds__(256) dn_update(DnDev D, int k, int b0) {
   update_block(At, Bt, Ct, czero, blk, threadIdx.x & 63);
 }
 
+// (Round 3, not kept: trailing update of column k and panel of column k + 1 in ONE launch — the panel wavefronts wait on per-tile
+//  counters for the quadrants of their tiles, the tiles of column k + 1 are updated first.  Producer and consumer may sit on
+//  different XCDs, whose L2s are not coherent with each other: the hand-over needs either an agent-scope release per quadrant (an
+//  L2 write-back: 0.46 -> 0.55 ms at one problem, 1.10 -> 2.05 ms at eight) or device-scope write-through stores and loads
+//  (0.63 / 1.30 ms; 32 problems 3.27 -> 5.10 ms).  A kernel boundary is the cheaper hand-over on this part.)
 // (Round 3: a workgroup-per-tile variant with both operand tiles staged in LDS once — a quarter of the operand traffic out of L2 —
 //  was built for batches: 18.7 us per step at 8 problems against 18.1 us for the kernel above.  One or two workgroups of 80 KB per
 //  CU serialise their load and multiply phases; the many small independent wavefronts of this kernel overlap them.  Not kept.)
@@ -897,6 +1069,7 @@ struct DenseState {
   std::vector<GraphEntry> graphs;
   hipStream_t cap = nullptr;
   bool use_graph = true;
+  bool panel2 = true;  // column-block panel kernel (dn_panel2)
   int misses = 0;  // consecutive calls whose argument set was not cached (a caller that hands over fresh buffers every step)
 };
 
@@ -971,6 +1144,10 @@ int setup_common(DenseState* st, int ns, int nv, int64_t batch, std::string& err
 #endif
   d.ns = ns; d.nv = nv; d.T = (ns + TS - 1) / TS; d.nsp = d.T * TS;
   d.nlt = d.T * (d.T + 1) / 2;
+  if (st->panel2 && hipFuncSetAttribute(reinterpret_cast<const void*>(dn_panel2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Panel2Lds)) != hipSuccess) {
+    (void)hipGetLastError();
+    st->panel2 = false;  // the one-wavefront-per-tile panel kernel needs no opt-in
+  }
   std::vector<int> lI, lJ;
   for (int J = 0; J < d.T; J++) for (int I = J; I < d.T; I++) { lI.push_back(I); lJ.push_back(J); }
   int rc;
@@ -992,10 +1169,11 @@ int setup_common(DenseState* st, int ns, int nv, int64_t batch, std::string& err
 
 }  // namespace
 
-int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::string& err, bool use_graph, int syrk_wgs) {
+int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::string& err, bool use_graph, int syrk_wgs, bool panel_blocks) {
   DenseState* st = new DenseState();
   st->batch = batch;
   st->use_graph = use_graph;
+  st->panel2 = panel_blocks;
   *out = st;
   DnDev& d = st->d;
   d.n = P.n; d.m = P.m; d.p = P.p; d.nnz = P.nnz;
@@ -1083,10 +1261,11 @@ int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::strin
 }
 
 int dense_create_general(DenseState** out, int32_t ns, int32_t nv, int32_t nslots, const int32_t* d_pos, int64_t batch, std::string& err,
-                         bool use_graph) {
+                         bool use_graph, bool panel_blocks) {
   DenseState* st = new DenseState();
   st->batch = batch;
   st->use_graph = use_graph;
+  st->panel2 = panel_blocks;
   st->general = true;
   *out = st;
   DnDev& d = st->d;
@@ -1116,7 +1295,8 @@ int enqueue_factor(DenseState* st, double eig_tol, hipStream_t stream, std::stri
   //  branches of the graph — so that one problem's latency-bound panel overlaps the others' updates: measured at 8 problems
   //  1.109 ms in lockstep, 1.090 with two branches, 1.175 with four, 1.45 with eight.  Not kept.)
   for (int k = 0; k < d.T; k++) {
-    hipLaunchKernelGGL(dn_panel, dim3((d.T + 2) / 3, B), dim3(256), 0, stream, d, k, eig_tol, 0);
+    if (st->panel2) hipLaunchKernelGGL(dn_panel2, dim3(d.T, B), dim3(512), sizeof(Panel2Lds), stream, d, k, eig_tol);
+    else hipLaunchKernelGGL(dn_panel, dim3((d.T + 2) / 3, B), dim3(256), 0, stream, d, k, eig_tol, 0);
     const int nt = d.T - 1 - k, ntr = nt * (nt + 1) / 2 + (k + 1) * nt;
     if (ntr > 0) hipLaunchKernelGGL(dn_update, dim3(4 * ntr, B), dim3(256), 0, stream, d, k, 0);
   }
