@@ -98,10 +98,15 @@ __device__ __forceinline__ double bcast(double v, int a, int grp4) {
 // fix-up steps; a zero or non-finite pivot still yields inf/NaN, which fails the inertia test anyway)
 // v_rcp_f64 is good to ~2^-25 (measured on gfx950); one Newton step brings the reciprocal to ~10 ulp, and the
 // residual correction of the quotient squares that error away: q' = q + (w - d q) r = (w/d)(1 - eps^2).
+#ifndef CNL_QUICK_DIV
+#define CNL_QUICK_DIV 0
+#endif
 __device__ __forceinline__ double fast_div(double w, double d) {
   double r = __builtin_amdgcn_rcp(d);
+#if !CNL_QUICK_DIV
   const double e = fma(-d, r, 1.0);
   r = fma(r, e, r);
+#endif
   const double q = w * r;
   const double res = fma(-d, q, w);
   return fma(res, r, q);
