@@ -207,8 +207,23 @@ def main():
         for _ in range(min(5, max(2, args.steps))):
             prob.step()
             kms.append(LDLT.last_kernel_ms())
-    LDLT.set_timing(False)
     kern_ms = float(np.mean(kms))
+    # the forward sweep alone (try_to_factorize: assembly + LDL^T + inertia, no solve), same timing mode: what is left of kern_ms
+    # is the backward sweep (the two sweeps are bound by different things)
+    fwd_ms = None
+    try:
+        fms = []
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                hipldl._check(hipldl.lib().cnl_factorize_dev(LDLT._h, prob.vals.data_ptr(), 2.220446049250313e-16, prob.succ.data_ptr(), stream.cuda_stream))
+                torch.cuda.synchronize()
+                fms.append(LDLT.last_kernel_ms())
+            prob.step()   # leaves the handle and `succ` as the timed loop left them
+            torch.cuda.synchronize()
+        fwd_ms = float(np.mean(fms[1:]))
+    except Exception:
+        fwd_ms = None
+    LDLT.set_timing(False)
 
     ok = counts[1] == counts[0]
     nchk = min(B, 4)
@@ -247,6 +262,7 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_src,
                      "measured_hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                      "bytes_per_system": b_alg, "nnzL_star": nnzL_star, "kernel_ms": kern_ms, "kernel": "newton2_kernel",
+                     "forward_sweep_ms": fwd_ms, "backward_sweep_ms": (kern_ms - fwd_ms) if fwd_ms else None,
                      "kernel_is_whole_step": bool(LDLT.config.get("lean")) and bool(LDLT.plan_array("brec")[7] & 256),
                      "note": "since round 3 the lean kernel recovers the residual components in its backward sweep: no post-pass, kernel_ms == step_ms; "
                              "rounds 1-2 (and round 3 before that change) priced a kernel that left 1.2 ms of the step to a second kernel on the same algorithmic bytes "

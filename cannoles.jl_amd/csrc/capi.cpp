@@ -38,6 +38,9 @@ struct cnl_plan {
   bool split_mode = false;    // bidirectional-chain plan for a batch between one and two wavefronts per SIMD (capi.cpp, run_split)
 };
 
+#ifndef CNL_PIPE_UPLOADERS
+#define CNL_PIPE_UPLOADERS 2
+#endif
 struct cnl_handle {
   cnl_plan* plan = nullptr;
   int device = 0;
@@ -80,7 +83,8 @@ struct cnl_handle {
   bool in_split = false;
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  hipStream_t pipe_stream[3] = {nullptr, nullptr, nullptr};  // chunked host-pointer calls: two compute streams, one for the results
+  static constexpr int kPipeUp = CNL_PIPE_UPLOADERS;  // host threads that upload chunks of a host-pointer call (each on its own stream)
+  hipStream_t pipe_stream[kPipeUp + 1] = {};  // chunked host-pointer calls: the uploaders' compute streams, one more for the results
   std::vector<hipEvent_t> pipe_ev;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
@@ -1287,7 +1291,7 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
   const int device = h->device;
   std::thread down([&]() {
     (void)hipSetDevice(device);
-    hipStream_t st = h->pipe_stream[2];
+    hipStream_t st = h->pipe_stream[cnl_handle::kPipeUp];
     auto chk = [&](hipError_t e, const char* what) {
       if (e != hipSuccess && wrc == CNL_OK) { wrc = CNL_ERR_HIP; wmsg = std::string(what) + ": " + hipGetErrorString(e); }
       return e == hipSuccess;
@@ -1322,12 +1326,14 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
   });
   // two uploaders (the calling thread and a helper) take alternate chunks, each on a stream of its own: a copy out of pageable
   // memory keeps a host thread busy (the runtime pins or stages the pages), and one thread alone does not fill the link
-  int urc[2] = {CNL_OK, CNL_OK};
-  std::string umsg[2];
+  constexpr int NU = cnl_handle::kPipeUp;
+  int urc[NU];
+  for (int& r_ : urc) r_ = CNL_OK;
+  std::string umsg[NU];
   auto uploader = [&](int u) {
     if (u) (void)hipSetDevice(device);
     hipStream_t st = h->pipe_stream[u];
-    for (size_t c = (size_t)u; c < nchunks; c += 2) {
+    for (size_t c = (size_t)u; c < nchunks; c += NU) {
       {
         std::lock_guard<std::mutex> lk(mu);
         if (abort_) return;
@@ -1358,14 +1364,14 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
   };
   const bool tm = h->timing;
   h->timing = false;
-  std::thread up1(uploader, 1);
+  std::vector<std::thread> ups;
+  for (int u = 1; u < NU; u++) ups.emplace_back(uploader, u);
   uploader(0);
-  up1.join();
+  for (std::thread& th : ups) th.join();
   h->timing = tm;
   down.join();
-  (void)hipStreamSynchronize(h->pipe_stream[0]);
-  (void)hipStreamSynchronize(h->pipe_stream[1]);
-  for (int u = 0; u < 2; u++) if (urc[u] != CNL_OK) return fail(urc[u], umsg[u]);
+  for (int u = 0; u < NU; u++) (void)hipStreamSynchronize(h->pipe_stream[u]);
+  for (int u = 0; u < NU; u++) if (urc[u] != CNL_OK) return fail(urc[u], umsg[u]);
   if (wrc != CNL_OK) return fail(wrc, "download: " + wmsg);
   h->last_vals = h->d_vals;
   h->factorized = true;
