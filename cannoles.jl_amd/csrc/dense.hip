@@ -516,27 +516,33 @@ __device__ __forceinline__ void blk_update(double (&x)[16], double w, double nl)
 // pivot later at the earliest.  No branch inside (lane-0 stores go to dump slots otherwise).
 template <int JJ>
 __device__ __forceinline__ void diag_own(Panel2Lds& P, double (&a)[16], int q, int lane, int li, int nreal, double eig_tol, int& np, int& nz,
-                                         double d, double r1) {
-  // here: a[JJ] is final, d = its pivot (same value in every lane), r1 ~ 1 / d (rcp + one Newton step: 2^-50)
+                                         double rr, double wprev, double nlprev) {
+  // here: a[JJ] is final; rr = v_rcp_f64 of an APPROXIMATION of its pivot (good to 2^-25, like the instruction itself), started
+  // a pivot ago; wprev / nlprev: operand register and multiplier of the PREVIOUS pivot, whose updates of the columns >= JJ + 2
+  // are still due.  Two chains of ~150 cycles run side by side (a dependent fp64 operation is 32 cycles on this part):
+  //   pivot (v_readlane) -> Newton step on rr against the exact pivot -> multiplier -> next column            (vector path)
+  //   next pivot's approximation a11 - w1 (w1 rr) -> v_rcp_f64                                               (scalar-valued path)
   const int J = 16 * q + JJ;
   const double col = a[JJ];
   P.W[J * 64 + lane] = col;
+  const double d = readlane_f64(col, J);
   np += (J < nreal) & (d > eig_tol); nz += (J < nreal) & (fabs(d) <= eig_tol);
+  double rrn = 1.0;
+  double w1 = 0.0;
+  if constexpr (JJ + 1 < 16) {
+    w1 = readlane_f64(col, J + 1);
+    const double a11 = readlane_f64(a[JJ + 1], J + 1);
+    const double dapp = fma(-w1, w1 * rr, a11);
+    rrn = __builtin_amdgcn_rcp(dapp);
+    DN_PIN(rrn);  // issued here, ahead of the deferred updates below
+  }
+  const double e = fma(-d, rr, 1.0);
+  const double r1 = fma(rr, e, rr);
   const double l = col * r1;
   const double nl = -l;
-  double dn = 1.0, r1n = 1.0;
-  if constexpr (JJ + 1 < 16) {
-    // The NEXT pivot ahead of the vector path: d' = a11 - w1 (w1 / d) is what lane J + 1 of the updated column will hold (the same
-    // two operations, bit for bit), so its reciprocal chain (rcp, Newton step) runs next to this pivot's column update instead of
-    // behind it: 5 dependent fp64 operations per pivot instead of 8 (a dependent v_fma_f64 is 32 cycles on this part).
-    const double w1 = readlane_f64(col, J + 1), a11 = readlane_f64(a[JJ + 1], J + 1);
-    const double m = w1 * r1;
-    dn = fma(-w1, m, a11);
-    const double r0n = __builtin_amdgcn_rcp(dn);
-    const double en = fma(-dn, r0n, 1.0);
-    r1n = fma(r0n, en, r0n);
-    a[JJ + 1] = fma(w1, nl, a[JJ + 1]);
-  }
+  if constexpr (JJ + 1 < 16) a[JJ + 1] = fma(w1, nl, a[JJ + 1]);
+  // the column after that feeds the next region's a11: scalar operand as well, no LDS round trip on the chain
+  if constexpr (JJ + 2 < 16) a[JJ + 2] = fma(readlane_f64(col, J + 2), nl, a[JJ + 2]);
   {  // the reciprocal the other wavefronts use: one more Newton step, off the chain
     const double e1 = fma(-d, r1, 1.0);
     P.inv[lane == 0 ? J : TS + (lane & 7)] = fma(r1, e1, r1);
@@ -544,11 +550,12 @@ __device__ __forceinline__ void diag_own(Panel2Lds& P, double (&a)[16], int q, i
   asm volatile("" ::: "memory");
   __hip_atomic_store(&P.pub[lane == 0 ? 0 : 2 + (lane & 7)], J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // LDS keeps a wave's operations in order
   asm volatile("" ::: "memory");
-  if constexpr (JJ + 2 < 16 && !(DN_P2_ABL & 4)) {
-    const double w = P.W[J * 64 + 16 * q + li];
-    blk_update<JJ + 2>(a, w, nl);
-  }
-  if constexpr (JJ + 1 < 16) diag_own<JJ + 1>(P, a, q, lane, li, nreal, eig_tol, np, nz, dn, r1n);
+  // operand register of THIS pivot's remaining updates (columns >= JJ + 3): read back now, used a pivot later, behind the next
+  // chain's first instructions — its LDS round trip never stalls the in-order issue
+  double w = 0.0;
+  if constexpr (JJ + 3 < 16 && !(DN_P2_ABL & 4)) w = P.W[J * 64 + 16 * q + li];
+  if constexpr (JJ >= 1 && JJ + 2 < 16 && !(DN_P2_ABL & 4)) blk_update<JJ + 2>(a, wprev, nlprev);
+  if constexpr (JJ + 1 < 16) diag_own<JJ + 1>(P, a, q, lane, li, nreal, eig_tol, np, nz, rrn, w, nl);
 }
 
 __device__ __forceinline__ void panel2_diag_block(Panel2Lds& P, const double* __restrict__ tile, int q, int lane, int nreal, double eig_tol,
@@ -574,27 +581,35 @@ __device__ __forceinline__ void panel2_diag_block(Panel2Lds& P, const double* __
     blk_update<0>(a, w, -l);
   }
   np = 0; nz = 0;
-  const double d0 = readlane_f64(a[0], 16 * q);
-  const double r00 = __builtin_amdgcn_rcp(d0);
-  diag_own<0>(P, a, q, lane, li, nreal, eig_tol, np, nz, d0, fma(r00, fma(-d0, r00, 1.0), r00));
+  diag_own<0>(P, a, q, lane, li, nreal, eig_tol, np, nz, __builtin_amdgcn_rcp(readlane_f64(a[0], 16 * q)), 0.0, 0.0);
 }
 
+// own pivots JJ .. JJ + 3 of a row block: the four reciprocals and operand registers are read from LDS TOGETHER behind one wait
+// on the publisher, so that the chain from pivot to pivot is one update and one multiplication (in-kernel stamps, round 3: with an
+// LDS round trip for the reciprocal and another for the operands per pivot a row block needed 350 ticks per pivot against the
+// diagonal tile's 300 — the row tiles, not the pivot chain, set the length of the panel step)
 template <int JJ>
 __device__ __forceinline__ void rows_own(Panel2Lds& P, double (&x)[16], int q, int lane, int li, double* __restrict__ wout) {
-  const int J = 16 * q + JJ;
-  if constexpr ((JJ & 3) == 0) lds_wait_ge(&P.pub[0], J + 4);
-  if (wout) wout[lane + 64 * J] = -x[JJ];  // -l d: the B operand of this column's trailing update
-  const double l = x[JJ] * P.inv[J];
-  P.Lr[J * 64 + lane] = l;
-  x[JJ] = l;
-  asm volatile("" ::: "memory");
-  __hip_atomic_store(&P.pub[lane == 0 ? 1 : 2 + (lane & 7)], J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  asm volatile("" ::: "memory");
-  if constexpr (JJ + 1 < 16) {
-    const double w = P.W[J * 64 + 16 * q + li];
-    blk_update<JJ + 1>(x, w, -l);
-    rows_own<JJ + 1>(P, x, q, lane, li, wout);
+  const int J0 = 16 * q + JJ;
+  lds_wait_ge(&P.pub[0], J0 + 4);
+  double iv[4], w[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { iv[u] = P.inv[J0 + u]; w[u] = P.W[(J0 + u) * 64 + 16 * q + li]; }
+#define DN_ROWS_PIVOT(U)                                                                       \
+  {                                                                                            \
+    constexpr int C = JJ + U;                                                                  \
+    if (wout) wout[lane + 64 * (J0 + U)] = -x[C];  /* -l d: the B operand of this column's trailing update */ \
+    const double l = x[C] * iv[U];                                                             \
+    P.Lr[(J0 + U) * 64 + lane] = l;                                                            \
+    x[C] = l;                                                                                  \
+    if constexpr (C + 1 < 16) blk_update<C + 1>(x, w[U], -l);                                  \
   }
+  DN_ROWS_PIVOT(0) DN_ROWS_PIVOT(1) DN_ROWS_PIVOT(2) DN_ROWS_PIVOT(3)
+#undef DN_ROWS_PIVOT
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(&P.pub[lane == 0 ? 1 : 2 + (lane & 7)], J0 + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  if constexpr (JJ + 4 < 16) rows_own<JJ + 4>(P, x, q, lane, li, wout);
 }
 
 __device__ __forceinline__ void panel2_rows_block(Panel2Lds& P, const double* __restrict__ in, double* __restrict__ out, double* __restrict__ wout,
@@ -621,10 +636,16 @@ __global__ void __launch_bounds__(512) dn_panel2(DnDev D, int k, double eig_tol)
   Panel2Lds& P = *reinterpret_cast<Panel2Lds*>(dn_p2_lds);
   const int b = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (threadIdx.x == 0) { P.pub[0] = 0; P.pub[1] = 0; }
+#ifdef DN_STAMPS
+  const long long st0 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
   if (wave < 4) {
     int np, nz;
     panel2_diag_block(P, D.S + (size_t)b * D.T * D.T * TT + tile_off(D.T, k, k), wave, lane, min(64, D.ns - 64 * k), eig_tol, np, nz);
+#ifdef DN_STAMPS
+    if (lane == 0 && blockIdx.x == 0) { long long* sp = reinterpret_cast<long long*>(D.jxp); sp[D.T * 4 + k * 8 + wave] = __builtin_amdgcn_s_memtime() - st0; }
+#endif
     if (blockIdx.x == 0) {
       if (lane >= 16 * wave && lane < 16 * wave + 16) D.dv[(size_t)b * D.nsp + 64 * k + lane] = P.W[lane * 64 + lane];  // own column: written by this wave
       if (lane == 0) {
@@ -637,6 +658,9 @@ __global__ void __launch_bounds__(512) dn_panel2(DnDev D, int k, double eig_tol)
     const double* in; double* out; double* wout; bool ident;
     row_tile_ptrs(D, b, k, rt, in, out, wout, ident);
     panel2_rows_block(P, in, out, wout, ident, wave - 4, lane);
+#ifdef DN_STAMPS
+    if (lane == 0 && blockIdx.x == 0) { long long* sp = reinterpret_cast<long long*>(D.jxp); sp[D.T * 4 + k * 8 + wave] = __builtin_amdgcn_s_memtime() - st0; }
+#endif
   }
 }
 
@@ -1434,6 +1458,9 @@ int dense_enqueue(DenseState* st, int mode, double* vals, const double* rhs, dou
       std::vector<long long> hs(d.T * 4);
       (void)hipMemcpy(hs.data(), d.jxp, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);
       for (int k2 = 0; k2 < d.T; k2++) fprintf(stderr, "[dn stamps] k=%d diag %lld rows %lld %lld %lld\n", k2, hs[k2 * 4], hs[k2 * 4 + 1], hs[k2 * 4 + 2], hs[k2 * 4 + 3]);
+      std::vector<long long> h2(d.T * 8);
+      (void)hipMemcpy(h2.data(), reinterpret_cast<long long*>(d.jxp) + d.T * 4, h2.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      for (int k2 = 0; k2 < d.T; k2++) fprintf(stderr, "[dn stamps2] k=%d diag blocks %lld %lld %lld %lld rows %lld %lld %lld %lld\n", k2, h2[k2 * 8], h2[k2 * 8 + 1], h2[k2 * 8 + 2], h2[k2 * 8 + 3], h2[k2 * 8 + 4], h2[k2 * 8 + 5], h2[k2 * 8 + 6], h2[k2 * 8 + 7]);
     }
 #endif
     if (mode == 1) return 0;
