@@ -1004,7 +1004,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
   }
   if (h->plan->D.active) {
     std::string derr;
-    int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_syrk_wgs, h->plan->opt.dense_panel_blocks != 0);
+    int drc = cnl::dense_create(&h->dense, h->plan->D, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_syrk_wgs, h->plan->opt.dense_panel_blocks);
     if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
   } else if (!h->plan->gpos.empty() && !h->use_v2 &&
              // S0, S and G in 64 x 64 tiles per problem: small batches always, larger ones while the tiles stay below 8 GB
@@ -1014,7 +1014,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     const cnl::Cond& C2 = h->plan->C;
     h->gops.ns = (int32_t)C2.N2; h->gops.nv = (int32_t)nvar; h->gops.nslots = (int32_t)C2.ncs; h->gops.cstride = C2.cstride;
     if ((rc = upload(h, h->plan->gpos, &h->gops.d_pos))) return bail(rc);
-    int drc = cnl::dense_create_general(&h->gdense, (int32_t)C2.N2, (int32_t)nvar, (int32_t)C2.ncs, h->gops.d_pos, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_panel_blocks != 0);
+    int drc = cnl::dense_create_general(&h->gdense, (int32_t)C2.N2, (int32_t)nvar, (int32_t)C2.ncs, h->gops.d_pos, batch, derr, h->plan->opt.dense_graph != 0, h->plan->opt.dense_panel_blocks);
     if (drc) return bail(fail(CNL_ERR_HIP, "dense backend: " + derr));
   }
   {

@@ -29,7 +29,7 @@ bool detect_dense(DensePlan& D, int64_t N, int64_t nnz, const int64_t* rows1, co
                   int64_t ncon);
 
 struct DenseState;  // device buffers
-int dense_create(DenseState** st, const DensePlan& D, int64_t batch, std::string& err, bool use_graph = true, int syrk_wgs = 0, bool panel_blocks = true);
+int dense_create(DenseState** st, const DensePlan& D, int64_t batch, std::string& err, bool use_graph = true, int syrk_wgs = 0, int panel_blocks = 1);
 void dense_destroy(DenseState* st);
 
 // mode: 0 newton (ladder + solve), 1 factorize, 2 solve.  All pointers are device pointers, problem-major as in the ABI.
@@ -49,7 +49,7 @@ struct GeneralOps {
 };
 // d_pos (device, owned by the caller): position i + ns * j of every slot of the condensed system
 int dense_create_general(DenseState** st, int32_t ns, int32_t nv, int32_t nslots, const int32_t* d_pos, int64_t batch, std::string& err,
-                         bool use_graph = true, bool panel_blocks = true);
+                         bool use_graph = true, int panel_blocks = 1);
 // cbuf: condensed buffer of the batch (matrix part filled; rhs part filled for mode 0 / 2); xpos / xzer: inertia counts of the
 // condensed residual pivots per problem (device ints); d2: [batch][ns] receives -x (reduced numbering); rho_fill: per problem
 // pointer stride info to write the last rho tried back into the caller's vals (vals + b * nnz + rho_begin, nv entries).

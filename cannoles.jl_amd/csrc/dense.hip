@@ -1094,6 +1094,7 @@ struct DenseState {
   hipStream_t cap = nullptr;
   bool use_graph = true;
   bool panel2 = true;  // column-block panel kernel (dn_panel2)
+  bool panel2_auto = true;  // ... chosen by batch x tiles (setup_common)
   int misses = 0;  // consecutive calls whose argument set was not cached (a caller that hands over fresh buffers every step)
 };
 
@@ -1168,6 +1169,10 @@ int setup_common(DenseState* st, int ns, int nv, int64_t batch, std::string& err
 #endif
   d.ns = ns; d.nv = nv; d.T = (ns + TS - 1) / TS; d.nsp = d.T * TS;
   d.nlt = d.T * (d.T + 1) / 2;
+  // The column-block panel kernel shortens the latency of a step at the price of T workgroups per problem that each refactorise
+  // the diagonal tile with four wavefronts (the one-wavefront kernel: T / 3 workgroups).  It pays while the step is latency-bound:
+  // measured crossovers at 96 .. 640 problems of order 256 (T = 4) and at 32 problems of order 1050 (T = 17).
+  if (st->panel2_auto) st->panel2 = (long long)batch * d.T <= 512;
   if (st->panel2 && hipFuncSetAttribute(reinterpret_cast<const void*>(dn_panel2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Panel2Lds)) != hipSuccess) {
     (void)hipGetLastError();
     st->panel2 = false;  // the one-wavefront-per-tile panel kernel needs no opt-in
@@ -1193,11 +1198,11 @@ int setup_common(DenseState* st, int ns, int nv, int64_t batch, std::string& err
 
 }  // namespace
 
-int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::string& err, bool use_graph, int syrk_wgs, bool panel_blocks) {
+int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::string& err, bool use_graph, int syrk_wgs, int panel_blocks) {
   DenseState* st = new DenseState();
   st->batch = batch;
   st->use_graph = use_graph;
-  st->panel2 = panel_blocks;
+  st->panel2 = panel_blocks != 0; st->panel2_auto = panel_blocks == 1;
   *out = st;
   DnDev& d = st->d;
   d.n = P.n; d.m = P.m; d.p = P.p; d.nnz = P.nnz;
@@ -1285,11 +1290,11 @@ int dense_create(DenseState** out, const DensePlan& P, int64_t batch, std::strin
 }
 
 int dense_create_general(DenseState** out, int32_t ns, int32_t nv, int32_t nslots, const int32_t* d_pos, int64_t batch, std::string& err,
-                         bool use_graph, bool panel_blocks) {
+                         bool use_graph, int panel_blocks) {
   DenseState* st = new DenseState();
   st->batch = batch;
   st->use_graph = use_graph;
-  st->panel2 = panel_blocks;
+  st->panel2 = panel_blocks != 0; st->panel2_auto = panel_blocks == 1;
   st->general = true;
   *out = st;
   DnDev& d = st->d;

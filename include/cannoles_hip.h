@@ -103,7 +103,8 @@ typedef struct cnl_options {
                                   partly single-stream, concurrently (csrc/capi.cpp, run_split)                                 */
   int32_t lean_kernel;         /* 1: plans of fast-class row-form fronts run the kernels' instantiation without the cold paths  */
   int32_t rows_in_backward;    /* 1: the lean kernel recovers the residual components in its backward sweep (no post-pass)      */
-  int32_t dense_panel_blocks;  /* 1: dense backend: panel step with four column-block wavefronts per tile (dn_panel2)             */
+  int32_t dense_panel_blocks;  /* dense backend, panel step with four column-block wavefronts per tile (dn_panel2): 0 never,
+                                  1 while the step is latency-bound (batch x tiles <= 512; default), 2 always                    */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);
