@@ -697,7 +697,11 @@ static_assert(PVR == ROWS_KM + 1, "the raw-value prefetch registers double as th
     RSRC = src_[ROWS_KM + 1] - P.nnz;                                                  \
   }
 // image position of pair K (compile-time) out of the lane's position words
+#ifdef CNL_DBG_NOCONF   // timing probe (results wrong): the row products' atomics land on sixteen consecutive doubles per problem — what do their bank conflicts cost?
+#define ROW_POS(PW, K) ((unsigned)(l + 16 * ((K) & 7)))
+#else
 #define ROW_POS(PW, K) (((unsigned)(PW)[(K) >> 2] >> (8 * ((K) & 3))) & 255u)
+#endif
 
 // ==========================================================================================
 // dataflow execution of a staged plan: wait until *p >= target, then make the producer's global stores visible; signal = all
