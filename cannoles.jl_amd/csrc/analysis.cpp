@@ -721,6 +721,30 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     fprintf(stderr, "[cnl] chose %s%s\n", cands[best].name.c_str(), opt.latency ? " (latency plan)" : "");
   }
   Cand& C = cands[best];
+  if (!opt.split_positions.empty()) {
+    // cut the named supernodes (a cut inside a supernode only makes its first part the child of its second part)
+    ivec nf, ni;
+    const int32_t ns0 = (int32_t)C.sn_first.size() - 1;
+    for (int32_t s0 = 0; s0 < ns0; s0++) {
+      const int32_t a = C.sn_first[s0], c = C.sn_first[s0 + 1];
+      ivec cuts;
+      for (int32_t q : opt.split_positions) if (q > a && q < c) cuts.push_back(q);
+      std::sort(cuts.begin(), cuts.end());
+      cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+      int32_t start = a;
+      bool first = true;
+      for (size_t k = 0; k <= cuts.size(); k++) {
+        const int32_t end = k < cuts.size() ? cuts[k] : c;
+        nf.push_back(start);
+        ni.push_back(first ? std::min<int32_t>(C.sn_indep[s0], end - start) : 0);  // independence is known for the leading pivots only
+        first = false;
+        start = end;
+      }
+    }
+    nf.push_back(C.sn_first[ns0]);
+    C.sn_first.swap(nf);
+    C.sn_indep.swap(ni);
+  }
   P.order_name = C.name; P.cost = C.cost; P.cpath = C.cpath; P.nnzL = C.nnzL; P.nnzL_exact = C.nnzL_exact;
   P.perm = C.perm;
   P.iperm.assign(N, 0);
@@ -1062,6 +1086,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
   // every condensed residual pivot d_r is "owned" by the first front that stages it: that front counts it in the inertia
   std::unordered_map<int32_t, char> d_claimed;
   P.rows_fronts = 0; P.listprod_fronts = 0;
+  P.rows_overflow.clear();
   for (int32_t s = 0; s < ns; s++) {
     const FrontHdr& F = P.fronts[s];
     size_t r0 = rec.size();
@@ -1140,7 +1165,7 @@ int write_forward_records(Plan& P, const DirectLists* D) {
         if (it == row_of.end()) { it = row_of.emplace(p_.d, (int32_t)rows.size()).first; rows.push_back(Row()); rows.back().d = p_.d; }
         rows[it->second].pr.push_back({p_.a, p_.b, p_.pos});
       }
-      if (rows.size() > 16) ok = false;
+      if (rows.size() > 16) { ok = false; if (F.npiv >= 2) P.rows_overflow.push_back(F.first_piv + F.npiv / 2); }
       for (auto& R : rows) {
         if (!ok) break;
         for (auto& q : R.pr)
@@ -1210,6 +1235,9 @@ int write_forward_records(Plan& P, const DirectLists* D) {
           rowsec.clear();
         }
       }
+      if (rowsec.empty() && getenv("CNL_VERBOSE"))
+        fprintf(stderr, "[cnl] row form refused: front %d (npiv %d nupd %d), %zu products, %zu rows%s\n", s, F.npiv, F.nupd, prs.size(), rows.size(),
+                rows.size() > 16 ? " (> 16 rows)" : "");
     }
     const bool rowform = !rowsec.empty();
     if (rowform) prs.clear();

@@ -773,12 +773,28 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
     p->P.row_products = o.row_products != 0;
     p->P.row_min_products = 72;
     int drc = cnl::write_forward_records(p->P, &D);
-    // A plan whose fronts are ALL row-form runs the kernels' lean instantiation (10 % faster on chain-like orders), which is
-    // worth more than the few rounds a handful of small fronts save with product lists: when the list fronts are few, give
-    // them the row form as well.
-    if (!drc && o.row_products && o.lean_kernel && p->P.listprod_fronts > 0 && 8 * p->P.listprod_fronts <= p->P.rows_fronts) {
+    // A plan whose fronts are ALL fast-class row-form fronts runs the kernels' lean instantiation and recovers the residual
+    // components in its backward sweep (no post-pass): worth more than the few rounds small fronts save with product lists, so
+    // every front is given the row form when that makes the whole plan lean.  A front whose residual rows do not fit the row form's
+    // sixteen lanes is cut in two (same order, one more front) and the records are written again.
+    const bool fast_only = p->P.ncls[1] == 0 && p->P.ncls[2] == 0;
+    if (!drc && o.row_products && o.lean_kernel && fast_only && p->P.listprod_fronts > 0) {
       p->P.row_min_products = 1;
       drc = cnl::write_forward_records(p->P, &D);
+      if (!drc && p->P.listprod_fronts > 0 && !p->P.rows_overflow.empty() && p->P.rows_overflow.size() <= 64) {
+        cnl::Options opt2 = opt;
+        opt2.split_positions = p->P.rows_overflow;
+        cnl::Plan P2;
+        std::string msg2;
+        if (cnl::build_plan(P2, p->C.N2, p->C.ncs + nvar, p->C.rows2.data(), p->C.cols2.data(), nvar, p->C.nequ2, ncon, opt2, msg2) == 0 &&
+            P2.v2_ok && P2.ncls[1] == 0 && P2.ncls[2] == 0) {
+          P2.row_products = true; P2.row_min_products = 1;
+          if (cnl::write_forward_records(P2, &D) == 0 && P2.listprod_fronts == 0) {
+            if (verbose) fprintf(stderr, "[cnl] %zu front(s) with more than 16 residual rows cut in two: %d -> %d fronts\n", p->P.rows_overflow.size(), p->P.nsuper, P2.nsuper);
+            p->P = std::move(P2);
+          }
+        }
+      }
       if (!drc && p->P.listprod_fronts > 0) {  // some front cannot take the row form: the lists' threshold again
         p->P.row_min_products = 72;
         drc = cnl::write_forward_records(p->P, &D);

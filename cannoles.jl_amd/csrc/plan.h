@@ -55,6 +55,9 @@ struct Options {
   int wait_thr = 2;        // update matrices that wait for more than this many fronts go to the global scratch
   int verbose = 0;
   std::string force_order; // pick an ordering candidate by name (experiments)
+  // elimination positions (of the chosen order) at which a supernode must be cut in two: the caller found a front whose condensed
+  // residual rows do not fit the row form's sixteen lanes (Plan::rows_overflow) and asks for the same plan with that front split
+  std::vector<int32_t> split_positions;
 };
 
 // One task of the staged execution: fronts [f0, f1) (a complete subtree, or a single front above the cut) processed by
@@ -112,6 +115,7 @@ struct Plan {
   bool row_products = true;   // direct records of fast fronts may use the row form (RF_ROWS)
   int32_t row_min_products = 72;  // ... from this many products on (analysis.cpp); 1 when that makes the whole plan row-form (lean kernel)
   int32_t rows_fronts = 0, listprod_fronts = 0;  // fast fronts in row form / with product lists
+  std::vector<int32_t> rows_overflow;  // fronts refused by the row form for MORE THAN 16 rows: the elimination position in their middle
   bool back_rows = false;  // the backward records recover the condensed residual components themselves (write_backward_rows)
   bool d_outer = false;  // backward records name solution components in the caller's numbering (set with rec_direct)
   int32_t nnz_outer = 0, n_outer = 0;  // outer (reference) nnz and N when rec_direct
