@@ -204,7 +204,7 @@ def test_record_streams_reproduce_the_oracle(shape):
     assert np.abs(d[kept] - d0[kept]).max() <= 1e-10 * np.abs(d0).max()
 
 
-@pytest.mark.parametrize("shape", [(200, 4, 2, 1), (1000, 10, 2, 64), (1000, 10, 2, 1), (600, 6, 3, 8), (400, 0, 2, 4), (2400, 12, 2, 1024), (3000, 6, 2, 2048)])
+@pytest.mark.parametrize("shape", [(200, 4, 2, 1), (1000, 10, 2, 64), (1000, 10, 2, 1), (600, 6, 3, 8), (400, 0, 2, 4), (2400, 12, 2, 1024), (3000, 6, 2, 2048), (10000, 50, 2, 1)])
 def test_staged_plans_reproduce_the_oracle(shape):
     """Latency plans (what cnl_create builds for small batches: bushy order, elimination tree cut into tasks) executed by
     tests/support/rec_sim.py::StagedSim the way the STAGED kernel runs them — every task on its own LDS stack, task roots
@@ -217,6 +217,11 @@ def test_staged_plans_reproduce_the_oracle(shape):
     plan = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=batch)
     tasks = plan.array("tasks").reshape(-1, 8)
     assert len(tasks) > 1 and plan.array("stage_ptr")[-1] == len(tasks)
+    if shape == (10000, 50, 2, 1):
+        # the headline pattern's nested-dissection order has ONE front with 17 condensed residual rows: the analysis cuts it in two
+        # (Options::split_positions), so that every front takes the row form and the plan runs the lean kernel with the residual
+        # components recovered by the backward records
+        assert plan.info["order"] == "nd32+early" and plan.info["nsuper"] == 1926 and plan.array("brec")[7] & 256
     if batch >= 1024:   # mid-size batches: a few large parts in canonical order, each one task
         assert plan.info["order"].startswith("ndc") and (tasks[:, 2] - tasks[:, 1]).max() > 20
     vals, rhs = syn.band_values(s, 78)
