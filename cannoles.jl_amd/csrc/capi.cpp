@@ -535,8 +535,11 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
         if ((rc = launch_redo(h, a, stream))) return rc;
         if (h->timing) HIPCHK(hipEventRecord(h->ev1, stream));
       } else if ((rc = launch(h, a, stream))) return rc;
-      e = cnl::launch_expand(h->dc, const_cast<double*>(h->last_vals), d_rhs, nullptr, h->d_cbuf, d_d, nullptr, 0, B, stream);
-      if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
+      // (lean plans: the solve-only instantiation has recovered the residual components in its backward sweep)
+      if (!(h->lean && h->plan->P.back_rows)) {
+        e = cnl::launch_expand(h->dc, const_cast<double*>(h->last_vals), d_rhs, nullptr, h->d_cbuf, d_d, nullptr, 0, B, stream);
+        if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("expand: ") + hipGetErrorString(e));
+      }
     } else {
       if (!h->last_vals) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
       e = C.tiled_ok ? cnl::launch_condense_tiled(h->dc, h->last_vals, d_rhs, h->d_cbuf, 4, C.ch_region[3], B, stream)

@@ -747,7 +747,9 @@ __device__ __forceinline__ void task_done(int* counter, int lane, bool release =
 // out-of-line front classes, raw-value staging and product lists.  Those paths are never executed for such plans, but they sit
 // in the middle of the hot loop's code, cost registers (256 with spills against 187) and instruction-cache footprint: the
 // lean instantiation is 10 % faster on the headline (same box: 965 k -> 1 058 k systems/s).
-template <bool STAGED, bool LATE, bool LEAN>
+// SOLVE: the lean instantiation of solve_ldl! (MODE_SOLVE only): forward substitution + backward sweep with the residual components
+// recovered by the backward records — nothing of the factorisation is compiled in, no post-pass behind the launch.
+template <bool STAGED, bool LATE, bool LEAN, bool SOLVE = false>
 __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(const DevPlan2 Pin, const LaunchArgs Ain) {
   DevPlan2 P = Pin;
   P.rec = as_global(Pin.rec); P.brec = as_global(Pin.brec);
@@ -860,7 +862,8 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   // goes into column 0 of the stored panel, where the backward sweep below expects it.  The host sends a plan here only
   // when every front is of the fast class (order <= 16, LDS staging).
   constexpr bool CNL_LEAN = LEAN;
-  if (!CNL_LEAN && A.mode == MODE_SOLVE && (!STAGED || A.phase == 0)) {
+  static_assert(!SOLVE || LEAN, "the solve-only instantiation is a lean one");
+  if ((SOLVE || (!CNL_LEAN && A.mode == MODE_SOLVE)) && (!STAGED || A.phase == 0)) {
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
     int4 R0, R1, R2;
     double pvr[PVR], prr[2], prh = 0.0;
@@ -899,7 +902,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       cvec[l] = 0.0;
       const int raw_off = aoff + 2 * nasm;
       const bool rowform = flags & RF_ROWS;
-      if (nraw > 0 && !rowform) {
+      if (!CNL_LEAN && nraw > 0 && !rowform) {
 #pragma unroll
         for (int j = 0; j < PVR; j++)
           if (j * 16 < nrawv) {
@@ -940,7 +943,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
           const int pos = (int)ROW_POS(pw_, ROWS_KM * (ROWS_KM + 1) / 2 + q), prow = tri_row(pos);
           if (pos == tri2(prow) && pos < FAST_IMG_TRI) __hip_atomic_fetch_add(&cvec[prow], tr * pvr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
-      } else {
+      } else if (!CNL_LEAN) {
         const int* pw = rec + raw_off + nraw + l;
         for (int e = 0; e < nprod; e += 16) {
           const int w = pw[e], pos = w & 255, prow = tri_row(pos);
@@ -1037,7 +1040,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   }
 
   STAMP_DECL
-  const bool do_fwd = STAGED ? (A.phase == 0 && A.mode != MODE_SOLVE) : A.mode != MODE_SOLVE;
+  const bool do_fwd = !SOLVE && (STAGED ? (A.phase == 0 && A.mode != MODE_SOLVE) : A.mode != MODE_SOLVE);
   while (do_fwd) {
     STAMP_BEGIN
     // ---------------- forward pass over the record stream ----------------
@@ -1536,8 +1539,10 @@ hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const La
   // L rows one front late (LPend) where wavefronts share their SIMDs: from about one wavefront per SIMD on
   // (the lean instantiation does better with immediate stores: 1 058 k against 1 003 k systems/s)
   const bool lean = a.lean != 0 && a.mode != MODE_SOLVE;
-  const bool late = waves >= 1024 && !lean;
-  auto kern = lean ? newton2_kernel_t<false, false, true> : (late ? newton2_kernel_t<false, true, false> : newton2_kernel_t<false, false, false>);
+  const bool lean_solve = a.lean != 0 && a.back_rows != 0 && a.mode == MODE_SOLVE;
+  const bool late = waves >= 1024 && !lean && !lean_solve;
+  auto kern = lean_solve ? newton2_kernel_t<false, false, true, true>
+            : lean ? newton2_kernel_t<false, false, true> : (late ? newton2_kernel_t<false, true, false> : newton2_kernel_t<false, false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), lds_bytes, stream, P, a);
@@ -1567,7 +1572,9 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
   //  4 096: 938 k against 966 k — late only when the first stage fills both slots of every SIMD)
   const bool late = (long long)a.nquads * ntask0 >= 1920 && P.nsuper >= 128 * ntask0;
   const bool lean = a.lean != 0 && a.mode != MODE_SOLVE;
-  auto kern = lean ? (late ? newton2_kernel_t<true, true, true> : newton2_kernel_t<true, false, true>)
+  const bool lean_solve = a.lean != 0 && a.back_rows != 0 && a.mode == MODE_SOLVE;
+  auto kern = lean_solve ? newton2_kernel_t<true, false, true, true>
+            : lean ? (late ? newton2_kernel_t<true, true, true> : newton2_kernel_t<true, false, true>)
                    : (late ? newton2_kernel_t<true, true, false> : newton2_kernel_t<true, false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
