@@ -508,6 +508,20 @@ def call_pattern_block(torch, hipldl, s, rows, cols, vals_h, rhs_h, dev, local_r
     res["try_to_factorize_ms"] = med(lambda: hipldl.try_to_factorize(L1, v1, s.nvar, s.nequ, s.ncon, params[0]))
     res["solve_ldl_ms"] = med(lambda: hipldl.solve_ldl_(r1, L1.factor, d1))
     res["two_call_total_ms"] = res["try_to_factorize_ms"] + res["solve_ldl_ms"]
+    # the same call on a system that climbs the rho ladder (nfact = 6, BASELINE config 5's stress on this pattern): the host drives
+    # the ladder, every rung a staged try_to_factorize (csrc/capi.cpp; the device ladder of the sequential launch: ~39 ms)
+    try:
+        from cannoles_jl_amd import synthetic as syn_
+        vl, rl = syn_.batch_values(s, 1, cfg=5, stress="ladder")
+        vl0 = vl[0].copy()
+        outl = {}
+
+        def ladder_call():
+            outl["r"] = hipldl.newton_system_(d1, s.nvar, s.nequ, s.ncon, rl[0], vl0.copy(), L1, 0.0, params)
+        res["newton_system_nfact6_ms"] = med(ladder_call, reps=10)
+        res["nfact6_check"] = {"nfact": int(outl["r"][4]), "success": bool(outl["r"][1])}
+    except Exception as e:
+        res["newton_system_nfact6_ms"] = {"error": str(e)}
     # device-resident twins of the same three calls (HIP events)
     tv, tr = torch.from_numpy(v1[None].copy()).to(dev), torch.from_numpy(r1[None].copy()).to(dev)
     td = torch.zeros((1, s.N), dtype=torch.float64, device=dev)

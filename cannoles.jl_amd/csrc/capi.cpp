@@ -61,6 +61,8 @@ struct cnl_handle {
   int df_waves = 1024;
   std::vector<int32_t> stage_ptr;
   bool v2_solve = false;  // cnl_solve runs on the register-front kernel too (direct records, every front of the fast class)
+  bool first_attempt_only = false;  // newton_system on a staged handle: no sequential launch behind the staged attempt (the host ladder follows)
+  int* d_act = nullptr;   // [batch] problems whose rho slots the host ladder rewrites
   bool lean = false;      // every front of the fast class with row-form (or no) products: the kernels' LEAN instantiation serves it
   cnl::DevPlan2 dp2{};
   int wpb2 = 1;
@@ -484,12 +486,18 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
         // first attempt (rho as given) stage by stage: the tasks of the elimination tree run on different wavefronts; the
         // problems that fail it (rare) go through the whole ladder in the classic launch behind it
         if ((rc = launch_staged(h, a, stream))) return rc;
-        a.skip_done = 1;
-        const bool tm = h->timing;
-        h->timing = false;
-        rc = launch(h, a, stream);
-        h->timing = tm;
-        if (rc) return rc;
+        if (h->first_attempt_only) {
+          // the host ladder follows; the sequential launch only if a dataflow wait of the attempt gave up (it then redoes the whole
+          // call on the device, ladder included: the host finds the per-call status word set and leaves the results alone)
+          if ((rc = launch_redo(h, a, stream))) return rc;
+        } else {
+          a.skip_done = 1;
+          const bool tm = h->timing;
+          h->timing = false;
+          rc = launch(h, a, stream);
+          h->timing = tm;
+          if (rc) return rc;
+        }
         if (h->timing) HIPCHK(hipEventRecord(h->ev1, stream));
       } else if ((rc = launch(h, a, stream))) return rc;
       // (the lean instantiation has recovered the residual components in its backward sweep: plan.h, B_ROWS_FLAG)
@@ -672,7 +680,7 @@ void cnl_options_init(cnl_options* o) {
   o->multipliers_early = 1; o->condense = 1; o->direct_records = 1; o->register_front = 1; o->dense_backend = 1; o->general_dense = 1;
   o->staged = 1; o->dataflow = 1; o->dataflow_waves = 1024; o->dataflow_spin_limit = 1 << 22;
   o->waves_per_block = 0; o->v1_tpp = -1; o->v1_ppb = -1; o->v1_lds = -1; o->v1_solve = 0; o->lds_pad = 1;
-  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1;
+  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -1424,15 +1432,25 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   a.npos = h->d_npos;  // diagnostic build: per-wave phase stamps land here (cnl_debug_stamps)
 #endif
   std::memcpy(a.params, params, 9 * sizeof(double));
-  if ((rc = run(h, a, h->d_vals, h->d_rhs, h->d_d, h->stream))) return rc;
+  // Small batches on a staged handle: the rho ladder is driven from the HOST, like the reference's own newton_system!
+  // (src/CaNNOLeS.jl:1023-1047) — every rung is a staged try_to_factorize (all tasks of the elimination tree in parallel, ~0.1 ms)
+  // and a read-back of the success flags.  The sequential launch that takes failed problems through the ladder on the device
+  // walks the latency plan's fronts one after the other on ONE wavefront per four problems: 7.7 ms per rung for a system of
+  // cfg3's size (38 ms for nfact = 6, ten times one CPU core of the oracle); it stays the device-pointer calls' fallback.
+  const bool small = B * (size_t)P.N * sizeof(double) <= ((size_t)1 << 20);
+  const bool host_ladder = small && h->staged && !h->dense && !h->gdense && h->plan->opt.host_ladder != 0 && h->use_v2 && P.P.rec_direct && P.P.d_outer;
+  h->first_attempt_only = host_ladder;
+  rc = run(h, a, h->d_vals, h->d_rhs, h->d_d, h->stream);
+  h->first_attempt_only = false;
+  if (rc) return rc;
   h->last_vals = h->d_vals;
   // Small batches (the reference's own call: one system): every result goes to ONE pinned block of the handle with asynchronous
   // copies and a single synchronisation; the caller's arrays are then filled on the host by the reference's rules (d only
   // where the factorisation succeeded, the rho slots of vals only where the ladder wrote them).  Copies into pageable memory
   // block one by one, and the success flags would need a round trip of their own before d may be copied.
-  if (B * (size_t)P.N * sizeof(double) <= ((size_t)1 << 20)) {
+  if (small) {
     const size_t o_d = 0, o_tail = o_d + B * P.N * 8, o_rho = o_tail + B * P.nvar * 8, o_ro = o_rho + B * 8, o_nf = o_ro + B * 8,
-                 o_su = o_nf + B * 4, total = o_su + B * 4;
+                 o_su = o_nf + B * 4, o_up = (o_su + B * 4 + 7) & ~(size_t)7, total = o_up + B * 12 + 8;
     if (!h->pin || h->pin_bytes < total) {
       if (h->pin) (void)hipHostFree(h->pin);
       h->pin = nullptr;
@@ -1448,11 +1466,68 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     HIPCHK(hipMemcpyAsync(pb + o_ro, h->d_rho_old, B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pb + o_nf, h->d_nfact, B * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pb + o_su, h->d_success, B * 4, hipMemcpyDeviceToHost, h->stream));
+    int32_t* up_status = reinterpret_cast<int32_t*>(pb + o_up + B * 12);
+    *up_status = 0;
+    if (host_ladder && h->d_dep)  // per-call status of the dataflow execution (kernels2.hip, spin_until): waits that gave up
+      HIPCHK(hipMemcpyAsync(up_status, h->d_dep + 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4), 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     std::memcpy(rho, pb + o_rho, B * 8);
     std::memcpy(rho_old_out, pb + o_ro, B * 8);
     std::memcpy(nfact, pb + o_nf, B * 4);
     std::memcpy(success, pb + o_su, B * 4);
+    bool any_failed = false;
+    for (size_t b = 0; b < B; b++) any_failed |= !success[b];
+    if (host_ladder && any_failed && *up_status == 0) {
+      // ---- the ladder of src/CaNNOLeS.jl:1023-1047 for the problems whose first factorisation failed
+      const double rho0 = params[5], rhomax = params[6], rhomin = params[7], kdec = params[2], kinc = params[3], klarge = params[4];
+      if (!h->d_act && (rc = dalloc(h, &h->d_act, B))) return rc;
+      double* up_rho = reinterpret_cast<double*>(pb + o_up);
+      int32_t* up_act = reinterpret_cast<int32_t*>(pb + o_up + B * 8);
+      std::vector<char> act(B, 0);
+      std::vector<double> ro_in(B);
+      for (size_t b = 0; b < B; b++) {
+        ro_in[b] = rho_old ? rho_old[b] : 0.0;
+        if (!success[b]) { act[b] = 1; rho[b] = ro_in[b] == 0.0 ? rho0 : std::max(rhomin, kdec * ro_in[b]); }
+      }
+      bool any_act = true;
+      while (any_act) {
+        for (size_t b = 0; b < B; b++) { up_rho[b] = rho[b]; up_act[b] = act[b]; }
+        HIPCHK(hipMemcpyAsync(h->d_rho, up_rho, B * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_act, up_act, B * 4, hipMemcpyHostToDevice, h->stream));
+        hipError_t e = cnl::launch_fill_rho(h->d_vals, P.nnz, (int)P.nvar, h->d_rho, h->d_act, (int)B, h->stream);
+        if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("fill_rho: ") + hipGetErrorString(e));
+        cnl::LaunchArgs f{};
+        f.mode = cnl::MODE_FACTOR;
+        f.success = h->d_success; f.npos = h->d_npos; f.nzero = h->d_nzero;
+        std::memcpy(f.params, params, 9 * sizeof(double));
+        if ((rc = run(h, f, h->d_vals, nullptr, nullptr, h->stream))) return rc;
+        HIPCHK(hipMemcpyAsync(pb + o_su, h->d_success, B * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const int32_t* su = reinterpret_cast<const int32_t*>(pb + o_su);
+        any_act = false;
+        for (size_t b = 0; b < B; b++) {
+          if (!act[b]) continue;
+          nfact[b]++;
+          if (su[b]) { success[b] = 1; act[b] = 0; continue; }
+          rho[b] = ro_in[b] == 0.0 ? klarge * rho[b] : kinc * rho[b];
+          if (rho[b] > rhomax) act[b] = 0;   // the ladder ran out: rho keeps the value beyond rhomax, the slots the last one tried
+          else any_act = true;
+        }
+      }
+      for (size_t b = 0; b < B; b++)
+        if (rho[b] != 0.0 && rho[b] <= rhomax) rho_old_out[b] = rho[b];   // (rho != 0: the problem entered the ladder)
+      // solve_ldl! for everything that holds a valid factor now (the problems of the first attempt are solved again: same factor)
+      cnl::LaunchArgs sv{};
+      sv.mode = cnl::MODE_SOLVE;
+      std::memcpy(sv.params, params, 9 * sizeof(double));
+      h->last_vals = h->d_vals;
+      if ((rc = run(h, sv, nullptr, h->d_rhs, h->d_d, h->stream))) return rc;
+      HIPCHK(hipMemcpyAsync(pb + o_d, h->d_d, B * P.N * 8, hipMemcpyDeviceToHost, h->stream));
+      if (P.nvar > 0)
+        HIPCHK(hipMemcpy2DAsync(pb + o_tail, (size_t)P.nvar * 8, h->d_vals + (P.nnz - P.nvar), (size_t)P.nnz * 8, (size_t)P.nvar * 8, B,
+                                hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
     for (size_t b = 0; b < B; b++) {
       if (success[b]) std::memcpy(d + b * P.N, pb + o_d + b * P.N * 8, (size_t)P.N * 8);
       // rho tail of vals (the reference mutates get_vals(LDLT)[end-nvar+1:end] on retries only, src/CaNNOLeS.jl:1031,1038); the

@@ -105,6 +105,8 @@ typedef struct cnl_options {
   int32_t rows_in_backward;    /* 1: the lean kernel recovers the residual components in its backward sweep (no post-pass)      */
   int32_t dense_panel_blocks;  /* dense backend, panel step with four column-block wavefronts per tile (dn_panel2): 0 never,
                                   1 while the step is latency-bound (batch x tiles <= 512; default), 2 always                    */
+  int32_t host_ladder;         /* 1: small-batch host-pointer cnl_newton_system drives the rho ladder from the host, every rung a
+                                  staged try_to_factorize (default); 0: the device ladder of the sequential launch              */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);

@@ -1266,3 +1266,47 @@ def test_residual_components_in_the_backward_sweep(built, B):
 
 
 
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_host_driven_ladder_equals_the_device_ladder(built, B):
+    """The small-batch host-pointer newton_system! drives the rho ladder from the host — every rung a staged try_to_factorize
+    (csrc/capi.cpp; src/CaNNOLeS.jl:1023-1047) — instead of handing failed problems to the sequential device launch
+    (cnl_options.host_ladder = 0): both must return the oracle's (success, nfact, rho, rho_old) bit for bit, the rho slots of
+    vals as the reference leaves them, a solution for the problems that succeed and an untouched d for the hopeless one —
+    for a batch that mixes a convex problem (no ladder), ladder climbers with rho_old = 0 and rho_old > 0, and a hopeless one."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(600, 6)
+    rows, cols = s.kkt_pattern()
+    vals, rhs = syn.batch_values(s, B, cfg=5, stress="ladder")
+    off = s.offsets()
+    ro_in = np.zeros(B)
+    if B > 1:
+        v3, r3 = syn.batch_values(s, B, cfg=3)
+        vals[0], rhs[0] = v3[0], r3[0]                # convex: first factorisation succeeds
+        vals[1, off[0]:off[1]] = np.nan               # no rho repairs it
+        ro_in[3] = 2.5e-3                             # the ladder starts from max(rho_min, kappa_dec rho_old)
+    p = hipldl.default_params()
+    po = O.default_params()
+    orc = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
+    res = {}
+    for hl in (1, 0):
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(host_ladder=hl))
+        v = vals.copy()
+        d = np.full((B, s.N), 7.0)
+        out = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, ro_in if B > 1 else 0.0, p)
+        res[hl] = tuple(np.atleast_1d(np.asarray(x)).copy() for x in out[1:]) + (np.array(d, copy=True).reshape(B, s.N), v.reshape(B, -1).copy())
+        L.close()
+    for k in range(4):
+        assert np.array_equal(res[1][k], res[0][k]), k     # success, rho, rho_old, nfact: bit for bit
+    assert np.array_equal(res[1][5], res[0][5], equal_nan=True)   # vals: the rho slots as the reference leaves them
+    d0, ok0, rho0, ro0, nf0 = O.newton_system_batch(orc, B, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), ro_in, po)
+    assert np.array_equal(res[1][0].astype(bool), np.atleast_1d(ok0)) and np.array_equal(res[1][3], np.atleast_1d(nf0))
+    assert np.array_equal(res[1][1], np.atleast_1d(rho0)) and np.array_equal(res[1][2], np.atleast_1d(ro0))
+    assert res[1][3].max() >= 3                              # the ladder was climbed
+    for b in range(B):
+        if res[1][0][b]:
+            assert backward_error(s, res[1][5][b], rhs[b], res[1][4][b]) <= BWD_TOL
+            assert np.abs(res[1][4][b] - res[0][4][b]).max() <= 1e-9 * np.abs(res[0][4][b]).max()
+        else:
+            assert (res[1][4][b] == 7.0).all() and (res[0][4][b] == 7.0).all()
