@@ -1405,6 +1405,59 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
   return CNL_OK;
 }
 
+// The rho ladder of src/CaNNOLeS.jl:1023-1047 driven from the host for the problems whose first (staged) factorisation failed:
+// every rung is a staged try_to_factorize of the batch and a read-back of the success flags; the solve follows (cnl_newton_system).
+// up: pinned staging of 12 bytes per problem; su_pin: pinned, batch ints.  On return rho / rho_old_out / nfact / success hold the
+// reference's results and the device holds the factors and the solution of everything that succeeded.
+static int host_ladder_run(cnl_handle* h, const double params[9], const double* rho_old, double* rho, double* rho_old_out, int32_t* nfact,
+                           int32_t* success, char* up, int32_t* su_pin) {
+  const cnl_plan& P = *h->plan;
+  const size_t B = (size_t)h->batch;
+  int rc;
+  const double rho0 = params[5], rhomax = params[6], rhomin = params[7], kdec = params[2], kinc = params[3], klarge = params[4];
+  if (!h->d_act && (rc = dalloc(h, &h->d_act, B))) return rc;
+  double* up_rho = reinterpret_cast<double*>(up);
+  int32_t* up_act = reinterpret_cast<int32_t*>(up + B * 8);
+  std::vector<char> act(B, 0);
+  std::vector<double> ro_in(B);
+  for (size_t b = 0; b < B; b++) {
+    ro_in[b] = rho_old ? rho_old[b] : 0.0;
+    if (!success[b]) { act[b] = 1; rho[b] = ro_in[b] == 0.0 ? rho0 : std::max(rhomin, kdec * ro_in[b]); }
+  }
+  bool any_act = true;
+  while (any_act) {
+    for (size_t b = 0; b < B; b++) { up_rho[b] = rho[b]; up_act[b] = act[b]; }
+    HIPCHK(hipMemcpyAsync(h->d_rho, up_rho, B * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_act, up_act, B * 4, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = cnl::launch_fill_rho(h->d_vals, P.nnz, (int)P.nvar, h->d_rho, h->d_act, (int)B, h->stream);
+    if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("fill_rho: ") + hipGetErrorString(e));
+    cnl::LaunchArgs f{};
+    f.mode = cnl::MODE_FACTOR;
+    f.success = h->d_success; f.npos = h->d_npos; f.nzero = h->d_nzero;
+    std::memcpy(f.params, params, 9 * sizeof(double));
+    if ((rc = run(h, f, h->d_vals, nullptr, nullptr, h->stream))) return rc;
+    HIPCHK(hipMemcpyAsync(su_pin, h->d_success, B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    any_act = false;
+    for (size_t b = 0; b < B; b++) {
+      if (!act[b]) continue;
+      nfact[b]++;
+      if (su_pin[b]) { success[b] = 1; act[b] = 0; continue; }
+      rho[b] = ro_in[b] == 0.0 ? klarge * rho[b] : kinc * rho[b];
+      if (rho[b] > rhomax) act[b] = 0;   // the ladder ran out: rho keeps the value beyond rhomax, the slots the last one tried
+      else any_act = true;
+    }
+  }
+  for (size_t b = 0; b < B; b++)
+    if (rho[b] != 0.0 && rho[b] <= rhomax) rho_old_out[b] = rho[b];   // (rho != 0: the problem entered the ladder)
+  // solve_ldl! for everything that holds a valid factor now (the problems of the first attempt are solved again: same factor)
+  cnl::LaunchArgs sv{};
+  sv.mode = cnl::MODE_SOLVE;
+  std::memcpy(sv.params, params, 9 * sizeof(double));
+  h->last_vals = h->d_vals;
+  return run(h, sv, nullptr, h->d_rhs, h->d_d, h->stream);
+}
+
 int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d, const double* rho_old, const double params[9],
                       double* rho, double* rho_old_out, int32_t* nfact, int32_t* success) {
   if (!h || !vals || !rhs || !d || !params || !rho || !rho_old_out || !nfact || !success) return fail(CNL_ERR_ARG, "null argument");
@@ -1438,7 +1491,7 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   // walks the latency plan's fronts one after the other on ONE wavefront per four problems: 7.7 ms per rung for a system of
   // cfg3's size (38 ms for nfact = 6, ten times one CPU core of the oracle); it stays the device-pointer calls' fallback.
   const bool small = B * (size_t)P.N * sizeof(double) <= ((size_t)1 << 20);
-  const bool host_ladder = small && h->staged && !h->dense && !h->gdense && h->plan->opt.host_ladder != 0 && h->use_v2 && P.P.rec_direct && P.P.d_outer;
+  const bool host_ladder = h->staged && !h->dense && !h->gdense && h->plan->opt.host_ladder != 0 && h->use_v2 && P.P.rec_direct && P.P.d_outer;
   h->first_attempt_only = host_ladder;
   rc = run(h, a, h->d_vals, h->d_rhs, h->d_d, h->stream);
   h->first_attempt_only = false;
@@ -1478,50 +1531,7 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     bool any_failed = false;
     for (size_t b = 0; b < B; b++) any_failed |= !success[b];
     if (host_ladder && any_failed && *up_status == 0) {
-      // ---- the ladder of src/CaNNOLeS.jl:1023-1047 for the problems whose first factorisation failed
-      const double rho0 = params[5], rhomax = params[6], rhomin = params[7], kdec = params[2], kinc = params[3], klarge = params[4];
-      if (!h->d_act && (rc = dalloc(h, &h->d_act, B))) return rc;
-      double* up_rho = reinterpret_cast<double*>(pb + o_up);
-      int32_t* up_act = reinterpret_cast<int32_t*>(pb + o_up + B * 8);
-      std::vector<char> act(B, 0);
-      std::vector<double> ro_in(B);
-      for (size_t b = 0; b < B; b++) {
-        ro_in[b] = rho_old ? rho_old[b] : 0.0;
-        if (!success[b]) { act[b] = 1; rho[b] = ro_in[b] == 0.0 ? rho0 : std::max(rhomin, kdec * ro_in[b]); }
-      }
-      bool any_act = true;
-      while (any_act) {
-        for (size_t b = 0; b < B; b++) { up_rho[b] = rho[b]; up_act[b] = act[b]; }
-        HIPCHK(hipMemcpyAsync(h->d_rho, up_rho, B * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_act, up_act, B * 4, hipMemcpyHostToDevice, h->stream));
-        hipError_t e = cnl::launch_fill_rho(h->d_vals, P.nnz, (int)P.nvar, h->d_rho, h->d_act, (int)B, h->stream);
-        if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("fill_rho: ") + hipGetErrorString(e));
-        cnl::LaunchArgs f{};
-        f.mode = cnl::MODE_FACTOR;
-        f.success = h->d_success; f.npos = h->d_npos; f.nzero = h->d_nzero;
-        std::memcpy(f.params, params, 9 * sizeof(double));
-        if ((rc = run(h, f, h->d_vals, nullptr, nullptr, h->stream))) return rc;
-        HIPCHK(hipMemcpyAsync(pb + o_su, h->d_success, B * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        const int32_t* su = reinterpret_cast<const int32_t*>(pb + o_su);
-        any_act = false;
-        for (size_t b = 0; b < B; b++) {
-          if (!act[b]) continue;
-          nfact[b]++;
-          if (su[b]) { success[b] = 1; act[b] = 0; continue; }
-          rho[b] = ro_in[b] == 0.0 ? klarge * rho[b] : kinc * rho[b];
-          if (rho[b] > rhomax) act[b] = 0;   // the ladder ran out: rho keeps the value beyond rhomax, the slots the last one tried
-          else any_act = true;
-        }
-      }
-      for (size_t b = 0; b < B; b++)
-        if (rho[b] != 0.0 && rho[b] <= rhomax) rho_old_out[b] = rho[b];   // (rho != 0: the problem entered the ladder)
-      // solve_ldl! for everything that holds a valid factor now (the problems of the first attempt are solved again: same factor)
-      cnl::LaunchArgs sv{};
-      sv.mode = cnl::MODE_SOLVE;
-      std::memcpy(sv.params, params, 9 * sizeof(double));
-      h->last_vals = h->d_vals;
-      if ((rc = run(h, sv, nullptr, h->d_rhs, h->d_d, h->stream))) return rc;
+      if ((rc = host_ladder_run(h, params, rho_old, rho, rho_old_out, nfact, success, pb + o_up, reinterpret_cast<int32_t*>(pb + o_su)))) return rc;
       HIPCHK(hipMemcpyAsync(pb + o_d, h->d_d, B * P.N * 8, hipMemcpyDeviceToHost, h->stream));
       if (P.nvar > 0)
         HIPCHK(hipMemcpy2DAsync(pb + o_tail, (size_t)P.nvar * 8, h->d_vals + (P.nnz - P.nvar), (size_t)P.nnz * 8, (size_t)P.nvar * 8, B,
@@ -1539,7 +1549,32 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   }
   // the reference leaves d untouched when the factorisation fails (src/CaNNOLeS.jl:1049): copy back the rows that succeeded
   HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  int32_t status_word = 0;
+  if (host_ladder && h->d_dep)
+    HIPCHK(hipMemcpyAsync(&status_word, h->d_dep + 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4), 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  bool laddered = false;
+  if (host_ladder && status_word == 0) {
+    bool any_failed = false;
+    for (size_t b = 0; b < B; b++) any_failed |= !success[b];
+    if (any_failed) {
+      // first attempt's per-problem results (rho = 0, rho_old as given, nfact = 1), then the host ladder on top of them
+      HIPCHK(hipMemcpyAsync(rho, h->d_rho, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipMemcpyAsync(rho_old_out, h->d_rho_old, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipMemcpyAsync(nfact, h->d_nfact, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      const size_t need = B * 16;
+      if (!h->pin || h->pin_bytes < need) {
+        if (h->pin) (void)hipHostFree(h->pin);
+        h->pin = nullptr;
+        HIPCHK(hipHostMalloc(&h->pin, need, hipHostMallocDefault));
+        h->pin_bytes = need;
+      }
+      char* pb2 = static_cast<char*>(h->pin);
+      if ((rc = host_ladder_run(h, params, rho_old, rho, rho_old_out, nfact, success, pb2, reinterpret_cast<int32_t*>(pb2 + B * 12)))) return rc;
+      laddered = true;
+    }
+  }
   {
     size_t b0 = 0;
     while (b0 < B) {  // maximal runs of successful problems: one copy in the common case
@@ -1550,9 +1585,11 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
       b0 = b1;
     }
   }
-  HIPCHK(hipMemcpyAsync(rho, h->d_rho, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(rho_old_out, h->d_rho_old, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(nfact, h->d_nfact, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  if (!laddered) {
+    HIPCHK(hipMemcpyAsync(rho, h->d_rho, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rho_old_out, h->d_rho_old, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(nfact, h->d_nfact, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  }
   // rho tail of vals (the reference mutates get_vals(LDLT)[end-nvar+1:end], src/CaNNOLeS.jl:1031,1038)
   if (P.nvar > 0)
     HIPCHK(hipMemcpy2DAsync(vals + (P.nnz - P.nvar), (size_t)P.nnz * sizeof(double), h->d_vals + (P.nnz - P.nvar),

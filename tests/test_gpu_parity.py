@@ -1268,7 +1268,7 @@ def test_residual_components_in_the_backward_sweep(built, B):
 
 
 
-@pytest.mark.parametrize("B", [1, 4])
+@pytest.mark.parametrize("B", [1, 4, 120])   # 120: past the single pinned block of the smallest batches (separate copies)
 def test_host_driven_ladder_equals_the_device_ladder(built, B):
     """The small-batch host-pointer newton_system! drives the rho ladder from the host — every rung a staged try_to_factorize
     (csrc/capi.cpp; src/CaNNOLeS.jl:1023-1047) — instead of handing failed problems to the sequential device launch
