@@ -1298,6 +1298,9 @@ int cnl_solve(cnl_handle* h, const double* rhs, double* d) {
 // which is full duplex — while chunk c + 1 goes up (calling thread, alternating between two streams) chunk c is computed and the
 // results of chunk c - 1 come down (a helper thread of the call, third stream).  Copies between pageable host memory and the
 // device block their host thread, hence the second thread; the compute of a chunk hides behind the upload of the next.
+static int host_ladder_run(cnl_handle* h, const double params[9], const double* rho_old, double* rho, double* rho_old_out, int32_t* nfact,
+                           int32_t* success, char* up, int32_t* su_pin);
+
 static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rhs, double* d, const double* rho_old, const double params[9],
                                    double* rho, double* rho_old_out, int32_t* nfact, int32_t* success, size_t chunk) {
   const cnl_plan& P = *h->plan;
@@ -1391,16 +1394,46 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
   };
   const bool tm = h->timing;
   h->timing = false;
+  // staged handles: the chunks run the first attempt only; the problems that failed it go through the host-driven ladder on the
+  // whole (now device-resident) batch behind the last chunk (see cnl_newton_system)
+  const bool host_ladder = h->staged && !h->dense && !h->gdense && h->plan->opt.host_ladder != 0 && h->use_v2 && P.P.rec_direct && P.P.d_outer;
+  h->first_attempt_only = host_ladder;
   std::vector<std::thread> ups;
   for (int u = 1; u < NU; u++) ups.emplace_back(uploader, u);
   uploader(0);
   for (std::thread& th : ups) th.join();
+  h->first_attempt_only = false;
   h->timing = tm;
   down.join();
   for (int u = 0; u < NU; u++) (void)hipStreamSynchronize(h->pipe_stream[u]);
   for (int u = 0; u < NU; u++) if (urc[u] != CNL_OK) return fail(urc[u], umsg[u]);
   if (wrc != CNL_OK) return fail(wrc, "download: " + wmsg);
   h->last_vals = h->d_vals;
+  if (host_ladder) {
+    std::vector<char> failed(B, 0);
+    bool any_failed = false;
+    for (size_t b = 0; b < B; b++) { failed[b] = !success[b]; any_failed |= failed[b] != 0; }
+    if (any_failed) {
+      const size_t need = B * 16;
+      if (!h->pin || h->pin_bytes < need) {
+        if (h->pin) (void)hipHostFree(h->pin);
+        h->pin = nullptr;
+        HIPCHK(hipHostMalloc(&h->pin, need, hipHostMallocDefault));
+        h->pin_bytes = need;
+      }
+      char* pb2 = static_cast<char*>(h->pin);
+      int rc = host_ladder_run(h, params, rho_old, rho, rho_old_out, nfact, success, pb2, reinterpret_cast<int32_t*>(pb2 + B * 12));
+      if (rc) return rc;
+      for (size_t b = 0; b < B; b++) {
+        if (!failed[b]) continue;
+        if (success[b]) HIPCHK(hipMemcpyAsync(d + b * P.N, h->d_d + b * P.N, (size_t)P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (P.nvar > 0)
+          HIPCHK(hipMemcpyAsync(vals + b * P.nnz + (P.nnz - P.nvar), h->d_vals + b * P.nnz + (P.nnz - P.nvar), (size_t)P.nvar * sizeof(double),
+                                hipMemcpyDeviceToHost, h->stream));
+      }
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
+  }
   h->factorized = true;
   return CNL_OK;
 }

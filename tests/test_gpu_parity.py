@@ -945,8 +945,13 @@ def test_host_pointer_call_pipelined_in_chunks(built):
     torch.cuda.synchronize()
     assert np.array_equal(tsu.cpu().numpy().astype(bool), ok) and np.array_equal(tnf.cpu().numpy(), nf)
     assert np.array_equal(trho.cpu().numpy(), rho) and np.array_equal(tro.cpu().numpy(), ro)
-    good = np.nonzero(ok)[0]
+    good = np.nonzero(ok & (nf == 1))[0]
     assert np.array_equal(td.cpu().numpy()[good], d[good])
+    # the problem that climbed the ladder: on the host-pointer call the host drives the ladder (staged rungs, lean solve), the
+    # device-pointer call runs the device ladder — same decisions (above), solutions equal to rounding
+    for b in np.nonzero(ok & (nf > 1))[0]:
+        tdb = td[b].cpu().numpy()
+        assert np.abs(tdb - d[b]).max() <= 1e-11 * np.abs(d[b]).max()
     assert np.array_equal(tv.cpu().numpy()[:, -s.nvar:], v[:, -s.nvar:])
     orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
     for b in (0, 36, 38, 70, 99):
