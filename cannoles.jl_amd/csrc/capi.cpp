@@ -1510,6 +1510,51 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   HIPCHK(hipMemcpyAsync(h->d_rhs, rhs, B * P.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (rho_old) HIPCHK(hipMemcpyAsync(h->d_rho_old, rho_old, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
   else HIPCHK(hipMemsetAsync(h->d_rho_old, 0, B * sizeof(double), h->stream));
+  if (h->dense && !h->timing && h->plan->opt.host_ladder != 0) {
+    // Dense backend, host-pointer call: the reference's own sequence — try_to_factorize, the rho ladder on the host, solve_ldl! — with
+    // the library's multi-kernel factorisation for EVERY rung.  The fused device call decides its ladder on the device, where a
+    // problem that failed is refactorised by ONE workgroup walking all tiles (dn_ladder: 7.8 ms per rung at cfg2's size against
+    // 0.35 ms for the launch sequence): 48 ms for a cfg2 system that climbs to nfact = 7.  Costs one more synchronisation when
+    // nothing fails.
+    cnl::LaunchArgs f{};
+    f.mode = cnl::MODE_FACTOR;
+    f.success = h->d_success; f.npos = h->d_npos; f.nzero = h->d_nzero;
+    std::memcpy(f.params, params, 9 * sizeof(double));
+    if ((rc = run(h, f, h->d_vals, nullptr, nullptr, h->stream))) return rc;
+    HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    bool any_failed = false;
+    for (size_t b = 0; b < B; b++) {
+      rho[b] = 0.0; nfact[b] = 1; rho_old_out[b] = rho_old ? rho_old[b] : 0.0;
+      any_failed |= !success[b];
+    }
+    if (any_failed) {
+      const size_t need = B * 16;
+      if (!h->pin || h->pin_bytes < need) {
+        if (h->pin) (void)hipHostFree(h->pin);
+        h->pin = nullptr;
+        HIPCHK(hipHostMalloc(&h->pin, need, hipHostMallocDefault));
+        h->pin_bytes = need;
+      }
+      char* pb2 = static_cast<char*>(h->pin);
+      if ((rc = host_ladder_run(h, params, rho_old, rho, rho_old_out, nfact, success, pb2, reinterpret_cast<int32_t*>(pb2 + B * 12)))) return rc;
+    } else {
+      cnl::LaunchArgs sv{};
+      sv.mode = cnl::MODE_SOLVE;
+      std::memcpy(sv.params, params, 9 * sizeof(double));
+      if ((rc = run(h, sv, nullptr, h->d_rhs, h->d_d, h->stream))) return rc;
+    }
+    for (size_t b = 0; b < B; b++) {
+      if (success[b]) HIPCHK(hipMemcpyAsync(d + b * P.N, h->d_d + b * P.N, (size_t)P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      if (nfact[b] > 1 && P.nvar > 0)
+        HIPCHK(hipMemcpyAsync(vals + b * P.nnz + (P.nnz - P.nvar), h->d_vals + b * P.nnz + (P.nnz - P.nvar), (size_t)P.nvar * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->last_vals = h->d_vals;
+    h->factorized = true;
+    return CNL_OK;
+  }
   cnl::LaunchArgs a{};
   a.mode = cnl::MODE_NEWTON;
   a.rho_old = h->d_rho_old; a.rho = h->d_rho;
