@@ -1590,9 +1590,14 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     }
     char* pb = static_cast<char*>(h->pin);
     HIPCHK(hipMemcpyAsync(pb + o_d, h->d_d, B * P.N * 8, hipMemcpyDeviceToHost, h->stream));
-    if (P.nvar > 0)
+    // (with the host-driven ladder the first attempt never writes the rho slots: they come back only behind a ladder, or behind the
+    //  sequential redo of a dataflow time-out)
+    bool tail_valid = false;
+    if (P.nvar > 0 && !host_ladder) {
       HIPCHK(hipMemcpy2DAsync(pb + o_tail, (size_t)P.nvar * 8, h->d_vals + (P.nnz - P.nvar), (size_t)P.nnz * 8, (size_t)P.nvar * 8, B,
                               hipMemcpyDeviceToHost, h->stream));
+      tail_valid = true;
+    }
     HIPCHK(hipMemcpyAsync(pb + o_rho, h->d_rho, B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pb + o_ro, h->d_rho_old, B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pb + o_nf, h->d_nfact, B * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1611,16 +1616,23 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     if (host_ladder && any_failed && *up_status == 0) {
       if ((rc = host_ladder_run(h, params, rho_old, rho, rho_old_out, nfact, success, pb + o_up, reinterpret_cast<int32_t*>(pb + o_su)))) return rc;
       HIPCHK(hipMemcpyAsync(pb + o_d, h->d_d, B * P.N * 8, hipMemcpyDeviceToHost, h->stream));
-      if (P.nvar > 0)
+      if (P.nvar > 0) {
         HIPCHK(hipMemcpy2DAsync(pb + o_tail, (size_t)P.nvar * 8, h->d_vals + (P.nnz - P.nvar), (size_t)P.nnz * 8, (size_t)P.nvar * 8, B,
                                 hipMemcpyDeviceToHost, h->stream));
+        tail_valid = true;
+      }
       HIPCHK(hipStreamSynchronize(h->stream));
+    } else if (host_ladder && *up_status != 0 && P.nvar > 0) {
+      HIPCHK(hipMemcpy2DAsync(pb + o_tail, (size_t)P.nvar * 8, h->d_vals + (P.nnz - P.nvar), (size_t)P.nnz * 8, (size_t)P.nvar * 8, B,
+                              hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      tail_valid = true;
     }
     for (size_t b = 0; b < B; b++) {
       if (success[b]) std::memcpy(d + b * P.N, pb + o_d + b * P.N * 8, (size_t)P.N * 8);
       // rho tail of vals (the reference mutates get_vals(LDLT)[end-nvar+1:end] on retries only, src/CaNNOLeS.jl:1031,1038); the
       // device copy holds what the caller passed wherever the ladder did not write, so copying it back always is the same
-      if (P.nvar > 0) std::memcpy(vals + b * P.nnz + (P.nnz - P.nvar), pb + o_tail + b * P.nvar * 8, (size_t)P.nvar * 8);
+      if (P.nvar > 0 && tail_valid) std::memcpy(vals + b * P.nnz + (P.nnz - P.nvar), pb + o_tail + b * P.nvar * 8, (size_t)P.nvar * 8);
     }
     h->factorized = true;
     return CNL_OK;
