@@ -170,7 +170,9 @@ int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* su
 int cnl_solve(cnl_handle* h, const double* rhs, double* d);
 
 /* newton_system!(d, nvar, nequ, ncon, rhs, vals, LDLT, rho_old, params) — src/CaNNOLeS.jl:1008-1052,
- * fused on the device: factorise at rho=0, climb the rho ladder per problem on failure, solve.
+ * one call: factorise at rho=0, climb the rho ladder per problem on failure, solve.  On handles with a latency plan (small and
+ * mid-size batches) and on the dense backend the ladder of THIS (host-pointer) entry is driven from the host, every rung a
+ * parallel try_to_factorize of the batch (cnl_options.host_ladder); the device-pointer twin decides everything on the device.
  * vals (batch*nnz) is mutated: the rho slots receive the last rho tried, as the reference leaves them.
  * rho_old: batch inputs.  Outputs (batch each): rho, rho_old_out, nfact, success (= solve_success).  */
 int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d, const double* rho_old,
