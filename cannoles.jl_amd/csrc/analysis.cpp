@@ -707,7 +707,15 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     const double fill = rounds > 1.0 ? std::ceil(rounds - 1e-9) / rounds : 1.0;
     // (a wavefront that has its SIMD to itself runs 1.37 times faster than two sharing one: with fewer parts than slots the
     //  critical path shrinks accordingly)
-    const double alone = 0.73 + 0.27 * std::min(1.0, rounds);
+    double alone = 0.73 + 0.27 * std::min(1.0, rounds);
+    // The bidirectional chain (two tasks of ~500 full fronts per group) gains more than that from a SIMD of its own, and keeps some of
+    // it up to two wavefronts per SIMD (round 3, lean kernel, cfg3: 2.50 / 2.57 / 2.62 / 3.08 / 3.30 / 4.11 ms at 1024 / 1536 / 2048 /
+    // 2560 / 3072 / 4096 problems = 0.48 ... 0.82 of the model's path).  The other candidates' model costs run ~10 % high against it
+    // (their fronts are smaller than the model's unit), hence the handicap: the chain is taken where it wins clearly — from ~1800
+    // problems on (2048: 781 k systems/s against 592 k with eight parts) instead of from 3072.
+    // (only from ~0.9 wavefronts per SIMD on: below that the short chains of small systems lose to eight parts — cfg4 at 1280
+    //  problems 3.9 M against 5.2 M systems/s)
+    if (c.name.rfind("ndc2", 0) == 0 && rounds >= 0.43) alone = 1.10 * (0.49 + 0.33 * std::min(1.0, (rounds - 0.4) / 0.6));
     return std::max(c.cpath * alone, (c.cost + 3.5e4 * ntasks_est(c)) / par * fill) + 1e-3 * c.cost;
   };
   size_t best = 0;

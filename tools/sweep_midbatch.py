@@ -1,7 +1,7 @@
 """Mid-size batches: latency plans with a few LARGE canonical parts run as whole-subtree tasks (candidates ndc<K>+early)."""
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cases = [(512, "ndc16+early"), (512, "ndc32+early"), (768, "ndc16+early"), (1024, "ndc16+early"), (1536, "ndc8+early"), (5120, "ndc2+early"), (6144, "ndc2+early"), (256, "ndc16+early"), (256, "ndc32+early")]
+cases = [(B, f"ndc{k}+early") for B in (512, 768, 1024, 1536, 2048, 2560) for k in (2, 4, 8, 16, 32)] if len(sys.argv) < 2 else [(int(a.split(":")[0]), a.split(":")[1]) for a in sys.argv[1:]]
 for B, name in cases:
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(B), "--steps", "10", "--cpu-sample", "0", "--no-extras", "--opt", f"plan_kind=2,force_order={name}"], capture_output=True, text=True)
     try:
