@@ -57,6 +57,13 @@ struct cnl_handle {
   size_t pin_bytes = 0;
   int* d_dep = nullptr;   // dataflow counters of the staged execution (nullptr: one launch per stage)
   int* d_status = nullptr;  // [1] dataflow waits that gave up (sticky; kernels2.hip spin_until)
+  // counters of a staged call, ONE allocation behind d_gcnt, zeroed with one memset per call:
+  // [gcnt 2B | lgcnt 2B | lad LAD_WORDS * nquads | ldep 2 * tasks * nquads | stat 2 | dep 2 * tasks * nquads (dataflow only)]
+  int *d_lgcnt = nullptr, *d_lad = nullptr, *d_ldep = nullptr, *d_stat = nullptr;
+  long long zero_ints = 0;
+  int resident_waves = 0;   // wavefronts of the register-front kernel the device holds at once
+  int lad_mode = 0;         // in-kernel rho ladder of staged newton_system calls (kernels.h): 0 none, 1 behind the staged attempt, 2 fused
+  bool ladder_ran = false;  // the last launch_staged enqueued fused ladder launches (their commit / redo launch must follow)
   int ntasks = 0;
   int df_waves = 1024;
   std::vector<int32_t> stage_ptr;
@@ -242,7 +249,6 @@ int setup_v2(cnl_handle* h) {
     std::vector<int32_t> tk;
     for (const cnl::Task& t : P.tasks) { tk.push_back(t.rec_off); tk.push_back(t.f1 - t.f0); tk.push_back(t.brec_off); tk.push_back(t.is_root); tk.push_back(t.parent); tk.push_back(t.nchild); }
     if ((rc = upload(h, tk, &h->d_tasks))) return rc;
-    if ((rc = dalloc(h, &h->d_gcnt, (size_t)h->batch * 2))) return rc;
     // dataflow execution: per (task, group of four problems) a count of finished children (forward) and a done flag (backward)
     h->ntasks = (int)P.tasks.size();
     // (measured, tools/sweep_dataflow.py: one system 0.132 against 0.165 ms, eight 0.177 against 0.193 ms; cfg4's pattern with
@@ -260,12 +266,31 @@ int setup_v2(cnl_handle* h) {
         const long long by_lds = (long long)(std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : maxlds, 160 * 1024) / per_wg) * wpb;
         const long long resident = (long long)prop.multiProcessorCount * std::max<long long>(1, std::min<long long>(8, by_lds));
         h->df_waves = (int)std::min<long long>(h->df_waves, resident);
+        h->resident_waves = (int)std::min<long long>(resident, 1 << 20);
       }
     }
-    if (o.dataflow)
-      if ((rc = dalloc(h, &h->d_dep, 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4) + 2))) return rc;  // + the per-call status words
+    {
+      const size_t B = (size_t)h->batch, nq = (B + 3) / 4, tq = 2 * (size_t)h->ntasks * nq;
+      const size_t total = 4 * B + (size_t)cnl::LAD_WORDS * nq + tq + 2 + (o.dataflow ? tq : 0);
+      if ((rc = dalloc(h, &h->d_gcnt, total))) return rc;
+      if (hipMemset(h->d_gcnt, 0, total * sizeof(int)) != hipSuccess) return fail(CNL_ERR_HIP, "hipMemset failed");
+      h->d_lgcnt = h->d_gcnt + 2 * B;
+      h->d_lad = h->d_lgcnt + 2 * B;
+      h->d_ldep = h->d_lad + (size_t)cnl::LAD_WORDS * nq;
+      h->d_stat = h->d_ldep + tq;   // per-call status words (kernels2.hip, spin_until)
+      if (o.dataflow) h->d_dep = h->d_stat + 2;
+      h->zero_ints = (long long)total;
+    }
     h->stage_ptr = P.stage_ptr;
     h->staged = true;
+    // The in-kernel rho ladder needs all tasks of a group of four problems resident at once.  With more groups than the device
+    // holds the fused launch is repeated over ranges of groups; beyond four such launches the sequential launch keeps the job
+    // (plans of very many tasks on batches that large do not occur: the planner gives large batches few, large tasks).
+    h->lad_mode = 0;
+    if (o.device_ladder && h->resident_waves >= h->ntasks) {
+      const long long slots = h->resident_waves / h->ntasks, nq = (h->batch + 3) / 4;
+      if ((nq + slots - 1) / slots <= 4) h->lad_mode = o.device_ladder_fused ? 2 : 1;
+    }
   }
   h->v2_solve = P.rec_direct && P.d_outer && P.ncls[1] == 0 && P.ncls[2] == 0 && !o.v1_solve;
   h->lean = o.lean_kernel && P.rec_direct && P.d_outer && d.count_d && P.ncls[1] == 0 && P.ncls[2] == 0 && P.listprod_fronts == 0;
@@ -300,7 +325,11 @@ int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.lean = h->lean ? 1 : 0;
   a.back_rows = (h->lean && h->plan->P.back_rows) ? 1 : 0;
   a.status_total = h->d_status;
-  a.status_call = h->d_dep ? h->d_dep + 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4) : nullptr;
+  a.status_call = h->d_stat;   // (nullptr in views of the handle: one launch per stage, nothing waits)
+  a.lad = h->d_lad; a.lgcnt = h->d_lgcnt; a.ldep = h->d_ldep; a.lad_zero_ints = h->d_stat ? h->zero_ints : 0;
+  a.lad_capacity = h->resident_waves;
+  a.lad_mode = (a.mode == cnl::MODE_NEWTON && h->d_lad && !h->first_attempt_only) ? h->lad_mode : 0;
+  h->ladder_ran = a.lad_mode != 0;
   a.spin_limit = h->plan->opt.dataflow_spin_limit > 0 ? h->plan->opt.dataflow_spin_limit : (1 << 22);
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
   hipError_t e = cnl::launch_newton2_staged(h->dp2, h->wpb2, h->lds2, a, h->stage_ptr.data(), (int)h->stage_ptr.size() - 1, stream);
@@ -315,7 +344,7 @@ struct SubBatch {
   cnl_handle* h;
   int64_t batch;
   double *L, *gs, *scratch, *cbuf, *d2;
-  int *xpos, *xzer, *gcnt, *dep;
+  int *xpos, *xzer, *gcnt, *dep, *lad, *stat;
   const double* last_vals;
   bool staged;
   SubBatch(cnl_handle* h_, int64_t b0, int64_t nb, bool allow_staged = true) : h(h_) {
@@ -323,7 +352,7 @@ struct SubBatch {
     if (h->last_vals) h->last_vals += b0 * h->plan->nnz;
     if (!allow_staged) h->staged = false;
     batch = h->batch; L = h->d_L; gs = h->d_gs; scratch = h->d_scratch; cbuf = h->d_cbuf; d2 = h->d_d2;
-    xpos = h->d_xpos; xzer = h->d_xzer; gcnt = h->d_gcnt; dep = h->d_dep;
+    xpos = h->d_xpos; xzer = h->d_xzer; gcnt = h->d_gcnt; dep = h->d_dep; lad = h->d_lad; stat = h->d_stat;
     const cnl::Cond& C = h->plan->C;
     h->batch = nb;
     h->d_L += b0 * h->dp.lsize;
@@ -334,11 +363,11 @@ struct SubBatch {
     if (h->d_xpos) h->d_xpos += b0;
     if (h->d_xzer) h->d_xzer += b0;
     if (h->d_gcnt) h->d_gcnt += 2 * b0;
-    h->d_dep = nullptr;
+    h->d_dep = nullptr; h->d_lad = nullptr; h->d_stat = nullptr;   // views run one launch per stage and keep the sequential ladder
   }
   ~SubBatch() {
     h->batch = batch; h->d_L = L; h->d_gs = gs; h->d_scratch = scratch; h->d_cbuf = cbuf; h->d_d2 = d2;
-    h->d_xpos = xpos; h->d_xzer = xzer; h->d_gcnt = gcnt; h->d_dep = dep;
+    h->d_xpos = xpos; h->d_xzer = xzer; h->d_gcnt = gcnt; h->d_dep = dep; h->d_lad = lad; h->d_stat = stat;
     h->last_vals = last_vals; h->staged = staged;
   }
 };
@@ -382,9 +411,11 @@ int run_split(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d
   }
   h->in_split = false;
   h->timing = tm;
-  if (rc) return rc;
-  HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
-  HIPCHK(hipStreamWaitEvent(stream, h->ev_join, 0));
+  // join also when an enqueue failed: work already on the second stream must not overlap a later call's use of the handle's arrays
+  const hipError_t je = hipEventRecord(h->ev_join, h->aux_stream);
+  const hipError_t we = je == hipSuccess ? hipStreamWaitEvent(stream, h->ev_join, 0) : je;
+  if (rc) { if (we != hipSuccess) (void)hipStreamSynchronize(h->aux_stream); return rc; }
+  HIPCHK(we);
   if (a.mode == cnl::MODE_FACTOR) h->last_vals = d_vals;
   if (tm) {
     HIPCHK(hipEventRecord(h->ev1, stream));
@@ -398,7 +429,7 @@ int run_split(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d
 // exits at once unless a dataflow wait of the attempt gave up (kernels2.hip, spin_until).  newton_system has its classic launch
 // anyway (the rho ladder of the problems that failed the first attempt).
 int launch_redo(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
-  if (!a.status_call) return CNL_OK;  // one launch per stage: nothing waits, nothing can time out
+  if (!a.status_call || (!h->d_dep && !h->ladder_ran)) return CNL_OK;  // one launch per stage: nothing waits, nothing can time out
   const bool tm = h->timing;
   h->timing = false;
   a.only_if_status = 1;
@@ -486,10 +517,14 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
         // first attempt (rho as given) stage by stage: the tasks of the elimination tree run on different wavefronts; the
         // problems that fail it (rare) go through the whole ladder in the classic launch behind it
         if ((rc = launch_staged(h, a, stream))) return rc;
-        if (h->first_attempt_only) {
+        if (h->ladder_ran) {
+          // the problems that failed the attempt have climbed the rho ladder inside the fused launch(es) (kernels2.hip, phase 2);
+          // the sequential launch behind them commits rho_old and the rho slots — or, if a wait gave up, redoes the whole call
+          if ((rc = launch_redo(h, a, stream))) return rc;
+        } else if (h->first_attempt_only) {
           // the host ladder follows; the sequential launch only if a dataflow wait of the attempt gave up (it then redoes the whole
           // call on the device, ladder included: the host finds the per-call status word set and leaves the results alone)
-          if ((rc = launch_redo(h, a, stream))) return rc;
+          if (h->d_dep && (rc = launch_redo(h, a, stream))) return rc;
         } else {
           a.skip_done = 1;
           const bool tm = h->timing;
@@ -681,6 +716,9 @@ void cnl_options_init(cnl_options* o) {
   o->staged = 1; o->dataflow = 1; o->dataflow_waves = 1024; o->dataflow_spin_limit = 1 << 22;
   o->waves_per_block = 0; o->v1_tpp = -1; o->v1_ppb = -1; o->v1_lds = -1; o->v1_solve = 0; o->lds_pad = 1;
   o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
+  // (fused: measured slower than the separate launches on one system of cfg3's size, 0.140 against 0.118 ms — the rung loop costs
+  //  the kernel 50 VGPRs and 45 spilled SGPRs — so it is off by default)
+  o->device_ladder = 1; o->device_ladder_fused = 0;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -1453,11 +1491,14 @@ static int host_ladder_run(cnl_handle* h, const double params[9], const double* 
   int32_t* up_act = reinterpret_cast<int32_t*>(up + B * 8);
   std::vector<char> act(B, 0);
   std::vector<double> ro_in(B);
+  // split handles: only the chain part [0, split_staged) ran the first attempt alone; the single-stream part has been through the
+  // whole device ladder already (a problem that exhausted it there must not climb again: nfact would count twice)
+  const size_t first_only = (h->split_staged > 0 && (size_t)h->split_staged < B) ? (size_t)h->split_staged : B;
+  bool any_act = false;
   for (size_t b = 0; b < B; b++) {
     ro_in[b] = rho_old ? rho_old[b] : 0.0;
-    if (!success[b]) { act[b] = 1; rho[b] = ro_in[b] == 0.0 ? rho0 : std::max(rhomin, kdec * ro_in[b]); }
+    if (!success[b] && b < first_only) { act[b] = 1; any_act = true; rho[b] = ro_in[b] == 0.0 ? rho0 : std::max(rhomin, kdec * ro_in[b]); }
   }
-  bool any_act = true;
   while (any_act) {
     for (size_t b = 0; b < B; b++) { up_rho[b] = rho[b]; up_act[b] = act[b]; }
     HIPCHK(hipMemcpyAsync(h->d_rho, up_rho, B * 8, hipMemcpyHostToDevice, h->stream));
@@ -1481,7 +1522,7 @@ static int host_ladder_run(cnl_handle* h, const double params[9], const double* 
       else any_act = true;
     }
   }
-  for (size_t b = 0; b < B; b++)
+  for (size_t b = 0; b < first_only; b++)
     if (rho[b] != 0.0 && rho[b] <= rhomax) rho_old_out[b] = rho[b];   // (rho != 0: the problem entered the ladder)
   // solve_ldl! for everything that holds a valid factor now (the problems of the first attempt are solved again: same factor)
   cnl::LaunchArgs sv{};
@@ -1604,8 +1645,10 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     HIPCHK(hipMemcpyAsync(pb + o_su, h->d_success, B * 4, hipMemcpyDeviceToHost, h->stream));
     int32_t* up_status = reinterpret_cast<int32_t*>(pb + o_up + B * 12);
     *up_status = 0;
-    if (host_ladder && h->d_dep)  // per-call status of the dataflow execution (kernels2.hip, spin_until): waits that gave up
-      HIPCHK(hipMemcpyAsync(up_status, h->d_dep + 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4), 4, hipMemcpyDeviceToHost, h->stream));
+    // per-call status of the dataflow execution (kernels2.hip, spin_until): waits that gave up.  Only calls that ran in dataflow
+    // fashion on the whole handle can set it (split handles run through views: one launch per stage, nothing waits)
+    if (host_ladder && h->d_dep && h->d_stat && h->split_staged == 0)
+      HIPCHK(hipMemcpyAsync(up_status, h->d_stat, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     std::memcpy(rho, pb + o_rho, B * 8);
     std::memcpy(rho_old_out, pb + o_ro, B * 8);
@@ -1640,8 +1683,8 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   // the reference leaves d untouched when the factorisation fails (src/CaNNOLeS.jl:1049): copy back the rows that succeeded
   HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   int32_t status_word = 0;
-  if (host_ladder && h->d_dep)
-    HIPCHK(hipMemcpyAsync(&status_word, h->d_dep + 2 * (size_t)h->ntasks * (size_t)((h->batch + 3) / 4), 4, hipMemcpyDeviceToHost, h->stream));
+  if (host_ladder && h->d_dep && h->d_stat && h->split_staged == 0)
+    HIPCHK(hipMemcpyAsync(&status_word, h->d_stat, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   bool laddered = false;
   if (host_ladder && status_word == 0) {

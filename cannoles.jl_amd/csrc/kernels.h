@@ -115,7 +115,28 @@ struct LaunchArgs {
   int* status_call;
   int spin_limit;
   int only_if_status;
+  // In-kernel rho ladder of staged plans (phase == 2, kernels2.hip): ONE launch in which every task of the elimination tree of a
+  // group of four problems has a wavefront of its own; per rung the tasks factorise in dataflow fashion, the last one to finish
+  // applies the ladder rule of src/CaNNOLeS.jl:1029-1047 to the group's four problems and publishes the decision, the others
+  // wait for it; the backward sweeps of the tasks follow in the same launch.  All wavefronts of a launch must be resident at
+  // once (the host sizes lad_slots for that).
+  int* lad;              // [nquads][LAD_WORDS] control block per group of four problems (zeroed per call), see kernels2.hip
+  int* lgcnt;            // [batch][2] pivot counts of the current rung (zeroed per call, reset by the deciding wavefront)
+  int* ldep;             // [2][tasks][nquads] counters of the fused launch: children done (monotone over the rungs), task done (backward)
+  int lad_first;         // 1: the launch makes the first attempt too (rho as given); 0: only groups with a problem that failed the
+                         //    staged first attempt are processed (the others exit at once)
+  int lad_slots;         // groups of problems this launch covers, starting at quad0; wavefront index = task * lad_slots + slot
+  int quad0;
+  // host side of it (launch_newton2_staged): lad_mode 0 = no in-kernel ladder (the caller's sequential launch takes the failed
+  // problems), 1 = the fused launch(es) behind the staged first attempt, 2 = the fused launch makes the first attempt too;
+  // lad_capacity = wavefronts of this kernel the device holds at once; lad_zero_ints = ints to zero from gcnt on (gcnt, lgcnt,
+  // lad and ldep are one allocation, zeroed with one memset per call)
+  int lad_mode, lad_capacity;
+  long long lad_zero_ints;
 };
+constexpr int LAD_WORDS = 32;  // ints per group: [0] tasks that finished the rung, [1] epoch (2 * rung + final), [4..7] state of the
+                               // four problems (0 active, 1 factorised, 2 gave up), doubles at [8..15] rho last written to the
+                               // slots ("wrote"; 0: never laddered), at [16..23] the rho_old to commit
 
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);

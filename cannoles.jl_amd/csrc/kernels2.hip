@@ -27,6 +27,8 @@
 //  * L rows are stored to HBM straight from registers at their pivot step.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 // timing experiments only (tests/support/ablate.py): -DCNL_ABL=<bits> removes pieces of the hot path; results are wrong
@@ -724,6 +726,14 @@ __device__ __forceinline__ void spin_until(const int* p, int target, int limit, 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
 }
+// Commit of the in-kernel ladder for problem g of a group (see the only_if_status prologue of the kernel): out of line, so that
+// the hot instantiations pay nothing for it.
+__device__ __noinline__ void ladder_commit(const int* lq, int g, int l, double* rho_old, double* slots, int nvar) {
+  const double wr = reinterpret_cast<const double*>(lq + 8)[g], ro = reinterpret_cast<const double*>(lq + 16)[g];
+  if (wr == 0.0) return;   // the problem never climbed
+  if (l == 0) *rho_old = ro;
+  for (int i = l; i < nvar; i += 16) slots[i] = wr;
+}
 __device__ __forceinline__ void task_done(int* counter, int lane, bool release = true) {
   if (!counter) return;
 #ifndef CNL_DF_NOFENCE
@@ -749,7 +759,12 @@ __device__ __forceinline__ void task_done(int* counter, int lane, bool release =
 // lean instantiation is 10 % faster on the headline (same box: 965 k -> 1 058 k systems/s).
 // SOLVE: the lean instantiation of solve_ldl! (MODE_SOLVE only): forward substitution + backward sweep with the residual components
 // recovered by the backward records — nothing of the factorisation is compiled in, no post-pass behind the launch.
-template <bool STAGED, bool LATE, bool LEAN, bool SOLVE = false>
+// FUSED (round 4): the staged instantiation that runs the in-kernel rho ladder (LaunchArgs.phase == 2) — a separate instantiation,
+// because the loop over the rungs makes the forward sweep's state loop-carried (the plain staged kernel leaves after one sweep:
+// 162 VGPRs, three wavefronts per SIMD; with the rung loop 213).  FUSED && !STAGED: the sequential launch BEHIND the fused ones
+// (only_if_status): it commits the ladder's rho_old / rho slots, or redoes the call when a wait gave up — the commit is compiled
+// into this instantiation only (in the hot lean kernel the call cost four more spilled SGPRs).
+template <bool STAGED, bool LATE, bool LEAN, bool SOLVE = false, bool FUSED = false>
 __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(const DevPlan2 Pin, const LaunchArgs Ain) {
   DevPlan2 P = Pin;
   P.rec = as_global(Pin.rec); P.brec = as_global(Pin.brec);
@@ -772,10 +787,21 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   // deep, and the start-up latency of a task, not its fronts, is most of its critical path.
   const int* dep_wait = nullptr;
   int dep_target = 0;
+  int t_nchild_l = 0, t_parent_l = -1, tix_l = 0;   // fused ladder launch (phase 2): the task's links, kept for every rung
+  [[maybe_unused]] int* lad = nullptr;              // ... and the control block of its group of problems
   if constexpr (STAGED) {
-    int task = widx / A.nquads;
+    const bool fused = FUSED && A.phase == 2;
+    const int per = fused ? A.lad_slots : A.nquads;   // groups of problems this launch covers
+    int task = widx / per;
     if (task >= A.ntasks) return;
-    widx -= task * A.nquads;
+    widx -= task * per;
+    if (fused) {
+      widx += A.quad0;
+      if (!A.lad_first) {  // behind a staged first attempt: only groups with a problem that failed it have work (the common case: none)
+        const int pq = widx * 4 + (lane >> 4);
+        if (!__any(pq < A.batch && as_global(A.success)[pq < A.batch ? pq : 0] == 0)) return;
+      }
+    }
     // Dataflow execution (A.dep): ONE launch per phase covers every task.  Workgroups are dispatched in index order, tasks
     // are sorted by stage, so a task's children (forward) have smaller indices; the backward launch runs the indices in
     // reverse, parents first.  A wavefront waits on a device counter for the tasks it depends on: the lowest unfinished
@@ -784,7 +810,14 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     const int tix = A.task0 + task;
     const int32_t* tk = as_global(A.tasks) + 6 * tix;
     t_rec = rfl(tk[0]); t_nfr = rfl(tk[1]); t_brec = rfl(tk[2]); t_root = rfl(tk[3]);
-    if (A.dep) {
+    if (fused) {
+      // all tasks of the group are resident at once: forward counters are monotone over the rungs (target = rung * children)
+      t_parent_l = rfl(tk[4]); t_nchild_l = rfl(tk[5]); tix_l = tix;
+      int* depf = as_global(A.ldep);
+      if (t_nchild_l > 0) { dep_wait = depf + tix * A.nquads + widx; dep_target = t_nchild_l; }
+      if (t_parent_l >= 0) dep_signal = depf + t_parent_l * A.nquads + widx;
+      lad = as_global(A.lad) + (size_t)widx * LAD_WORDS;
+    } else if (A.dep) {
       const int t_parent = rfl(tk[4]), t_nchild = rfl(tk[5]);
       int* depf = as_global(A.dep);
       int* depb = depf + A.ntasks_all * A.nquads;
@@ -806,12 +839,23 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     // behind a staged attempt: only the problems that failed it are processed — all of them when a dataflow wait of the
     // attempt gave up (its results are then not to be trusted)
     const bool redo_all = A.status_call && __hip_atomic_load(as_global(A.status_call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    if (A.only_if_status && !redo_all) return;
+    if (A.only_if_status && !redo_all) {
+      // Behind the in-kernel ladder (phase 2 launches): no wait gave up, so its results stand — COMMIT what the ladder must not
+      // touch while a sequential redo may still need the caller's inputs: rho_old (in/out) and the rho slots of vals
+      // (src/CaNNOLeS.jl:1031,1038,1044-1046).  One wavefront per group of four problems; nothing to do unless a problem climbed.
+      if constexpr (FUSED) if (A.lad && A.mode == MODE_NEWTON && valid_) ladder_commit(as_global(A.lad) + (size_t)widx * LAD_WORDS, g, l, A.rho_old + prob, A.vals + (long long)prob * P.vstride + P.rho_begin, P.nvar);
+      return;
+    }
     if (A.skip_done && !redo_all && valid_ && as_global(A.success)[prob] == 1) valid_ = false;
     if (!__any(valid_)) return;
   }
   const bool valid = valid_;
-  const long long pclamp = valid ? prob : prob0;
+  // A problem the launch skips (skip_done: it succeeded in the staged attempt) still walks the stream with its wave-mates: it
+  // must read ITS OWN data, so that what it recomputes — and stores — is its own factor again.  (Until round 4 it was clamped to
+  // the first problem of the wave like a problem past the end of the batch, and the elimination, which only knows the batch
+  // size, overwrote its factor with the first problem's: a later solve_ldl! of that problem was wrong.)
+  const bool inb = prob < A.batch;
+  const long long pclamp = inb ? prob : prob0;
 
   const int wave_doubles = (P.recwords >> 1) + 4 * P.prob_doubles + 8;
   double* wbase = smem + wave * wave_doubles;
@@ -838,7 +882,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   const char* vals_wb = reinterpret_cast<const char*>(A.vals + (long long)prob0u * P.vstride);
 #endif
   const char* rhs_wb = has_rhs ? reinterpret_cast<const char*>(A.rhs + (long long)prob0u * P.rstride) : vals_wb;
-  const unsigned gsel = valid ? (unsigned)g : 0u;
+  const unsigned gsel = inb ? (unsigned)g : 0u;
 #ifdef CNL_DBG_VSTRIDE0
   const unsigned gofs_v = 0u;
 #else
@@ -855,6 +899,11 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   bool done = !valid, success = false, ovr = false;
   const double kdec = A.params[2], kinc = A.params[3], klarge = A.params[4], rho0 = A.params[5], rhomax = A.params[6],
                rhomin = A.params[7];
+  [[maybe_unused]] int rung = 0;  // fused ladder: factorisations this launch has made of the group
+  if constexpr (STAGED) {
+    // behind a staged first attempt the problems that failed it enter the ladder at its first rung (src/CaNNOLeS.jl:1030)
+    if (FUSED && A.phase == 2 && !A.lad_first && valid && A.success[prob] == 0) { rho = rho_old == 0.0 ? rho0 : fmax(rhomin, kdec * rho_old); ovr = true; }
+  }
 
   // ---------------- MODE_SOLVE: forward substitution with the stored factor (solve_ldl!, src/solver_types.jl:69-77) ------
   // Only the right-hand-side column of every front is assembled (plain rhs entries, the products -J_ra rhs_r / d_r of the
@@ -863,6 +912,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   // when every front is of the fast class (order <= 16, LDS staging).
   constexpr bool CNL_LEAN = LEAN;
   static_assert(!SOLVE || LEAN, "the solve-only instantiation is a lean one");
+  static_assert(!FUSED || !SOLVE, "the fused ladder is an execution of newton_system");
   if ((SOLVE || (!CNL_LEAN && A.mode == MODE_SOLVE)) && (!STAGED || A.phase == 0)) {
     const int4* rstream = reinterpret_cast<const int4*>(P.rec);
     int4 R0, R1, R2;
@@ -1040,7 +1090,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   }
 
   STAMP_DECL
-  const bool do_fwd = !SOLVE && (STAGED ? (A.phase == 0 && A.mode != MODE_SOLVE) : A.mode != MODE_SOLVE);
+  const bool do_fwd = !SOLVE && (STAGED ? ((A.phase == 0 || (FUSED && A.phase == 2)) && A.mode != MODE_SOLVE) : A.mode != MODE_SOLVE);
   while (do_fwd) {
     STAMP_BEGIN
     // ---------------- forward pass over the record stream ----------------
@@ -1317,12 +1367,92 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
     for (int o = 8; o > 0; o >>= 1) { rpos += __shfl_xor(rpos, o, 16); rzer += __shfl_xor(rzer, o, 16); }
     const int tpos = cnt[g * 2] + rpos, tzer = cnt[g * 2 + 1] + rzer;
     if constexpr (STAGED) {  // the counts of all tasks meet in global memory; the backward launches read them
+      int* gcw = as_global((FUSED && A.phase == 2) ? A.lgcnt : A.gcnt);
       if (valid && l == 0) {
-        if (tpos) atomicAdd(as_global(A.gcnt) + prob * 2, tpos);
-        if (tzer) atomicAdd(as_global(A.gcnt) + prob * 2 + 1, tzer);
+        if (tpos) atomicAdd(gcw + prob * 2, tpos);
+        if (tzer) atomicAdd(gcw + prob * 2 + 1, tzer);
       }
-      task_done(dep_signal, lane, A.df_live != 0);
-      return;
+      if (!FUSED || A.phase != 2) {
+        task_done(dep_signal, lane, A.df_live != 0);
+        return;
+      }
+      if constexpr (FUSED) {
+      // ---- fused ladder: the last task of the group to finish this rung decides (src/solver_types.jl:90-97, src/CaNNOLeS.jl:1023-1047)
+      rung++;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_wave_barrier();
+      int fin = 0;
+      if (lane == 0) {
+        if (dep_signal) __hip_atomic_fetch_add(dep_signal, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fin = __hip_atomic_fetch_add(lad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      fin = rfl(fin);
+      int* st_w = lad + 4;
+      double* wr_w = reinterpret_cast<double*>(lad + 8);
+      double* ro_w = reinterpret_cast<double*>(lad + 16);
+      int epoch;
+      if (fin == rung * A.ntasks_all - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // ladder state of problem g (replicated over its 16 lanes): from the control block, or — first rung — as the launch
+        // found it (after a staged first attempt: rho = 0, one factorisation, success flag)
+        int st = 0, nf = 0;
+        double rh = 0.0, wr = 0.0;
+        if (rung > 1) {
+          st = __hip_atomic_load(st_w + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          nf = __hip_atomic_load(A.nfact + pclamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          rh = __hip_atomic_load(A.rho + pclamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wr = __hip_atomic_load(wr_w + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (!A.lad_first) {
+          st = A.success[pclamp] == 1 ? 1 : 0;
+          nf = 1;
+          if (!st) { rh = rho; wr = rho; }   // the first rung's rho was formed in the prologue of every wavefront
+        }
+        if (!valid) st = 1;
+        const int tp = __hip_atomic_load(gcw + pclamp * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int tz = __hip_atomic_load(gcw + pclamp * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == 0) {
+          nf++;
+          if (tp == P.nvar && tz == 0) st = 1;
+          else if (nf == 1) { rh = rho_old == 0.0 ? rho0 : fmax(rhomin, kdec * rho_old); wr = rh; }
+          else if (rh <= rhomax) {
+            rh = rho_old == 0.0 ? klarge * rh : kinc * rh;
+            if (rh <= rhomax) wr = rh; else st = 2;
+          } else st = 2;
+        }
+        const bool fin_all = __all(st != 0);
+        if (valid && l == 0) {
+          __hip_atomic_store(st_w + g, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(wr_w + g, wr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(A.rho + prob, rh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(A.nfact + prob, nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(gcw + prob * 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(gcw + prob * 2 + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (fin_all) {
+            A.success[prob] = st == 1 ? 1 : 0;
+            ro_w[g] = (nf > 1 && rh <= rhomax) ? rh : rho_old;   // committed by the launch behind this one (only_if_status)
+          }
+        }
+        epoch = 2 * rung + (fin_all ? 1 : 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(lad + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        spin_until(lad + 1, 2 * rung, A.spin_limit, as_global(A.status_total), as_global(A.status_call));
+        epoch = rfl(__hip_atomic_load(lad + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+      // a wait that gave up anywhere: the sequential launch behind this one redoes the call; leave
+      if (rfl(__hip_atomic_load(as_global(A.status_call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
+      if (epoch & 1) {
+        success = valid && __hip_atomic_load(st_w + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
+        break;
+      }
+      // next rung: every problem of the group is factorised again with its current rho (a problem that is done repeats its
+      // last factorisation: same factor)
+      rho = __hip_atomic_load(A.rho + pclamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ovr = valid && rho != 0.0;
+      if (t_nchild_l > 0) { dep_wait = as_global(A.ldep) + tix_l * A.nquads + widx; dep_target = (rung + 1) * t_nchild_l; }
+      continue;
+      }
     }
     const bool ok = (CNL_ABL != 0) || (tpos == P.nvar && tzer == 0);
     if (A.mode == MODE_FACTOR) {
@@ -1354,9 +1484,17 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       for (int i = l; i < P.nvar; i += 16) vt[i] = wrote;
     }
   }
-  if constexpr (STAGED) {  // inertia rule on the sums of the forward launches (src/solver_types.jl:90-97)
-    const int* gc = as_global(A.gcnt) + pclamp * 2;
-    success = valid && (A.mode == MODE_SOLVE || (gc[0] == P.nvar && gc[1] == 0));  // solve_ldl! follows a successful factorisation
+  if constexpr (STAGED) {
+    if (FUSED && A.phase == 2) {
+      // fused ladder: `success` is the group's decision; the backward sweeps of the tasks run in dataflow fashion, parents first
+      int* depb = as_global(A.ldep) + A.ntasks_all * A.nquads;
+      dep_wait = nullptr;
+      if (t_parent_l >= 0) { dep_wait = depb + t_parent_l * A.nquads + widx; dep_target = 1; }
+      dep_signal = depb + tix_l * A.nquads + widx;
+    } else {  // inertia rule on the sums of the forward launches (src/solver_types.jl:90-97)
+      const int* gc = as_global(A.gcnt) + pclamp * 2;
+      success = valid && (A.mode == MODE_SOLVE || (gc[0] == P.nvar && gc[1] == 0));  // solve_ldl! follows a successful factorisation
+    }
     nfact = 1;
   }
   if (l == 0) cnt[8 + g] = (success && valid) ? 1 : 0;
@@ -1520,8 +1658,9 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   if (lane == 0 && A.npos) for (int k = 0; k < 8; k++) A.npos[(blockIdx.x * WPB + wave) * 8 + k] = (long long)st_acc[k];
 #endif
   if constexpr (STAGED) {
+    if (FUSED && A.phase == 2) { task_done(dep_signal, lane, true); return; }  // (outputs: written by the deciding wavefront; rho_old and the slots: committed behind)
     if (A.phase == 1) task_done(dep_signal, lane, A.df_live != 0);  // the children of this task may read its solution components now
-    // first attempt only: rho = 0, rho_old untouched; problems that failed are handed to the classic launch that follows
+    // first attempt only: rho = 0, rho_old untouched; problems that failed are handed to the launch that follows
     if (valid && l == 0 && t_root && A.mode == MODE_NEWTON) { A.rho[prob] = 0.0; A.nfact[prob] = 1; A.success[prob] = success ? 1 : 0; }
   } else if (valid && l == 0 && A.mode == MODE_NEWTON) {
     A.rho[prob] = rho;
@@ -1541,7 +1680,9 @@ hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const La
   const bool lean = a.lean != 0 && a.mode != MODE_SOLVE;
   const bool lean_solve = a.lean != 0 && a.back_rows != 0 && a.mode == MODE_SOLVE;
   const bool late = waves >= 1024 && !lean && !lean_solve;
-  auto kern = lean_solve ? newton2_kernel_t<false, false, true, true>
+  const bool commit = a.only_if_status != 0 && a.lad != nullptr && a.mode == MODE_NEWTON;   // behind fused ladder launches
+  auto kern = commit ? (lean ? newton2_kernel_t<false, false, true, false, true> : newton2_kernel_t<false, false, false, false, true>)
+            : lean_solve ? newton2_kernel_t<false, false, true, true>
             : lean ? newton2_kernel_t<false, false, true> : (late ? newton2_kernel_t<false, true, false> : newton2_kernel_t<false, false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
@@ -1578,8 +1719,12 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
                    : (late ? newton2_kernel_t<true, true, false> : newton2_kernel_t<true, false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
-  if (a.mode != MODE_SOLVE) {
-    e = hipMemsetAsync(a.gcnt, 0, (size_t)a.batch * 2 * sizeof(int), stream);
+  const bool ladder = a.mode == MODE_NEWTON && a.lad_mode != 0 && a.lad && a.lgcnt && a.ldep && a.status_call;
+  // counters of the call: [gcnt | lgcnt | lad | ldep | status | dep] is ONE allocation of the handle, zeroed with one memset
+  // (lad_zero_ints > 0); views of a handle (SubBatch) bring gcnt alone
+  const bool one_block = a.lad_zero_ints > 0;
+  if (one_block || a.mode != MODE_SOLVE) {
+    e = hipMemsetAsync(a.gcnt, 0, one_block ? (size_t)a.lad_zero_ints * sizeof(int) : (size_t)a.batch * 2 * sizeof(int), stream);
     if (e != hipSuccess) return e;
   }
   // newton: forward + backward; factorize: forward only, then the decision; solve: forward substitution + backward
@@ -1596,11 +1741,31 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
     // per stage — cfg3 64 problems 0.255 against 0.241 ms, cfg4 256 problems 1.51 M against 1.66 M systems/s: the fences of the
     // top launch cost what the saved launch boundaries gain.  So: all of the tree in one launch per phase, or none of it.
     if (s_df != 0) s_df = nstages;
-    // the two words behind the counters are the per-call status (see spin_until)
-    e = hipMemsetAsync(a.dep, 0, (2 * (size_t)ntasks_all * (size_t)a.nquads + 2) * sizeof(int), stream);
-    if (e != hipSuccess) return e;
+    if (!one_block) {  // (not reached: a.dep comes with the block)
+      e = hipMemsetAsync(a.dep, 0, 2 * (size_t)ntasks_all * (size_t)a.nquads * sizeof(int), stream);
+      if (e != hipSuccess) return e;
+    }
   }
   a.ntasks_all = ntasks_all;
+  // the in-kernel ladder: every task of a group of problems on a wavefront of its own, all of a launch resident at once
+  auto kern_f = lean ? newton2_kernel_t<true, false, true, false, true> : newton2_kernel_t<true, false, false, false, true>;
+  if (ladder) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  auto launch_ladder = [&](int first) {
+    const int slots = std::max(1, a.lad_capacity / ntasks_all);
+    for (int q0 = 0; q0 < a.nquads; q0 += slots) {
+      a.phase = 2; a.task0 = 0; a.ntasks = ntasks_all; a.df_live = 1; a.lad_first = first;
+      a.quad0 = q0; a.lad_slots = std::min(slots, a.nquads - q0);
+      const long long waves = (long long)ntasks_all * a.lad_slots;
+      hipLaunchKernelGGL(kern_f, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds_bytes, stream, P, a);
+    }
+  };
+  if (ladder && a.lad_mode == 2 && s_df == 0 && (long long)ntasks_all * a.nquads <= (long long)a.lad_capacity) {  // smallest batches: first attempt, ladder and backward sweeps in ONE launch
+    launch_ladder(1);
+    return hipGetLastError();
+  }
   auto launch_range = [&](int pass, int t0, int t1, int live = 0) {
     a.phase = pass; a.task0 = t0; a.ntasks = t1 - t0; a.df_live = live;
     const long long waves = (long long)a.ntasks * a.nquads;
@@ -1613,6 +1778,7 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
     if (s_df < nstages) launch_range(1, stage_ptr[s_df], ntasks_all, 1);
     for (int q = s_df - 1; q >= 0; q--) launch_range(1, stage_ptr[q], stage_ptr[q + 1]);
   }
+  if (ladder) launch_ladder(0);  // the problems that failed the attempt climb the rho ladder here (the other groups' wavefronts exit at once)
   if (a.mode == MODE_FACTOR)
     hipLaunchKernelGGL(staged_decide_kernel, dim3((a.batch + 255) / 256), dim3(256), 0, stream, a.gcnt, P.nvar, a.batch, a.success, a.npos, a.nzero);
   return hipGetLastError();

@@ -583,15 +583,16 @@ hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, cons
 // rho slots of the problems marked active: vals[b][nnz - nvar ..] = rho[b] (the host-driven ladder of the small-batch host call)
 __global__ void __launch_bounds__(256) fill_rho_kernel(double* __restrict__ vals, long long nnz, int nvar, const double* __restrict__ rho,
                                                        const int* __restrict__ active, int batch) {
-  const int b = blockIdx.y;
-  if (b >= batch || !active[b]) return;
-  const double r = rho[b];
-  double* t = vals + (long long)b * nnz + (nnz - nvar);
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < nvar; i += gridDim.x * 256) t[i] = r;
+  for (int b = blockIdx.y; b < batch; b += gridDim.y) {  // (gridDim.y is clamped to the launch limit of 65535)
+    if (!active[b]) continue;
+    const double r = rho[b];
+    double* t = vals + (long long)b * nnz + (nnz - nvar);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nvar; i += gridDim.x * 256) t[i] = r;
+  }
 }
 hipError_t launch_fill_rho(double* vals, long long nnz, int nvar, const double* rho, const int* active, int batch, hipStream_t stream) {
   if (nvar <= 0 || batch <= 0) return hipSuccess;
-  hipLaunchKernelGGL(fill_rho_kernel, dim3(std::min(64, (nvar + 255) / 256), batch), dim3(256), 0, stream, vals, nnz, nvar, rho, active, batch);
+  hipLaunchKernelGGL(fill_rho_kernel, dim3(std::min(64, (nvar + 255) / 256), std::min(batch, 65535)), dim3(256), 0, stream, vals, nnz, nvar, rho, active, batch);
   return hipGetLastError();
 }
 

@@ -107,6 +107,13 @@ typedef struct cnl_options {
                                   1 while the step is latency-bound (batch x tiles <= 512; default), 2 always                    */
   int32_t host_ladder;         /* 1: small-batch host-pointer cnl_newton_system drives the rho ladder from the host, every rung a
                                   staged try_to_factorize (default); 0: the device ladder of the sequential launch              */
+  int32_t device_ladder;       /* 1: device-pointer cnl_newton_system_dev on staged handles climbs the rho ladder inside ONE launch
+                                  in which every task of the elimination tree has a wavefront of its own (per rung the tasks
+                                  factorise in dataflow fashion, the last to finish applies the ladder rule; default); 0: the
+                                  sequential launch (one wavefront per four problems walks all fronts, per rung)                  */
+  int32_t device_ladder_fused; /* 1: on the smallest batches (where the first attempt would run in dataflow fashion) that launch makes
+                                  the first attempt and the backward sweeps too: newton_system is one launch (default 0: measured
+                                  slower than the separate launches, 0.140 against 0.118 ms for one system of cfg3's size)         */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);

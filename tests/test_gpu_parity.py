@@ -1315,3 +1315,125 @@ def test_host_driven_ladder_equals_the_device_ladder(built, B):
             assert np.abs(res[1][4][b] - res[0][4][b]).max() <= 1e-9 * np.abs(res[0][4][b]).max()
         else:
             assert (res[1][4][b] == 7.0).all() and (res[0][4][b] == 7.0).all()
+
+
+def _ladder_mix(syn, s, B):
+    """A batch that mixes a convex problem (no ladder), ladder climbers with rho_old = 0 and rho_old > 0 and a hopeless one."""
+    vals, rhs = syn.batch_values(s, B, cfg=5, stress="ladder")
+    off = s.offsets()
+    ro_in = np.zeros(B)
+    if B > 1:
+        v3, r3 = syn.batch_values(s, B, cfg=3)
+        vals[0], rhs[0] = v3[0], r3[0]                # convex: first factorisation succeeds
+        vals[1, off[0]:off[1]] = np.nan               # no rho repairs it
+        ro_in[3] = 2.5e-3                             # the ladder starts from max(rho_min, kappa_dec rho_old)
+        for b in range(5, B, 3):                      # a third of the larger batches is convex
+            vals[b], rhs[b] = v3[b], r3[b]
+    return vals, rhs, ro_in
+
+
+@pytest.mark.parametrize("mode", ["fused", "behind", "sequential"])
+@pytest.mark.parametrize("B", [1, 4, 120, 256])
+def test_device_ladder_of_the_dev_entry(built, B, mode):
+    """cnl_newton_system_dev on staged handles climbs the rho ladder of src/CaNNOLeS.jl:1029-1047 INSIDE one launch in which every
+    task of the elimination tree has a wavefront of its own (kernels2.hip, phase 2): `fused` — the launch makes the first attempt
+    too where the batch is small enough for the dataflow execution —, `behind` — only behind the staged first attempt —, and
+    `sequential` — the old one-wavefront-per-four-problems launch (cnl_options.device_ladder = 0).  All three must return the
+    oracle's (success, nfact, rho, rho_old) bit for bit, leave the rho slots of vals and rho_old as the reference leaves them, a
+    solution for the problems that succeed and an untouched d for the hopeless one; nothing is synchronised or read back by the
+    call itself (device pointers in, device pointers out), and a second call on the same handle gives the same answers."""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(600, 6)
+    rows, cols = s.kkt_pattern()
+    vals, rhs, ro_in = _ladder_mix(syn, s, B)
+    p = hipldl.default_params()
+    opts = {"fused": hipldl.Options(device_ladder_fused=1), "behind": hipldl.Options(), "sequential": hipldl.Options(device_ladder=0)}[mode]
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=opts)
+    assert L.config["kernel"] == "v2-staged"
+    orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
+    d0, ok0, rho0, ro0, nf0 = O.newton_system_batch(orc, B, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), ro_in, O.default_params())
+    ok0, rho0, ro0, nf0 = (np.atleast_1d(a) for a in (ok0, rho0, ro0, nf0))
+    v_ref = vals.copy()
+    O.newton_system_batch(orc, B, s.nvar, s.nequ, s.ncon, rhs, v_ref, ro_in, O.default_params())   # leaves the slots as the reference does
+    assert nf0.max() >= 3
+    dev = torch.device("cuda:0")
+    for rep in range(2):
+        t_vals = torch.tensor(vals, device=dev)
+        t_rhs = torch.tensor(rhs, device=dev)
+        t_d = torch.full((B, s.N), 7.0, dtype=torch.float64, device=dev)
+        t_ro = torch.tensor(ro_in, device=dev)
+        t_rho = torch.full((B,), -1.0, dtype=torch.float64, device=dev)
+        t_nf = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        t_ok = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        hipldl.newton_system_dev(L, t_vals.data_ptr(), t_rhs.data_ptr(), t_d.data_ptr(), t_ro.data_ptr(), t_rho.data_ptr(), t_nf.data_ptr(),
+                                 t_ok.data_ptr(), p, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ok, rho, ro, nf = t_ok.cpu().numpy(), t_rho.cpu().numpy(), t_ro.cpu().numpy(), t_nf.cpu().numpy()
+        assert np.array_equal(ok.astype(bool), ok0.astype(bool)), (mode, rep)
+        assert np.array_equal(nf, nf0), (mode, rep, nf, nf0)
+        assert np.array_equal(rho, rho0) and np.array_equal(ro, ro0), (mode, rep)
+        v = t_vals.cpu().numpy()
+        assert np.array_equal(v, v_ref, equal_nan=True)      # only the rho slots differ from the input, and as the reference leaves them
+        d = t_d.cpu().numpy()
+        for b in range(B):
+            if ok0[b]:
+                assert backward_error(s, v[b], rhs[b], d[b]) <= BWD_TOL
+                assert np.abs(d[b] - d0[b]).max() <= FWD_TOL * np.abs(d0[b]).max()
+            else:
+                assert (d[b] == 7.0).all()
+    assert L.dataflow_timeouts() == 0
+    # solve_ldl! uses the factorisation the ladder ended on
+    t_vals = torch.tensor(vals, device=dev)
+    t_ro = torch.tensor(ro_in, device=dev)
+    hipldl.newton_system_dev(L, t_vals.data_ptr(), t_rhs.data_ptr(), t_d.data_ptr(), t_ro.data_ptr(), t_rho.data_ptr(), t_nf.data_ptr(),
+                             t_ok.data_ptr(), p, stream=torch.cuda.current_stream().cuda_stream)
+    rhs2 = np.random.default_rng(5).standard_normal((B, s.N))
+    t_rhs2 = torch.tensor(rhs2, device=dev)
+    t_x = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
+    hipldl.lib().cnl_solve_dev(L._h, t_rhs2.data_ptr(), t_x.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    x, v = t_x.cpu().numpy(), t_vals.cpu().numpy()
+    for b in range(B):
+        if ok0[b]:
+            assert backward_error(s, v[b], rhs2[b], x[b]) <= BWD_TOL
+    L.close()
+
+
+def test_device_ladder_single_cfg3_system_and_timeouts(built):
+    """One system of BASELINE config 3's size that climbs to nfact = 6 through the device-pointer call (the entry the device-resident
+    loops use): results as the oracle's; then the same with cnl_options.dataflow_spin_limit = 1 — practically every wait of the
+    fused launch gives up, the waits are counted and the sequential launch behind it redoes the call from the caller's untouched
+    inputs (rho_old and the rho slots are only COMMITTED when no wait gave up)."""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(10000, 50)
+    rows, cols = s.kkt_pattern()
+    vals, rhs = syn.batch_values(s, 1, cfg=5, stress="ladder")
+    p = hipldl.default_params()
+    dev = torch.device("cuda:0")
+    for spin in (0, 1):
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=1,
+                                options=hipldl.Options(dataflow_spin_limit=spin) if spin else None)
+        orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
+        v0 = vals.copy()
+        d0, ok0, rho0, ro0, nf0 = O.newton_system_batch(orc, 1, s.nvar, s.nequ, s.ncon, rhs, v0, np.zeros(1), O.default_params())
+        assert int(np.atleast_1d(nf0)[0]) == 6
+        t_vals, t_rhs = torch.tensor(vals, device=dev), torch.tensor(rhs, device=dev)
+        t_d = torch.zeros((1, s.N), dtype=torch.float64, device=dev)
+        t_ro = torch.zeros(1, dtype=torch.float64, device=dev)
+        t_rho = torch.zeros(1, dtype=torch.float64, device=dev)
+        t_nf = torch.zeros(1, dtype=torch.int32, device=dev)
+        t_ok = torch.zeros(1, dtype=torch.int32, device=dev)
+        hipldl.newton_system_dev(L, t_vals.data_ptr(), t_rhs.data_ptr(), t_d.data_ptr(), t_ro.data_ptr(), t_rho.data_ptr(), t_nf.data_ptr(),
+                                 t_ok.data_ptr(), p, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(t_ok[0]) == 1 and int(t_nf[0]) == 6
+        assert float(t_rho[0]) == float(np.atleast_1d(rho0)[0]) and float(t_ro[0]) == float(np.atleast_1d(ro0)[0])
+        assert np.array_equal(t_vals.cpu().numpy(), v0)
+        d = t_d.cpu().numpy()[0]
+        assert backward_error(s, v0[0], rhs[0], d) <= BWD_TOL
+        assert np.abs(d - d0[0]).max() <= FWD_TOL * np.abs(d0[0]).max()
+        assert (L.dataflow_timeouts() > 0) == bool(spin)
+        L.close()
