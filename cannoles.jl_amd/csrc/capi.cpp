@@ -99,6 +99,10 @@ struct cnl_handle {
   bool timing = false;
   float last_ms = 0.f;
   bool factorized = false;
+  // success flags of the last HOST-pointer factorisation (cnl_factorize / cnl_newton_system), for cnl_solve: the reference never
+  // solves after a failed factorisation (src/CaNNOLeS.jl:1049) — a one-problem cnl_solve then is a call-sequence error, and a
+  // batched one leaves the rows of the failed problems untouched.  Unknown (empty) after a device-pointer factorisation.
+  std::vector<char> last_ok;
   cnl::DevJt djt{};  // transposed-Jacobian lists (row f1: residual / optimality vectors on the device)
   cnl::DenseState* dense = nullptr;
   cnl::DenseState* gdense = nullptr;  // dense treatment of an arbitrary condensed system (irregular sparsity, small batch)
@@ -688,7 +692,13 @@ extern "C" {
 static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* rows1, const int64_t* cols1, int64_t batch, int device);
 
 const char* cnl_last_error(void) { return g_err.c_str(); }
-int32_t cnl_version(void) { return 100; }
+// 0.2.0 (round 4: in-kernel device ladder, cnl_options grew).  An EXPERIMENT build (timing probes, diagnostic stamps: results may be
+// wrong, see kernels2.hip) reports a NEGATIVE version; hipldl.py and the Julia glue refuse to load one unless asked to.
+#ifdef CNL_EXPERIMENT
+int32_t cnl_version(void) { return -200; }
+#else
+int32_t cnl_version(void) { return 200; }
+#endif
 
 void cnl_default_params(double p[9]) {
   const double eps = 2.220446049250313e-16;  // eps(Float64); src/CaNNOLeS.jl:48-62
@@ -1265,7 +1275,7 @@ int cnl_factorize_dev(cnl_handle* h, const double* d_vals, double eig_tol, int32
   a.success = d_success;
   a.params[0] = eig_tol;
   int rc = run(h, a, const_cast<double*>(d_vals), nullptr, nullptr, (hipStream_t)stream);
-  if (rc == CNL_OK) { h->factorized = true; h->last_vals = d_vals; }
+  if (rc == CNL_OK) { h->factorized = true; h->last_vals = d_vals; h->last_ok.clear(); }
   return rc;
 }
 
@@ -1288,7 +1298,7 @@ int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, do
   a.rho_old = d_rho_old; a.rho = d_rho; a.nfact = d_nfact; a.success = d_success;
   std::memcpy(a.params, params, 9 * sizeof(double));
   int rc = run(h, a, d_vals, d_rhs, d_d, (hipStream_t)stream);
-  if (rc == CNL_OK) { h->factorized = true; h->last_vals = d_vals; }
+  if (rc == CNL_OK) { h->factorized = true; h->last_vals = d_vals; h->last_ok.clear(); }
   return rc;
 }
 
@@ -1312,6 +1322,7 @@ int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* su
   if (nzero) HIPCHK(hipMemcpyAsync(nzero, h->d_nzero, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->factorized = true;
+  h->last_ok.assign(success, success + B);
   return CNL_OK;
 }
 
@@ -1326,8 +1337,23 @@ int cnl_solve(cnl_handle* h, const double* rhs, double* d) {
   HIPCHK(hipMemcpyAsync(h->d_rhs, rhs, B * P.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   cnl::LaunchArgs a{};
   a.mode = cnl::MODE_SOLVE;
+  const bool known = h->last_ok.size() == B;
+  if (known && B == 1 && !h->last_ok[0])
+    return fail(CNL_ERR_STATE, "cnl_solve after a factorisation that failed (success = 0): there is no factor to solve with "
+                               "(the reference calls solve_ldl! only after a successful try_to_factorize, src/CaNNOLeS.jl:1049)");
   if ((rc = run(h, a, nullptr, h->d_rhs, h->d_d, h->stream))) return rc;
-  HIPCHK(hipMemcpyAsync(d, h->d_d, B * P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (!known) {
+    HIPCHK(hipMemcpyAsync(d, h->d_d, B * P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  } else {
+    size_t b0 = 0;
+    while (b0 < B) {  // rows of the problems that hold a factor; the others stay as the caller passed them
+      while (b0 < B && !h->last_ok[b0]) b0++;
+      size_t b1 = b0;
+      while (b1 < B && h->last_ok[b1]) b1++;
+      if (b1 > b0) HIPCHK(hipMemcpyAsync(d + b0 * P.N, h->d_d + b0 * P.N, (b1 - b0) * P.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      b0 = b1;
+    }
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   return CNL_OK;
 }
@@ -1473,6 +1499,7 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
     }
   }
   h->factorized = true;
+    h->last_ok.assign(success, success + B);
   return CNL_OK;
 }
 
@@ -1594,6 +1621,7 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     HIPCHK(hipStreamSynchronize(h->stream));
     h->last_vals = h->d_vals;
     h->factorized = true;
+    h->last_ok.assign(success, success + B);
     return CNL_OK;
   }
   cnl::LaunchArgs a{};
@@ -1610,7 +1638,10 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   // walks the latency plan's fronts one after the other on ONE wavefront per four problems: 7.7 ms per rung for a system of
   // cfg3's size (38 ms for nfact = 6, ten times one CPU core of the oracle); it stays the device-pointer calls' fallback.
   const bool small = B * (size_t)P.N * sizeof(double) <= ((size_t)1 << 20);
-  const bool host_ladder = h->staged && !h->dense && !h->gdense && h->plan->opt.host_ladder != 0 && h->use_v2 && P.P.rec_direct && P.P.d_outer;
+  // (handles whose in-kernel device ladder is available use that one: no round trip per rung — 0.67 against 0.9 ms for one system of
+  //  cfg3's size that climbs to nfact = 6)
+  const bool host_ladder = h->staged && !h->dense && !h->gdense && h->plan->opt.host_ladder != 0 && h->use_v2 && P.P.rec_direct && P.P.d_outer &&
+                           (h->lad_mode == 0 || h->split_staged > 0);
   h->first_attempt_only = host_ladder;
   rc = run(h, a, h->d_vals, h->d_rhs, h->d_d, h->stream);
   h->first_attempt_only = false;
@@ -1678,6 +1709,7 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
       if (P.nvar > 0 && tail_valid) std::memcpy(vals + b * P.nnz + (P.nnz - P.nvar), pb + o_tail + b * P.nvar * 8, (size_t)P.nvar * 8);
     }
     h->factorized = true;
+    h->last_ok.assign(success, success + B);
     return CNL_OK;
   }
   // the reference leaves d untouched when the factorisation fails (src/CaNNOLeS.jl:1049): copy back the rows that succeeded
@@ -1729,6 +1761,7 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
                             (size_t)P.nnz * sizeof(double), (size_t)P.nvar * sizeof(double), B, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->factorized = true;
+    h->last_ok.assign(success, success + B);
   return CNL_OK;
 }
 

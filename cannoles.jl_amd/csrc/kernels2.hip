@@ -35,6 +35,15 @@
 #ifndef CNL_ABL
 #define CNL_ABL 0
 #endif
+// Every switch that makes this file compute something else than the product (timing probes with wrong or unguaranteed results,
+// diagnostic stamps, the shortened division) compiles only in an EXPERIMENT build: -DCNL_EXPERIMENT=1, which also turns
+// cnl_version() negative (capi.cpp) so that such a library cannot pass for the product.
+#if (CNL_ABL != 0) || defined(CNL_DBG_NOCONF) || defined(CNL_DBG_VSTRIDE0) || defined(CNL_DBG_LSTRIDE0) || defined(CNL_DF_NOFENCE) || \
+    defined(CNL_STAMPS) || (defined(CNL_QUICK_DIV) && CNL_QUICK_DIV)
+#ifndef CNL_EXPERIMENT
+#error "timing probes / diagnostic builds need -DCNL_EXPERIMENT=1 (cnl_version() then reports an experimental library)"
+#endif
+#endif
 
 namespace cnl {
 
@@ -85,15 +94,9 @@ __device__ __forceinline__ T* as_global(T* p) {
 // broadcast lane (group base + a) of a TE-lane group
 template <int TE>
 __device__ __forceinline__ double bcast(double v, int a, int grp4) {
-  if (false) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), a);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), a);
-    return __hiloint2double(hi, lo);
-  } else {
-    int lo = __builtin_amdgcn_ds_bpermute(grp4 + a * 4, __double2loint(v));
-    int hi = __builtin_amdgcn_ds_bpermute(grp4 + a * 4, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-  }
+  int lo = __builtin_amdgcn_ds_bpermute(grp4 + a * 4, __double2loint(v));
+  int hi = __builtin_amdgcn_ds_bpermute(grp4 + a * 4, __double2hiint(v));
+  return __hiloint2double(hi, lo);
 }
 
 // w / d through a refined reciprocal: shorter dependent chain than the IEEE expansion (no scaling /

@@ -84,6 +84,38 @@ class CnlError(RuntimeError):
         self.code = code
 
 
+def loaded_hip_runtimes():
+    """paths of the HIP runtimes (libamdhip64) mapped into this process"""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
+def _one_hip_runtime():
+    """ONE HIP runtime per process, whatever the import order.  libcannoles_hip.so needs `libamdhip64.so.7`.  A PyTorch wheel
+    bundles its own copy (same SONAME, found through torch's rpath under the name `libamdhip64.so`):
+      * torch imported first: the loader satisfies our dependency with torch's copy (SONAME match) — one runtime;
+      * our library first, torch later: ours would pull in the system ROCm's runtime, torch then its bundled copy — two runtimes,
+        and the one that initialises second finds no device.
+    So when this process has no HIP runtime yet and a torch wheel with a bundled runtime is INSTALLED (not imported here), that
+    copy is loaded first: our library binds to it and a later `import torch` finds it already loaded.  Without torch (the Julia
+    drop-in, a C caller) the system runtime is used as linked."""
+    if loaded_hip_runtimes():
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass   # fall back to the runtime the library is linked against
+
+
 def lib():
     """Load libcannoles_hip.so (built by __graft_entry__.build / csrc/Makefile)."""
     global _lib
@@ -92,6 +124,7 @@ def lib():
             raise FileNotFoundError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)")
+        _one_hip_runtime()
         L = C.CDLL(LIB_PATH)
         vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int32
         L.cnl_last_error.restype = C.c_char_p
@@ -138,6 +171,9 @@ def lib():
         L.cnl_set_timing.argtypes = [vp, C.c_int]
         L.cnl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cnl_get_config.argtypes = [vp, _i64p]
+        if L.cnl_version() < 0 and not os.environ.get("CANNOLES_HIP_ALLOW_EXPERIMENT"):
+            raise RuntimeError(f"{LIB_PATH} is an EXPERIMENT build (cnl_version() = {L.cnl_version()}: timing probes / diagnostic "
+                               "stamps compiled in, results may be wrong); set CANNOLES_HIP_ALLOW_EXPERIMENT=1 to load it on purpose")
         _lib = L
     return _lib
 

@@ -55,6 +55,8 @@ end
 reference's 7-segment order (/root/reference/src/CaNNOLeS.jl:256-315).
 """
 function HIPFactor(N::Integer, rows::Vector{Int64}, cols::Vector{Int64}, nvar::Integer, nequ::Integer, ncon::Integer; device::Integer = 0)
+  # an EXPERIMENT build of the library (timing probes / diagnostic stamps compiled in) reports a negative version
+  ccall((:cnl_version, libcnl), Int32, ()) >= 200 || error("libcannoles_hip: ABI version 0.2.0 or later required (experiment builds are refused)")
   h = Ref{Ptr{Cvoid}}(C_NULL)
   check(ccall((:cnl_create, libcnl), Cint,
     (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Int64, Int64, Int64, Int64, Cint),
@@ -73,7 +75,11 @@ function factorize!(f::HIPFactor, vals::Vector{Float64}, eig_tol::Float64)
   return f.success[] != 0
 end
 
-"solve_ldl! — /root/reference/src/solver_types.jl:69-77: d = -(K^-1 rhs), rhs untouched"
+"""
+solve_ldl! — /root/reference/src/solver_types.jl:69-77: d = -(K^-1 rhs), rhs untouched.  The reference calls it only after a
+successful `try_to_factorize` (/root/reference/src/CaNNOLeS.jl:1049); after a failed one `cnl_solve` returns CNL_ERR_STATE and
+this throws `CnlError` (nothing is written to `d`).
+"""
 function solve!(f::HIPFactor, rhs::Vector{Float64}, d::Vector{Float64})
   check(ccall((:cnl_solve, libcnl), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), f.handle, rhs, d))
   return true

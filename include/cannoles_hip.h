@@ -172,8 +172,11 @@ const cnl_plan* cnl_get_plan(const cnl_handle* h);
 int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* success, int64_t* npos, int64_t* nzero);
 
 /* solve_ldl!(rhs, factor, d) — src/solver_types.jl:69-77: d = -(K^-1 rhs); rhs untouched.
- * Requires a preceding cnl_factorize.  Problems whose factorisation failed get NaN-free garbage
- * (the reference never solves after a failure, src/CaNNOLeS.jl:1049).                          */
+ * Requires a preceding cnl_factorize / cnl_newton_system.  The reference never solves after a failed factorisation
+ * (src/CaNNOLeS.jl:1049); here: with batch = 1 that call sequence returns CNL_ERR_STATE (nothing is written); in a batch the rows of
+ * d that belong to problems whose last host-pointer factorisation failed are left untouched.  After a device-pointer
+ * factorisation the flags are not known to the host: cnl_solve / cnl_solve_dev then write unspecified (finite or not) values for
+ * the problems that failed — the caller holds d_success and must not use those rows.                                          */
 int cnl_solve(cnl_handle* h, const double* rhs, double* d);
 
 /* newton_system!(d, nvar, nequ, ncon, rhs, vals, LDLT, rho_old, params) — src/CaNNOLeS.jl:1008-1052,

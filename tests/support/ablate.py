@@ -17,25 +17,26 @@ def libpath(bits):
 
 
 def flags(bits):
+    # every variant is an EXPERIMENT build (csrc/kernels2.hip refuses the probes otherwise; cnl_version() turns negative)
     if str(bits).startswith("RAW:"):   # raw compiler flags, '+' separated: RAW:-mllvm+-amdgpu-...=1
-        return " ".join(str(bits)[4:].split("+"))
+        return "-DCNL_EXPERIMENT=1 " + " ".join(str(bits)[4:].split("+"))
     if "=" in str(bits):
-        return " ".join("-D" + f for f in str(bits).split(","))
-    return f"-DCNL_ABL={bits}"
+        return "-DCNL_EXPERIMENT=1 " + " ".join("-D" + f for f in str(bits).split(","))
+    return f"-DCNL_EXPERIMENT=1 -DCNL_ABL={bits}"
 
 
 def build(bits_list):
     os.makedirs(OUTD, exist_ok=True)
     procs = []
     for bits in bits_list:
-        cmd = ["make", "-s", "-C", CSRC, "-B", f"OUT={libpath(bits)}", f"CXXFLAGS=-O3 -std=c++17 -fPIC {flags(bits)}"]
+        cmd = ["make", "-s", "-j4", "-C", CSRC, f"OUT={libpath(bits)}", f"OBJDIR={libpath(bits)[:-3]}_obj", f"CXXFLAGS=-O3 -std=c++17 -fPIC {flags(bits)}"]
         procs.append(subprocess.Popen(cmd))
     for p in procs:
         p.wait()
 
 
 def run_one(B, bits):
-    env = dict(os.environ, CANNOLES_HIP_LIB=libpath(bits))
+    env = dict(os.environ, CANNOLES_HIP_LIB=libpath(bits), CANNOLES_HIP_ALLOW_EXPERIMENT="1")
     code = f"""
 import sys; sys.path.insert(0, {ROOT!r})
 import numpy as np, torch

@@ -11,7 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "cannoles.jl_amd", "csrc")
 if not os.environ.get("CANNOLES_HIP_LIB"):  # otherwise: a variant built beforehand (tests/support/ablate.py build CNL_STAMPS=1,...)
-    subprocess.check_call(["make", "-s", "-C", csrc, "-B", "CXXFLAGS=-O3 -std=c++17 -fPIC -DCNL_STAMPS"])
+    # an EXPERIMENT build of its own (never over the product library): build_abl/libcnl_stamps.so
+    outd = os.path.join(ROOT, "build_abl")
+    os.makedirs(outd, exist_ok=True)
+    subprocess.check_call(["make", "-s", "-j4", "-C", csrc, f"OUT={outd}/libcnl_stamps.so", f"OBJDIR={outd}/stamps_obj",
+                           "CXXFLAGS=-O3 -std=c++17 -fPIC -DCNL_STAMPS -DCNL_EXPERIMENT=1"])
+    os.environ["CANNOLES_HIP_LIB"] = os.path.join(outd, "libcnl_stamps.so")
+os.environ.setdefault("CANNOLES_HIP_ALLOW_EXPERIMENT", "1")
 import cannoles_jl_amd  # noqa
 from cannoles_jl_amd import hipldl, synthetic as syn
 

@@ -609,10 +609,12 @@ def test_fixtures_f2_f3_through_the_hip_path(built):
     L.close()
 
 
-@pytest.mark.parametrize("B,kernel,order,forced", [(4608, "v2", "canonical", True), (4608, "v2-staged", "ndc2", False),
+@pytest.mark.parametrize("B,kernel,order,forced", [(8192, "v2", "canonical", False),   # THE headline plan of bench.py, as cnl_create picks it
+                                                   (4608, "v2", "canonical", True), (4608, "v2-staged", "ndc2", False),
                                                    (3584, "v2-staged", "ndc2", False), (1536, "v2-staged", "ndc", False)])
 def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, forced):
-    """The headline shape (cfg3 pattern, n = nequ = 1e4, ncon = 50): on the throughput kernel (single stream, forced here with
+    """The headline shape (cfg3 pattern, n = nequ = 1e4, ncon = 50): the headline batch itself (8192 problems, the plan cnl_create
+    picks: canonical+early on the single stream — what bench.py times), on the throughput kernel (single stream, forced here with
     cnl_options.plan_kind: it is what cnl_create picks from 7681 problems on), at a batch between one and two wavefronts per SIMD
     (B = 4608: 3584 problems on the bidirectional chain and 1024 on the single stream, CONCURRENTLY on two streams —
     csrc/capi.cpp, run_split), at one the bidirectional chain serves alone (B = 3584) and at one with many large parts
@@ -1295,16 +1297,24 @@ def test_host_driven_ladder_equals_the_device_ladder(built, B):
     po = O.default_params()
     orc = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
     res = {}
-    for hl in (1, 0):
-        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(host_ladder=hl))
+    # 1: host-driven ladder, 0: the sequential device launch, 2: the library's default (the in-kernel device ladder, round 4)
+    for hl in (1, 0, 2):
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B,
+                                options=None if hl == 2 else hipldl.Options(host_ladder=hl, device_ladder=0))
         v = vals.copy()
         d = np.full((B, s.N), 7.0)
         out = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, ro_in if B > 1 else 0.0, p)
         res[hl] = tuple(np.atleast_1d(np.asarray(x)).copy() for x in out[1:]) + (np.array(d, copy=True).reshape(B, s.N), v.reshape(B, -1).copy())
         L.close()
-    for k in range(4):
-        assert np.array_equal(res[1][k], res[0][k]), k     # success, rho, rho_old, nfact: bit for bit
-    assert np.array_equal(res[1][5], res[0][5], equal_nan=True)   # vals: the rho slots as the reference leaves them
+    for other in (0, 2):
+        for k in range(4):
+            assert np.array_equal(res[1][k], res[other][k]), (other, k)     # success, rho, rho_old, nfact: bit for bit
+        assert np.array_equal(res[1][5], res[other][5], equal_nan=True)   # vals: the rho slots as the reference leaves them
+        for b in range(B):
+            if res[1][0][b]:
+                assert np.abs(res[1][4][b] - res[other][4][b]).max() <= 1e-9 * np.abs(res[1][4][b]).max()
+            else:
+                assert (res[other][4][b] == 7.0).all()
     d0, ok0, rho0, ro0, nf0 = O.newton_system_batch(orc, B, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), ro_in, po)
     assert np.array_equal(res[1][0].astype(bool), np.atleast_1d(ok0)) and np.array_equal(res[1][3], np.atleast_1d(nf0))
     assert np.array_equal(res[1][1], np.atleast_1d(rho0)) and np.array_equal(res[1][2], np.atleast_1d(ro0))
@@ -1437,3 +1447,109 @@ def test_device_ladder_single_cfg3_system_and_timeouts(built):
         assert np.abs(d - d0[0]).max() <= FWD_TOL * np.abs(d0[0]).max()
         assert (L.dataflow_timeouts() > 0) == bool(spin)
         L.close()
+
+
+@pytest.mark.parametrize("order", ["torch_first", "lib_first", "no_torch"])
+def test_import_order_does_not_matter(built, order):
+    """A drop-in library must not depend on import order.  A PyTorch wheel bundles its own HIP runtime; loaded beside the system
+    ROCm's, the runtime that initialises second finds no device (measured on the pool: `lib_first` failed with "no ROCm-capable
+    device" until round 4).  cannoles.jl_amd/hipldl.py::_one_hip_runtime makes both orders end with ONE runtime in the process;
+    without torch the library runs on the runtime it is linked against.  Each order in a fresh process (no GPU call in this one
+    decides anything)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rt_probe.py"), order], capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-2000:]
+    assert "\nOK" in "\n" + r.stdout, out[-2000:]
+    assert "RUNTIMES 1 " in r.stdout, out[-2000:]
+
+
+def test_solve_after_a_failed_factorisation(built):
+    """The reference never calls solve_ldl! after a failed try_to_factorize (src/CaNNOLeS.jl:1049).  Through the C ABI a caller can:
+    with one problem that is a call-sequence error (CNL_ERR_STATE, d untouched); in a batch the rows of the failed problems stay
+    as the caller passed them and the others are solved (round 3 returned `NaN-free garbage` with CNL_OK)."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(400, 4)
+    rows, cols = s.kkt_pattern()
+    p = hipldl.default_params()
+    off = s.offsets()
+    vals, rhs = syn.batch_values(s, 4, cfg=4)
+    bad = vals.copy()
+    bad[2, off[0]:off[1]] = -50.0          # H_F far from positive definite: wrong inertia at the rho slots as given
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=4)
+    ok = hipldl.try_to_factorize(L, bad, s.nvar, s.nequ, s.ncon, p[0])
+    assert list(ok) == [True, True, False, True]
+    d = np.full((4, s.N), 7.0)
+    hipldl.solve_ldl_(rhs, L.factor, d)
+    assert (d[2] == 7.0).all()
+    for b in (0, 1, 3):
+        assert backward_error(s, bad[b], rhs[b], d[b]) <= BWD_TOL
+    L.close()
+    L1 = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=1)
+    assert not hipldl.try_to_factorize(L1, bad[2], s.nvar, s.nequ, s.ncon, p[0])
+    d1 = np.full(s.N, 7.0)
+    with pytest.raises(hipldl.CnlError) as ei:
+        hipldl.solve_ldl_(rhs[2], L1.factor, d1)
+    assert ei.value.code == 5 and (d1 == 7.0).all()
+    assert hipldl.try_to_factorize(L1, vals[2], s.nvar, s.nequ, s.ncon, p[0])
+    hipldl.solve_ldl_(rhs[2], L1.factor, d1)
+    assert backward_error(s, vals[2], rhs[2], d1) <= BWD_TOL
+    L1.close()
+
+
+@pytest.mark.parametrize("B", [1, 4, 4608])
+def test_duplicate_slots_are_summed_in_coo_order_on_the_device(built, B):
+    """set_vals! sums the COO entries of one matrix slot in COO order (src/solver_types.jl:53-59: zero, then `+=` entry by entry).
+    Here three variables without any Jacobian entry are appended to a band problem; their diagonal slot holds THREE COO entries —
+    H_F (1e16), H_c (-1e16) and the rho slot (1.0) — and is its own pivot (nothing else touches the node).  Only the COO order
+    gives (1e16 - 1e16) + 1 = 1; any other order gives 0 (a zero pivot: the factorisation would fail).  So success and
+    d_k == -rhs_k / 1 BIT FOR BIT show the order of the device's sums (round 3 checked fixture F2's slot only through d at 1e-12).
+    Staged plans (B = 1, 4) and the single-stream throughput kernel (B = 4608)."""
+    hipldl, syn, O = _mods()
+    base = syn.band_structure(40, 4)
+    n0, extra = base.nvar, 3
+    n = n0 + extra
+    iso = np.arange(n0 + 1, n + 1)
+    hF = (np.concatenate([base.hF[0], iso]), np.concatenate([base.hF[1], iso]))
+    hc = (np.arange(1, n + 1), np.arange(1, n + 1))
+    s = syn.Structure(n, base.nequ, base.ncon, hF, hc, base.jF, base.jc, name="band+isolated", meta=dict(base.meta))
+    rows, cols = s.kkt_pattern()
+    off, ob = s.offsets(), base.offsets()
+    vals = np.zeros((B, s.nnzNS))
+    rhs = np.zeros((B, s.N))
+    v0, r0 = syn.batch_values(base, min(B, 8), cfg=4)
+    for b in range(B):
+        vb, rb = v0[b % len(v0)], r0[b % len(v0)]
+        vals[b, off[0]:off[0] + base.nnzhF] = vb[ob[0]:ob[1]]
+        vals[b, off[0] + base.nnzhF:off[1]] = 1e16                       # H_F on the isolated diagonal
+        vals[b, off[1]:off[1] + n0] = vb[ob[1]:ob[2]]
+        vals[b, off[1] + n0:off[2]] = -1e16                              # H_c (stored negated by prepare_newton_system!)
+        vals[b, off[2]:off[3]] = vb[ob[2]:ob[3]]
+        vals[b, off[3]:off[4]] = vb[ob[3]:ob[4]]
+        vals[b, off[4]:off[5]] = -1.0
+        vals[b, off[5]:off[6]] = vb[ob[5]:ob[6]]
+        vals[b, off[6] + n0:off[7]] = 1.0                                # the rho slots of the isolated variables
+        rhs[b, :n0] = rb[:n0]
+        rhs[b, n0:n] = [3.25, -0.1 * (b + 1), 7.0]
+        rhs[b, n:] = rb[n0:]
+    p = hipldl.default_params()
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    v = vals.copy()
+    d, ok, rho, ro, nf = hipldl.newton_system_(np.zeros((B, s.N)), s.nvar, s.nequ, s.ncon, rhs, v, L, np.zeros(B), p)
+    ok, nf = np.atleast_1d(ok), np.atleast_1d(nf)
+    assert ok.all() and (nf == 1).all()
+    d = d.reshape(B, s.N)
+    assert np.array_equal(d[:, n0:n], -rhs[:, n0:n])          # pivot exactly 1.0: bit for bit
+    orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
+    for b in range(min(B, 4)):
+        d0, ok0, _, _, nf0 = O.newton_system_batch(orc, 1, s.nvar, s.nequ, s.ncon, rhs[b:b + 1], vals[b:b + 1].copy(), np.zeros(1), O.default_params())
+        assert bool(np.atleast_1d(ok0)[0]) and int(np.atleast_1d(nf0)[0]) == 1
+        assert np.array_equal(d0.reshape(-1)[n0:n], d[b, n0:n])
+        assert np.abs(d[b] - d0.reshape(-1)).max() <= FWD_TOL * np.abs(d0).max()
+    # the two-call sequence sums the same way
+    okf, npos, nzer = hipldl.try_to_factorize(L, vals if B > 1 else vals[0], s.nvar, s.nequ, s.ncon, p[0], return_inertia=True)
+    assert np.atleast_1d(okf).all() and (np.atleast_1d(npos) == s.nvar).all() and (np.atleast_1d(nzer) == 0).all()
+    L.close()

@@ -41,7 +41,7 @@ def test_abi_exports_every_declared_symbol(built):
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in cannoles_hip.h but not exported"
     assert declared >= set(hipldl.ABI_SYMBOLS)
-    assert hipldl.lib().cnl_version() >= 100
+    assert hipldl.lib().cnl_version() >= 200
 
 
 def test_default_params_match_reference(built, params):

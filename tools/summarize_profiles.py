@@ -29,10 +29,14 @@ for d in sorted(glob.glob(os.path.join(go, a.tag + "_pmc_*"))):
             if "cnl::" not in r["Kernel_Name"]: continue
             k = short(r["Kernel_Name"]).split("(")[0]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"], r["SGPR_Count"])
+            # (rocprofv3's LDS_Block_Size / Scratch_Size / VGPR_Count / SGPR_Count columns are NOT carried over: for these kernels they
+            #  read 0 / 0 / 96 / 112 whatever the code object holds — dynamic LDS is not in the descriptor, and the VGPR figure is not
+            #  the allocation.  The registers, spills and scratch of every instantiation are in profiles/<tag>_kernel_resources.txt,
+            #  written by tools/kernel_resources.sh from the compiler's own resource-usage remarks.)
+            meta[k] = (r["Grid_Size"], r["Workgroup_Size"])
 if acc:
     with open(os.path.join(pr, a.tag + "_pmc.csv"), "w", newline="") as f:
-        w = csv.writer(f); w.writerow(["Kernel", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "SGPR_Count", "Counter", "Dispatches", "Mean_per_dispatch"])
+        w = csv.writer(f); w.writerow(["Kernel", "Grid_Size", "Workgroup_Size", "Counter", "Dispatches", "Mean_per_dispatch"])
         for k in sorted(acc):
             for c in sorted(acc[k]):
                 v = acc[k][c]; w.writerow([k, *meta[k], c, len(v), sum(v) / len(v)])
