@@ -89,6 +89,7 @@ struct cnl_handle {
   int64_t *d_npos = nullptr, *d_nzero = nullptr;
   hipStream_t stream = nullptr;
   int64_t split_staged = 0;   // > 0: problems [0, split_staged) run staged, the rest single-stream, concurrently (run_split)
+  bool split_halves = false;  // ... or (round 4): the rest runs staged as well, BEHIND the first part on the same stream (two halves)
   bool in_split = false;
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -291,9 +292,13 @@ int setup_v2(cnl_handle* h) {
     // holds the fused launch is repeated over ranges of groups; beyond four such launches the sequential launch keeps the job
     // (plans of very many tasks on batches that large do not occur: the planner gives large batches few, large tasks).
     h->lad_mode = 0;
+    // Plans of a few LARGE tasks (the bidirectional chain of mid-size batches) keep the sequential launch when one fused launch
+    // cannot hold the batch: a rung there is the same chain of fronts either way, and two fused launches of two wavefronts per SIMD
+    // lose to one sequential launch of one (cfg5 at 4096 problems: 3.9 against 2.9 ms).
     if (o.device_ladder && h->resident_waves >= h->ntasks) {
       const long long slots = h->resident_waves / h->ntasks, nq = (h->batch + 3) / 4;
-      if ((nq + slots - 1) / slots <= 4) h->lad_mode = o.device_ladder_fused ? 2 : 1;
+      const long long launches = (nq + slots - 1) / slots;
+      if (launches == 1 || (launches <= 4 && h->ntasks >= 16)) h->lad_mode = o.device_ladder_fused ? 2 : 1;
     }
   }
   h->v2_solve = P.rec_direct && P.d_outer && P.ncls[1] == 0 && P.ncls[2] == 0 && !o.v1_solve;
@@ -395,6 +400,34 @@ int run_split(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d
   if (tm) HIPCHK(hipEventRecord(h->ev0, stream));
   h->timing = false;
   h->in_split = true;
+  if (h->split_halves) {
+    // Two halves, each on the bidirectional chain (two wavefronts per group of problems), one behind the other on the caller's
+    // stream: a half of 2304 .. 3840 problems runs at 0.81 .. 0.96 M systems/s, where the single-stream part of the concurrent
+    // split needs its >= 6 ms however few problems it holds (4608 problems: 6.5 ms = 707 k systems/s; two halves: ~5.7 ms).
+    int rc = CNL_OK;
+    for (int part = 0; part < 2 && rc == CNL_OK; part++) {
+      const int64_t b0 = part ? nA : 0, nb = part ? nB : nA;
+      SubBatch view(h, b0, nb, true);
+      cnl::LaunchArgs b = a;
+      if (b.rho_old) b.rho_old += b0;
+      if (b.rho) b.rho += b0;
+      if (b.nfact) b.nfact += b0;
+      if (b.success) b.success += b0;
+      if (b.npos) b.npos += b0;
+      if (b.nzero) b.nzero += b0;
+      rc = run(h, b, d_vals ? d_vals + b0 * nnz : nullptr, d_rhs ? d_rhs + b0 * N : nullptr, d_d ? d_d + b0 * N : nullptr, stream);
+    }
+    h->in_split = false;
+    h->timing = tm;
+    if (rc) return rc;
+    if (a.mode == cnl::MODE_FACTOR) h->last_vals = d_vals;
+    if (tm) {
+      HIPCHK(hipEventRecord(h->ev1, stream));
+      HIPCHK(hipEventSynchronize(h->ev1));
+      HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    }
+    return CNL_OK;
+  }
   HIPCHK(hipEventRecord(h->ev_fork, stream));
   HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
   int rc;
@@ -1075,6 +1108,13 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     // x groups of four problems on the chain (two wavefronts each), the rest on the single stream: 2 x + y = 2048 slots
     const int64_t nquads = (batch + 3) / 4, x = std::max<int64_t>(0, 2048 - nquads);
     h->split_staged = std::min<int64_t>(batch, 4 * x);
+    if (h->plan->opt.split_batch == 1 && batch <= 6400) {
+      // two halves on the chain (multiples of four problems), sequentially — measured against chain + single stream concurrently
+      // (cfg3's size, same box, k systems/s): 4608: 768 / 707, 5120: 836 / 790, 6144: 931 / 898, 6656: 912 / ~935, 7168: 956 / 959,
+      // 7424: 904 / ~965 — halves up to 6400 problems (see run_split)
+      h->split_halves = true;
+      h->split_staged = (((batch + 1) / 2) + 3) & ~(int64_t)3;
+    }
     if (h->split_staged == 0) h->staged = false;  // the whole batch on the single stream
   }
   if (h->plan->D.active) {
@@ -1520,7 +1560,7 @@ static int host_ladder_run(cnl_handle* h, const double params[9], const double* 
   std::vector<double> ro_in(B);
   // split handles: only the chain part [0, split_staged) ran the first attempt alone; the single-stream part has been through the
   // whole device ladder already (a problem that exhausted it there must not climb again: nfact would count twice)
-  const size_t first_only = (h->split_staged > 0 && (size_t)h->split_staged < B) ? (size_t)h->split_staged : B;
+  const size_t first_only = (h->split_staged > 0 && (size_t)h->split_staged < B && !h->split_halves) ? (size_t)h->split_staged : B;
   bool any_act = false;
   for (size_t b = 0; b < B; b++) {
     ro_in[b] = rho_old ? rho_old[b] : 0.0;
@@ -1664,12 +1704,9 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     HIPCHK(hipMemcpyAsync(pb + o_d, h->d_d, B * P.N * 8, hipMemcpyDeviceToHost, h->stream));
     // (with the host-driven ladder the first attempt never writes the rho slots: they come back only behind a ladder, or behind the
     //  sequential redo of a dataflow time-out)
+    // (the rho slots come back only where a ladder wrote them: nfact > 1 — known after the first synchronisation; copying them
+    //  on every call cost the common one-system call 40 us of its 0.24 ms)
     bool tail_valid = false;
-    if (P.nvar > 0 && !host_ladder) {
-      HIPCHK(hipMemcpy2DAsync(pb + o_tail, (size_t)P.nvar * 8, h->d_vals + (P.nnz - P.nvar), (size_t)P.nnz * 8, (size_t)P.nvar * 8, B,
-                              hipMemcpyDeviceToHost, h->stream));
-      tail_valid = true;
-    }
     HIPCHK(hipMemcpyAsync(pb + o_rho, h->d_rho, B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pb + o_ro, h->d_rho_old, B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pb + o_nf, h->d_nfact, B * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1696,11 +1733,16 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
         tail_valid = true;
       }
       HIPCHK(hipStreamSynchronize(h->stream));
-    } else if (host_ladder && *up_status != 0 && P.nvar > 0) {
-      HIPCHK(hipMemcpy2DAsync(pb + o_tail, (size_t)P.nvar * 8, h->d_vals + (P.nnz - P.nvar), (size_t)P.nnz * 8, (size_t)P.nvar * 8, B,
-                              hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      tail_valid = true;
+    } else if (P.nvar > 0) {
+      // the device climbed a ladder (in-kernel ladder, sequential launch, or the redo behind a dataflow time-out): rho slots back
+      bool climbed = false;
+      for (size_t b = 0; b < B; b++) climbed |= nfact[b] > 1;
+      if (climbed) {
+        HIPCHK(hipMemcpy2DAsync(pb + o_tail, (size_t)P.nvar * 8, h->d_vals + (P.nnz - P.nvar), (size_t)P.nnz * 8, (size_t)P.nvar * 8, B,
+                                hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        tail_valid = true;
+      }
     }
     for (size_t b = 0; b < B; b++) {
       if (success[b]) std::memcpy(d + b * P.N, pb + o_d + b * P.N * 8, (size_t)P.N * 8);

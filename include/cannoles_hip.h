@@ -99,8 +99,9 @@ typedef struct cnl_options {
   int32_t verbose;             /* 1: log plan decisions on stderr                                                               */
   int32_t multi_share_plan;    /* 1: cnl_multi_create analyses the pattern once for all shards of equal plan kind               */
   int32_t row_products;        /* 1: condensation products of small fronts organised per residual row (csrc/plan.h, RF_ROWS)    */
-  int32_t split_batch;         /* 1: batches between one and two wavefronts per SIMD run partly on the bidirectional chain,
-                                  partly single-stream, concurrently (csrc/capi.cpp, run_split)                                 */
+  int32_t split_batch;         /* batches between one and two wavefronts per SIMD (csrc/capi.cpp, run_split): 1 (default) two halves on
+                                  the bidirectional chain one behind the other (up to 6400 problems; above: as 2), 2 partly on the
+                                  chain, partly single-stream, concurrently (round 3's form), 0 the single stream                */
   int32_t lean_kernel;         /* 1: plans of fast-class row-form fronts run the kernels' instantiation without the cold paths  */
   int32_t rows_in_backward;    /* 1: the lean kernel recovers the residual components in its backward sweep (no post-pass)      */
   int32_t dense_panel_blocks;  /* dense backend, panel step with four column-block wavefronts per tile (dn_panel2): 0 never,
