@@ -31,7 +31,7 @@ FP64_MFMA_SPEC_TFLOPS = 78.6       # datasheet fp64 matrix peak
 FP64_MFMA_MEASURED_TFLOPS = 47.8   # v_mfma_f64_16x16x4_f64 loop, 4 waves/SIMD x 8 accumulators (profiles/r02_microbench.json)
 CANONICAL_NNZL_CFG3 = 346209  # nnz(L) of the order "r, x natural, lambda" at n=1e4, p=50
 CANONICAL_NNZL_CFG4 = 14529   # the same order at n=1e3, p=10 (BASELINE config 4 / 5)
-TRAFFIC_FILE = "r03_traffic.json"
+TRAFFIC_FILE = "r04_traffic.json"
 
 
 def band_batch(s, B, seed):

@@ -305,6 +305,11 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
 // One thread serves entry i of RPT problems: the index lists are read once and the launch has RPT times fewer
 // wavefronts (with one problem per thread the kernel is bound by the wavefront launch rate).
 constexpr int RPT = 4;
+// Entries of a column whose operands are loaded TOGETHER, ahead of the ordered sum.  A per-entry loop (index -> value -> add, with a
+// trip count the compiler does not know) serialises two memory round trips per entry: twelve for a band column, which is what
+// the kernel spent its time on (2.4 ms at 8192 systems of cfg3's size, 0.34 of the HBM rate; a workgroup walking several groups of
+// problems, or the slots staged through LDS, changed nothing).  The sum itself stays sequential in COO order.
+constexpr int RV_KF = 6, RV_KC = 2;
 __global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, const double* __restrict__ vals,
                                                                const double* __restrict__ r, const double* __restrict__ lambda,
                                                                const double* __restrict__ Fx, const double* __restrict__ cx,
@@ -327,12 +332,47 @@ __global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, 
       double s1[RPT], s2[RPT];
 #pragma unroll
       for (int q = 0; q < RPT; q++) s1[q] = s2[q] = 0.0;
-      for (int k = J.ptrF[i]; k < J.ptrF[i + 1]; k++) {
+      const int kf0 = J.ptrF[i], kf1 = J.ptrF[i + 1], kc0 = J.ptrC[i], kc1 = J.ptrC[i + 1];
+      {
+        // the first RV_KF entries: indices, then all operands, in flight together (entries past the end read slot / index 0 and
+        // are not added)
+        int sl[RV_KF], ix[RV_KF];
+#pragma unroll
+        for (int u = 0; u < RV_KF; u++) { const bool on = kf0 + u < kf1; sl[u] = on ? J.slotF[kf0 + u] : 0; ix[u] = on ? J.idxF[kf0 + u] : 0; }
+        double jv[RV_KF][RPT], xv[RV_KF][RPT];
+#pragma unroll
+        for (int u = 0; u < RV_KF; u++)
+#pragma unroll
+          for (int q = 0; q < RPT; q++) { jv[u][q] = vals[bq[q] * J.nnz + sl[u]]; xv[u][q] = r[bq[q] * J.nequ + ix[u]]; }
+#pragma unroll
+        for (int u = 0; u < RV_KF; u++)
+          if (kf0 + u < kf1) {
+#pragma unroll
+            for (int q = 0; q < RPT; q++) { const double t_ = jv[u][q] * xv[u][q]; s1[q] = s1[q] + t_; }
+          }
+      }
+      for (int k = kf0 + RV_KF; k < kf1; k++) {
         const int sl = J.slotF[k], ix = J.idxF[k];
 #pragma unroll
         for (int q = 0; q < RPT; q++) { const double t_ = vals[bq[q] * J.nnz + sl] * r[bq[q] * J.nequ + ix]; s1[q] = s1[q] + t_; }
       }
-      for (int k = J.ptrC[i]; k < J.ptrC[i + 1]; k++) {
+      {
+        int sl[RV_KC], ix[RV_KC];
+#pragma unroll
+        for (int u = 0; u < RV_KC; u++) { const bool on = kc0 + u < kc1; sl[u] = on ? J.slotC[kc0 + u] : 0; ix[u] = on ? J.idxC[kc0 + u] : 0; }
+        double jv[RV_KC][RPT], xv[RV_KC][RPT];
+#pragma unroll
+        for (int u = 0; u < RV_KC; u++)
+#pragma unroll
+          for (int q = 0; q < RPT; q++) { jv[u][q] = vals[bq[q] * J.nnz + sl[u]]; xv[u][q] = kc0 + u < kc1 ? lambda[bq[q] * J.ncon + ix[u]] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < RV_KC; u++)
+          if (kc0 + u < kc1) {
+#pragma unroll
+            for (int q = 0; q < RPT; q++) { const double t_ = jv[u][q] * xv[u][q]; s2[q] = s2[q] + t_; }
+          }
+      }
+      for (int k = kc0 + RV_KC; k < kc1; k++) {
         const int sl = J.slotC[k], ix = J.idxC[k];
 #pragma unroll
         for (int q = 0; q < RPT; q++) { const double t_ = vals[bq[q] * J.nnz + sl] * lambda[bq[q] * J.ncon + ix]; s2[q] = s2[q] + t_; }
