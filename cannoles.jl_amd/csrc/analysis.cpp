@@ -1095,6 +1095,11 @@ int write_forward_records(Plan& P, const DirectLists* D) {
   std::unordered_map<int32_t, char> d_claimed;
   P.rows_fronts = 0; P.listprod_fronts = 0;
   P.rows_overflow.clear();
+  // Structure of the update matrix every fast front leaves behind (row a: bit b set <=> entry (a, b) can be non-zero), for the
+  // band form of its parents (below); fronts of the other classes count as dense.
+  std::vector<std::array<uint16_t, 16>> ustruct(ns);
+  std::vector<char> udense(ns, 1);
+  P.band_fronts = 0;
   for (int32_t s = 0; s < ns; s++) {
     const FrontHdr& F = P.fronts[s];
     size_t r0 = rec.size();
@@ -1155,6 +1160,54 @@ int write_forward_records(Plan& P, const DirectLists* D) {
       std::vector<PR> q(prs.size());
       for (size_t i = 0; i < prs.size(); i++) q[i] = prs[key[i].second];
       prs.swap(q);
+    }
+    // ---- band form (plan.h): symbolic elimination of the front.  S[a] = columns b <= a where the assembled front can hold a
+    // non-zero: plain entries, condensation products, the children's update matrices through their extend-add maps.  Pivot i
+    // (from the top) updates row a only if entry (i, a) is in S; the updates fill S[a] |= S[i] (columns <= a).  When the row of
+    // every pivot lies inside [the nfix lowest columns] + [the CNL band columns right below the pivot], the record says so and
+    // the kernel runs the elimination that does not contain the other updates (kernels2.hip, eliminate16_dpp<LATE, BNF>).
+    int32_t band_word = 0;
+    if (strided) {
+      const int32_t f = 1 + F.nupd + F.npiv;
+      std::array<uint16_t, 16> S{};
+      auto mark = [&](int32_t pos) {
+        if (pos < 0 || pos >= FAST_IMG_TRI) return;
+        int32_t a = 0;
+        while ((int64_t)tri(a + 1) <= pos) a++;
+        S[a] |= (uint16_t)(1u << (pos - (int32_t)tri(a)));
+      };
+      for (auto& e : pes) mark(e.pos);
+      for (auto& p_ : prs) mark(p_.pos);
+      for (int32_t ci = F.child_begin; ci < F.child_end; ci++) {
+        const int32_t c = P.child_idx[ci];
+        const FrontHdr& C = P.fronts[c];
+        const int32_t* rel = P.rel_idx.data() + C.rel_begin;
+        for (int32_t a = 0; a <= C.nupd; a++)
+          for (int32_t b = 0; b <= a; b++)
+            if (udense[c] || (ustruct[c][a] >> b & 1)) S[rel[a]] |= (uint16_t)(1u << rel[b]);
+      }
+      constexpr int HW = 4;   // kernels2.hip: CNL_BAND_HW
+      int32_t need_fix = 0;   // smallest nfix that covers every pivot row
+      bool band_ok = true;
+      for (int32_t i = f - 1; i > F.nupd; i--) {
+        const uint16_t row = (uint16_t)(S[i] & ((1u << i) - 1u));
+        const uint16_t bandm = (uint16_t)(((1u << i) - 1u) & ~((i - HW > 0) ? ((1u << (i - HW)) - 1u) : 0u));
+        const uint16_t out = (uint16_t)(row & ~bandm);      // non-zeros outside the band: must be among the lowest columns
+        if (out) { int32_t hb = 15; while (!(out >> hb & 1)) hb--; need_fix = std::max(need_fix, hb + 1); }
+        for (int32_t a = 0; a < i; a++)
+          if (row >> a & 1) S[a] |= (uint16_t)(row & ((2u << a) - 1u));
+      }
+      if (need_fix > 3) band_ok = false;
+      const int32_t nfix = need_fix <= 2 ? 2 : 3;     // the kernel carries the forms with 2 and 3 fixed columns
+      // worth it only when it removes updates: some pivot must have rows outside its band + fixed columns
+      if (band_ok) {
+        int32_t removed = 0;
+        for (int32_t i = f - 1; i > F.nupd; i--) removed += std::max(0, i - HW - nfix);
+        if (removed > 0 && P.band_form) band_word = nfix | (HW << 8);
+      }
+      for (int32_t a = 0; a <= F.nupd; a++) ustruct[s][a] = S[a];
+      udense[s] = 0;
+      if (band_word) P.band_fronts++;
     }
     // ---- row form (plan.h, RF_ROWS): products grouped by residual row, operands in registers --------------------------
     ivec rowsec;
@@ -1325,7 +1378,8 @@ int write_forward_records(Plan& P, const DirectLists* D) {
     int32_t* H = rec.data() + r0;
     H[R_NPIV] = F.npiv; H[R_NUPD] = F.nupd; H[R_RECLEN] = (int32_t)(rec.size() - r0); H[R_NASM] = (int32_t)asrc.size();
     H[R_NCHILD] = F.child_end - F.child_begin; H[R_UOFF] = uoff2[s];
-    H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0) | (rowform ? RF_ROWS : 0) | (cls[s] << 8); H[R_FSOFF] = fsoff2[s];
+    H[R_FLAGS] = (uglob[s] ? RF_U_GLOBAL : 0) | (fsglob[s] ? RF_FS_GLOBAL : 0) | (rowform ? RF_ROWS : 0) | (cls[s] << 8);
+    H[R_FSOFF] = strided ? band_word : fsoff2[s];   // fast fronts stage in LDS at a fixed place: the word carries their band form
     P.rows_fronts += rowform ? 1 : 0;
     P.listprod_fronts += (!rowform && !prod.empty() && strided) ? 1 : 0;
     H[R_LPTR_LO] = F.lptr_lo; H[R_LPTR_HI] = F.lptr_hi; H[R_NASMV] = nasmv; H[R_ASM_OFF] = asm_off; H[R_CHILD_OFF] = child_off;

@@ -761,7 +761,7 @@ void cnl_options_init(cnl_options* o) {
   o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
   // (fused: measured slower than the separate launches on one system of cfg3's size, 0.140 against 0.118 ms — the rung loop costs
   //  the kernel 50 VGPRs and 45 spilled SGPRs — so it is off by default)
-  o->device_ladder = 1; o->device_ladder_fused = 0;
+  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -863,6 +863,7 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
     const int32_t old_len = p->P.rec_maxlen;
     const size_t old_words = p->P.rec.size();
     p->P.row_products = o.row_products != 0;
+    p->P.band_form = o.band_form != 0;
     p->P.row_min_products = 72;
     int drc = cnl::write_forward_records(p->P, &D);
     // A plan whose fronts are ALL fast-class row-form fronts runs the kernels' lean instantiation and recovers the residual
@@ -880,7 +881,7 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
         std::string msg2;
         if (cnl::build_plan(P2, p->C.N2, p->C.ncs + nvar, p->C.rows2.data(), p->C.cols2.data(), nvar, p->C.nequ2, ncon, opt2, msg2) == 0 &&
             P2.v2_ok && P2.ncls[1] == 0 && P2.ncls[2] == 0) {
-          P2.row_products = true; P2.row_min_products = 1;
+          P2.row_products = true; P2.row_min_products = 1; P2.band_form = o.band_form != 0;
           if (cnl::write_forward_records(P2, &D) == 0 && P2.listprod_fronts == 0) {
             if (verbose) fprintf(stderr, "[cnl] %zu front(s) with more than 16 residual rows cut in two: %d -> %d fronts\n", p->P.rows_overflow.size(), p->P.nsuper, P2.nsuper);
             p->P = std::move(P2);

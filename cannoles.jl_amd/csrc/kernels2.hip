@@ -353,7 +353,14 @@ __device__ __forceinline__ void flush_lrows(LPend& LP, char* L_wb0, int bm_) {
 #define CNL_DPP_POST(i)
 #define CNL_DPP_USTG(a) if (a <= nupd) Ug[tri2(a) + b] = R##a;
 #define CNL_DPP_USTL(a) if (a <= nupd) Ul[tri2(a) + b] = R##a;
-template <bool LATE>
+// BNF (round 4): band form of the front.  0: every pivot updates every row below it.  2 / 3: the analysis has shown (structurally,
+// analysis.cpp: band word of the record header) that pivot I's row holds non-zeros only in the BNF lowest columns (right-hand
+// side, multipliers) and in the CNL_BAND_HW columns right below the pivot — what the fronts of a band problem look like — so the
+// other row updates (w_a = 0 exactly) are not compiled in: 6 instead of 10.5 v_fmac_f64_dpp per pivot on cfg3's chain fronts,
+// and that instruction (14 cycles) is what the elimination phase is made of.
+constexpr int CNL_BAND_HW = 4;
+#define CNL_DPPU(I, A, RA) if constexpr (BNF == 0 || (A) < BNF || (A) >= (I) - CNL_BAND_HW) { CNL_DPPF(RA, w_, nl_, A) }
+template <bool LATE, int BNF>
 __device__ __forceinline__ void eliminate16_dpp(int P_prob_doubles, int P_u2_peak, long long P_gs_doubles, long long P_lsize, double* cL_,
                                                 double* cgs_, int cbatch, int lane, int prob0, int f, int nupd, long long lptr, int uoff,
                                                 bool uglob, double* pbase0, int* cnt, double eig_tol, LPend& LP) {
@@ -1356,7 +1363,12 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       else flush_lrows(LP, const_cast<char*>(L_wb), lp_bm);
       STAMP(1)
       // (5) eliminate in registers, store L rows and the update matrix
-      if (!(CNL_ABL & 1024)) eliminate16_dpp<LATE>(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol, LP);
+      if (!(CNL_ABL & 1024)) {
+        const int bandw = HDRW(hv, R_FSOFF);   // fast fronts: the band form (0: none), see eliminate16_dpp
+        if (bandw == (2 | (CNL_BAND_HW << 8))) eliminate16_dpp<LATE, 2>(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol, LP);
+        else if (bandw == (3 | (CNL_BAND_HW << 8))) eliminate16_dpp<LATE, 3>(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol, LP);
+        else eliminate16_dpp<LATE, 0>(P.prob_doubles, P.u2_peak, P.gs_doubles, P.lsize, c.L, c.gs, c.batch, lane, prob0, f, nupd, lptr, uoff, uglob, pbase0, cnt, eig_tol, LP);
+      }
       STAMP(3)
       if (uglob) gsync(); else wsync();
       roff = nroff;

@@ -115,6 +115,11 @@ struct Plan {
   bool row_products = true;   // direct records of fast fronts may use the row form (RF_ROWS)
   int32_t row_min_products = 72;  // ... from this many products on (analysis.cpp); 1 when that makes the whole plan row-form (lean kernel)
   int32_t rows_fronts = 0, listprod_fronts = 0;  // fast fronts in row form / with product lists
+  bool band_form = true;     // (cnl_options.band_form) let the records carry band forms
+  int32_t band_fronts = 0;   // fast fronts whose records carry a band form (R_FSOFF of a fast front: nfix | hw << 8, 0 = none):
+                             // every pivot row is structurally zero outside its nfix lowest columns (right-hand side,
+                             // multipliers) and the hw columns right below the pivot; the kernel's elimination then omits the
+                             // other row updates (kernels2.hip, eliminate16_dpp<LATE, BNF>; analysis.cpp, write_forward_records)
   std::vector<int32_t> rows_overflow;  // fronts refused by the row form for MORE THAN 16 rows: the elimination position in their middle
   bool back_rows = false;  // the backward records recover the condensed residual components themselves (write_backward_rows)
   bool d_outer = false;  // backward records name solution components in the caller's numbering (set with rec_direct)

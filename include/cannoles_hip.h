@@ -115,6 +115,9 @@ typedef struct cnl_options {
   int32_t device_ladder_fused; /* 1: on the smallest batches (where the first attempt would run in dataflow fashion) that launch makes
                                   the first attempt and the backward sweeps too: newton_system is one launch (default 0: measured
                                   slower than the separate launches, 0.140 against 0.118 ms for one system of cfg3's size)         */
+  int32_t band_form;           /* 1: fast fronts whose pivot rows are structurally zero outside a few fixed columns and the four
+                                  columns below the pivot (the fronts of band problems) run an elimination that does not contain
+                                  the other row updates (csrc/plan.h, band_fronts; default); 0: every pivot updates every row    */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);

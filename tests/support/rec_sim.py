@@ -22,6 +22,19 @@ B_HDR = 8
 B_ROWS_FLAG, BROWS_WORDS = 256, 16 * (ROWS_KM + 3)   # plan.h: residual rows recovered by the backward records
 
 
+BAND_HW = 4   # csrc/kernels2.hip: CNL_BAND_HW
+
+
+def band_rows(band_word, i):
+    """rows a < i that pivot i updates under the band form `band_word` of a fast front's record (R_FSOFF: nfix | hw << 8, 0 = all):
+    the nfix lowest rows and the hw rows right below the pivot (csrc/kernels2.hip, eliminate16_dpp<LATE, BNF>)"""
+    if band_word == 0:
+        return set(range(i))
+    nfix, hw = band_word & 255, band_word >> 8
+    assert hw == BAND_HW and nfix in (2, 3), band_word
+    return {a for a in range(i) if a < nfix or a >= i - hw}
+
+
 def tri(i):
     return i * (i + 1) // 2
 
@@ -112,6 +125,8 @@ class RecSim:
                     F[a, b] = img[pos_of(a, b)]
             lptr = int(H[R_LPTR_LO]) | (int(H[R_LPTR_HI]) << 31)
             tu = tri(1 + nupd)
+            band = int(H[R_FSOFF]) if strided else 0
+            self.stats["band"] = self.stats.get("band", 0) + (1 if band else 0)
             for i in range(f - 1, nupd, -1):
                 d = F[i, i]
                 npos += d > eig_tol
@@ -120,7 +135,12 @@ class RecSim:
                 lv = w / d
                 L[lptr + tri(i) - tu: lptr + tri(i) - tu + i] = lv
                 L[lptr + tri(i) - tu + i] = d
+                rows_i = band_rows(band, i)
                 for a in range(i):
+                    if a not in rows_i:   # the kernel does not contain this update: the operand must be an EXACT zero
+                        assert w[a] == 0.0, f"band form: pivot {i} of a front (npiv {npiv}, nupd {nupd}) has a non-zero {w[a]} in column {a}"
+                        self.stats["skipped"] = self.stats.get("skipped", 0) + 1
+                        continue
                     F[a, :a + 1] -= w[a] * lv[:a + 1]
             U[(1 if flags & RF_U_GLOBAL else 0, int(H[R_UOFF]))] = np.array([F[a, b] for a in range(nupd + 1) for b in range(a + 1)])
             off += int(H[R_RECLEN])
@@ -334,6 +354,7 @@ class StagedSim(RecSim):
                             F[a, b] = img[pos_of(a, b)]
                     lptr = int(H[R_LPTR_LO]) | (int(H[R_LPTR_HI]) << 31)
                     tu = tri(1 + nupd)
+                    band = int(H[R_FSOFF]) if strided else 0
                     for i in range(f - 1, nupd, -1):
                         dd = F[i, i]
                         npos += dd > eig_tol
@@ -342,7 +363,11 @@ class StagedSim(RecSim):
                         lv = w / dd
                         L[lptr + tri(i) - tu: lptr + tri(i) - tu + i] = lv
                         L[lptr + tri(i) - tu + i] = dd
+                        rows_i = band_rows(band, i)
                         for a in range(i):
+                            if a not in rows_i:   # not compiled into the kernel's band-form elimination: must be an exact zero
+                                assert w[a] == 0.0, f"band form: pivot {i} of front {s} has a non-zero {w[a]} in column {a}"
+                                continue
                             F[a, :a + 1] -= w[a] * lv[:a + 1]
                     uglob = bool(flags & RF_U_GLOBAL)
                     if s == f1 - 1:

@@ -1553,3 +1553,45 @@ def test_duplicate_slots_are_summed_in_coo_order_on_the_device(built, B):
     okf, npos, nzer = hipldl.try_to_factorize(L, vals if B > 1 else vals[0], s.nvar, s.nequ, s.ncon, p[0], return_inertia=True)
     assert np.atleast_1d(okf).all() and (np.atleast_1d(npos) == s.nvar).all() and (np.atleast_1d(nzer) == 0).all()
     L.close()
+
+
+@pytest.mark.parametrize("shape,B", [((2000, 10), 4608), ((2000, 10), 5), ((600, 0), 4608)])
+def test_band_form_elimination_equals_the_general_one(built, shape, B):
+    """Fronts whose pivot rows are structurally zero outside two or three fixed columns and the four columns below the pivot — the
+    chain fronts of band problems — run an elimination WITHOUT the other row updates (csrc/kernels2.hip, eliminate16_dpp<LATE, BNF>;
+    the analysis proves the zeros symbolically, csrc/analysis.cpp).  The omitted updates multiply exact zeros, so the factor, the
+    inertia and the solution must be the general elimination's (cnl_options.band_form = 0): same decisions, d equal to the last bit
+    (up to the sign of an exact zero), both within the oracle's tolerances."""
+    hipldl, syn, O = _mods()
+    n, p = shape
+    s = syn.band_structure(n, p)
+    rows, cols = s.kkt_pattern()
+    v8, r8 = syn.batch_values(s, 8, cfg=4)
+    vals, rhs = np.tile(v8, ((B + 7) // 8, 1))[:B].copy(), np.tile(r8, ((B + 7) // 8, 1))[:B].copy()
+    vals[min(3, B - 1)] = syn.band_values(s, 5003, stress="ladder")[0]     # one problem climbs the ladder
+    prm = hipldl.default_params()
+    out = {}
+    for bf in (1, 0):
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(band_form=bf))
+        rec = L.plan_array("rec")
+        from tests.support.rec_sim import R_HDR, R_RECLEN, R_FSOFF, R_FLAGS
+        off = nband = nfr = 0
+        while off < len(rec) and rec[off + R_RECLEN] > 0:
+            H = rec[off:off + R_HDR]
+            nband += int((int(H[R_FLAGS]) >> 8) == 16 and not (int(H[R_FLAGS]) & 2) and int(H[R_FSOFF]) != 0)
+            nfr += 1
+            off += int(H[R_RECLEN])
+        assert (nband > 0.5 * nfr) if (bf and B >= 4608) else (nband == 0 or bf)
+        d = np.zeros((B, s.N))
+        v = vals.copy()
+        d, ok, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, np.zeros(B), prm)
+        out[bf] = (np.array(d).reshape(B, s.N).copy(), np.atleast_1d(ok).copy(), np.atleast_1d(rho).copy(), np.atleast_1d(nf).copy(), L.plan_array("perm").astype(np.int64))
+        L.close()
+    assert np.array_equal(out[1][1], out[0][1]) and np.array_equal(out[1][2], out[0][2]) and np.array_equal(out[1][3], out[0][3])
+    assert out[1][1].all() and out[1][3].max() > 1
+    assert np.array_equal(out[1][0], out[0][0])      # (-0.0 == 0.0 under array_equal)
+    orc = O.Oracle(s.N, rows, cols, out[1][4])
+    for b in range(min(B, 6)):
+        d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs[b], vals[b].copy(), 0.0, O.default_params())
+        assert ok0 and nf0 == int(out[1][3][b]) and rho0 == float(out[1][2][b])
+        assert np.abs(out[1][0][b] - d0).max() <= FWD_TOL * np.abs(d0).max()

@@ -154,6 +154,25 @@ def test_cfg3_plan_quality(built):
     pl = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon)
     assert pl.info["nnzL_exact"] < 346209
     assert pl.info["v2"]["fronts16"] > 0.95 * pl.info["nsuper"]
+    # band form (round 4): the chain fronts of the headline plan carry it — pivot rows structurally zero outside the two lowest
+    # columns (right-hand side, multiplier) and the four columns below the pivot; 41 % of the row updates are not compiled in
+    from tests.support.rec_sim import R_HDR, R_RECLEN, R_FSOFF, R_FLAGS, R_NPIV, R_NUPD, band_rows
+    for band_form, expect in ((1, True), (0, False)):
+        rec = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, options=hipldl.Options(band_form=band_form)).array("rec")
+        off = nband = upd_all = upd_band = 0
+        while off < len(rec) and rec[off + R_RECLEN] > 0:
+            H = rec[off:off + R_HDR]
+            bw = int(H[R_FSOFF]) if (int(H[R_FLAGS]) >> 8) == 16 and not (int(H[R_FLAGS]) & 2) else 0
+            nband += bw != 0
+            npiv, nupd = int(H[R_NPIV]), int(H[R_NUPD])
+            for i in range(nupd + npiv, nupd, -1):
+                upd_all += i
+                upd_band += len(band_rows(bw, i))
+            off += int(H[R_RECLEN])
+        if expect:
+            assert nband >= 0.9 * pl.info["nsuper"] and upd_band <= 0.65 * upd_all, (nband, upd_band, upd_all)
+        else:
+            assert nband == 0 and upd_band == upd_all
 
 
 # ---- record streams of the register-front kernel, interpreted on the CPU -----------------------------------------

@@ -75,7 +75,7 @@ def run(B, names, n=10000, p=50, rounds=3):
     for r in range(rounds):
         for k in names:
             lib = os.path.join(OUTD, "ab_" + k, "libcannoles_hip.so")
-            env = dict(os.environ, CANNOLES_HIP_LIB=lib)
+            env = dict(os.environ, CANNOLES_HIP_LIB=lib, CANNOLES_HIP_ALLOW_EXPERIMENT="1")
             out = subprocess.run([sys.executable, "-c", RUN % {"root": ROOT, "B": B, "n": n, "p": p, "reps": reps}], env=env, capture_output=True, text=True)
             line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
             if not line:
