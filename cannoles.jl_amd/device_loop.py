@@ -153,9 +153,241 @@ def kkt_pattern_of(fam):
     return rows, cols, (nnzhF, nnzhc, len(jFr), len(jcr))
 
 
+PROFILE = False   # tools/time_device_loop.py --profile: wall time per section of a global step (synchronises at every section)
+
+
 def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=None, rtol=None, Fatol=None, Frtol=None, delta_dec=0.1,
                        device_index=0):
     """All B problems of `fam` in lockstep on the device.  Returns a dict of numpy arrays: solution [B, n], multipliers,
+    status (list of strings), iter, nfact, nlinsolve, nbk, objective, and `steps` (global steps = batched Newton rounds).
+
+    Round 4: the masks and the masked state updates of a global step are FOUR device kernels working in place on the state
+    (cnl_outer_begin_dev / _newton_done_dev / _trial_done_dev / _end_dev, csrc/outer_step.hip) instead of ~150 framework launches;
+    the step costs two host reads of a few flag words.  The model callbacks, the Armijo line search and the rare small-residual
+    branch are still framework expressions."""
+    import ctypes as C
+    from . import hipldl
+    t = fam.torch
+    dev = fam.device
+    eps = float(np.finfo(float).eps)
+    atol = np.sqrt(eps) if atol is None else atol
+    rtol = np.sqrt(eps) if rtol is None else rtol
+    Fatol = np.sqrt(eps) if Fatol is None else Fatol
+    Frtol = eps if Frtol is None else Frtol
+    params = hipldl.default_params() if params is None else np.ascontiguousarray(params, dtype=np.float64)
+    dmin, rhomax, gammaA = float(params[1]), float(params[6]), float(params[8])
+    s, B = fam.s, fam.B
+    n, m, p = s.nvar, s.nequ, s.ncon
+    N = n + m + p
+    P = max(p, 1)
+    rows, cols, (nnzhF, nnzhc, nnzjF, nnzjc) = kkt_pattern_of(fam)
+    nnz = len(rows)
+    L = hipldl.HIPLDLStruct(N, rows, cols, None, n, m, p, batch=B, device=device_index)
+    lib = hipldl.lib()
+    f64 = dict(dtype=t.float64, device=dev)
+    Z = lambda *sh: t.zeros(sh, **f64)
+    ZI = lambda dt, *sh: t.zeros(sh, dtype=dt, device=dev)
+    o_I = nnzhF + nnzhc + nnzjF + nnzjc
+
+    def new_vals():
+        v = t.ones((B, nnz), **f64)
+        v[:, o_I:o_I + m] = -1.0     # the -I block is set once (src/CaNNOLeS.jl:306); prepare never writes it
+        return v
+
+    vals_cur, vals_t = new_vals(), new_vals()
+    hc0 = Z(B, max(nnzhc, 1))
+    st = t.cuda.current_stream(dev).cuda_stream
+    ptr = lambda a: a.data_ptr()
+
+    def prepare(vals, hF, Jv_, Jcv_, delta_):
+        hipldl.prepare_newton_system_dev(L, nnzhF, nnzhc, nnzjF, nnzjc, ptr(hF) if hF is not None else 0, ptr(hc0) if p else 0, ptr(Jv_),
+                                         ptr(Jcv_) if p else 0, ptr(delta_) if p else 0, ptr(vals), st)
+
+    def resid_vectors(vals, r_, lam_, F_, c_, rhs_out, nrm_out):
+        """[dual; primal] = [Jx'r - Jc'lam; F - r; c] and the two infinity norms, from the J segments of `vals` (in place)"""
+        hipldl.residual_vectors_dev(L, ptr(vals), ptr(r_), ptr(lam_) if p else 0, ptr(F_), ptr(c_) if p else 0, ptr(rhs_out), ptr(nrm_out), st)
+
+    def multipliers(vals, r_, ones_if_zero):
+        lam_ = Z(B, P)
+        if p:
+            hipldl.cgls_multipliers_dev(L, ptr(vals), ptr(r_), ptr(lam_), 0, None, None, 0, ones_if_zero, 0, st)
+        return lam_
+
+    W = lambda mask, a, b: t.where(mask if a.dim() == 1 else mask[:, None], a, b)
+    smax = 100.0
+    dual_scaling = lambda l_: (t.clamp(l_.abs().sum(dim=1) / p, min=smax) / smax) if p > 0 else t.ones(B, **f64)
+    ninf = lambda a: a.abs().max(dim=1).values if a.shape[1] else Z(B)
+    cnorm2 = lambda c_: t.sqrt((c_ * c_).sum(dim=1)) if p else Z(B)
+
+    # ---- state (every array is updated IN PLACE from here on: the kernels hold its address) -------------------------
+    x = fam.d["x0"].clone()
+    Fx = fam.residual(x).contiguous()
+    fx = (0.5 * (Fx * Fx).sum(dim=1)).contiguous()
+    Jv = fam.jac_vals(x).contiguous()
+    Jcv = fam.jacc_vals(x)          # the family's constraints are linear: one array serves the current and the trial point
+    Jcv = Jcv.contiguous() if p else Z(B, 1)
+    cx = fam.cons(x).contiguous()
+    r = Fx.clone()
+    delta = t.ones(B, **f64)
+    prepare(vals_cur, None, Jv, Jcv, delta)
+    lam = multipliers(vals_cur, r, True)
+    rhs_cur, nrm0 = Z(B, N), Z(B, 2)
+    resid_vectors(vals_cur, r, lam, Fx, cx, rhs_cur, nrm0)
+    normdual, normprimal = nrm0[:, 0].clone(), nrm0[:, 1].clone()
+    epsF = (Fatol + Frtol * 2 * t.sqrt(fx)).contiguous()
+    epstol = (atol + rtol * normdual).contiguous()
+    epsc = t.sqrt(epstol).contiguous()
+
+    rv_rhs, rv_nrm = Z(B, N), Z(B, 2)
+
+    def small_res_check(mask):
+        """src/CaNNOLeS.jl:873-897 for the problems of `mask`: r = F, least-squares multipliers, dual, primal = [0; c] (in place)"""
+        r2 = W(mask, Fx, r)
+        prepare(vals_cur, None, Jv, Jcv, delta)
+        lam2 = multipliers(vals_cur, r2, False)
+        lam.copy_(W(mask, lam2, lam))
+        resid_vectors(vals_cur, r2, lam, r2, cx, rv_rhs, rv_nrm)   # F - r = 0 for the masked problems
+        rhs_cur.copy_(W(mask, rv_rhs, rhs_cur))
+        normdual.copy_(W(mask, rv_nrm[:, 0], normdual))
+        normprimal.copy_(W(mask, ninf(cx[:, :p]) if p else Z(B), normprimal))
+        r.copy_(r2)
+
+    small_residual = (2 * t.sqrt(fx) <= epsF) & (cnorm2(cx) <= epsc)
+    first_order = t.maximum(normdual / dual_scaling(lam), normprimal) <= epstol
+    chk0 = small_residual & ~first_order
+    if bool(chk0.any()):
+        small_res_check(chk0)
+        first_order = t.maximum(normdual / dual_scaling(lam), normprimal) <= epstol
+    UNKNOWN, FIRST, SMALL, EXC, TIRED, STALL = 0, 1, 2, 3, 4, 5
+    status = t.where(first_order, FIRST, t.where(small_residual, SMALL, UNKNOWN)).to(t.int32).contiguous()
+    eta = t.full((B,), 1.0 if p else 0.0, **f64)
+    epsk = t.full((B,), 1e3, **f64)
+    rho_old = Z(B)
+    it, inner = ZI(t.int32, B), ZI(t.int64, B)
+    nfact, nlin, nbk = ZI(t.int64, B), ZI(t.int64, B), ZI(t.int64, B)
+    phase0 = t.ones(B, dtype=t.bool, device=dev)
+    combined, combined_hat = Z(B), Z(B)
+    ndh, nph = normdual.clone(), normprimal.clone()
+    d = Z(B, N)
+    xt, rt, lamt, Ft, ct = x.clone(), r.clone(), lam.clone(), Fx.clone(), cx.clone()
+    Jt = Jv.clone()
+    rhs_t, nrm_t = Z(B, N), Z(B, 2)
+    d_new, rho_new, ro_tmp = Z(B, N), Z(B), Z(B)
+    nf_new, ok_new = ZI(t.int32, B), ZI(t.int32, B)
+    xt_e, rt_e, lamt_e, dlam_e = Z(B, n), Z(B, m), Z(B, P), Z(B, P)
+    xl, Fl, cl, lam_ls = Z(B, n), Z(B, m), Z(B, P), Z(B, P)
+    alpha, Dphi, phix = Z(B), Z(B), Z(B)
+    masks = {k: t.zeros(B, dtype=t.bool, device=dev) for k in ("act", "need", "brk", "ext", "lsm", "rej", "chk", "done_in", "tired", "small_res", "bt")}
+    flags = ZI(t.int32, 8)
+    flags_h = t.zeros(8, dtype=t.int32).pin_memory()
+    S = hipldl.cnl_outer_state()
+    for k, v in dict(B=B, n=n, m=m, p=p, P=P, N=N, nnzjF=nnzjF, nnzjc=nnzjc, max_inner=max_inner, dmin=dmin, rhomax=rhomax,
+                     delta_dec=delta_dec, smax=smax, gammaA=gammaA, eps2=eps ** 2).items():
+        setattr(S, k, v)
+    arrays = dict(status=status, it=it, flags=flags, nf_new=nf_new, ok_new=ok_new, inner=inner, nfact=nfact, nlin=nlin, phase0=phase0,
+                  normdual=normdual, normprimal=normprimal, combined=combined, combined_hat=combined_hat, delta=delta, ndh=ndh, nph=nph, fx=fx,
+                  epsk=epsk, epstol=epstol, epsF=epsF, epsc=epsc, rho_old=rho_old, d=d, d_new=d_new, ro_tmp=ro_tmp, rho_new=rho_new,
+                  x=x, r=r, Fx=Fx, cx=cx, Jv=Jv, Jcv=Jcv, lam=lam, rhs_cur=rhs_cur, xt=xt, rt=rt, Ft=Ft, ct=ct, Jt=Jt, Jct=Jcv, lamt=lamt,
+                  rhs_t=rhs_t, nrm_t=nrm_t, xt_e=xt_e, rt_e=rt_e, lamt_e=lamt_e, ls_g=rv_rhs, xl=xl, Fl=Fl, cl=cl, lam_ls=lam_ls, alpha=alpha,
+                  Dphi=Dphi, phix=phix, eta=eta, nbk=nbk, **masks)
+    for k, v in arrays.items():
+        assert v.is_contiguous(), k
+        setattr(S, k, v.data_ptr())
+    Sref = C.byref(S)
+    chk_ = hipldl._check
+
+    def read_flags():
+        flags_h.copy_(flags, non_blocking=True)
+        t.cuda.current_stream(dev).synchronize()
+        return flags_h.tolist()
+
+    import time as _time
+    prof = {} if PROFILE else None
+
+    def tick(name, t0):
+        if prof is not None:
+            t.cuda.synchronize(dev)
+            prof[name] = prof.get(name, 0.0) + (_time.perf_counter() - t0)
+        return _time.perf_counter()
+
+    t.cuda.synchronize(dev)
+    t_loop0 = _time.perf_counter()
+    steps = 0
+    # host synchronisations per global step: one for the branch flags of cnl_outer_begin_dev, one for (rejected, small-residual) behind
+    # cnl_outer_trial_done_dev, and one per round of backtracking when a line search runs
+    while steps < max_steps:
+        tk = _time.perf_counter()
+        chk_(lib.cnl_outer_begin_dev(Sref, st))
+        any_act, any_need, any_ext, any_ls = read_flags()[:4]
+        if not any_act:
+            break
+        steps += 1
+        tk = tick("begin", tk)
+        # ---- Newton step (skipped on the iteration right after a rejected extrapolation), :627-652
+        if any_need:
+            prepare(vals_cur, fam.hess_vals(x, r), Jv, Jcv, delta)
+            ro_tmp.copy_(rho_old)
+            hipldl.newton_system_dev(L, ptr(vals_cur), ptr(rhs_cur), ptr(d_new), ptr(ro_tmp), ptr(rho_new), ptr(nf_new), ptr(ok_new), params, st)
+        chk_(lib.cnl_outer_newton_done_dev(Sref, 1 if any_need else 0, st))
+        dx = d[:, :n]
+        tk = tick("newton", tk)
+        # ---- extrapolation step, :654-668
+        if any_ext:   # (a superset test: problems that broke above are masked out by `ext`)
+            hipldl.trial_point_dev(L, ptr(x), ptr(r), ptr(lam) if p else 0, ptr(d), 1e4, ptr(xt_e), ptr(rt_e), ptr(lamt_e) if p else 0,
+                                   ptr(dlam_e) if p else 0, st)
+            chk_(lib.cnl_outer_extrapolated_dev(Sref, st))
+        tk = tick("extrapolation", tk)
+        # ---- Armijo line search on the merit function, :1054-1112
+        if any_ls:
+            prepare(vals_cur, None, Jv, Jcv, delta)
+            resid_vectors(vals_cur, Fx, lam_ls, Fx, cx, rv_rhs, rv_nrm)      # dual part: Jx'Fx - Jc'(lam - c/delta), lam_ls by cnl_outer_newton_done_dev
+            chk_(lib.cnl_outer_ls_begin_dev(Sref, st))
+            Fl.copy_(fam.residual(xl))
+            cl.copy_(fam.cons(xl))
+            chk_(lib.cnl_outer_ls_test_dev(Sref, 1, st))
+            while read_flags()[6]:
+                chk_(lib.cnl_outer_ls_step_dev(Sref, st))
+                Fl.copy_(fam.residual(xl))       # (rows of problems that do not backtrack are recomputed from an unchanged xl: same values)
+                cl.copy_(fam.cons(xl))
+                chk_(lib.cnl_outer_ls_test_dev(Sref, 0, st))
+            chk_(lib.cnl_outer_ls_take_dev(Sref, st))
+        tk = tick("line_search", tk)
+        Ft.copy_(fam.residual(xt))
+        ct.copy_(fam.cons(xt))
+        # ---- optimality measures at the trial point, :722-732; acceptance and the state update, :733-800
+        Jt.copy_(fam.jac_vals(xt))
+        prepare(vals_t, None, Jt, Jcv, delta)
+        resid_vectors(vals_t, rt, lamt, Ft, ct, rhs_t, nrm_t)
+        tk = tick("trial_eval", tk)
+        chk_(lib.cnl_outer_trial_done_dev(Sref, st))
+        any_rej, any_chk = read_flags()[4:6]
+        tk = tick("trial_done", tk)
+        if any_rej:   # dual at (x, r, lam) again; primal keeps the trial's value, as in the reference (:742-747)
+            prepare(vals_cur, None, Jv, Jcv, delta)
+            resid_vectors(vals_cur, r, lam, Fx, cx, rv_rhs, rv_nrm)
+            rhs_cur[:, :n] = t.where(masks["rej"][:, None], rv_rhs[:, :n], rhs_cur[:, :n])
+        if any_chk:
+            small_res_check(masks["chk"])
+        chk_(lib.cnl_outer_end_dev(Sref, st))
+        tk = tick("rej_chk_end", tk)
+    t.cuda.synchronize(dev)
+    loop_seconds = _time.perf_counter() - t_loop0
+    names = {UNKNOWN: "unknown", FIRST: "first_order", SMALL: "small_residual", EXC: "exception", TIRED: "max_eval", STALL: "stalled"}
+    out = {"solution": x.cpu().numpy(), "multipliers": lam[:, :p].cpu().numpy(), "status": [names[int(v)] for v in status.cpu().numpy()],
+           "iter": it.cpu().numpy(), "nfact": nfact.cpu().numpy(), "nlinsolve": nlin.cpu().numpy(), "nbk": nbk.cpu().numpy(),
+           "objective": fx.cpu().numpy(), "steps": steps, "kernel": L.config["kernel"],
+           "loop_seconds": loop_seconds}   # the global steps alone (the symbolic analysis of the pattern and the start-up evaluations are not in it)
+    if prof is not None:
+        out["profile_ms_per_step"] = {k: 1e3 * v / max(steps, 1) for k, v in prof.items()}
+    L.close()
+    return out
+
+
+def solve_batch_device_framework(fam, params=None, max_steps=400, max_inner=10000, atol=None, rtol=None, Fatol=None, Frtol=None, delta_dec=0.1,
+                       device_index=0):
+    """The loop as rounds 2-3 ran it: masks and masked state updates as ~150 framework launches per global step.  Kept as the
+    executable restatement solve_batch_device is compared with (tests/test_gpu_parity.py).
+    All B problems of `fam` in lockstep on the device.  Returns a dict of numpy arrays: solution [B, n], multipliers,
     status (list of strings), iter, nfact, nlinsolve, nbk, objective, and `steps` (global steps = batched Newton rounds)."""
     from . import hipldl
     t = fam.torch

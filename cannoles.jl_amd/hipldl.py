@@ -39,6 +39,8 @@ ABI_SYMBOLS = [
     "cnl_cgls_multipliers_dev",
     "cnl_multi_create_ex", "cnl_multi_factorize_dev", "cnl_multi_solve_dev", "cnl_multi_newton_system_dev", "cnl_multi_synchronize",
     "cnl_multi_create", "cnl_multi_destroy", "cnl_multi_shards", "cnl_multi_factorize", "cnl_multi_solve", "cnl_multi_newton_system",
+    "cnl_outer_begin_dev", "cnl_outer_newton_done_dev", "cnl_outer_extrapolated_dev", "cnl_outer_trial_done_dev", "cnl_outer_end_dev",
+    "cnl_outer_ls_begin_dev", "cnl_outer_ls_test_dev", "cnl_outer_ls_step_dev", "cnl_outer_ls_take_dev",
 ]
 
 
@@ -53,6 +55,23 @@ class cnl_options(C.Structure):
             "dense_backend", "general_dense", "staged", "dataflow", "dataflow_waves", "dataflow_spin_limit", "waves_per_block",
             "v1_tpp", "v1_ppb", "v1_lds", "v1_solve", "lds_pad", "ubig", "wait_thr", "dense_graph", "dense_syrk_wgs", "verbose",
             "multi_share_plan", "row_products", "split_batch", "lean_kernel", "rows_in_backward", "dense_panel_blocks", "host_ladder", "device_ladder", "device_ladder_fused", "band_form")] + [("force_order", C.c_char * 32)]
+
+
+class cnl_outer_state(C.Structure):
+    """struct cnl_outer_state of include/cannoles_hip.h (row f3: bookkeeping of the batched outer loop); field order must match"""
+    _fields_ = ([(k, C.c_int64) for k in ("B", "n", "m", "p", "P", "N", "nnzjF", "nnzjc", "max_inner")] +
+                [(k, C.c_double) for k in ("dmin", "rhomax", "delta_dec", "smax")] +
+                [(k, C.c_void_p) for k in (
+                    "status", "it", "flags", "nf_new", "ok_new",
+                    "inner", "nfact", "nlin",
+                    "phase0", "act", "need", "brk", "ext", "lsm", "rej", "chk", "done_in", "tired", "small_res",
+                    "normdual", "normprimal", "combined", "combined_hat", "delta", "ndh", "nph", "fx", "epsk", "epstol", "epsF", "epsc", "rho_old",
+                    "d", "d_new", "ro_tmp", "rho_new",
+                    "x", "r", "Fx", "cx", "Jv", "Jcv", "lam", "rhs_cur",
+                    "xt", "rt", "Ft", "ct", "Jt", "Jct", "lamt", "rhs_t", "nrm_t",
+                    "xt_e", "rt_e", "lamt_e")] +
+                [(k, C.c_double) for k in ("gammaA", "eps2")] +
+                [(k, C.c_void_p) for k in ("ls_g", "xl", "Fl", "cl", "lam_ls", "alpha", "Dphi", "phix", "eta", "nbk", "bt")])
 
 
 def Options(**kw):
@@ -171,6 +190,11 @@ def lib():
         L.cnl_set_timing.argtypes = [vp, C.c_int]
         L.cnl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cnl_get_config.argtypes = [vp, _i64p]
+        for fn in ("cnl_outer_begin_dev", "cnl_outer_extrapolated_dev", "cnl_outer_trial_done_dev", "cnl_outer_end_dev", "cnl_outer_ls_begin_dev",
+                   "cnl_outer_ls_step_dev", "cnl_outer_ls_take_dev"):
+            getattr(L, fn).argtypes = [vp, vp]
+        L.cnl_outer_newton_done_dev.argtypes = [vp, C.c_int, vp]
+        L.cnl_outer_ls_test_dev.argtypes = [vp, C.c_int, vp]
         if L.cnl_version() < 0 and not os.environ.get("CANNOLES_HIP_ALLOW_EXPERIMENT"):
             raise RuntimeError(f"{LIB_PATH} is an EXPERIMENT build (cnl_version() = {L.cnl_version()}: timing probes / diagnostic "
                                "stamps compiled in, results may be wrong); set CANNOLES_HIP_ALLOW_EXPERIMENT=1 to load it on purpose")

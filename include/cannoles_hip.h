@@ -266,6 +266,52 @@ int cnl_multi_newton_system_dev(cnl_multi* m, double* const* d_vals, const doubl
                                 const double params[9], void* const* streams);
 int cnl_multi_synchronize(cnl_multi* m, void* const* streams);
 
+/* ---- bookkeeping of the batched outer / inner loop, device-resident -----------------------------------------
+ * A caller that runs `solve!` (src/CaNNOLeS.jl:612-864) for a batch of problems in lockstep keeps the loop's state as [batch, ...]
+ * arrays in HBM and every branch as a per-problem mask (cannoles.jl_amd/device_loop.py).  The four entry points below do the
+ * masks and the masked state updates of one global step IN PLACE on that state, one launch each (the reference's tests in the
+ * reference's operation order; minimum / maximum propagate NaN).  `cnl_outer_state` is plain device pointers and sizes; every
+ * array is problem-major.  Status codes: 0 unknown (active), 1 first_order, 2 small_residual, 3 exception, 4 max_eval.
+ *   cnl_outer_begin_dev        :612-626  start of an outer iteration for the problems in phase0; act, need (a Newton system is due);
+ *                                        flags[0..3] = any active / any need / any extrapolation step / any line-search step
+ *   cnl_outer_newton_done_dev  :633-659  did_newton != 0: d, rho_old, nfact, nlin from the Newton call's outputs (d_new, ro_tmp,
+ *                                        nf_new, rho_new, ok_new) where `need`; brk (`broken`); then ext / lsm and eps_k where ext
+ *   cnl_outer_extrapolated_dev :661-668  xt, rt, lamt <- the trial point cnl_trial_point_dev left in xt_e, rt_e, lamt_e, where ext
+ *   cnl_outer_trial_done_dev   :722-800  optimality measures at the trial point (nrm_t = the norms of cnl_residual_vectors_dev),
+ *                                        acceptance, x / r / Fx / cx / Jv / Jcv / lam / rhs_cur / fx / delta / inner updates, end-of-
+ *                                        inner-loop tests; rej, chk, done_in; flags[4] = any rejected, flags[5] = any small-residual check
+ *   cnl_outer_end_dev          :800-857  statuses, outer-iteration counters, phase0                                                */
+typedef struct cnl_outer_state {
+  int64_t B, n, m, p, P /* max(p, 1): row length of lam, cx, ct, lamt */, N, nnzjF, nnzjc, max_inner;
+  double dmin, rhomax, delta_dec, smax;
+  int32_t *status, *it, *flags /* [8] */, *nf_new, *ok_new;
+  int64_t *inner, *nfact, *nlin;
+  uint8_t *phase0, *act, *need, *brk, *ext, *lsm, *rej, *chk, *done_in, *tired, *small_res;
+  double *normdual, *normprimal, *combined, *combined_hat, *delta, *ndh, *nph, *fx, *epsk, *epstol, *epsF, *epsc, *rho_old;
+  double *d, *d_new, *ro_tmp, *rho_new;
+  double *x, *r, *Fx, *cx, *Jv, *Jcv, *lam, *rhs_cur;
+  double *xt, *rt, *Ft, *ct, *Jt, *Jct, *lamt, *rhs_t, *nrm_t /* [B][2] */;
+  double *xt_e, *rt_e, *lamt_e;
+  /* Armijo line search (src/CaNNOLeS.jl:1054-1112): ls_g = the [dual; primal] vector of cnl_residual_vectors_dev at (Fx, lam_ls) —
+   * its first n entries are the gradient of the merit function; xl / Fl / cl = trial point, F and c there (the caller evaluates
+   * the model); lam_ls = lam - c / delta; per problem: alpha, Dphi, phix, eta, nbk; bt = still backtracking; flags[6] = any bt  */
+  double gammaA, eps2;
+  double *ls_g, *xl, *Fl, *cl, *lam_ls, *alpha, *Dphi, *phix, *eta;
+  int64_t* nbk;
+  uint8_t* bt;
+} cnl_outer_state;
+int cnl_outer_begin_dev(const cnl_outer_state* st, void* stream);
+int cnl_outer_newton_done_dev(const cnl_outer_state* st, int did_newton, void* stream);
+int cnl_outer_extrapolated_dev(const cnl_outer_state* st, void* stream);
+int cnl_outer_trial_done_dev(const cnl_outer_state* st, void* stream);
+/* line search of the problems in lsm: ls_begin (Dphi, eta, phi(x), alpha = 1, xl = x + dx) -> [caller: Fl, cl = F(xl), c(xl)] ->
+ * ls_test(first = 1) -> while flags[6]: ls_step (alpha / 4, xl, nbk) -> [caller: Fl, cl] -> ls_test(0); then ls_take (xt, rt, lamt)   */
+int cnl_outer_ls_begin_dev(const cnl_outer_state* st, void* stream);
+int cnl_outer_ls_test_dev(const cnl_outer_state* st, int first, void* stream);
+int cnl_outer_ls_step_dev(const cnl_outer_state* st, void* stream);
+int cnl_outer_ls_take_dev(const cnl_outer_state* st, void* stream);
+int cnl_outer_end_dev(const cnl_outer_state* st, void* stream);
+
 /* Device time, in milliseconds, of the multifrontal kernel (the dominant kernel) of the last call,
  * measured with HIP events on the call's stream.  Enabling timing makes every call synchronise on
  * its stream, so it is meant for measurement loops, not for production (0 if not enabled).      */

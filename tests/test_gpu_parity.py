@@ -1131,6 +1131,12 @@ def test_f3_device_resident_lockstep_outer_loop(built, shape):
         work += one["nlinsolve"]
     assert got["nfact"].sum() > got["nlinsolve"].sum()        # the rho ladder was climbed somewhere
     assert got["steps"] < work                                 # lockstep: far fewer batched rounds than Newton systems
+    # the loop's bookkeeping as four device kernels (round 4, csrc/outer_step.hip) against the framework form of rounds 2-3
+    old = DL.solve_batch_device_framework(fam, prm)
+    assert old["steps"] == got["steps"] and old["status"] == got["status"]
+    for k in ("iter", "nlinsolve", "nfact", "nbk"):
+        assert np.array_equal(old[k], got[k]), k
+    assert np.allclose(old["solution"], got["solution"], atol=1e-9, rtol=1e-9)
 
 
 @pytest.mark.parametrize("dataflow", [True, False])

@@ -14,10 +14,14 @@ def main():
         fam = DL.BandQuadFamily(s, B, seed=7, torch=torch, device="cuda:0", curvature=1.5, start=1.0, noise=0.5)
         prm = hipldl.default_params()
         DL.solve_batch_device(fam, prm)
+        if "--profile" in sys.argv:
+            DL.PROFILE = True
+            print("profile", (n, p, B), json.dumps(DL.solve_batch_device(fam, prm)["profile_ms_per_step"]), flush=True)
+            DL.PROFILE = False
         t0 = time.perf_counter()
         got = DL.solve_batch_device(fam, prm)
         dt = time.perf_counter() - t0
-        rec = {"n": n, "p": p, "B": B, "seconds": dt, "problems_per_s": B / dt, "steps": got["steps"], "ms_per_step": 1e3 * dt / got["steps"],
+        rec = {"n": n, "p": p, "B": B, "seconds": dt, "problems_per_s": B / dt, "steps": got["steps"], "ms_per_step": 1e3 * got["loop_seconds"] / got["steps"], "setup_seconds": dt - got["loop_seconds"],
                "newton_systems": int(got["nlinsolve"].sum()), "factorisations": int(got["nfact"].sum()),
                "first_order": sum(st == "first_order" for st in got["status"]), "kernel": got["kernel"]}
         if os.path.isdir("oracle"):
