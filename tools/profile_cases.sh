@@ -22,4 +22,5 @@ run cfg4_B4096 $B --nvar 1000 --ncon 10 --batch 4096
 run dense_B1 $root/tools/bench_dense.py --batch 1
 run dense_B8 $root/tools/bench_dense.py --batch 8
 run irregular $root/tools/time_irregular.py
+run cfg5_B256 $root/tools/time_dev_ladder.py behind
 ls $out | grep ${tag}_ | head -40

@@ -17,6 +17,8 @@ from cannoles_jl_amd import hipldl, synthetic as syn  # noqa: E402
 dev = torch.device("cuda:0")
 stream = torch.cuda.Stream()
 MODES = {"fused": {"device_ladder_fused": 1}, "behind": {}, "sequential": {"device_ladder": 0}}
+if len(sys.argv) > 1:   # e.g. `behind` = the library's default only (profiling runs)
+    MODES = {k: MODES[k] for k in sys.argv[1].split(",")}
 
 
 def run(s, vals, rhs, B, mode, reps=30, restore=False):
