@@ -106,8 +106,9 @@ typedef struct cnl_options {
   int32_t rows_in_backward;    /* 1: the lean kernel recovers the residual components in its backward sweep (no post-pass)      */
   int32_t dense_panel_blocks;  /* dense backend, panel step with four column-block wavefronts per tile (dn_panel2): 0 never,
                                   1 while the step is latency-bound (batch x tiles <= 512; default), 2 always                    */
-  int32_t host_ladder;         /* 1: small-batch host-pointer cnl_newton_system drives the rho ladder from the host, every rung a
-                                  staged try_to_factorize (default); 0: the device ladder of the sequential launch              */
+  int32_t host_ladder;         /* 1: where the in-kernel device ladder is not available (device_ladder = 0, split handles, plans whose
+                                  tasks do not fit the device at once, the dense backend) the host-pointer cnl_newton_system drives
+                                  the rho ladder from the host, every rung a staged try_to_factorize (default); 0: the sequential launch */
   int32_t device_ladder;       /* 1: device-pointer cnl_newton_system_dev on staged handles climbs the rho ladder inside ONE launch
                                   in which every task of the elimination tree has a wavefront of its own (per rung the tasks
                                   factorise in dataflow fashion, the last to finish applies the ladder rule; default); 0: the
@@ -184,9 +185,12 @@ int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* su
 int cnl_solve(cnl_handle* h, const double* rhs, double* d);
 
 /* newton_system!(d, nvar, nequ, ncon, rhs, vals, LDLT, rho_old, params) — src/CaNNOLeS.jl:1008-1052,
- * one call: factorise at rho=0, climb the rho ladder per problem on failure, solve.  On handles with a latency plan (small and
- * mid-size batches) and on the dense backend the ladder of THIS (host-pointer) entry is driven from the host, every rung a
- * parallel try_to_factorize of the batch (cnl_options.host_ladder); the device-pointer twin decides everything on the device.
+ * one call: factorise at rho=0, climb the rho ladder per problem on failure, solve.  Both entries decide the ladder on the device:
+ * the single stream of large batches inside its one launch, latency plans (small and mid-size batches) inside one fused launch in
+ * which every task of the elimination tree has a wavefront of its own (cnl_options.device_ladder; kernels2.hip, phase 2).  Only where
+ * that launch cannot hold a batch's tasks at once — and on the dense backend — the ladder of THIS (host-pointer) entry is driven from
+ * the host, every rung a parallel try_to_factorize of the batch (cnl_options.host_ladder), and the device-pointer twin falls back
+ * to the sequential launch.
  * vals (batch*nnz) is mutated: the rho slots receive the last rho tried, as the reference leaves them.
  * rho_old: batch inputs.  Outputs (batch each): rho, rho_old_out, nfact, success (= solve_success).  */
 int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d, const double* rho_old,
