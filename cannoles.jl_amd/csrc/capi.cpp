@@ -1837,16 +1837,22 @@ int cnl_multi_create_ex(cnl_multi** mout, int64_t N, int64_t nnz, const int64_t*
     m->count.push_back(cnt);
     m->device.push_back(devices[i]);
   }
-  // The symbolic analysis runs ONCE ("done once on host and broadcast"): the plan is reference-counted, every
-  // shard's handle uploads its own copy of the index data to its device.  Shard sizes differ by at most one problem; the
-  // plan depends on the batch only through the plan kind and the wavefront slots per group of problems, so the first shard's
-  // plan serves all shards of the same kind (a second analysis only when the sizes straddle staged_max_batch).
+  // The symbolic analysis runs ONCE per shard size ("done once on host and broadcast"): the plan is reference-counted,
+  // every shard's handle uploads its own copy of the index data to its device.  Shard sizes differ by at most one problem: one
+  // analysis when the batch divides evenly, two otherwise.
+  // (round 4: one analysis per DISTINCT shard size — at most two, the sizes differ by at most one problem — so that every shard
+  //  runs exactly the plan cnl_create would pick for its own batch: with the first shard's plan for all, a shard on the other
+  //  side of a planning boundary (latency / throughput, split eligibility) got its neighbour's plan)
   cnl_plan* shared[2] = {nullptr, nullptr};
-  auto kind_of = [&](int64_t cnt) { return o.plan_kind == CNL_PLAN_LATENCY || (o.plan_kind == CNL_PLAN_AUTO && cnt <= (o.staged_max_batch > 0 ? o.staged_max_batch : 4096)) ? 1 : 0; };
+  int64_t shared_count[2] = {-1, -1};
   for (size_t i = 0; i < m->count.size() && !rc; i++) {
     cnl_plan* plan = nullptr;
     if (o.multi_share_plan) {
-      const int k = kind_of(m->count[i]);
+      const int k = shared_count[0] == m->count[i] ? 0 : (shared_count[1] == m->count[i] ? 1 : (shared_count[0] < 0 ? 0 : 1));
+      if (shared_count[k] != m->count[i]) {
+        if (shared[k]) { cnl_plan_destroy(shared[k]); shared[k] = nullptr; }   // (a third size: cannot happen with balanced shards)
+        shared_count[k] = m->count[i];
+      }
       if (!shared[k]) rc = cnl_plan_create_ex(&shared[k], N, nnz, rows1, cols1, nvar, nequ, ncon, m->count[i], &o);
       if (!rc) { plan = shared[k]; plan->refs.fetch_add(1); }
     } else {

@@ -966,7 +966,8 @@ def test_host_pointer_call_pipelined_in_chunks(built):
 def test_multi_device_resident_twins_share_one_analysis(built):
     """cnl_multi_*_dev: every shard's arrays already live on its device, the calls only enqueue and cnl_multi_synchronize waits —
     nothing crosses PCIe per call (the host-pointer cnl_multi_* calls are link-bound by construction).  One GPU here: the device
-    is named twice.  The shards share ONE symbolic analysis (same plan object behind both handles: identical order and records)."""
+    is named twice.  Shards of equal size share ONE symbolic analysis; here the sizes are 5 and 4, so each gets the plan cnl_create
+    would pick for its own batch (round 4: one analysis per distinct shard size)."""
     import torch
     hipldl, syn, O = _mods()
     s = syn.band_structure(300, 4)
