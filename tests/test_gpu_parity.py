@@ -1602,3 +1602,17 @@ def test_band_form_elimination_equals_the_general_one(built, shape, B):
         d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs[b], vals[b].copy(), 0.0, O.default_params())
         assert ok0 and nf0 == int(out[1][3][b]) and rho0 == float(out[1][2][b])
         assert np.abs(out[1][0][b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+
+
+def test_bench_multi_front_end(built):
+    """bench.py --multi: the whole job from ONE process through cnl_multi_newton_system_dev + cnl_multi_synchronize (the
+    second front end).  A small instance of the same driver: two shards on the one device, every problem must succeed and the rate
+    must be a number."""
+    import torch
+    hipldl, syn, O = _mods()
+    import bench as BM
+    s = syn.band_structure(300, 4, name="cfg3")
+    rows, cols = s.kkt_pattern()
+    dt, nprob, ok, shards = BM.multi_front_end(torch, hipldl, s, rows, cols, [0, 0], 20, steps=3, warmup=1)
+    assert ok and nprob == 40 and dt > 0
+    assert [(a, c) for a, c, _ in shards] == [(0, 20), (20, 20)]
