@@ -91,6 +91,11 @@ struct cnl_handle {
   int64_t split_staged = 0;   // > 0: problems [0, split_staged) run staged, the rest single-stream, concurrently (run_split)
   bool split_halves = false;  // ... or (round 4): the rest runs staged as well, BEHIND the first part on the same stream (two halves)
   bool in_split = false;
+  // (round 4) a batch a little above what fills the machine on the bidirectional chain (staged_max_batch < batch <= 5/4 of it):
+  // problems [0, split_staged) run on this handle's chain plan, the REMAINDER on a handle of its own with the many-part latency
+  // plan cnl_create picks for that small batch, one behind the other on the caller's stream (run_split)
+  cnl_handle* tail = nullptr;
+  bool tail_fresh = false;    // the factors of the remainder live in the tail handle (false: in this handle's storage — chunked host calls)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   static constexpr int kPipeUp = CNL_PIPE_UPLOADERS;  // host threads that upload chunks of a host-pointer call (each on its own stream)
@@ -400,6 +405,49 @@ int run_split(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d
   if (tm) HIPCHK(hipEventRecord(h->ev0, stream));
   h->timing = false;
   h->in_split = true;
+  if (h->tail) {
+    // 4096 problems fill every wavefront slot on the bidirectional chain (4.1 ms at cfg3's size); a remainder of r <= 1024 problems
+    // takes 0.5 .. 1.7 ms on its own many-part plan, where two halves of the whole batch need 2 x 3 ms (4608 problems: 5.95 -> 5.0 ms)
+    cnl_handle* t = h->tail;
+    const bool on_tail = a.mode != cnl::MODE_SOLVE || h->tail_fresh;
+    int rc;
+    {
+      SubBatch view(h, 0, nA, true);
+      cnl::LaunchArgs b = a;
+      rc = run(h, b, d_vals, d_rhs, d_d, stream);
+    }
+    if (rc == CNL_OK) {
+      cnl::LaunchArgs b = a;
+      if (b.rho_old) b.rho_old += nA;
+      if (b.rho) b.rho += nA;
+      if (b.nfact) b.nfact += nA;
+      if (b.success) b.success += nA;
+      if (b.npos) b.npos += nA;
+      if (b.nzero) b.nzero += nA;
+      double* tv = d_vals ? d_vals + nA * nnz : nullptr;
+      const double* tr = d_rhs ? d_rhs + nA * N : nullptr;
+      double* td = d_d ? d_d + nA * N : nullptr;
+      if (on_tail) {
+        t->first_attempt_only = h->first_attempt_only;
+        rc = run(t, b, tv, tr, td, stream);
+        t->first_attempt_only = false;
+        if (rc == CNL_OK && a.mode != cnl::MODE_SOLVE) { t->last_vals = tv; t->factorized = true; h->tail_fresh = true; }
+      } else {
+        SubBatch view(h, nA, nB, true);
+        rc = run(h, b, tv, tr, td, stream);
+      }
+    }
+    h->in_split = false;
+    h->timing = tm;
+    if (rc) return rc;
+    if (a.mode == cnl::MODE_FACTOR) h->last_vals = d_vals;
+    if (tm) {
+      HIPCHK(hipEventRecord(h->ev1, stream));
+      HIPCHK(hipEventSynchronize(h->ev1));
+      HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    }
+    return CNL_OK;
+  }
   if (h->split_halves) {
     // Two halves, each on the bidirectional chain (two wavefronts per group of problems), one behind the other on the caller's
     // stream: a half of 2304 .. 3840 problems runs at 0.81 .. 0.96 M systems/s, where the single-stream part of the concurrent
@@ -761,7 +809,7 @@ void cnl_options_init(cnl_options* o) {
   o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
   // (fused: measured slower than the separate launches on one system of cfg3's size, 0.140 against 0.118 ms — the rung loop costs
   //  the kernel 50 VGPRs and 45 spilled SGPRs — so it is off by default)
-  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1;
+  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -1117,6 +1165,20 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
       h->split_staged = (((batch + 1) / 2) + 3) & ~(int64_t)3;
     }
     if (h->split_staged == 0) h->staged = false;  // the whole batch on the single stream
+    // a remainder of at most a quarter of the machine-filling batch: its own handle with its own (many-part) plan — run_split
+    const int64_t smb = ((plan->opt.staged_max_batch > 0 ? plan->opt.staged_max_batch : 4096)) & ~(int64_t)3;
+    if (h->staged && plan->opt.split_batch == 1 && plan->opt.split_tail != 0 && batch > smb && batch - smb <= smb / 4) {
+      cnl_options o2 = plan->opt;
+      cnl_handle* t = nullptr;
+      if (cnl_create_ex(&t, N, nnz, rows1, cols1, nvar, nequ, ncon, batch - smb, device, &o2) == CNL_OK) {
+        if (t->staged && t->use_v2 && !t->dense && !t->gdense && !t->tail && t->split_staged == 0) {
+          h->tail = t; h->split_halves = false; h->split_staged = smb;
+        } else {
+          cnl_destroy(t);
+        }
+      }
+      if (hipSetDevice(device) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipSetDevice failed"));
+    }
   }
   if (h->plan->D.active) {
     std::string derr;
@@ -1193,6 +1255,7 @@ int cnl_destroy(cnl_handle* h) {
   if (h->pin) (void)hipHostFree(h->pin);
   cnl::dense_destroy(h->dense);
   cnl::dense_destroy(h->gdense);
+  if (h->tail) { cnl_destroy(h->tail); h->tail = nullptr; (void)hipSetDevice(h->device); }
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1211,12 +1274,19 @@ const cnl_plan* cnl_get_plan(const cnl_handle* h) { return h ? h->plan : nullptr
 int cnl_dataflow_timeouts(cnl_handle* h, int64_t* count) {
   if (!h || !count) return fail(CNL_ERR_ARG, "null argument");
   *count = 0;
-  if (!h->d_status) return CNL_OK;
-  HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipDeviceSynchronize());
-  int v = 0;
-  HIPCHK(hipMemcpy(&v, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
-  *count = v;
+  if (h->d_status) {
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    int v = 0;
+    HIPCHK(hipMemcpy(&v, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    *count = v;
+  }
+  if (h->tail) {
+    int64_t tc = 0;
+    const int rc = cnl_dataflow_timeouts(h->tail, &tc);
+    if (rc) return rc;
+    *count += tc;
+  }
   return CNL_OK;
 }
 
@@ -1294,6 +1364,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   cfg[4] = (h->batch + h->cfg.ppb - 1) / h->cfg.ppb;
   cfg[5] = (h->dense || h->gdense) ? 3 : (h->use_v2 ? (h->staged ? 4 : 2) : 1);
   if (h->lean && !h->dense && !h->gdense) cfg[5] |= 16;  // newton_system / factorize run the kernels' LEAN instantiation
+  if (h->tail) cfg[5] |= 32;                             // the remainder of the batch runs on a handle of its own (split_tail)
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;
   return CNL_OK;
@@ -1499,6 +1570,7 @@ static int newton_system_pipelined(cnl_handle* h, double* vals, const double* rh
   };
   const bool tm = h->timing;
   h->timing = false;
+  h->tail_fresh = false;   // the chunks factorise every problem in THIS handle's storage (views), the remainder's handle is not used
   // staged handles: the chunks run the first attempt only; the problems that failed it go through the host-driven ladder on the
   // whole (now device-resident) batch behind the last chunk (see cnl_newton_system)
   const bool host_ladder = h->staged && !h->dense && !h->gdense && h->plan->opt.host_ladder != 0 && h->use_v2 && P.P.rec_direct && P.P.d_outer;
@@ -1561,7 +1633,7 @@ static int host_ladder_run(cnl_handle* h, const double params[9], const double* 
   std::vector<double> ro_in(B);
   // split handles: only the chain part [0, split_staged) ran the first attempt alone; the single-stream part has been through the
   // whole device ladder already (a problem that exhausted it there must not climb again: nfact would count twice)
-  const size_t first_only = (h->split_staged > 0 && (size_t)h->split_staged < B && !h->split_halves) ? (size_t)h->split_staged : B;
+  const size_t first_only = (h->split_staged > 0 && (size_t)h->split_staged < B && !h->split_halves && !h->tail) ? (size_t)h->split_staged : B;
   bool any_act = false;
   for (size_t b = 0; b < B; b++) {
     ro_in[b] = rho_old ? rho_old[b] : 0.0;

@@ -119,6 +119,10 @@ typedef struct cnl_options {
   int32_t band_form;           /* 1: fast fronts whose pivot rows are structurally zero outside a few fixed columns and the four
                                   columns below the pivot (the fronts of band problems) run an elimination that does not contain
                                   the other row updates (csrc/plan.h, band_fronts; default); 0: every pivot updates every row    */
+  int32_t split_tail;          /* 1: a batch of staged_max_batch + r problems, r <= staged_max_batch / 4, runs its first
+                                  staged_max_batch problems on the bidirectional chain and the remainder on a handle of its own
+                                  with the many-part latency plan of a batch of r, one behind the other (default); 0: split_batch's
+                                  two halves                                                                                     */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);
@@ -329,7 +333,7 @@ int cnl_last_kernel_ms(cnl_handle* h, float* ms);
  * [4]=grid size (those five describe the general kernel, kernels.hip), [5]=2 if the register-front
  * kernel (kernels2.hip) serves newton_system/factorize (4: with staged execution of the first attempt), 3 dense backend, else 1;
  * + 16 when newton_system / factorize run the LEAN instantiation (fast-class fronts with row-form products only), [6]=its wavefronts per workgroup,
- * [7]=its LDS bytes per workgroup.                                                              */
+ * [7]=its LDS bytes per workgroup; [5] + 32 when the remainder of the batch runs on a handle of its own (cnl_options.split_tail). */
 int cnl_get_config(const cnl_handle* h, int64_t cfg[8]);
 
 #ifdef __cplusplus

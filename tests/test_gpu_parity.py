@@ -30,7 +30,7 @@ def backward_error(s, vals, rhs, d):
     return np.abs(res).max() / (abs(K).sum(axis=1).max() * np.abs(d).max() + np.abs(rhs).max())
 
 
-def run_case(s, vals, rhs, rho_old=None, fwd_tol=FWD_TOL, check_fwd=True, options=None):
+def run_case(s, vals, rhs, rho_old=None, fwd_tol=FWD_TOL, check_fwd=True, options=None, own_order=True):
     hipldl, syn, O = _mods()
     B = vals.shape[0]
     rows, cols = s.kkt_pattern()
@@ -63,6 +63,18 @@ def run_case(s, vals, rhs, rho_old=None, fwd_tol=FWD_TOL, check_fwd=True, option
         assert backward_error(s, vv, rhs[b], d[b]) <= BWD_TOL
         if check_fwd:
             assert np.abs(d[b] - d0[b]).max() / np.abs(d0[b]).max() <= fwd_tol
+    # ... and against the oracle on an elimination order the product had no part in (r-nodes, x in natural order, multipliers:
+    # oracle.canonical_perm, the order SURVEY 8d prices): the reference's own order (AMD) is a third one, and decisions that
+    # hold on two unrelated orders are not an artefact of handing the oracle the product's permutation
+    if own_order:
+        orc2 = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
+        v2 = vals.copy()
+        d2, ok2, rho2, ro2, nf2 = O.newton_system_batch(orc2, B, s.nvar, s.nequ, s.ncon, rhs, v2, ro, p_oracle)
+        assert np.array_equal(ok, ok2) and np.array_equal(nfact, nf2) and np.array_equal(rho, rho2) and np.array_equal(ro_out, ro2)
+        if check_fwd:
+            for b in range(B):
+                if ok2[b]:
+                    assert np.abs(d[b] - d2[b]).max() / np.abs(d2[b]).max() <= fwd_tol
     info, cfg = LDLT.info, LDLT.config
     LDLT.close()
     return info, cfg
@@ -911,6 +923,105 @@ def test_split_batch_factorize_then_solve(built):
             d0 = orc.solve_ldl(rhs[b])
             assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
     L.close()
+
+
+def test_split_tail_remainder_on_its_own_plan(built):
+    """A batch a little above the one that fills the machine on the bidirectional chain (4096 + r problems, r <= 1024): the first
+    4096 problems run on the handle's chain plan, the remainder on a handle of its own with the many-part plan of a batch of r, one
+    behind the other (csrc/capi.cpp, run_split; cnl_options.split_tail).  Against the two-halves form (split_tail = 0) on the same
+    data: every decision (success, nfact, rho, rho_old, the rho slots) bit for bit, d to the forward tolerance (the remainder's plan
+    has another elimination order); a sample of both parts against the oracle — ladder climbers in both parts, a hopeless problem
+    in the remainder.  Then the call sequences that must find each part's own factor: try_to_factorize_dev + solve_dev, and the
+    chunked host-pointer newton_system (which factorises EVERY problem in the first handle's storage) followed by solve_ldl!."""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(600, 6)
+    rows, cols = s.kkt_pattern()
+    B, nA = 4096 + 200, 4096
+    v8, r8 = syn.batch_values(s, 8, cfg=3)
+    rng = np.random.default_rng(11)
+    vals = np.tile(v8, (B // 8, 1)) * (1.0 + 1e-3 * rng.standard_normal((B, 1)))
+    rhs = np.tile(r8, (B // 8, 1)) + 1e-3 * np.arange(B)[:, None]
+    off = s.offsets()
+    vals[:, off[4]:off[5]] = -1.0
+    hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
+    dg = off[0] + np.nonzero(hF_r == hF_c)[0]
+    climbers = [5, 4090, 4096, 4200, B - 1]
+    for b in climbers:
+        vals[b, dg[:50]] = -40.0        # wrong inertia at rho = 0: climbs the ladder
+    hopeless = 4101
+    vals[hopeless, off[0]:off[1]] = np.nan
+    ro_in = np.zeros(B)
+    ro_in[4200] = 2.5e-3
+    p = hipldl.default_params()
+    dev = torch.device("cuda", 0)
+    res = {}
+    for tail in (1, 0):
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(split_tail=tail))
+        assert L.config["kernel"] == "v2-staged" and L.info["order"].startswith("ndc2") and L.config["tail"] == bool(tail)
+        v = torch.from_numpy(vals).to(dev)
+        r = torch.from_numpy(rhs).to(dev)
+        d = torch.full((B, s.N), 7.0, dtype=torch.float64, device=dev)
+        ro = torch.from_numpy(ro_in).to(dev)
+        rho = torch.ones(B, dtype=torch.float64, device=dev)
+        nf = torch.zeros(B, dtype=torch.int32, device=dev)
+        ok = torch.zeros(B, dtype=torch.int32, device=dev)
+        hipldl.newton_system_dev(L, v.data_ptr(), r.data_ptr(), d.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), ok.data_ptr(), p, 0)
+        torch.cuda.synchronize()
+        assert L.dataflow_timeouts() == 0
+        out = [ok.cpu().numpy(), nf.cpu().numpy(), rho.cpu().numpy(), ro.cpu().numpy(), v[:, -s.nvar:].cpu().numpy(), d.cpu().numpy()]
+        # solve_dev right behind it: another right-hand side with the factors the call left (each part's own)
+        d2 = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
+        r2 = r * 0.5
+        hipldl._check(hipldl.lib().cnl_solve_dev(L._h, r2.data_ptr(), d2.data_ptr(), 0))
+        torch.cuda.synchronize()
+        out.append(d2.cpu().numpy())
+        # try_to_factorize_dev (rho slots as the ladder left them) + solve_dev
+        ok2 = torch.zeros(B, dtype=torch.int32, device=dev)
+        hipldl._check(hipldl.lib().cnl_factorize_dev(L._h, v.data_ptr(), float(p[0]), ok2.data_ptr(), 0))
+        d3 = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
+        hipldl._check(hipldl.lib().cnl_solve_dev(L._h, r.data_ptr(), d3.data_ptr(), 0))
+        torch.cuda.synchronize()
+        out += [ok2.cpu().numpy(), d3.cpu().numpy()]
+        # chunked host-pointer call, then solve_ldl! with host pointers
+        vh = vals.copy()
+        dh = np.full((B, s.N), 7.0)
+        dh, okh, rhoh, roh, nfh = hipldl.newton_system_(dh, s.nvar, s.nequ, s.ncon, rhs, vh, L, ro_in, p)
+        d4 = np.zeros((B, s.N))
+        hipldl.solve_ldl_(0.5 * rhs, L.factor, d4)
+        out += [np.asarray(okh), np.asarray(nfh), np.asarray(rhoh), np.asarray(roh), vh[:, -s.nvar:].copy(), np.array(dh, copy=True).reshape(B, s.N), d4]
+        res[tail] = out
+        if tail:
+            perm = L.plan_array("perm").astype(np.int64)
+        L.close()
+    a, b_ = res[1], res[0]
+    good = a[0] == 1
+    assert good.sum() == B - 1 and not good[hopeless]
+    for k in (0, 1, 2, 3):
+        assert np.array_equal(a[k], b_[k]), k
+        assert np.array_equal(a[k], a[9 + k].astype(a[k].dtype)), k     # the host-pointer call decides the same
+    assert np.array_equal(a[4], b_[4], equal_nan=True) and np.array_equal(a[4], a[13], equal_nan=True)
+    assert (a[1][climbers] > 1).all() and (a[1][[0, 100, 4097, 4150]] == 1).all()
+    assert np.array_equal(a[7][good], np.ones(B - 1, dtype=a[7].dtype))     # the refactorisation with the final rho succeeds
+    for k in (5, 6, 8, 14, 15):     # d of newton_system_dev, solve_dev, factorize_dev + solve_dev, host newton_system, host solve
+        x, y = a[k], b_[k]
+        if k in (5, 14):
+            assert (x[hopeless] == 7.0).all() and (y[hopeless] == 7.0).all()
+        scale = np.abs(y[good]).max(axis=1, keepdims=True)
+        assert (np.abs(x[good] - y[good]) <= FWD_TOL * scale).all(), k
+    assert (np.abs(a[6][good] - 0.5 * a[5][good]) <= FWD_TOL * np.abs(a[5][good]).max(axis=1, keepdims=True)).all()
+    assert (np.abs(a[8][good] - a[5][good]) <= FWD_TOL * np.abs(a[5][good]).max(axis=1, keepdims=True)).all()
+    assert (np.abs(a[15][good] - 0.5 * a[14][good]) <= FWD_TOL * np.abs(a[14][good]).max(axis=1, keepdims=True)).all()
+    orc = O.Oracle(s.N, rows, cols, perm)
+    po = O.default_params()
+    for b in climbers + [0, 4095, 4097, hopeless]:
+        vv = vals[b].copy()
+        d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs[b], vv, float(ro_in[b]), po)
+        assert bool(ok0) == bool(a[0][b]) and (nf0, rho0, ro0) == (int(a[1][b]), float(a[2][b]), float(a[3][b])), b
+        assert np.array_equal(a[4][b], vv[-s.nvar:], equal_nan=True)
+        if ok0:
+            assert np.abs(a[5][b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+            assert backward_error(s, vv, rhs[b], a[5][b]) <= BWD_TOL
 
 
 def test_host_pointer_call_pipelined_in_chunks(built):
