@@ -628,10 +628,10 @@ def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, 
     """The headline shape (cfg3 pattern, n = nequ = 1e4, ncon = 50): the headline batch itself (8192 problems, the plan cnl_create
     picks: canonical+early on the single stream — what bench.py times), on the throughput kernel (single stream, forced here with
     cnl_options.plan_kind: it is what cnl_create picks from 7681 problems on), at a batch between one and two wavefronts per SIMD
-    (B = 4608: 3584 problems on the bidirectional chain and 1024 on the single stream, CONCURRENTLY on two streams —
-    csrc/capi.cpp, run_split), at one the bidirectional chain serves alone (B = 3584) and at one with many large parts
-    (B = 1536): the whole batch through cnl_newton_system_dev, a random sample of 32 problems against the oracle; in the
-    split batch one problem of each part also climbs the rho ladder."""
+    (B = 4608: the first 4096 problems on the bidirectional chain, the remaining 512 behind them on a handle of their own with a
+    many-part plan — csrc/capi.cpp, run_split, cnl_options.split_tail), at one the bidirectional chain serves alone (B = 3584) and
+    at one with many large parts (B = 1536): the whole batch through cnl_newton_system_dev, a random sample of 32 problems
+    against the oracle; in the split batch one problem of each part also climbs the rho ladder."""
     import torch
     hipldl, syn, O = _mods()
     import bench as BM
@@ -650,17 +650,17 @@ def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, 
             host[int(b)] = (vh[b - b0].copy(), rh[b - b0].copy())
     p = hipldl.default_params()
     split = B == 4608 and not forced
-    if split:   # one problem in the chain part and one in the single-stream part need rho > 0
+    if split:   # one problem in the chain part and one in the remainder need rho > 0
         off = s.offsets()
         hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
         dg = torch.from_numpy(off[0] + np.nonzero(hF_r == hF_c)[0][:400]).to(dev)
         for b in (int(pick[0]), int(pick[-1])):
             vals[b, dg] = -30.0
             host[b][0][dg.cpu().numpy()] = -30.0
-        assert pick[0] < 3584 <= pick[-1]
+        assert pick[0] < 4096 <= pick[-1]
     L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B,
                             options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT) if forced else None)
-    assert L.config["kernel"] == kernel and L.info["order"].startswith(order)
+    assert L.config["kernel"] == kernel and L.info["order"].startswith(order) and L.config["tail"] == split
     d = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
     ro = torch.zeros(B, dtype=torch.float64, device=dev)
     rho = torch.ones(B, dtype=torch.float64, device=dev)
@@ -891,7 +891,7 @@ def test_lean_and_full_instantiations_agree_with_the_oracle(built, shape, B, lea
 
 def test_split_batch_factorize_then_solve(built):
     """try_to_factorize + solve_ldl! (src/solver_types.jl:69-98) on a batch between one and two wavefronts per SIMD: the handle
-    runs 4 x (2048 - groups) problems on the bidirectional chain and the rest single-stream, concurrently (run_split); both
+    runs its first 4096 problems on the bidirectional chain and the remaining 904 on a handle of their own (run_split); both
     parts must give the oracle's inertia decisions and solutions, and solve_ldl! must find each part's own factor."""
     hipldl, syn, O = _mods()
     s = syn.band_structure(600, 6)
