@@ -255,6 +255,17 @@ int setup_v2(cnl_handle* h) {
   h->staged = false;
   if ((rc = dalloc(h, &h->d_status, 1))) return rc;
   if (hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess) return fail(CNL_ERR_HIP, "hipMemset failed");
+  {
+    // wavefronts of this kernel the device holds at once: two per SIMD by the register budget of every instantiation
+    // (profiles/r04_kernel_resources.txt), and what the LDS of a CU holds
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) {
+      const size_t per_wg = (size_t)wpb * wave_bytes + 512;
+      const long long by_lds = (long long)(std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : maxlds, 160 * 1024) / per_wg) * wpb;
+      const long long resident = (long long)prop.multiProcessorCount * std::max<long long>(1, std::min<long long>(8, by_lds));
+      h->resident_waves = (int)std::min<long long>(resident, 1 << 20);
+    }
+  }
   if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && o.staged) {
     std::vector<int32_t> tk;
     for (const cnl::Task& t : P.tasks) { tk.push_back(t.rec_off); tk.push_back(t.f1 - t.f0); tk.push_back(t.brec_off); tk.push_back(t.is_root); tk.push_back(t.parent); tk.push_back(t.nchild); }
@@ -265,20 +276,10 @@ int setup_v2(cnl_handle* h) {
     //  29 tasks: 32 problems 0.110 against 0.131 ms.  With more wavefronts than about half the machine's slots the waiting ones
     //  crowd out the working ones — cfg3, 501 tasks: sixteen problems 0.233 against 0.196 ms, 256: 82 k against 367 k systems/s —
     //  so only the top stages whose tasks x groups of problems number at most 1024 run that way; env CNL_DATAFLOW_WAVES)
+    // a wavefront that waits occupies its slot: never more waiting wavefronts than the device holds at once (the scheme
+    // relies on the lowest unfinished workgroup being resident; kernels2.hip)
     h->df_waves = o.dataflow_waves > 0 ? o.dataflow_waves : 1024;
-    {
-      // a wavefront that waits occupies its slot: never more waiting wavefronts than the device holds at once (the scheme
-      // relies on the lowest unfinished workgroup being resident; kernels2.hip).  Slots: two wavefronts per SIMD by the
-      // register budget of the kernel, and what the LDS of a CU holds.
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) {
-        const size_t per_wg = (size_t)wpb * wave_bytes + 512;
-        const long long by_lds = (long long)(std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : maxlds, 160 * 1024) / per_wg) * wpb;
-        const long long resident = (long long)prop.multiProcessorCount * std::max<long long>(1, std::min<long long>(8, by_lds));
-        h->df_waves = (int)std::min<long long>(h->df_waves, resident);
-        h->resident_waves = (int)std::min<long long>(resident, 1 << 20);
-      }
-    }
+    if (h->resident_waves > 0) h->df_waves = std::min(h->df_waves, h->resident_waves);
     {
       const size_t B = (size_t)h->batch, nq = (B + 3) / 4, tq = 2 * (size_t)h->ntasks * nq;
       const size_t total = 4 * B + (size_t)cnl::LAD_WORDS * nq + tq + 2 + (o.dataflow ? tq : 0);
@@ -395,7 +396,7 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
 // synchronisation).  Both parts use the SAME plan — the chain order has the throughput order's fronts, and the classic launch
 // runs any plan's records from end to end (it already does behind every staged attempt).
 int run_split(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, double* d_d, hipStream_t stream) {
-  if (!h->aux_stream) {
+  if (!h->aux_stream && !h->tail && !h->split_halves) {
     HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -528,7 +529,7 @@ int launch_redo(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, double* d_d, hipStream_t stream) {
   const cnl::Cond& C = h->plan->C;
   int rc = CNL_OK;
-  if (h->split_staged > 0 && !h->in_split && h->staged && h->split_staged < h->batch) return run_split(h, a, d_vals, d_rhs, d_d, stream);
+  if (h->split_staged > 0 && !h->in_split && (h->staged || h->tail) && h->split_staged < h->batch) return run_split(h, a, d_vals, d_rhs, d_d, stream);
   if (h->dense) {
     // dense residual block: J'WJ + tiled dense LDL^T on the fp64 matrix cores (csrc/dense.hip); asynchronous, the rho ladder
     // is decided on the device
@@ -1176,6 +1177,23 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
         } else {
           cnl_destroy(t);
         }
+      }
+      if (hipSetDevice(device) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipSetDevice failed"));
+    }
+  }
+  if (!plan->latency && !plan->split_mode && h->use_v2 && !h->staged && h->resident_waves > 0 && plan->opt.plan_kind == CNL_PLAN_AUTO &&
+      plan->opt.split_tail != 0 && plan->opt.force_order[0] == 0 && !plan->D.active && plan->gpos.empty()) {
+    // The single stream gives a group of four problems ONE wavefront for all fronts, and the device holds `resident_waves` of
+    // them: a batch of k full machine loads + r problems runs k + 1 rounds, the last one for the r problems alone (cfg3's size:
+    // 8448 problems 13.0 ms against 7.9 ms for 8192).  The remainder as a batch of its own has a better plan (many parts, the
+    // bidirectional chain, ...): it gets a handle of its own, enqueued behind the full loads (run_split).
+    const int64_t cap = 4 * (int64_t)h->resident_waves, r = batch % cap;
+    if (batch > cap && r > 0 && r <= cap - cap / 16) {
+      cnl_options o2 = plan->opt;
+      cnl_handle* t = nullptr;
+      if (cnl_create_ex(&t, N, nnz, rows1, cols1, nvar, nequ, ncon, r, device, &o2) == CNL_OK) {
+        if (t->staged && t->use_v2 && !t->dense && !t->gdense) { h->tail = t; h->split_staged = batch - r; }
+        else cnl_destroy(t);
       }
       if (hipSetDevice(device) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipSetDevice failed"));
     }

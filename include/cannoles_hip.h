@@ -119,10 +119,11 @@ typedef struct cnl_options {
   int32_t band_form;           /* 1: fast fronts whose pivot rows are structurally zero outside a few fixed columns and the four
                                   columns below the pivot (the fronts of band problems) run an elimination that does not contain
                                   the other row updates (csrc/plan.h, band_fronts; default); 0: every pivot updates every row    */
-  int32_t split_tail;          /* 1: a batch of staged_max_batch + r problems, r <= staged_max_batch / 4, runs its first
-                                  staged_max_batch problems on the bidirectional chain and the remainder on a handle of its own
-                                  with the many-part latency plan of a batch of r, one behind the other (default); 0: split_batch's
-                                  two halves                                                                                     */
+  int32_t split_tail;          /* 1: the remainder of a batch above a machine-filling one runs on a handle of its own, with the plan
+                                  cnl_create picks for a batch of that size, behind the rest on the caller's stream (default):
+                                  staged_max_batch + r problems, r <= staged_max_batch / 4 (first part on the bidirectional
+                                  chain), and k full loads of the single stream (four problems per resident wavefront: 8192 at
+                                  cfg3's size) + r problems; 0: split_batch's two halves / the single stream's extra round        */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);

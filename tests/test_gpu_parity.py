@@ -925,19 +925,22 @@ def test_split_batch_factorize_then_solve(built):
     L.close()
 
 
-def test_split_tail_remainder_on_its_own_plan(built):
+@pytest.mark.parametrize("nA,kernel,order", [(4096, "v2-staged", "ndc2"), (8192, "v2", "canonical")])
+def test_split_tail_remainder_on_its_own_plan(built, nA, kernel, order):
     """A batch a little above the one that fills the machine on the bidirectional chain (4096 + r problems, r <= 1024): the first
     4096 problems run on the handle's chain plan, the remainder on a handle of its own with the many-part plan of a batch of r, one
     behind the other (csrc/capi.cpp, run_split; cnl_options.split_tail).  Against the two-halves form (split_tail = 0) on the same
     data: every decision (success, nfact, rho, rho_old, the rho slots) bit for bit, d to the forward tolerance (the remainder's plan
     has another elimination order); a sample of both parts against the oracle — ladder climbers in both parts, a hopeless problem
     in the remainder.  Then the call sequences that must find each part's own factor: try_to_factorize_dev + solve_dev, and the
-    chunked host-pointer newton_system (which factorises EVERY problem in the first handle's storage) followed by solve_ldl!."""
+    chunked host-pointer newton_system (which factorises EVERY problem in the first handle's storage) followed by solve_ldl!.
+    Second case: the single stream (one wavefront per four problems, 8192 problems fill the machine) with 200 problems more — without
+    the remainder handle they cost a second round of all fronts."""
     import torch
     hipldl, syn, O = _mods()
     s = syn.band_structure(600, 6)
     rows, cols = s.kkt_pattern()
-    B, nA = 4096 + 200, 4096
+    B = nA + 200
     v8, r8 = syn.batch_values(s, 8, cfg=3)
     rng = np.random.default_rng(11)
     vals = np.tile(v8, (B // 8, 1)) * (1.0 + 1e-3 * rng.standard_normal((B, 1)))
@@ -946,19 +949,19 @@ def test_split_tail_remainder_on_its_own_plan(built):
     vals[:, off[4]:off[5]] = -1.0
     hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
     dg = off[0] + np.nonzero(hF_r == hF_c)[0]
-    climbers = [5, 4090, 4096, 4200, B - 1]
+    climbers = [5, nA - 6, nA, nA + 104, B - 1]
     for b in climbers:
         vals[b, dg[:50]] = -40.0        # wrong inertia at rho = 0: climbs the ladder
-    hopeless = 4101
+    hopeless = nA + 5
     vals[hopeless, off[0]:off[1]] = np.nan
     ro_in = np.zeros(B)
-    ro_in[4200] = 2.5e-3
+    ro_in[nA + 104] = 2.5e-3
     p = hipldl.default_params()
     dev = torch.device("cuda", 0)
     res = {}
     for tail in (1, 0):
         L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(split_tail=tail))
-        assert L.config["kernel"] == "v2-staged" and L.info["order"].startswith("ndc2") and L.config["tail"] == bool(tail)
+        assert L.config["kernel"] == kernel and L.info["order"].startswith(order) and L.config["tail"] == bool(tail)
         v = torch.from_numpy(vals).to(dev)
         r = torch.from_numpy(rhs).to(dev)
         d = torch.full((B, s.N), 7.0, dtype=torch.float64, device=dev)
@@ -1001,7 +1004,7 @@ def test_split_tail_remainder_on_its_own_plan(built):
         assert np.array_equal(a[k], b_[k]), k
         assert np.array_equal(a[k], a[9 + k].astype(a[k].dtype)), k     # the host-pointer call decides the same
     assert np.array_equal(a[4], b_[4], equal_nan=True) and np.array_equal(a[4], a[13], equal_nan=True)
-    assert (a[1][climbers] > 1).all() and (a[1][[0, 100, 4097, 4150]] == 1).all()
+    assert (a[1][climbers] > 1).all() and (a[1][[0, 100, nA + 1, nA + 54]] == 1).all()
     assert np.array_equal(a[7][good], np.ones(B - 1, dtype=a[7].dtype))     # the refactorisation with the final rho succeeds
     for k in (5, 6, 8, 14, 15):     # d of newton_system_dev, solve_dev, factorize_dev + solve_dev, host newton_system, host solve
         x, y = a[k], b_[k]
@@ -1014,7 +1017,7 @@ def test_split_tail_remainder_on_its_own_plan(built):
     assert (np.abs(a[15][good] - 0.5 * a[14][good]) <= FWD_TOL * np.abs(a[14][good]).max(axis=1, keepdims=True)).all()
     orc = O.Oracle(s.N, rows, cols, perm)
     po = O.default_params()
-    for b in climbers + [0, 4095, 4097, hopeless]:
+    for b in climbers + [0, nA - 1, nA + 1, hopeless]:
         vv = vals[b].copy()
         d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs[b], vv, float(ro_in[b]), po)
         assert bool(ok0) == bool(a[0][b]) and (nf0, rho0, ro0) == (int(a[1][b]), float(a[2][b]), float(a[3][b])), b

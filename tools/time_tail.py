@@ -1,5 +1,6 @@
-"""Batches a little above the one that fills the machine on the bidirectional chain (cfg3's size: 4096 problems): the remainder
-on a handle of its own (cnl_options.split_tail = 1) against the two halves (0), cnl_newton_system_dev, same box, interleaved.
+"""Batches above one that fills the machine — on the bidirectional chain (cfg3's size: 4096 problems) or on the single stream (8192):
+the remainder on a handle of its own (cnl_options.split_tail = 1) against the two halves / the single stream's extra round (0),
+cnl_newton_system_dev, same box, interleaved.
 usage: time_tail.py [batches, comma separated]     writes gpurun_out/tail_timing.json"""
 import json
 import os
@@ -15,7 +16,7 @@ import bench as BM  # noqa: E402
 
 dev = torch.device("cuda:0")
 stream = torch.cuda.Stream()
-batches = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4096, 4100, 4352, 4608, 4864, 5120, 5376]
+batches = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4096, 4100, 4352, 4608, 4864, 5120, 5376, 8448, 9216, 10240, 12288, 14336]
 s = syn.band_structure(10000, 50)
 rows, cols = s.kkt_pattern()
 p = hipldl.default_params()
