@@ -39,7 +39,7 @@
 // diagnostic stamps, the shortened division) compiles only in an EXPERIMENT build: -DCNL_EXPERIMENT=1, which also turns
 // cnl_version() negative (capi.cpp) so that such a library cannot pass for the product.
 #if (CNL_ABL != 0) || defined(CNL_DBG_NOCONF) || defined(CNL_DBG_VSTRIDE0) || defined(CNL_DBG_LSTRIDE0) || defined(CNL_DF_NOFENCE) || \
-    defined(CNL_STAMPS) || (defined(CNL_QUICK_DIV) && CNL_QUICK_DIV)
+    defined(CNL_STAMPS) || (defined(CNL_QUICK_DIV) && CNL_QUICK_DIV) || defined(CNL_DBG_COALJ)
 #ifndef CNL_EXPERIMENT
 #error "timing probes / diagnostic builds need -DCNL_EXPERIMENT=1 (cnl_version() then reports an experimental library)"
 #endif
@@ -680,6 +680,15 @@ __device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_pro
     if (nv_ + 16 < nr_) prr[1] = GATHER_R(src_[PVR + 1]); else prr[1] = 0.0;           \
   }
 
+// timing probe (results wrong): the Jacobian operands of the row form read 16 CONSECUTIVE doubles per problem and instruction (from
+// row 0's first operand on: the same 5 x 16 doubles a front of 16 band rows owns) instead of one operand of each row (lane stride
+// = row length) — what do the vector-memory pipeline's extra line look-ups of the strided form cost?  1: forward, 2: backward, 3: both
+// (round 4: nothing — 7.97 against 8.06 ms — although a strided gather costs a CU 58 cycles against 17, tools/vmem_bench.hip)
+#ifdef CNL_DBG_COALJ
+#define ROWJ_SRC(BIT, RECP, ROFF, J, SRCJ) ((CNL_DBG_COALJ & (BIT)) ? (((RECP) + (ROFF))[16] + 16 * (J) + l) : (SRCJ))
+#else
+#define ROWJ_SRC(BIT, RECP, ROFF, J, SRCJ) (SRCJ)
+#endif
 // Row form of the condensation products (plan.h, RF_ROWS): lane l takes residual row l of the front.  Seven gathers without a
 // guard: the row's pivot (kept in pvr[ROWS_KM]), its ROWS_KM Jacobian operands (pvr[0 ..]) and its right-hand-side entry.
 static_assert(PVR == ROWS_KM + 1, "the raw-value prefetch registers double as the row operands");
@@ -689,7 +698,7 @@ static_assert(PVR == ROWS_KM + 1, "the raw-value prefetch registers double as th
     int src_[ROWS_KM + 2];                                                             \
     _Pragma("unroll") for (int j = 0; j < ROWS_KM + 2; j++) src_[j] = sp_[j * 16];     \
     pvr[ROWS_KM] = GATHER_V(src_[0]);                                                  \
-    _Pragma("unroll") for (int j = 0; j < ROWS_KM; j++) pvr[j] = GATHER_V(src_[1 + j]); \
+    _Pragma("unroll") for (int j = 0; j < ROWS_KM; j++) pvr[j] = GATHER_V(ROWJ_SRC(1, RECP, ROFF, j, src_[1 + j])); \
     prr[0] = GATHER_R(src_[ROWS_KM + 1]);                                              \
     prr[1] = 0.0;                                                                      \
   }
@@ -703,7 +712,8 @@ static_assert(PVR == ROWS_KM + 1, "the raw-value prefetch registers double as th
     int src_[ROWS_KM + 3];                                                             \
     _Pragma("unroll") for (int j = 0; j < ROWS_KM + 3; j++) src_[j] = (ON) ? sp_[j * 16] : 0; \
     if (!(ON)) { src_[ROWS_KM + 1] = P.nnz; src_[ROWS_KM + 2] = 0x11111; }             \
-    _Pragma("unroll") for (int j = 0; j < ROWS_KM + 1; j++) DST[j] = GATHER_V(src_[j]); \
+    DST[0] = GATHER_V(src_[0]);                                                        \
+    _Pragma("unroll") for (int j = 1; j < ROWS_KM + 1; j++) DST[j] = GATHER_V(ROWJ_SRC(2, RECP, ROFF, j - 1, src_[j])); \
     DST[ROWS_KM + 1] = GATHER_R(src_[ROWS_KM + 1]);                                    \
     IXW = src_[ROWS_KM + 2];                                                           \
     RSRC = src_[ROWS_KM + 1] - P.nnz;                                                  \
