@@ -355,7 +355,9 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
     BASELINE config 2 on the dense backend, and the vectors either side of the system (row f1)."""
     # ---- small batches of the same pattern: handles planned for latency (staged execution of the elimination tree)
     sb = {}
-    for bs in (4096, 1024, 256, 1):   # two large parts (the bidirectional chain), many large parts, and the bushy tree
+    # 4608: the chain's 4096 + a remainder of 512 on a handle of its own (cnl_options.split_tail); then two large parts (the
+    # bidirectional chain), many large parts, and the bushy tree
+    for bs in (4608, 4096, 1024, 256, 1):
         if bs > B:
             continue
         p2 = DeviceProblem(torch, hipldl, s, rows, cols, vals[:bs], rhs[:bs], bs, local_rank, stream)
@@ -364,6 +366,8 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
         sb[f"B{bs}"] = {"systems_per_s": bs / (ms * 1e-3), "ms_per_call": ms, "ordering": p2.L.info["order"], "kernel": p2.L.config["kernel"],
                         "fronts": p2.L.info["nsuper"], "all_success": bool((p2.succ == 1).all().item()),
                         "backward_error": backward_error(s, rows, cols, vals_h[0], rhs_h[0], dh[0])}
+        if p2.L.config["tail"]:
+            sb[f"B{bs}"]["remainder_handle"] = True
         p2.close()
     out["small_batch"] = sb
     # ---- PCIe-inclusive: cnl_newton_system with HOST pointers (what the Julia glue calls): H2D of vals/rhs, the step, D2H of d

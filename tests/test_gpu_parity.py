@@ -1027,6 +1027,46 @@ def test_split_tail_remainder_on_its_own_plan(built, nA, kernel, order):
             assert backward_error(s, vv, rhs[b], a[5][b]) <= BWD_TOL
 
 
+@pytest.mark.parametrize("B", [4097, 8193, 8192 + 4096 + 3])
+def test_split_tail_odd_remainders(built, B):
+    """Remainders that are not multiples of four problems (a wavefront serves four): one problem behind a full load of the single
+    stream (its handle runs the single-system dataflow plan), one behind the chain's 4096, and a remainder that is itself split
+    (4099 problems behind 8192: the remainder handle owns a remainder handle).  Host-pointer newton_system (chunked), every decision
+    and a sample of solutions against the oracle; a ladder climber sits in the last problem."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(240, 4)
+    rows, cols = s.kkt_pattern()
+    v8, r8 = syn.batch_values(s, 8, cfg=3)
+    rng = np.random.default_rng(B)
+    vals = np.tile(v8, (B // 8 + 1, 1))[:B] * (1.0 + 1e-3 * rng.standard_normal((B, 1)))
+    rhs = np.tile(r8, (B // 8 + 1, 1))[:B] + 1e-3 * np.arange(B)[:, None]
+    off = s.offsets()
+    vals[:, off[4]:off[5]] = -1.0
+    hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
+    dg = off[0] + np.nonzero(hF_r == hF_c)[0]
+    vals[B - 1, dg[:40]] = -40.0
+    p = hipldl.default_params()
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    if B > 8192:
+        assert L.config["tail"] and L.config["kernel"] == "v2"
+    v = vals.copy()
+    d = np.full((B, s.N), 7.0)
+    d, ok, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, np.zeros(B), p)
+    assert ok.all() and nf[B - 1] > 1 and (nf[:B - 1] == 1).all()
+    d2 = np.zeros((B, s.N))
+    hipldl.solve_ldl_(2.0 * rhs, L.factor, d2)
+    orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
+    po = O.default_params()
+    for b in sorted({0, 4095, 4096, 4097 % B, 8191 % B, 8192 % B, B - 2, B - 1}):
+        vv = vals[b].copy()
+        d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs[b], vv, 0.0, po)
+        assert ok0 and (nf0, rho0, ro0) == (int(nf[b]), float(rho[b]), float(ro[b])), b
+        assert np.array_equal(v[b, -s.nvar:], vv[-s.nvar:])
+        assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+        assert np.abs(d2[b] - 2.0 * d0).max() <= FWD_TOL * 2.0 * np.abs(d0).max()
+    L.close()
+
+
 def test_host_pointer_call_pipelined_in_chunks(built):
     """cnl_newton_system with host pointers on a batch above 96 MB runs chunk by chunk (upload of chunk c + 1, compute of chunk c
     and download of chunk c - 1 overlap; csrc/capi.cpp, newton_system_pipelined).  Every output must equal the device-resident
