@@ -695,12 +695,15 @@ int ensure_staging(cnl_handle* h) {
   if ((rc = dalloc(h, &h->d_vals, (size_t)h->batch * P.nnz))) return rc;
   if ((rc = dalloc(h, &h->d_rhs, (size_t)h->batch * P.N))) return rc;
   if ((rc = dalloc(h, &h->d_d, (size_t)h->batch * P.N))) return rc;
-  if ((rc = dalloc(h, &h->d_rho_old, (size_t)h->batch))) return rc;
-  if ((rc = dalloc(h, &h->d_rho, (size_t)h->batch))) return rc;
-  if ((rc = dalloc(h, &h->d_nfact, (size_t)h->batch))) return rc;
-  if ((rc = dalloc(h, &h->d_success, (size_t)h->batch))) return rc;
-  if ((rc = dalloc(h, &h->d_npos, (size_t)h->batch * 2 + 64))) return rc;
-  if ((rc = dalloc(h, &h->d_nzero, (size_t)h->batch))) return rc;
+  // the per-problem results of a call in ONE block, [rho | rho_old | nfact | success] and [npos | nzero]: a small host-pointer
+  // call brings each group back with one copy (every copy of a few bytes is a transfer of its own on the stream: ~8 us)
+  const size_t B = (size_t)h->batch;
+  if ((rc = dalloc(h, &h->d_rho, 3 * B + 8))) return rc;
+  h->d_rho_old = h->d_rho + B;
+  h->d_nfact = reinterpret_cast<int32_t*>(h->d_rho_old + B);
+  h->d_success = h->d_nfact + B;
+  if ((rc = dalloc(h, &h->d_npos, B * 2 + 64))) return rc;   // (+ 64: the phase stamps of diagnostic builds land here)
+  h->d_nzero = h->d_npos + B;
   return CNL_OK;
 }
 
@@ -1447,10 +1450,24 @@ int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* su
   a.params[0] = eig_tol;
   if ((rc = run(h, a, h->d_vals, nullptr, nullptr, h->stream))) return rc;
   h->last_vals = h->d_vals;
-  HIPCHK(hipMemcpyAsync(success, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-  if (npos) HIPCHK(hipMemcpyAsync(npos, h->d_npos, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-  if (nzero) HIPCHK(hipMemcpyAsync(nzero, h->d_nzero, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  {
+    // results through the handle's pinned block: asynchronous copies (a copy into pageable memory blocks, one after the other),
+    // the inertia counts with one copy (npos | nzero are one block on the device, ensure_staging), a single synchronisation
+    const size_t o_su = 0, o_np = (B * 4 + 7) & ~(size_t)7, total = o_np + B * 16;
+    if (!h->pin || h->pin_bytes < total) {
+      if (h->pin) (void)hipHostFree(h->pin);
+      h->pin = nullptr;
+      HIPCHK(hipHostMalloc(&h->pin, total, hipHostMallocDefault));
+      h->pin_bytes = total;
+    }
+    char* pb = static_cast<char*>(h->pin);
+    HIPCHK(hipMemcpyAsync(pb + o_su, h->d_success, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (npos || nzero) HIPCHK(hipMemcpyAsync(pb + o_np, h->d_npos, B * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::memcpy(success, pb + o_su, B * sizeof(int32_t));
+    if (npos) std::memcpy(npos, pb + o_np, B * sizeof(int64_t));
+    if (nzero) std::memcpy(nzero, pb + o_np + B * 8, B * sizeof(int64_t));
+  }
   h->factorized = true;
   h->last_ok.assign(success, success + B);
   return CNL_OK;
@@ -1798,10 +1815,9 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     // (the rho slots come back only where a ladder wrote them: nfact > 1 — known after the first synchronisation; copying them
     //  on every call cost the common one-system call 40 us of its 0.24 ms)
     bool tail_valid = false;
-    HIPCHK(hipMemcpyAsync(pb + o_rho, h->d_rho, B * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(pb + o_ro, h->d_rho_old, B * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(pb + o_nf, h->d_nfact, B * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(pb + o_su, h->d_success, B * 4, hipMemcpyDeviceToHost, h->stream));
+    // rho, rho_old, nfact, success: one block on both sides (ensure_staging), one copy
+    static_assert(sizeof(double) == 8 && sizeof(int32_t) == 4, "layout of the result block");
+    HIPCHK(hipMemcpyAsync(pb + o_rho, h->d_rho, B * 24, hipMemcpyDeviceToHost, h->stream));
     int32_t* up_status = reinterpret_cast<int32_t*>(pb + o_up + B * 12);
     *up_status = 0;
     // per-call status of the dataflow execution (kernels2.hip, spin_until): waits that gave up.  Only calls that ran in dataflow
