@@ -11,7 +11,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, program, args...
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${name}_stats -o p -- python3 "$@" > $out/${tag}_${name}_stats.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${name}_stats -o p -- python3 "$@" > $out/${tag}_${name}_stats.log 2>&1
 }
 B="$root/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-extras"
 run staged_B256 $B --batch 256
