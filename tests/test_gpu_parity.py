@@ -1205,6 +1205,47 @@ def test_multi_device_handle_shards_one_caller(built):
     M2.close()
 
 
+def test_multi_device_shards_with_remainder_handles(built):
+    """Two shards of 8200 problems each (device list [0, 0]): every shard is a full load of the single stream plus 8 problems on a
+    remainder handle of its own (cnl_options.split_tail), its host thread drives both.  Results of the two-call sequence and of
+    newton_system against a sample from the oracle, a ladder climber in each shard's remainder."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(120, 3)
+    rows, cols = s.kkt_pattern()
+    B = 16400
+    v8, r8 = syn.batch_values(s, 8, cfg=3)
+    rng = np.random.default_rng(21)
+    vals = np.tile(v8, (B // 8, 1)) * (1.0 + 1e-3 * rng.standard_normal((B, 1)))
+    rhs = np.tile(r8, (B // 8, 1)) + 1e-3 * np.arange(B)[:, None]
+    off = s.offsets()
+    vals[:, off[4]:off[5]] = -1.0
+    hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
+    dg = off[0] + np.nonzero(hF_r == hF_c)[0]
+    climbers = [8195, 16399]
+    for b in climbers:
+        vals[b, dg[:30]] = -40.0
+    p = hipldl.default_params()
+    M = hipldl.MultiHIPLDLStruct(s.N, rows, cols, s.nvar, s.nequ, s.ncon, B, [0, 0])
+    assert [(a, c) for a, c, _ in M.shards] == [(0, 8200), (8200, 8200)]
+    v = vals.copy()
+    d, ok, rho, ro, nf = M.newton_system_(np.full((B, s.N), 7.0), rhs, v, np.zeros(B), p)
+    assert ok.all() and (nf[climbers] > 1).all() and (np.delete(nf, climbers) == 1).all()
+    okf = M.try_to_factorize(v, p[0])        # the rho slots as the ladder left them: every factorisation succeeds
+    assert okf.all()
+    d2 = np.zeros((B, s.N))
+    M.solve_ldl_(rhs, d2)
+    M.close()
+    orc = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
+    po = O.default_params()
+    for b in [0, 8191, 8192, 8199, 8200, 16391, 16392] + climbers:
+        vv = vals[b].copy()
+        d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs[b], vv, 0.0, po)
+        assert ok0 and (nf0, rho0, ro0) == (int(nf[b]), float(rho[b]), float(ro[b])), b
+        assert np.array_equal(v[b, -s.nvar:], vv[-s.nvar:])
+        assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+        assert np.abs(d2[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+
+
 def test_failed_problems_leave_d_untouched(built):
     """newton_system! solves only after a successful factorisation (src/CaNNOLeS.jl:1049): the caller's d of a problem whose
     ladder runs out (rho > rho_max) is left as it was, through the host-pointer call."""
