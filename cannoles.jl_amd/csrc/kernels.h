@@ -160,6 +160,7 @@ hipError_t launch_trial_point(const DevJt& J, const double* x, const double* r, 
                               double max_dlambda, double* xt, double* rt, double* lambdat, double* dlambda, int batch,
                               hipStream_t stream);
 hipError_t launch_fill_rho(double* vals, long long nnz, int nvar, const double* rho, const int* active, int batch, hipStream_t stream);
+hipError_t launch_lds_fill(int pattern, hipStream_t stream);   // debugging aid, see kernels_aux.hip
 hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, const double* d2, const double* cbuf, double* dout,
                          const int* success, int copy_rho_tail, int batch, hipStream_t stream);
 // largest dynamic LDS a workgroup may use on the current device

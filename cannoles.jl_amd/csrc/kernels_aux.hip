@@ -630,6 +630,39 @@ __global__ void __launch_bounds__(256) fill_rho_kernel(double* __restrict__ vals
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nvar; i += gridDim.x * 256) t[i] = r;
   }
 }
+// debugging aid (capi.cpp, env CNL_DBG_LDSFILL): leaves a byte pattern in the LDS of every CU, so that a kernel that reads LDS it
+// has not written — whatever the previous kernel left there — fails reproducibly instead of depending on the process's history
+__global__ void __launch_bounds__(256) lds_fill_kernel(int pattern, int* sink) {
+  extern __shared__ int lds_fill_buf[];
+  const int n = 40 * 1024 / 4;
+  for (int i = threadIdx.x; i < n; i += 256) lds_fill_buf[i] = pattern;
+  __syncthreads();
+  if (sink && lds_fill_buf[(threadIdx.x * 37) % n] == 12345) sink[0] = 1;
+}
+// the same for private (scratch) memory: spilled registers and out-of-line frames of the kernels that use scratch start from
+// whatever the previous scratch user left
+__global__ void __launch_bounds__(256) scratch_fill_kernel(int pattern, int n, int* sink) {
+  volatile int a[640];
+  for (int i = 0; i < 640; i++) a[i] = pattern;
+  int acc = 0;
+  for (int i = 0; i < n; i++) acc += a[(i * 37 + threadIdx.x) % 640];
+  if (sink && acc == 12345) sink[0] = acc;
+}
+// ... and for the vector registers (a wavefront starts with whatever the previous owner of its registers left in them)
+__global__ void __launch_bounds__(256) vgpr_fill_kernel(int pattern) {
+  asm volatile(".irp r,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71,72,73,74,75,76,77,78,79,80,81,82,83,84,85,86,87,88,89,90,91,92,93,94,95,96,97,98,99,100,101,102,103,104,105,106,107,108,109,110,111,112,113,114,115,116,117,118,119,120,121,122,123,124,125,126,127,128,129,130,131,132,133,134,135,136,137,138,139,140,141,142,143,144,145,146,147,148,149,150,151,152,153,154,155,156,157,158,159,160,161,162,163,164,165,166,167,168,169,170,171,172,173,174,175,176,177,178,179,180,181,182,183,184,185,186,187,188,189,190,191,192,193,194,195,196,197,198,199,200,201,202,203,204,205,206,207,208,209,210,211,212,213,214,215,216,217,218,219,220,221,222,223,224,225,226,227,228,229,230,231,232,233,234,235,236,237,238,239,240,241,242,243,244,245,246,247,248,249,250,251,252,253,254,255\n v_mov_b32 v\\r, %0\n .endr" :: "v"(pattern) : "memory", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+}
+hipError_t launch_lds_fill(int pattern, hipStream_t stream) {
+  if (getenv("CNL_DBG_SCRATCHFILL")) {
+    hipLaunchKernelGGL(scratch_fill_kernel, dim3(256 * 8), dim3(256), 0, stream, pattern, 0, (int*)nullptr);
+    hipLaunchKernelGGL(vgpr_fill_kernel, dim3(256 * 8), dim3(256), 0, stream, pattern);
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lds_fill_kernel, dim3(256 * 16), dim3(256), 40 * 1024, stream, pattern, (int*)nullptr);   // four workgroups of 40 KB per CU, several rounds
+  return hipGetLastError();
+}
+
 hipError_t launch_fill_rho(double* vals, long long nnz, int nvar, const double* rho, const int* active, int batch, hipStream_t stream) {
   if (nvar <= 0 || batch <= 0) return hipSuccess;
   hipLaunchKernelGGL(fill_rho_kernel, dim3(std::min(64, (nvar + 255) / 256), std::min(batch, 65535)), dim3(256), 0, stream, vals, nnz, nvar, rho, active, batch);

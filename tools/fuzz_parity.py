@@ -1,0 +1,94 @@
+"""Randomised parity run (GPU box; not part of the test-suite): many small irregular and band structures, batch sizes that are
+not multiples of four, both plan kinds, positive-definite and indefinite top-left blocks (the latter climb the rho ladder) — the
+host-pointer newton_system!, then try_to_factorize + solve_ldl! with the rho the ladder left, against the oracle on the order
+SURVEY 8d prices (oracle.canonical_perm), i.e. an order the product had no part in.  Decisions bit for bit, d to 1e-8.
+usage: fuzz_parity.py [cases] [first seed]      prints one line per failure and a summary; exit code 1 on any failure"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cannoles_jl_amd  # noqa: F401,E402
+from cannoles_jl_amd import hipldl, synthetic as syn  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+p = hipldl.default_params()
+po = O.default_params()
+# FUZZ_OPTS="device_ladder=0,dataflow=0": cnl_options fields applied to every case (bisecting a failure)
+extra = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("FUZZ_OPTS", "").split(",") if kv)}
+fails = 0
+kinds = {}
+for case in range(ncases):
+    seed = seed0 + case
+    rng = np.random.default_rng(100000 + seed)
+    fam = rng.integers(3)
+    if fam == 0:
+        n = int(rng.integers(6, 120)); m = int(rng.integers(max(2, n // 2), 2 * n)); pc = int(rng.integers(0, min(6, n // 2) + 1))
+        s = syn.random_structure(n, m, pc, float(rng.uniform(0.03, 0.3)), seed, hess=bool(rng.integers(4)))
+    elif fam == 1:
+        pc = int(rng.integers(0, 5)); blocks = int(rng.integers(8, 60)); n = (pc if pc else 1) * blocks
+        s = syn.band_structure(n, pc, hw=int(rng.integers(1, 4)))
+    else:
+        n = int(rng.integers(130, 400)); m = int(rng.integers(n, n + 60)); pc = int(rng.integers(0, 4))
+        s = syn.random_structure(n, m, pc, float(rng.uniform(0.01, 0.04)), seed)
+    B = int(rng.choice([1, 2, 3, 5, 7, 17, 33, 64]))
+    posdef = bool(rng.integers(3))
+    if fam == 1:
+        vals, rhs = syn.batch_values(s, B, cfg=seed % 7, stress=None if posdef else "ladder")
+    else:
+        vals = np.empty((B, s.nnzNS)); rhs = np.empty((B, s.N))
+        for b in range(B):
+            vals[b], rhs[b] = syn.random_values(s, 7000 * seed + b, posdef=posdef or bool(rng.integers(2)))
+    ro_in = np.where(rng.uniform(size=B) < 0.3, 10.0 ** rng.uniform(-6, -1, B), 0.0)
+    rows, cols = s.kkt_pattern()
+    kind = [hipldl.PLAN_AUTO, hipldl.PLAN_THROUGHPUT, hipldl.PLAN_LATENCY][int(rng.integers(3))]
+    tag = f"case {seed} fam {fam} n {s.nvar} m {s.nequ} p {s.ncon} B {B} kind {kind} posdef {posdef}"
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("RUN", tag, flush=True)
+    try:
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(plan_kind=kind, **extra))
+        kinds[L.config["kernel"]] = kinds.get(L.config["kernel"], 0) + 1
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("   ", L.config["kernel"], L.info["order"], flush=True)
+        v = vals.copy()
+        d = np.full((B, s.N), 7.0)
+        d, ok, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, ro_in if B > 1 else float(ro_in[0]), p)
+        ok, rho, ro, nf = (np.atleast_1d(np.asarray(x)) for x in (ok, rho, ro, nf))
+        d = np.asarray(d).reshape(B, s.N)
+        orc = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
+        v0 = vals.copy()
+        d0, ok0, rho0, ro0, nf0 = O.newton_system_batch(orc, B, s.nvar, s.nequ, s.ncon, rhs, v0, ro_in, po)
+        bad = []
+        if not (np.array_equal(ok.astype(bool), np.atleast_1d(ok0).astype(bool)) and np.array_equal(nf, np.atleast_1d(nf0))
+                and np.array_equal(rho, np.atleast_1d(rho0)) and np.array_equal(ro, np.atleast_1d(ro0))):
+            bad.append("decisions")
+        if not np.array_equal(v.reshape(B, -1)[:, -s.nvar:], v0[:, -s.nvar:], equal_nan=True):
+            bad.append("rho slots")
+        for b in range(B):
+            if np.atleast_1d(ok0)[b]:
+                if not np.abs(d[b] - d0[b]).max() <= 1e-8 * max(1e-300, np.abs(d0[b]).max()):
+                    bad.append(f"d[{b}] rel {np.abs(d[b] - d0[b]).max() / np.abs(d0[b]).max():.2e}")
+            elif not (d[b] == 7.0).all():
+                bad.append(f"d[{b}] touched")
+        # the two-call sequence with the rho the ladder left
+        okf = np.atleast_1d(hipldl.try_to_factorize(L, v, s.nvar, s.nequ, s.ncon, p[0]))
+        if not np.array_equal(okf.astype(bool), np.atleast_1d(ok0).astype(bool)):
+            bad.append("try_to_factorize with the final rho")
+        elif okf.all():
+            d2 = np.zeros((B, s.N))
+            hipldl.solve_ldl_(2.0 * rhs, L.factor, d2)
+            for b in range(B):
+                if not np.abs(d2[b] - 2.0 * d0[b]).max() <= 2e-8 * max(1e-300, np.abs(d0[b]).max()):
+                    bad.append(f"solve d[{b}]")
+        L.close()
+        if bad:
+            fails += 1
+            print("FAIL", tag, bad[:4], flush=True)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print("ERROR", tag, repr(e)[:300], flush=True)
+print(f"{ncases} cases, {fails} failures, kernels {kinds}", flush=True)
+sys.exit(1 if fails else 0)
