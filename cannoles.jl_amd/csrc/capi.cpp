@@ -245,7 +245,7 @@ int setup_v2(cnl_handle* h) {
   }
   // the kernel addresses vals / rhs / L of the 4 problems of a wave with 32-bit byte offsets from the first one
   if (4 * 8 * (uint64_t)std::max<int64_t>({d.lsize, d.vstride, d.rstride, d.dstride, (int64_t)d.nnz + d.N0}) >= (1ull << 32)) return CNL_OK;
-  const size_t wave_bytes = ((size_t)(d.recwords >> 1) + 4 * (size_t)d.prob_doubles + 8) * sizeof(double);
+  const size_t wave_bytes = ((size_t)(d.recwords >> 1) + 4 * (size_t)d.prob_doubles + 16) * sizeof(double);   // + 16: counters, flags, slow_front's scalars (kernels2.hip)
   size_t maxlds = std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024);
   if (wave_bytes + 512 > maxlds) return CNL_OK;  // does not fit: stay on v1
   // waves per workgroup: small workgroups give the dispatcher freedom; 2 keeps the launch grid moderate

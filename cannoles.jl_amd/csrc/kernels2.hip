@@ -489,14 +489,19 @@ struct SlowArgs {  // the few plan scalars the out-of-line path needs (passed by
   long long gs_doubles, lsize, vstride, rstride;
   const int* rec;
 };
-__device__ __attribute__((noinline)) void slow_front(const int* prec_, int P_prob_doubles, int P_u2_peak, int P_nnz, int P_rho_begin,
-                                                     long long P_gs_doubles, long long P_lsize, long long P_vstride, long long P_rstride,
+// (round 4: the eight plan scalars come through the wavefront's LDS block — SLOW_ARGS_AT, written once per kernel — so that every
+//  argument of the call travels in registers: with 25 parameters seven dwords went over the stack)
+constexpr int SLOW_ARGS_AT = 16;   // ints behind `cnt`: eight 64-bit slots
+__device__ __attribute__((noinline)) void slow_front(const int* prec_,
                                                      const double* vals_, const double* rhs_, double* L_,
                                                      double* gs_, int batch, int lane, int prob0, const int* rec, int roff,
                                                      double* pbase0, int* cnt, double eig_tol, double rho, bool ovr, bool count_d) {
   SlowArgs P;
-  P.prob_doubles = P_prob_doubles; P.u2_peak = P_u2_peak; P.nnz = P_nnz; P.rho_begin = P_rho_begin;
-  P.gs_doubles = P_gs_doubles; P.lsize = P_lsize; P.vstride = P_vstride; P.rstride = P_rstride; P.rec = prec_;
+  {
+    const long long* ps = reinterpret_cast<const long long*>(cnt + SLOW_ARGS_AT);
+    P.prob_doubles = (int)rfl((int)ps[0]); P.u2_peak = (int)rfl((int)ps[1]); P.nnz = (int)rfl((int)ps[2]); P.rho_begin = (int)rfl((int)ps[3]);
+    P.gs_doubles = ps[4]; P.lsize = ps[5]; P.vstride = ps[6]; P.rstride = ps[7]; P.rec = prec_;
+  }
   const double* vals = as_global(vals_);
   const double* rhsb = as_global(rhs_);
   double* Lb = as_global(L_);
@@ -877,7 +882,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   const bool inb = prob < A.batch;
   const long long pclamp = inb ? prob : prob0;
 
-  const int wave_doubles = (P.recwords >> 1) + 4 * P.prob_doubles + 8;
+  const int wave_doubles = (P.recwords >> 1) + 4 * P.prob_doubles + 16;
   double* wbase = smem + wave * wave_doubles;
   int* recbuf = reinterpret_cast<int*>(wbase);  // forward: one record of up to reccap words; backward: two of breccap
   double* pbase0 = wbase + (P.recwords >> 1);
@@ -885,6 +890,14 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   double* myU = pbase0 + g * P.prob_doubles;
   double* myFs = myU + P.u2_peak;
   double* jraw = myU + P.jraw_off;  // raw values of the current front's products (reciprocal pivots first)
+  if constexpr (!LEAN) {   // plan scalars of the out-of-line path (slow_front)
+    if (lane == 0) {
+      long long* ps = reinterpret_cast<long long*>(cnt + SLOW_ARGS_AT);
+      ps[0] = P.prob_doubles; ps[1] = P.u2_peak; ps[2] = P.nnz; ps[3] = P.rho_begin;
+      ps[4] = P.gs_doubles; ps[5] = P.lsize; ps[6] = P.vstride; ps[7] = P.rstride;
+    }
+    wsync();
+  }
 
   Ctx2 c;
   c.vals = A.vals; c.rhs = A.rhs; c.L = A.L; c.gs = A.scratch; c.dout = A.d; c.batch = A.batch;
@@ -1152,7 +1165,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         if (!CNL_LEAN && !fast0) {
           // rare: large or globally staged front, handled out of line
           if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }
-          if (!(CNL_ABL & 2048)) slow_front(P.rec, P.prob_doubles, P.u2_peak, P.nnz, P.rho_begin, P.gs_doubles, P.lsize, P.vstride, P.rstride, A.vals, has_rhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, recw, roff, pbase0, cnt, eig_tol, rho, ovr, P.count_d != 0);
+          if (!(CNL_ABL & 2048)) slow_front(P.rec, A.vals, has_rhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, recw, roff, pbase0, cnt, eig_tol, rho, ovr, P.count_d != 0);
           gsync();
           roff = nxt_off;
           s++;

@@ -5,6 +5,8 @@ Tolerances (fp64, stated per SURVEY.md §7 "Hard parts"):
   * backward: max|K d + rhs| / (||K||_inf max|d| + max|rhs|) <= 1e-13
   * (success, nfact, rho, rho_old) identical to the oracle's.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1244,6 +1246,25 @@ def test_multi_device_shards_with_remainder_handles(built):
         assert np.array_equal(v[b, -s.nvar:], vv[-s.nvar:])
         assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
         assert np.abs(d2[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+
+
+@pytest.mark.parametrize("fill", [None, "0x3f800001", "0xffffffff"])
+def test_randomised_parity_is_independent_of_what_earlier_kernels_left(built, fill):
+    """tools/fuzz_parity.py (120 small irregular and band structures, batches that are not multiples of four, every plan kind, ladder
+    climbers; every decision bit for bit and d to 1e-8 against the oracle on an order the product had no part in) — in a process
+    of its own, once as it is and twice with every launch preceded by kernels that leave a byte pattern in the LDS, the scratch
+    memory and the vector registers of the device (CNL_DBG_SCRATCHFILL / CNL_DBG_LDSFILL).  Round 4: the staged instantiations with
+    out-of-line front classes took decisions that depended on the scratch contents of earlier kernels — invisible to a test-suite
+    whose processes start with zeroed scratch."""
+    import subprocess, sys
+    env = dict(os.environ)
+    if fill:
+        env.update(CNL_DBG_SCRATCHFILL="1", CNL_DBG_LDSFILL=fill)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "0" if fill != "0xffffffff" else "300"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "120 cases, 0 failures" in r.stdout
 
 
 def test_failed_problems_leave_d_untouched(built):
