@@ -1248,8 +1248,8 @@ def test_multi_device_shards_with_remainder_handles(built):
         assert np.abs(d2[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
 
 
-@pytest.mark.parametrize("fill", [None, "0x3f800001", "0xffffffff"])
-def test_randomised_parity_is_independent_of_what_earlier_kernels_left(built, fill):
+@pytest.mark.parametrize("fill,wide,seed0", [(None, False, 0), ("0x3f800001", False, 0), ("0xffffffff", False, 300), ("0x3f800001", True, 9000)])
+def test_randomised_parity_is_independent_of_what_earlier_kernels_left(built, fill, wide, seed0):
     """tools/fuzz_parity.py (120 small irregular and band structures, batches that are not multiples of four, every plan kind, ladder
     climbers; every decision bit for bit and d to 1e-8 against the oracle on an order the product had no part in) — in a process
     of its own, once as it is and twice with every launch preceded by kernels that leave a byte pattern in the LDS, the scratch
@@ -1260,8 +1260,10 @@ def test_randomised_parity_is_independent_of_what_earlier_kernels_left(built, fi
     env = dict(os.environ)
     if fill:
         env.update(CNL_DBG_SCRATCHFILL="1", CNL_DBG_LDSFILL=fill)
+    if wide:   # + the dense-Jacobian family, band batches up to 1023, batches just above a small staged_max_batch (split / remainder
+        env.update(FUZZ_WIDE="1")   # handle), random execution switches
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "0" if fill != "0xffffffff" else "300"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", str(seed0)],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "120 cases, 0 failures" in r.stdout

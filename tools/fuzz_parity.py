@@ -24,8 +24,17 @@ kinds = {}
 for case in range(ncases):
     seed = seed0 + case
     rng = np.random.default_rng(100000 + seed)
-    fam = rng.integers(3)
-    if fam == 0:
+    fam = rng.integers(3) if not os.environ.get("FUZZ_WIDE") else rng.integers(6)
+    if fam == 3:     # dense Jacobian (BASELINE config 2's shape, small): the dense backend with its device-side ladder
+        n = int(rng.integers(20, 150)); m = int(rng.integers(n, 2 * n + 1))
+        s = syn.dense_structure(n, m)
+    elif fam == 5:   # a batch just above a (small) staged_max_batch: the chain + a remainder handle, or two halves (capi.cpp, run_split)
+        pc = int(rng.integers(1, 4)); blocks = int(rng.integers(30, 80)); n = pc * blocks
+        s = syn.band_structure(n, pc, hw=2)
+    elif fam == 4:   # band family at larger batches: staged plans with many groups of problems, the in-kernel ladder over several groups
+        pc = int(rng.integers(1, 6)); blocks = int(rng.integers(20, 80)); n = pc * blocks
+        s = syn.band_structure(n, pc, hw=int(rng.integers(1, 3)))
+    elif fam == 0:
         n = int(rng.integers(6, 120)); m = int(rng.integers(max(2, n // 2), 2 * n)); pc = int(rng.integers(0, min(6, n // 2) + 1))
         s = syn.random_structure(n, m, pc, float(rng.uniform(0.03, 0.3)), seed, hess=bool(rng.integers(4)))
     elif fam == 1:
@@ -35,9 +44,30 @@ for case in range(ncases):
         n = int(rng.integers(130, 400)); m = int(rng.integers(n, n + 60)); pc = int(rng.integers(0, 4))
         s = syn.random_structure(n, m, pc, float(rng.uniform(0.01, 0.04)), seed)
     B = int(rng.choice([1, 2, 3, 5, 7, 17, 33, 64]))
+    if fam == 4:
+        B = int(rng.choice([66, 130, 257, 514, 1023]))
+    smb = 0
+    if fam == 5:
+        smb = int(rng.choice([32, 64, 128]))
+        B = smb + int(rng.choice([1, 2, 3, 4, 5, 9, smb // 4, smb // 4 + 1, smb // 2, smb - 8]))
     posdef = bool(rng.integers(3))
-    if fam == 1:
+    if fam in (1, 4, 5):
         vals, rhs = syn.batch_values(s, B, cfg=seed % 7, stress=None if posdef else "ladder")
+        if fam in (4, 5) and not posdef:   # only some problems climb
+            vg, rg = syn.batch_values(s, B, cfg=3)
+            keep = rng.uniform(size=B) < 0.7
+            vals[keep], rhs[keep] = vg[keep], rg[keep]
+    elif fam == 3:
+        vals = np.empty((B, s.nnzNS)); rhs = np.empty((B, s.N))
+        for b in range(B):
+            vals[b], rhs[b] = syn.dense_values(s, 9000 * seed + b)
+        if not posdef:
+            off = s.offsets()
+            hr, hc_ = np.asarray(s.hF[0]), np.asarray(s.hF[1])
+            dgi = off[0] + np.nonzero(hr == hc_)[0]
+            for b in range(B):
+                if rng.integers(2):
+                    vals[b, dgi[: max(1, len(dgi) // 3)]] = -5.0
     else:
         vals = np.empty((B, s.nnzNS)); rhs = np.empty((B, s.N))
         for b in range(B):
@@ -45,14 +75,28 @@ for case in range(ncases):
     ro_in = np.where(rng.uniform(size=B) < 0.3, 10.0 ** rng.uniform(-6, -1, B), 0.0)
     rows, cols = s.kkt_pattern()
     kind = [hipldl.PLAN_AUTO, hipldl.PLAN_THROUGHPUT, hipldl.PLAN_LATENCY][int(rng.integers(3))]
-    tag = f"case {seed} fam {fam} n {s.nvar} m {s.nequ} p {s.ncon} B {B} kind {kind} posdef {posdef}"
+    ropt = {}
+    if fam == 5:
+        kind = hipldl.PLAN_AUTO
+        ropt["staged_max_batch"] = smb
+        if rng.integers(3) == 0:
+            ropt["split_tail"] = 0
+        if rng.integers(4) == 0:
+            ropt["split_batch"] = 2
+    if os.environ.get("FUZZ_WIDE"):   # random execution switches on top
+        for k, vs in (("dataflow", (1, 0)), ("band_form", (1, 0)), ("host_ladder", (1, 0)), ("device_ladder", (1, 0)), ("device_ladder_fused", (0, 1)),
+                      ("lean_kernel", (1, 0)), ("rows_in_backward", (1, 0)), ("row_products", (1, 0)), ("dense_graph", (1, 0))):
+            if rng.integers(4) == 0:
+                ropt[k] = vs[1]
+    tag = f"case {seed} fam {fam} n {s.nvar} m {s.nequ} p {s.ncon} B {B} kind {kind} posdef {posdef} {ropt}"
     if os.environ.get("FUZZ_VERBOSE"):
         print("RUN", tag, flush=True)
     try:
-        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(plan_kind=kind, **extra))
-        kinds[L.config["kernel"]] = kinds.get(L.config["kernel"], 0) + 1
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(plan_kind=kind, **{**ropt, **extra}))
+        kk = L.config["kernel"] + ("+tail" if L.config["tail"] else "") + ("+split" if fam == 5 and L.info["order"].startswith("ndc2") and not L.config["tail"] else "")
+        kinds[kk] = kinds.get(kk, 0) + 1
         if os.environ.get("FUZZ_VERBOSE"):
-            print("   ", L.config["kernel"], L.info["order"], flush=True)
+            print("   ", L.config["kernel"], L.info["order"], "tail" if L.config["tail"] else "", flush=True)
         v = vals.copy()
         d = np.full((B, s.N), 7.0)
         d, ok, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, ro_in if B > 1 else float(ro_in[0]), p)
