@@ -4,7 +4,7 @@ not multiples of anything), against the oracle's restatements —
   residual_vectors  bit for bit (rhs and both infinity norms, NaN included)
   prepare_newton_system  bit for bit (sign bits included)
   trial_point  xt / rt bit for bit, the capped multiplier step to 4e-15
-  cgls_multipliers  Jx'r bit for bit, the iteration count, lambda to 1e-9
+  cgls_multipliers  Jx'r bit for bit, the iteration count, lambda to 1e-8 of its largest component
 usage: fuzz_aux.py [cases] [first seed]      one line per failure and a summary; exit code 1 on any failure"""
 import os
 import sys
@@ -112,7 +112,7 @@ for case in range(ncases):
                     bad.append(f"cgls Jxtr[{b}]")
                 if its[b] != it0:
                     bad.append(f"cgls iterations[{b}] {its[b]} != {it0}")
-                elif not np.allclose(lam2[b], lam0, rtol=1e-9, atol=1e-11):
+                elif not np.abs(lam2[b] - lam0).max() <= 1e-8 * max(1e-300, np.abs(lam0).max()):   # (CGLS on the normal equations: cond^2 amplifies the rounding of a different summation order)
                     bad.append(f"cgls lambda[{b}]")
         L.close()
     except Exception as e:  # noqa: BLE001
