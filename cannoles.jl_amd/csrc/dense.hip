@@ -537,7 +537,13 @@ __device__ __forceinline__ void diag_own(Panel2Lds& P, double (&a)[16], int q, i
     DN_PIN(rrn);  // issued here, ahead of the deferred updates below
   }
   const double e = fma(-d, rr, 1.0);
-  const double r1 = fma(rr, e, rr);
+  double r1 = fma(rr, e, rr);
+  // The approximation a11 - w1 (w1 rr) loses what the subtraction cancels: a pivot 10^-6 times its two terms is known to 2^-25 x
+  // 10^6 = 3 % only, and one Newton step leaves the multipliers with an error of 10^-3 — enough to turn an inertia count (round 4,
+  // tools/fuzz_parity.py case 40828: a rank-deficient Gauss-Newton block regularised with rho = 1.7e-3, 92 positive pivots
+  // counted instead of 94 by try_to_factorize, while the ladder's own sequential refactorisation counted 94).  When the residual
+  // of the speculative reciprocal is not small, the reciprocal is formed from the exact pivot (wave-uniform branch, rare).
+  if (!(fabs(e) <= 0x1p-24)) r1 = recip(d);
   const double l = col * r1;
   const double nl = -l;
   if constexpr (JJ + 1 < 16) a[JJ + 1] = fma(w1, nl, a[JJ + 1]);
