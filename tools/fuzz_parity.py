@@ -26,7 +26,7 @@ for case in range(ncases):
     rng = np.random.default_rng(100000 + seed)
     fam = rng.integers(3) if not os.environ.get("FUZZ_WIDE") else rng.integers(6)
     if fam == 3:     # dense Jacobian (BASELINE config 2's shape, small): the dense backend with its device-side ladder
-        n = int(rng.integers(20, 150)); m = int(rng.integers(n, 2 * n + 1))
+        n = int(rng.integers(20, 150)); m = int(rng.integers(max(2, n // 2), 2 * n + 1))   # also fewer residuals than variables
         s = syn.dense_structure(n, m)
     elif fam == 5:   # a batch just above a (small) staged_max_batch: the chain + a remainder handle, or two halves (capi.cpp, run_split)
         pc = int(rng.integers(1, 4)); blocks = int(rng.integers(30, 80)); n = pc * blocks
@@ -72,6 +72,12 @@ for case in range(ncases):
         vals = np.empty((B, s.nnzNS)); rhs = np.empty((B, s.N))
         for b in range(B):
             vals[b], rhs[b] = syn.random_values(s, 7000 * seed + b, posdef=posdef or bool(rng.integers(2)))
+    if os.environ.get("FUZZ_WIDE") and rng.integers(3) == 0:   # badly scaled problems: every problem of the batch by its own power of ten
+        sc = 10.0 ** rng.integers(-5, 6, B)
+        off_ = s.offsets()
+        vals = vals * sc[:, None]
+        vals[:, off_[4]:off_[5]] = -1.0    # the -I block is not the caller's to scale (src/CaNNOLeS.jl:970)
+        rhs = rhs * sc[:, None]
     ro_in = np.where(rng.uniform(size=B) < 0.3, 10.0 ** rng.uniform(-6, -1, B), 0.0)
     rows, cols = s.kkt_pattern()
     kind = [hipldl.PLAN_AUTO, hipldl.PLAN_THROUGHPUT, hipldl.PLAN_LATENCY][int(rng.integers(3))]
