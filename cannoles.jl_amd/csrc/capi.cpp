@@ -543,6 +543,8 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
   const cnl::Cond& C = h->plan->C;
   int rc = CNL_OK;
   if (h->split_staged > 0 && !h->in_split && (h->staged || h->tail) && h->split_staged < h->batch) return run_split(h, a, d_vals, d_rhs, d_d, stream);
+  if (h->dense || h->gdense)
+    if (const char* pat = getenv("CNL_DBG_LDSFILL")) (void)cnl::launch_lds_fill((int)strtol(pat, nullptr, 0), stream);
   if (h->dense) {
     // dense residual block: J'WJ + tiled dense LDL^T on the fp64 matrix cores (csrc/dense.hip); asynchronous, the rho ladder
     // is decided on the device

@@ -20,6 +20,7 @@ po = O.default_params()
 # FUZZ_OPTS="device_ladder=0,dataflow=0": cnl_options fields applied to every case (bisecting a failure)
 extra = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("FUZZ_OPTS", "").split(",") if kv)}
 fails = 0
+subnoise = 0
 kinds = {}
 for case in range(ncases):
     seed = seed0 + case
@@ -114,13 +115,42 @@ for case in range(ncases):
         bad = []
         if not (np.array_equal(ok.astype(bool), np.atleast_1d(ok0).astype(bool)) and np.array_equal(nf, np.atleast_1d(nf0))
                 and np.array_equal(rho, np.atleast_1d(rho0)) and np.array_equal(ro, np.atleast_1d(ro0))):
+            # a first factorisation with a pivot below the rounding noise of the matrix has no determined inertia (DESIGN section 5,
+            # test_near_singular_sweep_decisions): such a problem may legitimately enter the ladder on one side and not on the other
+            ok0a, nf0a = np.atleast_1d(ok0), np.atleast_1d(nf0)
+            differ = [b for b in range(B) if (bool(ok[b]), int(nf[b]), float(rho[b]), float(ro[b])) !=
+                      (bool(ok0a[b]), int(nf0a[b]), float(np.atleast_1d(rho0)[b]), float(np.atleast_1d(ro0)[b]))]
+            noise = []
+            for b in differ:
+                if {int(nf[b]), int(nf0a[b])} == {1, 2} or 1 in (int(nf[b]), int(nf0a[b])):
+                    orc.try_to_factorize(vals[b].copy(), s.nvar, s.nequ, s.ncon, po[0])
+                    Dab = np.abs(orc.D)
+                    if Dab.min() <= 1e-11 * Dab.max():
+                        noise.append(b)
+            if len(noise) == len(differ):
+                subnoise += 1
+                L.close()
+                continue
             bad.append("decisions")
+            if os.environ.get("FUZZ_VERBOSE"):
+                print("    hip   ok", ok.astype(int), "nf", nf, "rho", rho, "ro", ro, flush=True)
+                print("    orcl  ok", np.atleast_1d(ok0).astype(int), "nf", np.atleast_1d(nf0), "rho", np.atleast_1d(rho0), "ro", np.atleast_1d(ro0), flush=True)
+                print("    rho_old in", ro_in, flush=True)
         if not np.array_equal(v.reshape(B, -1)[:, -s.nvar:], v0[:, -s.nvar:], equal_nan=True):
             bad.append("rho slots")
+        def berr(vv, rr, dd):   # normwise backward error of K d = -rhs with the values (rho slots included) the call left
+            import scipy.sparse as sp
+            Kl = sp.coo_matrix((vv, (rows - 1, cols - 1)), shape=(s.N, s.N)).tocsr()
+            K = Kl + sp.tril(Kl, -1).T
+            return np.abs(K @ dd + rr).max() / (abs(K).sum(axis=1).max() * np.abs(dd).max() + np.abs(rr).max())
         for b in range(B):
             if np.atleast_1d(ok0)[b]:
                 if not np.abs(d[b] - d0[b]).max() <= 1e-8 * max(1e-300, np.abs(d0[b]).max()):
-                    bad.append(f"d[{b}] rel {np.abs(d[b] - d0[b]).max() / np.abs(d0[b]).max():.2e}")
+                    # ill-conditioned systems (rank-deficient blocks held up by a small rho): the solution is only as good as the
+                    # condition number allows on either side — what must hold is the backward error
+                    be, be0 = berr(v0[b], rhs[b], d[b]), berr(v0[b], rhs[b], d0[b])
+                    if not be <= max(1e-13, 10.0 * be0):   # (no pivoting on either side: element growth shows in both)
+                        bad.append(f"d[{b}] rel {np.abs(d[b] - d0[b]).max() / np.abs(d0[b]).max():.2e} backward error {be:.1e} (oracle {be0:.1e})")
             elif not (d[b] == 7.0).all():
                 bad.append(f"d[{b}] touched")
         # the two-call sequence with the rho the ladder left
@@ -132,7 +162,9 @@ for case in range(ncases):
             hipldl.solve_ldl_(2.0 * rhs, L.factor, d2)
             for b in range(B):
                 if not np.abs(d2[b] - 2.0 * d0[b]).max() <= 2e-8 * max(1e-300, np.abs(d0[b]).max()):
-                    bad.append(f"solve d[{b}]")
+                    be, be0 = berr(v0[b], 2.0 * rhs[b], d2[b]), berr(v0[b], 2.0 * rhs[b], 2.0 * d0[b])
+                    if not be <= max(1e-13, 10.0 * be0):
+                        bad.append(f"solve d[{b}] backward error {be:.1e} (oracle {be0:.1e})")
         L.close()
         if bad:
             fails += 1
@@ -140,5 +172,5 @@ for case in range(ncases):
     except Exception as e:  # noqa: BLE001
         fails += 1
         print("ERROR", tag, repr(e)[:300], flush=True)
-print(f"{ncases} cases, {fails} failures, kernels {kinds}", flush=True)
+print(f"{ncases} cases, {fails} failures, kernels {kinds}" + (f", {subnoise} case(s) with sub-noise first pivots decided differently (not failures)" if subnoise else ""), flush=True)
 sys.exit(1 if fails else 0)
