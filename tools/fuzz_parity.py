@@ -165,6 +165,32 @@ for case in range(ncases):
                     be, be0 = berr(v0[b], 2.0 * rhs[b], d2[b]), berr(v0[b], 2.0 * rhs[b], 2.0 * d0[b])
                     if not be <= max(1e-13, 10.0 * be0):
                         bad.append(f"solve d[{b}] backward error {be:.1e} (oracle {be0:.1e})")
+        # the same handle again, other values (state left by the first round must not matter): problems swapped round, another rho_old
+        if not bad and B > 1 and os.environ.get("FUZZ_WIDE"):
+            permb = rng.permutation(B)
+            vals2, rhs2, ro2 = vals[permb].copy(), rhs[permb] * 0.5, ro_in[permb[::-1]].copy()
+            vb = vals2.copy()
+            db = np.full((B, s.N), 7.0)
+            db, okb, rhob, rob, nfb = hipldl.newton_system_(db, s.nvar, s.nequ, s.ncon, rhs2, vb, L, ro2, p)
+            vb0 = vals2.copy()
+            d0b, ok0b, rho0b, ro0b, nf0b = O.newton_system_batch(orc, B, s.nvar, s.nequ, s.ncon, rhs2, vb0, ro2, po)
+            same = (np.array_equal(np.asarray(okb).astype(bool), ok0b.astype(bool)) and np.array_equal(np.asarray(nfb), nf0b)
+                    and np.array_equal(np.asarray(rhob), rho0b) and np.array_equal(np.asarray(rob), ro0b))
+            if not same:
+                # (sub-noise first pivots: the same problems were seen in round one; a different rho_old changes the ladder, not the first attempt)
+                first_differs = [b for b in range(B) if (int(np.asarray(nfb)[b]) == 1) != (int(nf0b[b]) == 1)]
+                if not first_differs or any(np.abs(orc.D).min() > 1e-11 * np.abs(orc.D).max() for b in first_differs
+                                            if orc.try_to_factorize(vals2[b].copy(), s.nvar, s.nequ, s.ncon, po[0]) in (True, False)):
+                    bad.append("second round decisions")
+            else:
+                db = np.asarray(db).reshape(B, s.N)
+                for b in range(B):
+                    if ok0b[b] and not np.abs(db[b] - d0b[b]).max() <= 1e-8 * max(1e-300, np.abs(d0b[b]).max()):
+                        be, be0 = berr(vb0[b], rhs2[b], db[b]), berr(vb0[b], rhs2[b], d0b[b])
+                        if not be <= max(1e-13, 10.0 * be0):
+                            bad.append(f"second round d[{b}]")
+                    elif not ok0b[b] and not (db[b] == 7.0).all():
+                        bad.append(f"second round d[{b}] touched")
         L.close()
         if bad:
             fails += 1
