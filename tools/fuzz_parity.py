@@ -25,10 +25,29 @@ kinds = {}
 for case in range(ncases):
     seed = seed0 + case
     rng = np.random.default_rng(100000 + seed)
-    fam = rng.integers(3) if not os.environ.get("FUZZ_WIDE") else rng.integers(6)
+    fam = rng.integers(3) if not os.environ.get("FUZZ_WIDE") else rng.integers(7)
     if fam == 3:     # dense Jacobian (BASELINE config 2's shape, small): the dense backend with its device-side ladder
         n = int(rng.integers(20, 150)); m = int(rng.integers(max(2, n // 2), 2 * n + 1))   # also fewer residuals than variables
         s = syn.dense_structure(n, m)
+    elif fam == 6:   # degenerate patterns: residual rows without entries, variables no residual touches, constraints on one variable, duplicates
+        n = int(rng.integers(4, 70)); m = int(rng.integers(1, 2 * n)); pc = int(rng.integers(0, 4))
+        mask = rng.uniform(size=(m, n)) < float(rng.uniform(0.02, 0.2))
+        mask[:, rng.integers(n)] = False                      # a variable without residual entries
+        if m > 2:
+            mask[rng.integers(m), :] = False                  # a residual row without entries
+        jr_, jc_ = np.nonzero(mask)
+        if len(jr_) == 0:
+            jr_, jc_ = np.array([0]), np.array([0])
+        dup = rng.integers(len(jr_), size=max(1, len(jr_) // 8))   # duplicate Jacobian entries (summed, src/solver_types.jl:53-59)
+        jr_, jc_ = np.concatenate([jr_, jr_[dup]]), np.concatenate([jc_, jc_[dup]])
+        hd = np.arange(1, n + 1)
+        hF_ = (np.concatenate([hd, hd[: n // 3]]), np.concatenate([hd, hd[: n // 3]]))   # diagonal, some entries twice
+        if pc:
+            cr_ = np.repeat(np.arange(1, pc + 1), 2); cc_ = rng.integers(1, n + 1, size=2 * pc)
+            hc_s = (hd[: n // 2], hd[: n // 2])
+        else:
+            cr_ = cc_ = np.zeros(0, np.int64); hc_s = (np.zeros(0, np.int64), np.zeros(0, np.int64))
+        s = syn.Structure(n, m, pc, hF_, hc_s, (jr_ + 1, jc_ + 1), (cr_, cc_), name="degenerate")
     elif fam == 5:   # a batch just above a (small) staged_max_batch: the chain + a remainder handle, or two halves (capi.cpp, run_split)
         pc = int(rng.integers(1, 4)); blocks = int(rng.integers(30, 80)); n = pc * blocks
         s = syn.band_structure(n, pc, hw=2)
