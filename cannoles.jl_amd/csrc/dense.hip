@@ -543,7 +543,8 @@ __device__ __forceinline__ void diag_own(Panel2Lds& P, double (&a)[16], int q, i
   // tools/fuzz_parity.py case 40828: a rank-deficient Gauss-Newton block regularised with rho = 1.7e-3, 92 positive pivots
   // counted instead of 94 by try_to_factorize, while the ladder's own sequential refactorisation counted 94).  When the residual
   // of the speculative reciprocal is not small, the reciprocal is formed from the exact pivot (wave-uniform branch, rare).
-  if (!(fabs(e) <= 0x1p-24)) r1 = recip(d);
+  // (tested on the exponent field: an integer compare on the chain instead of an fp64 one; NaN and Inf take the exact path too)
+  if ((__double2hiint(e) & 0x7fffffff) > 0x3e700000) r1 = recip(d);
   const double l = col * r1;
   const double nl = -l;
   if constexpr (JJ + 1 < 16) a[JJ + 1] = fma(w1, nl, a[JJ + 1]);
