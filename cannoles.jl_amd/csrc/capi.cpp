@@ -277,7 +277,7 @@ int setup_v2(cnl_handle* h) {
   //  instantiations run the same 300 cases clean with scratch full of garbage.  Such plans keep the single stream until the cause
   //  is found; every BASELINE configuration is of the fast class.)
   const bool fast_class_only = P.ncls[1] == 0 && P.ncls[2] == 0 && P.listprod_fronts == 0;
-  if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && o.staged && (fast_class_only || getenv("CNL_DBG_STAGE_ALL"))) {
+  if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && o.staged && (fast_class_only || o.staged_large_fronts != 0)) {
     std::vector<int32_t> tk;
     for (const cnl::Task& t : P.tasks) { tk.push_back(t.rec_off); tk.push_back(t.f1 - t.f0); tk.push_back(t.brec_off); tk.push_back(t.is_root); tk.push_back(t.parent); tk.push_back(t.nchild); }
     if ((rc = upload(h, tk, &h->d_tasks))) return rc;
@@ -828,7 +828,7 @@ void cnl_options_init(cnl_options* o) {
   o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
   // (fused: measured slower than the separate launches on one system of cfg3's size, 0.140 against 0.118 ms — the rung loop costs
   //  the kernel 50 VGPRs and 45 spilled SGPRs — so it is off by default)
-  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1;
+  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,

@@ -61,7 +61,9 @@ void cnl_default_params(double params[9]);
 
 /* ---- options ----------------------------------------------------------------------------------------------------------
  * Everything that selects a plan or an execution is an ARGUMENT: the library reads no environment variable that changes what it
- * computes (CNL_VERBOSE only adds log lines on stderr).  cnl_options_init fills the defaults — the choices cnl_create makes by
+ * computes (CNL_VERBOSE only adds log lines on stderr; the debugging aids CNL_DBG_LDSFILL / CNL_DBG_SCRATCHFILL launch kernels that leave
+ * a byte pattern in LDS, scratch and registers in front of every launch, CNL_DBG_GUARD surrounds every device allocation with filled guard
+ * zones — the library's results must not, and do not, depend on either).  cnl_options_init fills the defaults — the choices cnl_create makes by
  * itself; the `_ex` entry points take a modified copy.  Used by tests and measurement tools to force a plan kind or an execution
  * the automatic choice would not pick for that batch; a drop-in caller never needs it (the reference has no counterpart:
  * `ldl_analyze` takes no options, src/solver_types.jl:63).                                                                       */
@@ -124,6 +126,9 @@ typedef struct cnl_options {
                                   staged_max_batch + r problems, r <= staged_max_batch / 4 (first part on the bidirectional
                                   chain), and k full loads of the single stream (four problems per resident wavefront: 8192 at
                                   cfg3's size) + r problems; 0: split_batch's two halves / the single stream's extra round        */
+  int32_t staged_large_fronts; /* 0 (default): plans with out-of-line front classes (order 17 .. 64) or product lists keep the single
+                                  stream — on such plans the staged instantiations gave results that depended on what earlier
+                                  kernels had left in scratch memory; 1: stage them all the same (for the hunt) */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);
