@@ -165,5 +165,6 @@ hipError_t launch_expand(const DevCond& C, double* vals, const double* rhs, cons
                          const int* success, int copy_rho_tail, int batch, hipStream_t stream);
 // largest dynamic LDS a workgroup may use on the current device
 size_t max_lds_bytes();
+int lds_attr_cap(int need);   // value for hipFuncAttributeMaxDynamicSharedMemorySize: the device's limit (kernels2.hip)
 
 }  // namespace cnl

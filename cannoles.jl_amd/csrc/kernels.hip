@@ -354,7 +354,7 @@ size_t max_lds_bytes() {
 template <int TPP, int PPB, bool LDSW>
 static hipError_t launch_t(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream) {
   auto kfn = newton_kernel<TPP, PPB, LDSW>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr_cap((int)cfg.lds_bytes));
   if (e != hipSuccess) return e;
   const int grid = (a.batch + PPB - 1) / PPB;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(TPP * PPB), cfg.lds_bytes, stream, P, a);

@@ -1708,6 +1708,13 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   }
 }
 
+// The per-function limit of dynamic LDS is process-wide state: it is always set to the SAME value (what the device allows), so that two
+// host threads that drive handles with different LDS needs cannot lower it under each other's launches.
+int lds_attr_cap(int need) {
+  const int cap = (int)std::min<size_t>(max_lds_bytes(), (size_t)160 * 1024);
+  return cap > need ? cap : need;
+}
+
 hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream) {
   if (wpb < 1 || wpb > 4) return hipErrorInvalidConfiguration;
   const int waves = (a.batch + 3) / 4;
@@ -1722,7 +1729,7 @@ hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const La
   auto kern = commit ? (lean ? newton2_kernel_t<false, false, true, false, true> : newton2_kernel_t<false, false, false, false, true>)
             : lean_solve ? newton2_kernel_t<false, false, true, true>
             : lean ? newton2_kernel_t<false, false, true> : (late ? newton2_kernel_t<false, true, false> : newton2_kernel_t<false, false, false>);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr_cap((int)lds_bytes));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), lds_bytes, stream, P, a);
   return hipGetLastError();
@@ -1755,7 +1762,7 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
   auto kern = lean_solve ? newton2_kernel_t<true, false, true, true>
             : lean ? (late ? newton2_kernel_t<true, true, true> : newton2_kernel_t<true, false, true>)
                    : (late ? newton2_kernel_t<true, true, false> : newton2_kernel_t<true, false, false>);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr_cap((int)lds_bytes));
   if (e != hipSuccess) return e;
   const bool ladder = a.mode == MODE_NEWTON && a.lad_mode != 0 && a.lad && a.lgcnt && a.ldep && a.status_call;
   // counters of the call: [gcnt | lgcnt | lad | ldep | status | dep] is ONE allocation of the handle, zeroed with one memset
@@ -1788,7 +1795,7 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
   // the in-kernel ladder: every task of a group of problems on a wavefront of its own, all of a launch resident at once
   auto kern_f = lean ? newton2_kernel_t<true, false, true, false, true> : newton2_kernel_t<true, false, false, false, true>;
   if (ladder) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_f), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr_cap((int)lds_bytes));
     if (e != hipSuccess) return e;
   }
   auto launch_ladder = [&](int first) {

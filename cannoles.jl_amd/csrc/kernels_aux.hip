@@ -599,7 +599,7 @@ hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const dou
   if (nchunks <= 0) return hipSuccess;
   const size_t lds = (size_t)TPB * (size_t)C.tile_max * sizeof(double) + (size_t)C.chunk_ncon_max * 8 + ((size_t)C.chunk_nslot_max + 8) * 4;
   {  // per device and cheap: set on every launch (a process may drive several devices from several threads)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(condense_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(condense_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr_cap((int)lds));
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(condense_tiled_kernel, dim3(nchunks, (batch + TPB - 1) / TPB), dim3(256), lds, stream, C, vals, rhs, cbuf, mask, batch);

@@ -1269,6 +1269,51 @@ def test_randomised_parity_is_independent_of_what_earlier_kernels_left(built, fi
     assert "120 cases, 0 failures" in r.stdout
 
 
+def test_two_host_threads_with_handles_of_their_own(built):
+    """Two host threads, each with a handle of its own (different patterns: different kernels, LDS sizes and plans), calling
+    newton_system! concurrently 40 times: every call's results equal the same call made alone.  (The per-function limit of dynamic
+    LDS is process-wide state of the runtime; the launchers always set it to the device's limit, so that one thread cannot lower
+    it under the other's launch.)"""
+    import threading
+    hipldl, syn, O = _mods()
+    specs = [(syn.band_structure(2000, 10), 16, 4), (syn.random_structure(60, 80, 4, 0.1, seed=9), 5, 3), (syn.band_structure(300, 3), 1, 4)]
+    p = hipldl.default_params()
+    jobs = []
+    for s, B, cfg in specs:
+        rows, cols = s.kkt_pattern()
+        if s.name == "band":
+            vals, rhs = syn.batch_values(s, B, cfg=cfg)
+        else:
+            vals = np.stack([syn.random_values(s, 50 + b)[0] for b in range(B)]); rhs = np.stack([syn.random_values(s, 50 + b)[1] for b in range(B)])
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+        d = np.zeros((B, s.N))
+        ref = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, np.zeros(B) if B > 1 else 0.0, p)
+        jobs.append((s, B, L, vals, rhs, [np.array(x, copy=True) for x in ref]))
+    errors = []
+
+    def work(k):
+        s, B, L, vals, rhs, ref = jobs[k]
+        try:
+            for it in range(40):
+                d = np.zeros((B, s.N))
+                out = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, np.zeros(B) if B > 1 else 0.0, p)
+                for a, b in zip(out, ref):
+                    if not np.array_equal(np.asarray(a), b):
+                        errors.append((k, it))
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for job in jobs:
+        job[2].close()
+    assert not errors, errors
+
+
 def test_failed_problems_leave_d_untouched(built):
     """newton_system! solves only after a successful factorisation (src/CaNNOLeS.jl:1049): the caller's d of a problem whose
     ladder runs out (rho > rho_max) is left as it was, through the host-pointer call."""
