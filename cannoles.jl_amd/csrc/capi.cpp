@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/cannoles_hip.h"
+#include "band.h"
 #include "condense.h"
 #include "dense.h"
 #include "kernels.h"
@@ -36,6 +37,8 @@ struct cnl_plan {
   cnl_options opt{};          // the options the plan was built with (the handle reads its execution switches from here)
   std::atomic<int> refs{1};   // handles of a cnl_multi share one analysis (read-only after creation)
   bool split_mode = false;    // bidirectional-chain plan for a batch between one and two wavefronts per SIMD (capi.cpp, run_split)
+  cnl::BandPlan band;         // (round 5) band program of a throughput plan (csrc/band.h); band.ok == false: the pattern is no band
+  std::vector<int32_t> band_info, band_pinfo[2];
 };
 
 #ifndef CNL_PIPE_UPLOADERS
@@ -828,7 +831,7 @@ void cnl_options_init(cnl_options* o) {
   o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
   // (fused: measured slower than the separate launches on one system of cfg3's size, 0.140 against 0.118 ms — the rung loop costs
   //  the kernel 50 VGPRs and 45 spilled SGPRs — so it is off by default)
-  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0;
+  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0; o->band_kernel = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -841,6 +844,12 @@ static int resolve_options(const cnl_options* in, cnl_options& out) {
   if (in->struct_size != (int32_t)sizeof(cnl_options)) return fail(CNL_ERR_ARG, "cnl_options.struct_size does not match this library (use cnl_options_init)");
   out = *in;
   out.force_order[sizeof(out.force_order) - 1] = 0;
+#ifndef CNL_EXPERIMENT
+  // (round 5) known to give wrong results — scratch-history-dependent decisions and memory faults, DESIGN 4b item 8 — and still
+  // un-root-caused: not selectable in a product build
+  if (out.staged_large_fronts != 0)
+    return fail(CNL_ERR_ARG, "cnl_options.staged_large_fronts needs an experiment build (-DCNL_EXPERIMENT=1): the staged execution of plans with large fronts is known to be wrong");
+#endif
   return CNL_OK;
 }
 
@@ -1001,6 +1010,16 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
     }
   }
   if (o.dense_backend) cnl::detect_dense(p->D, N, nnz, rows1, cols1, nvar, nequ, ncon);
+  // (round 5) large batches of band-structured problems: the sliding-window elimination with one lane per (problem, part)
+  if (!latency && o.band_kernel && p->C.active && !p->D.active) {
+    cnl::build_band_plan(p->band, N, nnz, rows1, cols1, nvar, nequ, ncon, o.band_kernel == 2 ? 1 : 2);
+    if (verbose) fprintf(stderr, "[cnl] band program: %s%s\n", p->band.ok ? "ok" : "no: ", p->band.ok ? "" : p->band.why.c_str());
+  }
+  {
+    const cnl::BandPlan& Bp = p->band;
+    p->band_info = {Bp.ok ? 1 : 0, Bp.nparts, Bp.m0, Bp.n, Bp.N, Bp.nnz, (int32_t)Bp.lsize};
+    for (int q = 0; q < 2; q++) p->band_pinfo[q] = {Bp.part[q].nsteps, Bp.part[q].nepochs, Bp.part[q].npiv, Bp.part[q].nevents, (int32_t)Bp.part[q].loff};
+  }
   // Irregular sparsity: when the fill makes fronts larger than the register-front kernel takes and the condensed system is of
   // moderate order, one dense LDL^T of the whole condensed matrix beats the general multifrontal kernel by far
   // (csrc/dense.h; chosen at handle creation for small batches; CNL_NO_GDENSE=1 disables)
@@ -1073,6 +1092,18 @@ int cnl_plan_get(const cnl_plan* plan, const char* name, int32_t* out, int64_t* 
   else if (s == "stage_ptr") { src = P.stage_ptr.data(); n = (int64_t)P.stage_ptr.size(); }
   else if (s == "rec") { src = P.rec.data(); n = P.v2_ok ? (int64_t)P.rec.size() : 0; }     // record streams of the
   else if (s == "brec") { src = P.brec.data(); n = P.v2_ok ? (int64_t)P.brec.size() : 0; }  // register-front kernel
+  else if (s == "band_info") { src = plan->band_info.data(); n = (int64_t)plan->band_info.size(); }   // band program (csrc/band.h)
+  else if (s.rfind("band_", 0) == 0 && s.size() >= 6 && (s.back() == '0' || s.back() == '1')) {
+    const int q = s.back() - '0';
+    const cnl::BandPart& Q = plan->band.part[q];
+    const std::string k = s.substr(5, s.size() - 6);
+    if (k == "part") { src = plan->band_pinfo[q].data(); n = (int64_t)plan->band_pinfo[q].size(); }
+    else if (k == "fops") { src = Q.fops.data(); n = (int64_t)Q.fops.size(); }
+    else if (k == "bops") { src = Q.bops.data(); n = (int64_t)Q.bops.size(); }
+    else if (k == "epochs") { src = Q.epochs.data(); n = (int64_t)Q.epochs.size(); }
+    else if (k == "borders") { src = Q.borders.data(); n = (int64_t)Q.borders.size(); }
+    else return fail(CNL_ERR_ARG, "unknown plan array: " + s);
+  }
   else return fail(CNL_ERR_ARG, "unknown plan array: " + s);
   if (out) {
     if (*count < n) return fail(CNL_ERR_ARG, "buffer too small");

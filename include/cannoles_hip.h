@@ -128,7 +128,14 @@ typedef struct cnl_options {
                                   cfg3's size) + r problems; 0: split_batch's two halves / the single stream's extra round        */
   int32_t staged_large_fronts; /* 0 (default): plans with out-of-line front classes (order 17 .. 64) or product lists keep the single
                                   stream — on such plans the staged instantiations gave results that depended on what earlier
-                                  kernels had left in scratch memory; 1: stage them all the same (for the hunt) */
+                                  kernels had left in scratch memory.  1 stages them all the same and is KNOWN TO BE
+                                  WRONG (memory faults, wrong rho-ladder decisions): accepted only by an experiment build of the
+                                  library (-DCNL_EXPERIMENT=1, cnl_version() < 0); a product build answers CNL_ERR_ARG          */
+  int32_t band_kernel;         /* (round 5) 1 (default): a throughput handle whose pattern is a band in the natural order of the
+                                  variables (every residual row and Hessian entry within five consecutive variables, every
+                                  constraint row a run of its own) runs newton_system on the band kernels (csrc/band.h: one lane per
+                                  problem and half of the chain, operands streamed through LDS); 2: the same with the chain in one
+                                  part; 0: the register-front kernel                                                              */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);
