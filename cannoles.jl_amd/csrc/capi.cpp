@@ -117,6 +117,14 @@ struct cnl_handle {
   cnl::DenseState* gdense = nullptr;  // dense treatment of an arbitrary condensed system (irregular sparsity, small batch)
   cnl::GeneralOps gops{};
   double* d_cgls_ws = nullptr;  // [batch][2 * nvar] workspace of cnl_cgls_multipliers_dev, allocated on first use
+  // (round 5) band kernels (csrc/band.h): newton_system of a throughput handle whose pattern is a band
+  bool band = false;
+  cnl::BandDev bd{};
+  int band_nl = 16;            // problems per workgroup
+  double* d_Lband = nullptr;   // [batch][bd.lsize] factor records of the band kernels
+  bool band_fresh = false;     // the last factorisation was made by the band kernels: a later solve_ldl! needs the register-front
+                               // kernel's factor of the same values first (launch)
+  int32_t* d_band_ok = nullptr;   // [batch] success flags of that refactorisation (not reported)
 };
 
 namespace {
@@ -333,9 +341,25 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.back_rows = (h->lean && h->plan->P.back_rows) ? 1 : 0;
   a.L = h->d_L;
   a.scratch = h->d_scratch;
-  if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));  // events bracket the multifrontal kernel only
   hipError_t e;
-  if (h->use_v2 && (a.mode != cnl::MODE_SOLVE || h->v2_solve)) {
+  if (h->band && a.mode == cnl::MODE_SOLVE && h->band_fresh && a.vals) {
+    // solve_ldl! behind a newton_system! of the band kernels: their factor records are not what the solve sweeps read, so the
+    // register-front kernel factorises the same values first (the rho slots hold what the ladder wrote: the same factor)
+    cnl::LaunchArgs f = a;
+    f.mode = cnl::MODE_FACTOR; f.rhs = nullptr; f.d = nullptr; f.success = h->d_band_ok; f.npos = nullptr; f.nzero = nullptr;
+    f.rho = nullptr; f.rho_old = nullptr; f.nfact = nullptr;
+    e = cnl::launch_newton2(h->dp2, h->wpb2, h->lds2, f, stream);
+    if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("refactorisation for solve_ldl!: ") + hipGetErrorString(e));
+    h->band_fresh = false;
+  }
+  if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));  // events bracket the multifrontal kernel only
+  if (h->band && a.mode == cnl::MODE_NEWTON && !a.skip_done && !a.only_if_status && a.rhs) {
+    cnl::LaunchArgs b = a;
+    b.L = h->d_Lband;
+    e = cnl::launch_band(h->bd, h->band_nl, b, stream);
+    h->band_fresh = true;
+  } else if (h->use_v2 && (a.mode != cnl::MODE_SOLVE || h->v2_solve)) {
+    if (a.mode == cnl::MODE_FACTOR) h->band_fresh = false;
     a.scratch = h->d_gs;
     e = cnl::launch_newton2(h->dp2, h->wpb2, h->lds2, a, stream);
   } else {
@@ -374,7 +398,8 @@ int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 struct SubBatch {
   cnl_handle* h;
   int64_t batch;
-  double *L, *gs, *scratch, *cbuf, *d2;
+  double *L, *gs, *scratch, *cbuf, *d2, *Lband;
+  int32_t* band_ok;
   int *xpos, *xzer, *gcnt, *dep, *lad, *stat;
   const double* last_vals;
   bool staged;
@@ -384,6 +409,9 @@ struct SubBatch {
     if (!allow_staged) h->staged = false;
     batch = h->batch; L = h->d_L; gs = h->d_gs; scratch = h->d_scratch; cbuf = h->d_cbuf; d2 = h->d_d2;
     xpos = h->d_xpos; xzer = h->d_xzer; gcnt = h->d_gcnt; dep = h->d_dep; lad = h->d_lad; stat = h->d_stat;
+    Lband = h->d_Lband; band_ok = h->d_band_ok;
+    if (h->d_Lband) h->d_Lband += b0 * h->bd.lsize;
+    if (h->d_band_ok) h->d_band_ok += b0;
     const cnl::Cond& C = h->plan->C;
     h->batch = nb;
     h->d_L += b0 * h->dp.lsize;
@@ -399,7 +427,7 @@ struct SubBatch {
   ~SubBatch() {
     h->batch = batch; h->d_L = L; h->d_gs = gs; h->d_scratch = scratch; h->d_cbuf = cbuf; h->d_d2 = d2;
     h->d_xpos = xpos; h->d_xzer = xzer; h->d_gcnt = gcnt; h->d_dep = dep; h->d_lad = lad; h->d_stat = stat;
-    h->last_vals = last_vals; h->staged = staged;
+    h->last_vals = last_vals; h->staged = staged; h->d_Lband = Lband; h->d_band_ok = band_ok;
   }
 };
 
@@ -831,7 +859,7 @@ void cnl_options_init(cnl_options* o) {
   o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
   // (fused: measured slower than the separate launches on one system of cfg3's size, 0.140 against 0.118 ms — the rung loop costs
   //  the kernel 50 VGPRs and 45 spilled SGPRs — so it is off by default)
-  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0; o->band_kernel = 1;
+  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0; o->band_kernel = 1; o->band_problems_per_group = 0;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -1203,6 +1231,29 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
   }
   if ((rc = choose_config(h))) return bail(rc);
   if ((rc = setup_v2(h))) return bail(rc);
+  if (plan->band.ok && plan->opt.band_kernel && h->use_v2 && !h->staged && h->v2_solve && h->lean && plan->P.back_rows && !plan->latency && !plan->split_mode) {
+    // band kernels for newton_system (csrc/band.h); the register-front kernel keeps try_to_factorize / solve_ldl!
+    const cnl::BandPlan& Bp = plan->band;
+    cnl::BandDev& bd = h->bd;
+    for (int q = 0; q < Bp.nparts; q++) {
+      if ((rc = upload(h, Bp.part[q].fops, &bd.fops[q]))) return bail(rc);
+      if ((rc = upload(h, Bp.part[q].bops, &bd.bops[q]))) return bail(rc);
+      if ((rc = upload(h, Bp.part[q].epochs, &bd.epochs[q]))) return bail(rc);
+      if ((rc = upload(h, Bp.part[q].borders, &bd.borders[q]))) return bail(rc);
+      bd.nsteps[q] = Bp.part[q].nsteps; bd.nepochs[q] = Bp.part[q].nepochs; bd.loff[q] = Bp.part[q].loff;
+    }
+    bd.nparts = Bp.nparts; bd.m0 = Bp.m0; bd.n = Bp.n; bd.N = Bp.N; bd.nnz = Bp.nnz; bd.nvar = (int32_t)nvar; bd.lsize = Bp.lsize;
+    h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : 16;
+    if (h->band_nl != 8 && h->band_nl != 16 && h->band_nl != 32) return bail(fail(CNL_ERR_ARG, "band_problems_per_group must be 8, 16 or 32"));
+    // 32-bit byte offsets inside a workgroup's problems
+    const uint64_t span = 8ull * (uint64_t)h->band_nl * (uint64_t)std::max<int64_t>({(int64_t)nnz, N, bd.lsize});
+    if (span < (1ull << 32) && cnl::band_lds_bytes(bd.nparts, h->band_nl) <= std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024)) {
+      if ((rc = dalloc(h, &h->d_Lband, (size_t)batch * (size_t)bd.lsize + 64))) return bail(rc);
+      if ((rc = dalloc(h, &h->d_band_ok, (size_t)batch))) return bail(rc);
+      if (hipMemset(h->d_Lband, 0, ((size_t)batch * (size_t)bd.lsize + 64) * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
+      h->band = true;
+    }
+  }
   if (plan->split_mode && h->staged) {
     // x groups of four problems on the chain (two wavefronts each), the rest on the single stream: 2 x + y = 2048 slots
     const int64_t nquads = (batch + 3) / 4, x = std::max<int64_t>(0, 2048 - nquads);
@@ -1432,6 +1483,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   cfg[5] = (h->dense || h->gdense) ? 3 : (h->use_v2 ? (h->staged ? 4 : 2) : 1);
   if (h->lean && !h->dense && !h->gdense) cfg[5] |= 16;  // newton_system / factorize run the kernels' LEAN instantiation
   if (h->tail) cfg[5] |= 32;                             // the remainder of the batch runs on a handle of its own (split_tail)
+  if (h->band) cfg[5] |= 64;                             // newton_system runs on the band kernels (csrc/band.h)
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;
   return CNL_OK;

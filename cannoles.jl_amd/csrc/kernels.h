@@ -138,6 +138,22 @@ constexpr int LAD_WORDS = 32;  // ints per group: [0] tasks that finished the ru
                                // four problems (0 active, 1 factorised, 2 gave up), doubles at [8..15] rho last written to the
                                // slots ("wrote"; 0: never laddered), at [16..23] the rho_old to commit
 
+// device-resident band program (band.h; kernels: band.hip)
+struct BandDev {
+  const int32_t* fops[2];
+  const int32_t* bops[2];
+  const int32_t* epochs[2];
+  const int32_t* borders[2];
+  int32_t nsteps[2], nepochs[2];
+  long long loff[2];
+  int32_t nparts, m0, n, N, nnz, nvar;
+  long long lsize;
+};
+// newton_system! / try_to_factorize of a.batch problems on the band kernels, nl problems per workgroup (8, 16 or 32); a.L = the
+// band factor storage [batch][P.lsize]
+hipError_t launch_band(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream);
+size_t band_lds_bytes(int nparts, int nl);
+
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_newton2(const DevPlan2& P, int wpb, size_t lds_bytes, const LaunchArgs& a, hipStream_t stream);
