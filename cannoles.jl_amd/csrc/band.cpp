@@ -205,7 +205,7 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
       RowOp ro;
       ro.di = q.dsrc; ro.rr = rhs_src(n + r); ro.r = (int32_t)r;
       for (int s = 0; s < BAND_NB; s++) ro.j[s] = -1;
-      for (size_t i = 0; i < q.xs.size(); i++) ro.j[pos[q.xs[i]] % BAND_NB] = q.srcs[i];
+      for (size_t i = 0; i < q.xs.size(); i++) ro.j[pos[q.xs[i]] - (u - BAND_HW)] = q.srcs[i];   // live position: 0 = the step's pivot, HW = the entering variable
       S[u].rows.push_back(ro);
       rlo = std::min(rlo, (int32_t)r); rhi = std::max(rhi, (int32_t)r);
     }
@@ -265,8 +265,7 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
     Packer pk;
     pk.len[0] = (int32_t)nnz; pk.len[1] = (int32_t)N; pk.len[2] = (int32_t)(lpart + 8);
     const int32_t ZB = BAND_ZERO_OFF * 8;
-    // An epoch is a run of at most BAND_EPOCH steps whose operands fit the pieces and whose outputs fit the rings: shortened where
-    // they do not (the ends of the chain, where several residual rows complete at one variable).
+    // An epoch is a run of BAND_EPOCH steps whose operands must fit the pieces and whose outputs the rings.
     std::string why_not;
     auto try_epoch = [&](const int32_t u0, const int32_t u1, int32_t* E) -> bool {
       auto no = [&](const std::string& w) { why_not = w; return false; };
@@ -278,6 +277,10 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
         if (st.flags & BF_PIVOT_X) { x_lo = std::min(x_lo, st.xpiv); x_hi = std::max(x_hi, st.xpiv); x_cnt++; }
         for (const RowOp& ro : st.rows) { r_lo = std::min(r_lo, ro.r); r_hi = std::max(r_hi, ro.r); r_cnt++; }
       }
+      int32_t oplen = 0;
+      for (int32_t u = u0; u < u1; u++) oplen += BAND_SW + BAND_RW * (int32_t)S[u].rows.size();
+      if (oplen > BAND_REC_MAX) return no("the blocks of an epoch do not fit the record buffer");
+      E[BE_OPLEN] = oplen;
       const int32_t lbase = ev_hi >= 0 ? ev_lo * BAND_LREC : 0, lcnt = ev_hi >= 0 ? (ev_hi - ev_lo + 1) * BAND_LREC : 0;
       if (lcnt > BAND_LOUT_MAX) return no("more factor records in an epoch than the ring holds");
       if (x_cnt && x_hi - x_lo + 1 != x_cnt) return no("pivots of an epoch are not consecutive variables");
@@ -362,14 +365,21 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
     };
     for (int32_t u0 = 0; u0 < nsteps;) {
       std::vector<int32_t> E(BAND_EW, 0);
-      int32_t cnt = std::min<int32_t>(BAND_EPOCH, nsteps - u0);
-      while (cnt >= 1 && !try_epoch(u0, u0 + cnt, E.data())) cnt--;
-      if (cnt < 1) return no(why_not);
+      // every epoch but the last has exactly BAND_EPOCH steps: the kernels' step code is specialised by step number modulo
+      // BAND_EPOCH (= the number of window slots), so an epoch starts at slot 0
+      const int32_t cnt = std::min<int32_t>(BAND_EPOCH, nsteps - u0);
+      if (!try_epoch(u0, u0 + cnt, E.data())) return no(why_not);
       E[BE_NSTEP] = cnt;
       Q.epochs.insert(Q.epochs.end(), E.begin(), E.end());
       u0 += cnt;
     }
     Q.nepochs = (int32_t)(Q.epochs.size() / BAND_EW);
+    {
+      int32_t fo = 0;
+      for (int32_t e = 0; e < Q.nepochs; e++) { Q.epochs[(size_t)e * BAND_EW + BE_FOFF] = fo; fo += Q.epochs[(size_t)e * BAND_EW + BE_OPLEN]; }
+      int32_t bo = 0;
+      for (int32_t e = Q.nepochs - 1; e >= 0; e--) { Q.epochs[(size_t)e * BAND_EW + BE_BOFF] = bo; bo += Q.epochs[(size_t)e * BAND_EW + BE_OPLEN]; }
+    }
     for (int32_t u = 0; u < nsteps; u++) Q.fops.insert(Q.fops.end(), fblocks[u].begin(), fblocks[u].end());
     // backward order: steps reversed, the rows of a step reversed
     for (int32_t u = nsteps - 1; u >= 0; u--) {
@@ -379,8 +389,8 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
       for (int i = nr - 1; i >= 0; i--) Q.bops.insert(Q.bops.end(), blk.begin() + BAND_SW + BAND_RW * i, blk.begin() + BAND_SW + BAND_RW * (i + 1));
     }
     // slack for the kernels' prefetch of the next block
-    Q.fops.resize(Q.fops.size() + 64, 0);
-    Q.bops.resize(Q.bops.size() + 64, 0);
+    Q.fops.resize(Q.fops.size() + BAND_REC_MAX + 64, 0);
+    Q.bops.resize(Q.bops.size() + BAND_REC_MAX + 64, 0);
     (void)rlo; (void)rhi;
   }
   B.lsize = loff + 8;

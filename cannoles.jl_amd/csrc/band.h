@@ -26,8 +26,11 @@ namespace cnl {
 
 constexpr int BAND_HW = 4;          // variables a pivot is coupled to inside the band (window = BAND_HW + 1 band slots)
 constexpr int BAND_NB = BAND_HW + 1;
-constexpr int BAND_EPOCH = 8;       // steps per epoch (one round of operand pieces)
+constexpr int BAND_EPOCH = 8;       // steps per epoch (one round of operand pieces) = window slots: variable number t of a part lives in
+                                    // slot t % 8 (five consecutive slots are live at a time), so step u of an epoch always works on the same slots
+constexpr int BAND_NS = BAND_EPOCH;
 constexpr int BAND_NPIECE = 16;     // 64-byte operand pieces per epoch and lane
+constexpr int BAND_REC_MAX = 320;    // ints of step + row blocks per epoch (LDS record buffer of a wavefront)
 constexpr int BAND_LREC = 6;        // factor doubles per pivot: band multipliers, border multiplier, z  (see band.hip)
 
 // LDS block of one lane, in doubles: [operand pieces | factor-out ring | dx-out ring | dr-out ring | zero cell]
@@ -58,7 +61,7 @@ enum {
 };
 enum { BF_ENTER_B = 1, BF_PIVOT_B = 2, BF_PIVOT_X = 4, BF_ENTER_X = 8 };
 // row block (BAND_RW ints) behind the step block, one per residual row completed by the step
-enum { BR_DI = 0, BR_J0, BR_RR = BR_J0 + BAND_NB, BR_DR, BAND_RW = 8 };
+enum { BR_DI = 0, BR_J0 /* + live position: 0 = the step's pivot .. HW = the entering variable */, BR_RR = BR_J0 + BAND_NB, BR_DR, BAND_RW = 8 };
 // epoch block
 enum {
   BE_FP = 0,                       // forward operand pieces: element index | array << 28 (0 vals, 1 rhs), -1 unused
@@ -68,8 +71,10 @@ enum {
   BE_DXLO, BE_DXCNT,               // solution components of the epoch's band pivots: d[lo .. lo + cnt)
   BE_DRLO, BE_DRCNT,               // ... of its residual rows
   BE_NSTEP,                        // steps of the epoch
-  BE_SPARE,
-  BAND_EW = 40
+  BE_FOFF,                         // first int of the epoch's step blocks in fops / bops, and their length: the blocks of an
+  BE_BOFF,                         //   epoch go through an LDS record buffer of BAND_REC_MAX ints per wavefront
+  BE_OPLEN,
+  BAND_EW = 44
 };
 // border table: BAND_BW ints per border
 enum { BB_DSRC = 0, BB_RHS, BB_DOUT, BB_SPARE, BAND_BW = 4 };

@@ -33,6 +33,8 @@ __device__ __forceinline__ cptr as_const(const int* p) { return (cptr)(const __a
 
 constexpr int NPC = BAND_NPIECE;
 constexpr int LANE_D = BAND_LANE_DOUBLES;
+constexpr int EXCH_OFF = BAND_ZERO_OFF - 48;   // junction exchange (46 doubles) in a lane block: over the out rings, idle between the sweeps
+static_assert(EXCH_OFF >= BAND_LOUT_OFF, "exchange area inside the out rings");
 
 __device__ __forceinline__ constexpr int sidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 
@@ -49,84 +51,103 @@ __device__ __forceinline__ double rdiv(double w, double d, double r) {
   return fma(res, r, q);
 }
 
+// The window: BAND_NS slots, of which the five that hold the variables entered last are live (the allocator sees that: every
+// index below is a compile-time constant, so the dead slots' registers are free).
+constexpr int NS = BAND_NS;
 struct Win {
-  double S[15];   // band slots, packed lower triangle
-  double X[5];    // border row
+  double S[NS * (NS + 1) / 2];   // band slots, packed lower triangle
+  double X[NS];                  // border row
   double S55;
-  double c[5];    // right-hand side
+  double c[NS];                  // right-hand side
   double c5;
 };
+// live slot k of step phase PH: 0 = the step's pivot .. BAND_HW = the entering variable
+__device__ __forceinline__ constexpr int lslot(int PH, int k) { return (PH - BAND_HW + k + NS) % NS; }
 
 #define LDSD(off) (*reinterpret_cast<const double*>(myb + (off)))
 #define LDSW(off) (*reinterpret_cast<double*>(myb + (off)))
 
-// one forward step with enter slot PH, pivot slot (PH + 1) % 5
+// Step and row blocks of the current epoch sit in the wavefront's LDS record buffer (copied there by the mover with the operand
+// pieces): every compute lane reads the same address (one broadcast read), the operand offsets stay in VGPRs — they are only ever
+// added to the lane's LDS base — and the flags word goes to an SGPR for the wave-uniform branches.
+struct Rec { int v[BAND_SW]; };
+struct RowRec { int v[BAND_RW]; };
+__device__ __forceinline__ void load_rec(Rec& R, const char* recb, int o) {
+  const int4* q = reinterpret_cast<const int4*>(recb + 4 * o);
+#pragma unroll
+  for (int k = 0; k < BAND_SW / 4; k++) { const int4 t = q[k]; R.v[4 * k] = t.x; R.v[4 * k + 1] = t.y; R.v[4 * k + 2] = t.z; R.v[4 * k + 3] = t.w; }
+}
+__device__ __forceinline__ void load_row(RowRec& R, const char* recb, int o) {
+  const int4* q = reinterpret_cast<const int4*>(recb + 4 * o);
+#pragma unroll
+  for (int k = 0; k < BAND_RW / 4; k++) { const int4 t = q[k]; R.v[4 * k] = t.x; R.v[4 * k + 1] = t.y; R.v[4 * k + 2] = t.z; R.v[4 * k + 3] = t.w; }
+}
+
+// one forward step of phase PH = step number % 8: enter slot PH, pivot slot PH - 4; fl = flags word (wave-uniform), o = int
+// offset of the step block in the record buffer
 template <int PH>
-__device__ __forceinline__ void fstep(Win& W, cptr st, char* myb, const double* __restrict__ gvals, const double* __restrict__ grhs,
-                                      cptr borders, long long pv, long long pr, bool has_rhs, double rho, bool ovr, double tol,
-                                      int& npos, int& nzer) {
-  constexpr int es = PH, ps = (PH + 1) % BAND_NB;
-  const int fl = st[BS_FLAGS];
+__device__ __forceinline__ void fstep(Win& W, const Rec& st, const int fl, const char* recb, const int o, char* myb, const double* __restrict__ gvals,
+                                      const double* __restrict__ grhs, cptr borders, long long pv, long long pr, bool has_rhs, double rho, bool ovr,
+                                      double tol, int& npos, int& nzer) {
+  constexpr int es = PH, ps = lslot(PH, 0);
   // ---- enter ----
   {
-    double dg = (LDSD(st[BS_DG0]) + LDSD(st[BS_DG1])) + LDSD(st[BS_DG2]);
-    double rv = LDSD(st[BS_RHO]);
+    double dg = (LDSD(st.v[BS_DG0]) + LDSD(st.v[BS_DG1])) + LDSD(st.v[BS_DG2]);
+    double rv = LDSD(st.v[BS_RHO]);
     if (!(fl & (1 << 16))) rv = ovr ? rho : rv;
     W.S[sidx(es, es)] = dg + rv;
 #pragma unroll
-    for (int k = 1; k <= BAND_HW; k++) {
-      const int s = (es - k + BAND_NB) % BAND_NB;
-      W.S[sidx(es, s)] = LDSD(st[BS_OD + 2 * (k - 1)]) + LDSD(st[BS_OD + 2 * (k - 1) + 1]);
-    }
-    W.X[es] = LDSD(st[BS_BC0]) + LDSD(st[BS_BC1]);
-    W.c[es] = LDSD(st[BS_RX]);
+    for (int k = 1; k <= BAND_HW; k++) W.S[sidx(es, lslot(PH, BAND_HW - k))] = LDSD(st.v[BS_OD + 2 * (k - 1)]) + LDSD(st.v[BS_OD + 2 * (k - 1) + 1]);
+    W.X[es] = LDSD(st.v[BS_BC0]) + LDSD(st.v[BS_BC1]);
+    W.c[es] = LDSD(st.v[BS_RX]);
   }
   // ---- residual rows completed by the entering variable: products -J_a J_b / d_r, counted in the inertia ----
   const int nrows = (fl >> 8) & 255;
   for (int i = 0; i < nrows; i++) {
-    cptr rb = st + BAND_SW + BAND_RW * i;
-    const double dr = LDSD(rb[BR_DI]);
+    RowRec rb;
+    load_row(rb, recb, o + BAND_SW + BAND_RW * i);
+    const double dr = LDSD(rb.v[BR_DI]);
     npos += dr > tol;
     nzer += fabs(dr) <= tol;
     const double r = rrcp(dr);
     const double w = rdiv(-1.0, dr, r);
     double J[BAND_NB];
 #pragma unroll
-    for (int s = 0; s < BAND_NB; s++) J[s] = LDSD(rb[BR_J0 + s]);
-    const double tr = LDSD(rb[BR_RR]) * w;
+    for (int k = 0; k < BAND_NB; k++) J[k] = LDSD(rb.v[BR_J0 + k]);
+    const double tr = LDSD(rb.v[BR_RR]) * w;
 #pragma unroll
-    for (int a = 0; a < BAND_NB; a++) {
-      const double ta = J[a] * w;
+    for (int ka = 0; ka < BAND_NB; ka++) {
+      const double ta = J[ka] * w;
 #pragma unroll
-      for (int b = 0; b <= a; b++) W.S[sidx(a, b)] = fma(ta, J[b], W.S[sidx(a, b)]);
-      W.c[a] = fma(tr, J[a], W.c[a]);
+      for (int kb = 0; kb <= ka; kb++) W.S[sidx(lslot(PH, ka), lslot(PH, kb))] = fma(ta, J[kb], W.S[sidx(lslot(PH, ka), lslot(PH, kb))]);
+      W.c[lslot(PH, ka)] = fma(tr, J[ka], W.c[lslot(PH, ka)]);
     }
   }
   // ---- border pivot ----
   if (fl & BF_PIVOT_B) {
-    cptr bt = borders + BAND_BW * st[BS_BORDER];
+    cptr bt = borders + BAND_BW * __builtin_amdgcn_readfirstlane(st.v[BS_BORDER]);
     W.S55 += gvals[pv + bt[BB_DSRC]];
     W.c5 += has_rhs ? grhs[pr + bt[BB_RHS]] : 0.0;
     const double d = W.S55;
     npos += d > tol;
     nzer += fabs(d) <= tol;
     const double r = rrcp(d);
-    double l[BAND_NB];
+    double l[BAND_NB], w[BAND_NB];
 #pragma unroll
-    for (int s = 0; s < BAND_NB; s++) l[s] = rdiv(W.X[s], d, r);
+    for (int k = 0; k < BAND_NB; k++) { w[k] = W.X[lslot(PH, k)]; l[k] = rdiv(w[k], d, r); }
     const double z = rdiv(W.c5, d, r);
 #pragma unroll
-    for (int a = 0; a < BAND_NB; a++) {
+    for (int ka = 0; ka < BAND_NB; ka++) {
 #pragma unroll
-      for (int b = 0; b <= a; b++) W.S[sidx(a, b)] = fma(W.X[a], -l[b], W.S[sidx(a, b)]);
-      W.c[a] = fma(W.X[a], -z, W.c[a]);
+      for (int kb = 0; kb <= ka; kb++) W.S[sidx(lslot(PH, ka), lslot(PH, kb))] = fma(w[ka], -l[kb], W.S[sidx(lslot(PH, ka), lslot(PH, kb))]);
+      W.c[lslot(PH, ka)] = fma(w[ka], -z, W.c[lslot(PH, ka)]);
     }
-    char* lo = myb + st[BS_LB];
+    double* lo = reinterpret_cast<double*>(myb + st.v[BS_LB]);
 #pragma unroll
-    for (int s = 0; s < BAND_NB; s++) reinterpret_cast<double*>(lo)[s] = l[s];
-    reinterpret_cast<double*>(lo)[BAND_NB] = z;
+    for (int k = 0; k < BAND_NB; k++) lo[k] = l[k];
+    lo[BAND_NB] = z;
 #pragma unroll
-    for (int s = 0; s < BAND_NB; s++) W.X[s] = 0.0;
+    for (int k = 0; k < BAND_NB; k++) W.X[lslot(PH, k)] = 0.0;
     W.S55 = 0.0; W.c5 = 0.0;
   }
   // ---- band pivot ----
@@ -137,135 +158,125 @@ __device__ __forceinline__ void fstep(Win& W, cptr st, char* myb, const double* 
     const double r = rrcp(d);
     double l[BAND_NB], w[BAND_NB];
 #pragma unroll
-    for (int s = 0; s < BAND_NB; s++) { w[s] = W.S[sidx(s, ps)]; l[s] = rdiv(w[s], d, r); }
+    for (int k = 1; k < BAND_NB; k++) { w[k] = W.S[sidx(lslot(PH, k), ps)]; l[k] = rdiv(w[k], d, r); }
     const double w5 = W.X[ps], l5 = rdiv(w5, d, r), z = rdiv(W.c[ps], d, r);
 #pragma unroll
-    for (int a = 0; a < BAND_NB; a++) {
-      if (a == ps) continue;
+    for (int ka = 1; ka < BAND_NB; ka++) {
 #pragma unroll
-      for (int b = 0; b <= a; b++) {
-        if (b == ps) continue;
-        W.S[sidx(a, b)] = fma(w[a], -l[b], W.S[sidx(a, b)]);
-      }
-      W.X[a] = fma(w5, -l[a], W.X[a]);
-      W.c[a] = fma(w[a], -z, W.c[a]);
+      for (int kb = 1; kb <= ka; kb++) W.S[sidx(lslot(PH, ka), lslot(PH, kb))] = fma(w[ka], -l[kb], W.S[sidx(lslot(PH, ka), lslot(PH, kb))]);
+      W.X[lslot(PH, ka)] = fma(w5, -l[ka], W.X[lslot(PH, ka)]);
+      W.c[lslot(PH, ka)] = fma(w[ka], -z, W.c[lslot(PH, ka)]);
     }
     W.S55 = fma(w5, -l5, W.S55);
     W.c5 = fma(w5, -z, W.c5);
-    double* lo = reinterpret_cast<double*>(myb + st[BS_LX]);
-    int k = 0;
+    double* lo = reinterpret_cast<double*>(myb + st.v[BS_LX]);
 #pragma unroll
-    for (int s = 0; s < BAND_NB; s++) {
-      if (s == ps) continue;
-      lo[k++] = l[s];
-    }
+    for (int k = 1; k < BAND_NB; k++) lo[k - 1] = l[k];
     lo[4] = l5;
     lo[5] = z;
   }
 }
 
-// one backward step (pivot slot (PH + 1) % 5): x of the band pivot, then of the border pivot, then the residual components
+// one backward step of phase PH: x of the band pivot, then of the border pivot, then the residual components
 template <int PH>
-__device__ __forceinline__ void bstep(double (&xs)[6], cptr st, char* myb, cptr borders, double* __restrict__ gd,
-                                      long long pd, bool okme) {
-  constexpr int ps = (PH + 1) % BAND_NB;
-  const int fl = st[BS_FLAGS];
+__device__ __forceinline__ void bstep(double (&xs)[NS + 1], const Rec& st, const int fl, const char* recb, const int o, char* myb, cptr borders,
+                                      double* __restrict__ gd, long long pd, bool okme) {
+  constexpr int ps = lslot(PH, 0);
   if (fl & BF_PIVOT_X) {
-    const double* lo = reinterpret_cast<const double*>(myb + st[BS_LX]);
+    const double* lo = reinterpret_cast<const double*>(myb + st.v[BS_LX]);
     double x = lo[5];
-    int k = 0;
 #pragma unroll
-    for (int s = 0; s < BAND_NB; s++) {
-      if (s == ps) continue;
-      x = fma(-lo[k++], xs[s], x);
-    }
-    x = fma(-lo[4], xs[5], x);
+    for (int k = 1; k < BAND_NB; k++) x = fma(-lo[k - 1], xs[lslot(PH, k)], x);
+    x = fma(-lo[4], xs[NS], x);
     xs[ps] = x;
-    LDSW(st[BS_DX]) = -x;
+    LDSW(st.v[BS_DX]) = -x;
   }
   if (fl & BF_PIVOT_B) {
-    const double* lo = reinterpret_cast<const double*>(myb + st[BS_LB]);
+    const double* lo = reinterpret_cast<const double*>(myb + st.v[BS_LB]);
     double x = lo[BAND_NB];
 #pragma unroll
-    for (int s = 0; s < BAND_NB; s++) x = fma(-lo[s], xs[s], x);
-    xs[5] = x;
-    if (okme) gd[pd + borders[BAND_BW * st[BS_BORDER] + BB_DOUT]] = -x;
+    for (int k = 0; k < BAND_NB; k++) x = fma(-lo[k], xs[lslot(PH, k)], x);
+    xs[NS] = x;
+    if (okme) gd[pd + borders[BAND_BW * __builtin_amdgcn_readfirstlane(st.v[BS_BORDER]) + BB_DOUT]] = -x;
   }
   const int nrows = (fl >> 8) & 255;
   for (int i = 0; i < nrows; i++) {
-    cptr rb = st + BAND_SW + BAND_RW * i;
-    double acc = -LDSD(rb[BR_RR]);
+    RowRec rb;
+    load_row(rb, recb, o + BAND_SW + BAND_RW * i);
+    double acc = -LDSD(rb.v[BR_RR]);
 #pragma unroll
-    for (int s = 0; s < BAND_NB; s++) acc = fma(LDSD(rb[BR_J0 + s]), xs[s], acc);
-    const double dr = LDSD(rb[BR_DI]);
-    LDSW(rb[BR_DR]) = rdiv(acc, dr, rrcp(dr));
+    for (int k = 0; k < BAND_NB; k++) acc = fma(LDSD(rb.v[BR_J0 + k]), xs[lslot(PH, k)], acc);
+    const double dr = LDSD(rb.v[BR_DI]);
+    LDSW(rb.v[BR_DR]) = rdiv(acc, dr, rrcp(dr));
   }
-  if (fl & BF_ENTER_B) xs[5] = 0.0;
+  if (fl & BF_ENTER_B) xs[NS] = 0.0;
 }
 
 }  // namespace
 
-// control block of a workgroup in LDS: per problem [rho | flags], then one word "all done"
+// LDS of a workgroup: [part][NL] lane blocks | [part] record buffers | control block: per problem [rho | flags], one word "all done"
 template <int NL>
 __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(const BandDev P, const LaunchArgs Ain) {
   constexpr int NI = NL / 8;
   extern __shared__ double lds[];
-  LaunchArgs A = Ain;
-  A.vals = as_global(Ain.vals); A.rhs = as_global(Ain.rhs); A.d = as_global(Ain.d); A.L = as_global(Ain.L);
-  A.rho_old = as_global(Ain.rho_old); A.rho = as_global(Ain.rho); A.nfact = as_global(Ain.nfact); A.success = as_global(Ain.success);
-  A.npos = as_global(Ain.npos); A.nzero = as_global(Ain.nzero);
+  const int mode = Ain.mode, batch = Ain.batch;
+  double* const gvals = as_global(Ain.vals);
+  const double* const grhs = as_global(Ain.rhs);
+  double* const gd = as_global(Ain.d);
+  double* const gL = as_global(Ain.L);
   const int lane = threadIdx.x & 63;
   const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lq = lane >> 3, le = lane & 7;
   const int prob0 = blockIdx.x * NL;
-  const int batch = A.batch;
-  const bool has_rhs = A.mode == MODE_NEWTON && A.rhs != nullptr;
+  const bool has_rhs = mode == MODE_NEWTON && grhs != nullptr;
   char* wblk = reinterpret_cast<char*>(lds + (size_t)part * NL * LANE_D);
-  double* ctrl = lds + (size_t)P.nparts * NL * LANE_D;   // [NL] rho, [NL] flags (1 ovr, 2 ok), [1] all done
-  cptr fops = as_const(P.fops[part]);
-  cptr bops = as_const(P.bops[part]);
+  char* recb = reinterpret_cast<char*>(lds + (size_t)P.nparts * NL * LANE_D) + (size_t)part * BAND_REC_MAX * 4;
+  double* ctrl = reinterpret_cast<double*>(reinterpret_cast<char*>(lds + (size_t)P.nparts * NL * LANE_D) + (size_t)P.nparts * BAND_REC_MAX * 4);
+  const int* fops_g = as_global(P.fops[part]);
+  const int* bops_g = as_global(P.bops[part]);
   cptr epochs = as_const(P.epochs[part]);
   cptr borders = as_const(P.borders[part]);
   const int nepochs = P.nepochs[part];
-  // mover offsets: elements from the first problem of the workgroup (32-bit: NL problems span < 4 GB)
-  const double* vbase = A.vals + (long long)prob0 * P.nnz;
-  const double* rbase = has_rhs ? A.rhs + (long long)prob0 * P.N : A.vals;
-  double* lbase_g = A.L + (long long)prob0 * P.lsize + P.loff[part];
-  double* dbase = A.d ? A.d + (long long)prob0 * P.N : nullptr;
-  // per-lane byte offsets of the mover (wave-uniform base pointer + 32-bit offset: one global_load / global_store each)
-  unsigned voffb[NI], roffb[NI], loffb[NI], doffb[NI], ldsb[NI];
+  const int nnz = P.nnz, N = P.N;
+  const long long lsize = P.lsize;
+  // mover: wave-uniform base pointers + 32-bit per-lane byte offsets (NL problems span < 4 GB)
+  const double* vbase = gvals + (long long)prob0 * nnz;
+  const double* rbase = has_rhs ? grhs + (long long)prob0 * N : gvals;
+  double* lbase_g = gL + (long long)prob0 * lsize + P.loff[part];
+  double* dbase = gd ? gd + (long long)prob0 * N : nullptr;
+  unsigned voffb[NI], roffb[NI], loffb[NI], ldsb[NI];
   bool movok[NI];
 #pragma unroll
   for (int i = 0; i < NI; i++) {
     int pl = i * 8 + lq;
     movok[i] = prob0 + pl < batch;
     if (!movok[i]) pl = batch - 1 - prob0;
-    voffb[i] = ((unsigned)pl * (unsigned)P.nnz + (unsigned)le) << 3;
-    roffb[i] = ((unsigned)pl * (unsigned)P.N + (unsigned)le) << 3;
-    loffb[i] = ((unsigned)pl * (unsigned)P.lsize + (unsigned)le) << 3;
-    doffb[i] = roffb[i];
+    voffb[i] = ((unsigned)pl * (unsigned)nnz + (unsigned)le) << 3;
+    roffb[i] = ((unsigned)pl * (unsigned)N + (unsigned)le) << 3;
+    loffb[i] = ((unsigned)pl * (unsigned)lsize + (unsigned)le) << 3;
     ldsb[i] = ((unsigned)(i * 8 + lq) * (unsigned)LANE_D + (unsigned)le) << 3;
   }
   // compute lanes
   const bool clane = lane < NL;
   const int cprob = prob0 + (clane ? lane : 0);
   const bool valid = clane && cprob < batch;
-  const int cpl = valid ? cprob - prob0 : batch - 1 - prob0;   // problem whose block this lane computes on
+  const int cpl = valid ? cprob - prob0 : batch - 1 - prob0;   // problem whose data this lane's block holds
   char* myb = wblk + (size_t)(clane ? lane : 0) * LANE_D * 8;
-  const long long pv = (long long)(prob0 + cpl) * P.nnz, pr = (long long)(prob0 + cpl) * P.N;
-  // every block's zero cell
-  for (int t = lane; t < NL; t += 64) *reinterpret_cast<double*>(wblk + ((size_t)t * LANE_D + BAND_ZERO_OFF) * 8) = 0.0;
+  const long long pv = (long long)(prob0 + cpl) * nnz, pr = (long long)(prob0 + cpl) * N;
+  for (int t = lane; t < NL; t += 64) *reinterpret_cast<double*>(wblk + ((size_t)t * LANE_D + BAND_ZERO_OFF) * 8) = 0.0;   // every block's zero cell
 
-  const double tol = A.params[0], kdec = A.params[2], kinc = A.params[3], klarge = A.params[4], rho0 = A.params[5], rhomax = A.params[6],
-               rhomin = A.params[7];
+  const double tol = Ain.params[0], kdec = Ain.params[2], kinc = Ain.params[3], klarge = Ain.params[4], rho0 = Ain.params[5], rhomax = Ain.params[6],
+               rhomin = Ain.params[7];
   double rho = 0.0, wrote = 0.0;
-  double rho_old = (A.mode == MODE_NEWTON && valid) ? A.rho_old[cprob] : 0.0;
+  double rho_old = (mode == MODE_NEWTON && valid) ? as_global(Ain.rho_old)[cprob] : 0.0;
   int nfact = 0;
   bool done = !valid, success = false, ovr = false;
 
   double stg[NPC][NI];   // operand pieces in flight
+  int4 rstg[2];          // step blocks in flight (two 16-byte words per lane: 512 ints)
   unsigned pmask = 0;    // pieces of the epoch whose operands are in flight
-  auto issue = [&](cptr E, int ofs) {
+  static_assert(BAND_REC_MAX <= 512, "record buffer: two dwordx4 per lane");
+  auto issue = [&](cptr E, int ofs, const int* ops_g, int opoff) {
     pmask = 0;
 #pragma unroll
     for (int k = 0; k < NPC; k++) {
@@ -289,6 +300,10 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
         }
       }
     }
+    // the epoch's step / row blocks (the streams are padded: reading past the epoch's blocks is harmless)
+    const int4* rp = reinterpret_cast<const int4*>(ops_g + opoff) + lane;
+    rstg[0] = rp[0];
+    if (BAND_REC_MAX > 256) rstg[1] = rp[64];
   };
   auto commit = [&]() {
 #pragma unroll
@@ -297,43 +312,42 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 #pragma unroll
         for (int i = 0; i < NI; i++) *reinterpret_cast<double*>(wblk + ldsb[i] + (BAND_IN_OFF + 8 * k) * 8) = stg[k][i];
       }
+    reinterpret_cast<int4*>(recb)[lane] = rstg[0];
+    if (BAND_REC_MAX > 256 && lane < (BAND_REC_MAX - 256) / 4) reinterpret_cast<int4*>(recb)[64 + lane] = rstg[1];
   };
 
   Win W;
   int npos = 0, nzer = 0;
   double lj[6], zj[4];   // junction factor (first wavefront)
+  for (int q = 0; q < 6; q++) lj[q] = 0.0;
+  for (int q = 0; q < 4; q++) zj[q] = 0.0;
   while (true) {
     // ================= forward: assembly, elimination, forward substitution =================
 #pragma unroll
-    for (int q = 0; q < 15; q++) W.S[q] = 0.0;
+    for (int q = 0; q < NS * (NS + 1) / 2; q++) W.S[q] = 0.0;
 #pragma unroll
-    for (int q = 0; q < 5; q++) { W.X[q] = 0.0; W.c[q] = 0.0; }
+    for (int q = 0; q < NS; q++) { W.X[q] = 0.0; W.c[q] = 0.0; }
     W.S55 = 0.0; W.c5 = 0.0;
     npos = 0; nzer = 0;
-    issue(epochs, BE_FP);
-    int o = 0, u = 0;
+    issue(epochs, BE_FP, fops_g, 0);
     for (int e = 0; e < nepochs; e++) {
       cptr E = epochs + e * BAND_EW;
       commit();
-      if (e + 1 < nepochs) issue(E + BAND_EW, BE_FP);
+      if (e + 1 < nepochs) issue(E + BAND_EW, BE_FP, fops_g, E[BAND_EW + BE_FOFF]);
+      // The steps of the epoch: step t works on the slots of phase t (every epoch but the last has BAND_EPOCH steps), so the eight
+      // instantiations follow each other in straight-line code and the window keeps its registers from step to step.
       const int nst = E[BE_NSTEP];
-      if (clane) {
-        for (int t = 0; t < nst; t++) {
-          cptr st = fops + o;
-          const int nrows = (st[BS_FLAGS] >> 8) & 255;
-          switch (u % BAND_NB) {
-            case 0: fstep<0>(W, st, myb, A.vals, A.rhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer); break;
-            case 1: fstep<1>(W, st, myb, A.vals, A.rhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer); break;
-            case 2: fstep<2>(W, st, myb, A.vals, A.rhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer); break;
-            case 3: fstep<3>(W, st, myb, A.vals, A.rhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer); break;
-            default: fstep<4>(W, st, myb, A.vals, A.rhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer); break;
-          }
-          o += BAND_SW + BAND_RW * nrows;
-          u++;
-        }
-      } else {
-        for (int t = 0; t < nst; t++) { o += BAND_SW + BAND_RW * ((fops[o + BS_FLAGS] >> 8) & 255); u++; }
+      int o = 0;
+#define BAND_FSTEP(PHV)                                                                                                     \
+      if (PHV < nst) {                                                                                                      \
+        Rec st;                                                                                                             \
+        load_rec(st, recb, o);                                                                                              \
+        const int fl = __builtin_amdgcn_readfirstlane(st.v[BS_FLAGS]);                                                      \
+        if (clane) fstep<PHV>(W, st, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer);   \
+        o += BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                                         \
       }
+      BAND_FSTEP(0) BAND_FSTEP(1) BAND_FSTEP(2) BAND_FSTEP(3) BAND_FSTEP(4) BAND_FSTEP(5) BAND_FSTEP(6) BAND_FSTEP(7)
+      static_assert(BAND_EPOCH == 8, "eight step instantiations per epoch");
       // factor records of the epoch: 64-byte pieces from the out ring
       const int lb = E[BE_LBASE], lc = E[BE_LCNT];
       char* lout = reinterpret_cast<char*>(lbase_g) + ((long long)lb << 3);
@@ -353,32 +367,33 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     if (P.nparts == 2) {
       // windows to LDS (slot order): the junction reads both with run-time slot numbers
       if (clane) {
-        double* ex = reinterpret_cast<double*>(myb + BAND_DX_OFF * 8);
+        double* ex = reinterpret_cast<double*>(myb + EXCH_OFF * 8);
+        // (46 doubles: the exchange area runs over the dx / dr rings and the tail of the factor-out ring, all idle between the sweeps)
 #pragma unroll
-        for (int q = 0; q < 15; q++) ex[q] = W.S[q];
+        for (int q = 0; q < NS * (NS + 1) / 2; q++) ex[q] = W.S[q];
 #pragma unroll
-        for (int q = 0; q < 5; q++) ex[15 + q] = W.c[q];
-        ex[20] = (double)npos; ex[21] = (double)nzer;
+        for (int q = 0; q < NS; q++) ex[36 + q] = W.c[q];
+        ex[44] = (double)npos; ex[45] = (double)nzer;
       }
       __syncthreads();
       if (part == 0 && clane) {
-        const double* exL = reinterpret_cast<const double*>(myb + BAND_DX_OFF * 8);
-        const double* exR = reinterpret_cast<const double*>(myb + (size_t)NL * LANE_D * 8 + BAND_DX_OFF * 8);
-        const int tL = P.m0 % BAND_NB, tR = (P.n - 1 - P.m0) % BAND_NB;
+        const double* exL = reinterpret_cast<const double*>(myb + EXCH_OFF * 8);
+        const double* exR = reinterpret_cast<const double*>(myb + (size_t)NL * LANE_D * 8 + EXCH_OFF * 8);
+        const int tL = P.m0 % NS, tR = (P.n - 1 - P.m0) % NS;
         double SJ[10], cJ[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const int aL = (tL + i) % BAND_NB, aR = (tR - i + BAND_NB) % BAND_NB;
+          const int aL = (tL + i) % NS, aR = (tR - i + NS) % NS;
 #pragma unroll
           for (int j = 0; j <= i; j++) {
-            const int bL = (tL + j) % BAND_NB, bR = (tR - j + BAND_NB) % BAND_NB;
+            const int bL = (tL + j) % NS, bR = (tR - j + NS) % NS;
             const int iL = aL >= bL ? aL * (aL + 1) / 2 + bL : bL * (bL + 1) / 2 + aL;
             const int iR = aR >= bR ? aR * (aR + 1) / 2 + bR : bR * (bR + 1) / 2 + aR;
             SJ[i * (i + 1) / 2 + j] = exL[iL] + exR[iR];
           }
-          cJ[i] = exL[15 + aL] + exR[15 + aR];
+          cJ[i] = exL[36 + aL] + exR[36 + aR];
         }
-        tpos += (int)exR[20]; tzer += (int)exR[21];
+        tpos += (int)exR[44]; tzer += (int)exR[45];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const double d = SJ[sidx(i, i)];
@@ -401,11 +416,11 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     bool alldone = true;
     if (part == 0) {
       const bool ok = tpos == P.nvar && tzer == 0;
-      if (A.mode == MODE_FACTOR) {
+      if (mode == MODE_FACTOR) {
         if (valid) {
-          A.success[cprob] = ok ? 1 : 0;
-          if (A.npos) A.npos[cprob] = tpos;
-          if (A.nzero) A.nzero[cprob] = tzer;
+          as_global(Ain.success)[cprob] = ok ? 1 : 0;
+          if (Ain.npos) as_global(Ain.npos)[cprob] = tpos;
+          if (Ain.nzero) as_global(Ain.nzero)[cprob] = tzer;
         }
         done = true;
       } else if (!done) {
@@ -433,12 +448,12 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     }
     if (alldone) break;
   }
-  if (A.mode == MODE_FACTOR) return;
+  if (mode == MODE_FACTOR) return;
   // ================= backward: d = -K^-1 rhs where the factorisation succeeded =================
   {
-    double xs[6];
+    double xs[NS + 1];
 #pragma unroll
-    for (int q = 0; q < 6; q++) xs[q] = 0.0;
+    for (int q = 0; q < NS + 1; q++) xs[q] = 0.0;
     if (P.nparts == 2) {
       if (part == 0 && clane) {
         double xj[4];
@@ -446,22 +461,22 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
         xj[2] = fma(-lj[sidx(2, 2)], xj[3], zj[2]);
         xj[1] = fma(-lj[sidx(2, 1)], xj[3], fma(-lj[sidx(1, 1)], xj[2], zj[1]));
         xj[0] = fma(-lj[sidx(2, 0)], xj[3], fma(-lj[sidx(1, 0)], xj[2], fma(-lj[sidx(0, 0)], xj[1], zj[0])));
-        double* ex = reinterpret_cast<double*>(myb + BAND_DX_OFF * 8);
-        double* exR = reinterpret_cast<double*>(myb + (size_t)NL * LANE_D * 8 + BAND_DX_OFF * 8);
+        double* ex = reinterpret_cast<double*>(myb + EXCH_OFF * 8);
+        double* exR = reinterpret_cast<double*>(myb + (size_t)NL * LANE_D * 8 + EXCH_OFF * 8);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           ex[i] = xj[i]; exR[i] = xj[i];
-          if (valid && success) A.d[(long long)cprob * P.N + P.m0 + i] = -xj[i];
+          if (valid && success) gd[(long long)cprob * N + P.m0 + i] = -xj[i];
         }
       }
       __syncthreads();
       if (clane) {
-        const double* ex = reinterpret_cast<const double*>(myb + BAND_DX_OFF * 8);
-        const int t0 = part == 0 ? P.m0 % BAND_NB : (P.n - 1 - P.m0) % BAND_NB;
+        const double* ex = reinterpret_cast<const double*>(myb + EXCH_OFF * 8);
+        const int t0 = part == 0 ? P.m0 % NS : (P.n - 1 - P.m0) % NS;
 #pragma unroll
-        for (int s = 0; s < BAND_NB; s++) {
-          // junction variable i sits in slot (t0 + i) % 5 (first part) / (t0 - i) % 5 (second part)
-          const int i = part == 0 ? (s - t0 + BAND_NB) % BAND_NB : (t0 - s + BAND_NB) % BAND_NB;
+        for (int s = 0; s < NS; s++) {
+          // junction variable i sits in slot (t0 + i) % 8 (first part) / (t0 - i) % 8 (second part)
+          const int i = part == 0 ? (s - t0 + NS) % NS : (t0 - s + NS) % NS;
           xs[s] = i < 4 ? ex[i] : 0.0;
         }
       }
@@ -473,31 +488,23 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 #pragma unroll
     for (int i = 0; i < NI; i++) movst[i] = movok[i] && ctrl[NL + i * 8 + lq] != 0.0;
     const bool okme = valid && ctrl[NL + lane % NL] != 0.0 && clane;
-    const long long pd = (long long)(prob0 + cpl) * P.N;
-    issue(epochs + (nepochs - 1) * BAND_EW, BE_BP);
-    int o = 0, u = P.nsteps[part] - 1;
+    const long long pd = (long long)(prob0 + cpl) * N;
+    issue(epochs + (nepochs - 1) * BAND_EW, BE_BP, bops_g, 0);
     for (int e = nepochs - 1; e >= 0; e--) {
       cptr E = epochs + e * BAND_EW;
       commit();
-      if (e > 0) issue(E - BAND_EW, BE_BP);
+      if (e > 0) issue(E - BAND_EW, BE_BP, bops_g, E[BE_BOFF - BAND_EW]);
       const int nst = E[BE_NSTEP];
-      if (clane) {
-        for (int t = 0; t < nst; t++) {
-          cptr st = bops + o;
-          const int nrows = (st[BS_FLAGS] >> 8) & 255;
-          switch (u % BAND_NB) {
-            case 0: bstep<0>(xs, st, myb, borders, A.d, pd, okme); break;
-            case 1: bstep<1>(xs, st, myb, borders, A.d, pd, okme); break;
-            case 2: bstep<2>(xs, st, myb, borders, A.d, pd, okme); break;
-            case 3: bstep<3>(xs, st, myb, borders, A.d, pd, okme); break;
-            default: bstep<4>(xs, st, myb, borders, A.d, pd, okme); break;
-          }
-          o += BAND_SW + BAND_RW * nrows;
-          u--;
-        }
-      } else {
-        for (int t = 0; t < nst; t++) { o += BAND_SW + BAND_RW * ((bops[o + BS_FLAGS] >> 8) & 255); u--; }
+      int o = 0;
+#define BAND_BSTEP(PHV)                                                                              \
+      if (PHV < nst) {                                                                               \
+        Rec st;                                                                                      \
+        load_rec(st, recb, o);                                                                       \
+        const int fl = __builtin_amdgcn_readfirstlane(st.v[BS_FLAGS]);                               \
+        if (clane) bstep<PHV>(xs, st, fl, recb, o, myb, borders, gd, pd, okme);                      \
+        o += BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                  \
       }
+      BAND_BSTEP(7) BAND_BSTEP(6) BAND_BSTEP(5) BAND_BSTEP(4) BAND_BSTEP(3) BAND_BSTEP(2) BAND_BSTEP(1) BAND_BSTEP(0)
       // solution components of the epoch
       const int xlo = E[BE_DXLO], xc = E[BE_DXCNT], rlo = E[BE_DRLO], rc = E[BE_DRCNT];
       char* dxo = reinterpret_cast<char*>(dbase) + ((long long)xlo << 3);
@@ -508,11 +515,11 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
         for (int i = 0; i < NI; i++) {
           if (cpc * 8 < xc) {
             const double x = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_DX_OFF + 8 * cpc) * 8);
-            if (movst[i] && cpc * 8 + le < xc) *reinterpret_cast<double*>(dxo + doffb[i] + 64 * cpc) = x;
+            if (movst[i] && cpc * 8 + le < xc) *reinterpret_cast<double*>(dxo + roffb[i] + 64 * cpc) = x;
           }
           if (cpc * 8 < rc) {
             const double x = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_DR_OFF + 8 * cpc) * 8);
-            if (movst[i] && cpc * 8 + le < rc) *reinterpret_cast<double*>(dro + doffb[i] + 64 * cpc) = x;
+            if (movst[i] && cpc * 8 + le < rc) *reinterpret_cast<double*>(dro + roffb[i] + 64 * cpc) = x;
           }
         }
       }
@@ -522,10 +529,10 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   if (part == 0) {
     if (nfact > 1 && rho <= rhomax) rho_old = rho;
     if (valid) {
-      A.rho[cprob] = rho;
-      A.rho_old[cprob] = rho_old;
-      A.nfact[cprob] = nfact;
-      A.success[cprob] = success ? 1 : 0;
+      as_global(Ain.rho)[cprob] = rho;
+      as_global(Ain.rho_old)[cprob] = rho_old;
+      as_global(Ain.nfact)[cprob] = nfact;
+      as_global(Ain.success)[cprob] = success ? 1 : 0;
     }
     // rho slots of the problems that climbed (src/CaNNOLeS.jl:1031,1038,1044-1046): the last nvar entries of vals
     for (int q = 0; q < NL; q++) {
@@ -533,14 +540,14 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       const int vq = __builtin_amdgcn_readlane((int)valid, q);
       if (nf > 1 && vq) {
         const double wq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wrote), q), __builtin_amdgcn_readlane(__double2loint(wrote), q));
-        double* vt = A.vals + (long long)(prob0 + q) * P.nnz + (P.nnz - P.nvar);
+        double* vt = gvals + (long long)(prob0 + q) * nnz + (nnz - P.nvar);
         for (int i = lane; i < P.nvar; i += 64) vt[i] = wq;
       }
     }
   }
 }
 
-size_t band_lds_bytes(int nparts, int nl) { return ((size_t)nparts * nl * LANE_D + 2 * nl + 8) * sizeof(double); }
+size_t band_lds_bytes(int nparts, int nl) { return ((size_t)nparts * nl * LANE_D + 2 * nl + 8) * sizeof(double) + (size_t)nparts * BAND_REC_MAX * 4; }
 
 hipError_t launch_band(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream) {
   const size_t ldsb = band_lds_bytes(P.nparts, nl);

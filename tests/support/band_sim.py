@@ -5,6 +5,7 @@ infrastructure: it pins the GENERATOR against the oracle without a GPU."""
 import numpy as np
 
 HW, NB, EPOCH, NPIECE, LREC = 4, 5, 8, 16, 6
+NS = EPOCH   # window slots: variable number t of a part lives in slot t % NS; the border row is index NS
 IN_OFF, LOUT_OFF, LOUT_MAX = 0, NPIECE * 8, 64
 DX_OFF = LOUT_OFF + LOUT_MAX
 DX_MAX = 16
@@ -12,14 +13,14 @@ DR_OFF = DX_OFF + DX_MAX
 DR_MAX = 16
 ZERO_OFF = DR_OFF + DR_MAX
 LANE = ZERO_OFF + 1
-SW, RW, EW, BW = 20, 8, 40, 4
+SW, RW, EW, BW = 20, 8, 44, 4
 BS_FLAGS, BS_DG0, BS_RHO, BS_OD = 0, 1, 4, 5
 BS_BC0 = BS_OD + 2 * HW
 BS_BC1, BS_RX, BS_LB, BS_LX, BS_DX, BS_BORDER = BS_BC0 + 1, BS_BC0 + 2, BS_BC0 + 3, BS_BC0 + 4, BS_BC0 + 5, BS_BC0 + 6
 BF_ENTER_B, BF_PIVOT_B, BF_PIVOT_X = 1, 2, 4
 BR_DI, BR_J0, BR_RR, BR_DR = 0, 1, 1 + NB, 2 + NB
 BE_FP, BE_BP = 0, NPIECE
-BE_LBASE, BE_LCNT, BE_DXLO, BE_DXCNT, BE_DRLO, BE_DRCNT, BE_NSTEP = (2 * NPIECE + i for i in range(7))
+BE_LBASE, BE_LCNT, BE_DXLO, BE_DXCNT, BE_DRLO, BE_DRCNT, BE_NSTEP, BE_FOFF, BE_BOFF, BE_OPLEN = (2 * NPIECE + i for i in range(10))
 
 
 class BandSim:
@@ -51,8 +52,8 @@ class BandSim:
         nzer = np.zeros(B, np.int64)
         wins = []
         for q, P in enumerate(self.parts):
-            S = np.zeros((6, 6, B))
-            c = np.zeros((6, B))
+            S = np.zeros((NS + 1, NS + 1, B))
+            c = np.zeros((NS + 1, B))
             blk = np.zeros((B, LANE))
             ops, o = P["fops"], 0
             Lq = Lst[:, P["loff"]:]
@@ -67,12 +68,15 @@ class BandSim:
                         Lq[:, Ep[BE_LBASE]: Ep[BE_LBASE] + Ep[BE_LCNT]] = blk[:, LOUT_OFF: LOUT_OFF + Ep[BE_LCNT]]
                     blk[:, :ZERO_OFF] = np.nan   # stale operands must not be read
                     self._load_pieces(blk, E[BE_FP: BE_FP + NPIECE], (vals, rhs))
+                    assert o == E[BE_FOFF] and E[BE_OPLEN] <= 320
                 st = ops[o: o + SW]
                 fl = int(st[BS_FLAGS])
                 nrows = (fl >> 8) & 255
                 assert (st[1:BS_LB + 2] % 8 == 0).all()
                 v = lambda off: blk[:, off // 8]
-                es, ps = u % NB, (u + 1) % NB
+                es = u % NS
+                live = [(u - HW + k) % NS for k in range(NB)]   # live slots: [0] = this step's pivot .. [HW] = the entering variable
+                ps = live[0]
                 # enter
                 diag = (v(st[BS_DG0]) + v(st[BS_DG0 + 1])) + v(st[BS_DG0 + 2])
                 rv = v(st[BS_RHO])
@@ -80,9 +84,9 @@ class BandSim:
                     rv = np.where(ovr, rho, rv)
                 S[es, es] = diag + rv
                 for k in range(1, HW + 1):
-                    s = (es - k) % NB
+                    s = (es - k) % NS
                     S[es, s] = S[s, es] = v(st[BS_OD + 2 * (k - 1)]) + v(st[BS_OD + 2 * (k - 1) + 1])
-                S[5, es] = S[es, 5] = v(st[BS_BC0]) + v(st[BS_BC1])
+                S[NS, es] = S[es, NS] = v(st[BS_BC0]) + v(st[BS_BC1])
                 c[es] = v(st[BS_RX])
                 # rows
                 for i in range(nrows):
@@ -91,36 +95,40 @@ class BandSim:
                     npos += dr > tol
                     nzer += np.abs(dr) <= tol
                     w = -1.0 / dr
-                    J = [v(rb[BR_J0 + s]) for s in range(NB)]
+                    J = [v(rb[BR_J0 + k]) for k in range(NB)]
                     tr = v(rb[BR_RR]) * w
-                    for a in range(NB):
-                        ta = J[a] * w
-                        for b in range(a + 1):
-                            S[a, b] = S[a, b] + ta * J[b]
+                    for ka in range(NB):
+                        a = live[ka]
+                        ta = J[ka] * w
+                        for kb in range(ka + 1):
+                            b = live[kb]
+                            S[a, b] = S[a, b] + ta * J[kb]
                             S[b, a] = S[a, b]
-                        c[a] = c[a] + tr * J[a]
+                        c[a] = c[a] + tr * J[ka]
                 # border pivot
                 if fl & BF_PIVOT_B:
                     bt = P["borders"][st[BS_BORDER]]
-                    S[5, 5] = S[5, 5] + vals[:, bt[0]]
-                    c[5] = c[5] + rhs[:, bt[1]]
-                    d = S[5, 5].copy()
+                    S[NS, NS] = S[NS, NS] + vals[:, bt[0]]
+                    c[NS] = c[NS] + rhs[:, bt[1]]
+                    d = S[NS, NS].copy()
                     npos += d > tol
                     nzer += np.abs(d) <= tol
-                    w = S[5, :NB].copy()
+                    w = np.stack([S[NS, live[k]] for k in range(NB)])
                     l = w / d
-                    z = c[5] / d
-                    for a in range(NB):
-                        for b in range(a + 1):
-                            S[a, b] = S[a, b] - w[a] * l[b]
+                    z = c[NS] / d
+                    for ka in range(NB):
+                        a = live[ka]
+                        for kb in range(ka + 1):
+                            b = live[kb]
+                            S[a, b] = S[a, b] - w[ka] * l[kb]
                             S[b, a] = S[a, b]
-                        c[a] = c[a] - w[a] * z
+                        c[a] = c[a] - w[ka] * z
                     off = st[BS_LB] // 8
                     blk[:, off: off + NB] = l.T
                     blk[:, off + NB] = z
-                    S[5, :] = 0.0
-                    S[:, 5] = 0.0
-                    c[5] = 0.0
+                    S[NS, :] = 0.0
+                    S[:, NS] = 0.0
+                    c[NS] = 0.0
                 # band pivot
                 if fl & BF_PIVOT_X:
                     d = S[ps, ps].copy()
@@ -129,20 +137,16 @@ class BandSim:
                     w = S[:, ps].copy()
                     l = w / d
                     z = c[ps] / d
-                    oth = [s for s in range(6) if s != ps]
-                    for a in oth:
-                        for b in oth:
-                            if b <= a:
-                                S[a, b] = S[a, b] - w[a] * l[b]
-                                S[b, a] = S[a, b]
+                    oth = live[1:] + [NS]
+                    for ia, a in enumerate(oth):
+                        for b in oth[: ia + 1]:
+                            S[a, b] = S[a, b] - w[a] * l[b]
+                            S[b, a] = S[a, b]
                         c[a] = c[a] - w[a] * z
                     off = st[BS_LX] // 8
-                    k = 0
-                    for s in range(NB):
-                        if s != ps:
-                            blk[:, off + k] = l[s]
-                            k += 1
-                    blk[:, off + 4] = l[5]
+                    for k in range(1, NB):
+                        blk[:, off + k - 1] = l[live[k]]
+                    blk[:, off + 4] = l[NS]
                     blk[:, off + 5] = z
                     S[ps, :] = np.nan   # a pivoted slot holds nothing until the next variable enters it
                     S[:, ps] = np.nan
@@ -154,8 +158,8 @@ class BandSim:
         junction = None
         if self.nparts == 2:
             n, m0 = self.n, self.m0
-            sL = [(m0 + i) % NB for i in range(HW)]
-            sR = [(n - 1 - m0 - i) % NB for i in range(HW)]
+            sL = [(m0 + i) % NS for i in range(HW)]
+            sR = [(n - 1 - m0 - i) % NS for i in range(HW)]
             (SL, cL), (SR, cR) = wins
             SJ = np.zeros((HW, HW, B))
             cJ = np.zeros((HW, B))
@@ -192,10 +196,10 @@ class BandSim:
                 xj[i] = zj[i] - sum(lj[a, i] * xj[a] for a in range(i + 1, HW))
                 d[:, m0 + i] = -xj[i]
         for q, P in enumerate(self.parts):
-            xs = np.zeros((6, B))
+            xs = np.zeros((NS + 1, B))
             if xj is not None:
                 for i in range(HW):
-                    xs[((m0 + i) if q == 0 else (n - 1 - m0 - i)) % NB] = xj[i]
+                    xs[((m0 + i) if q == 0 else (n - 1 - m0 - i)) % NS] = xj[i]
             blk = np.zeros((B, LANE))
             ops, o = P["bops"], 0
             Lq = Lst[:, P["loff"]:]
@@ -206,37 +210,36 @@ class BandSim:
                     E = P["epochs"][ep_of[u]]
                     blk[:, :ZERO_OFF] = np.nan
                     self._load_pieces(blk, E[BE_BP: BE_BP + NPIECE], (vals, rhs, Lq))
+                    assert o == E[BE_BOFF]
                 st = ops[o: o + SW]
                 fl = int(st[BS_FLAGS])
                 nrows = (fl >> 8) & 255
                 v = lambda off: blk[:, off // 8]
-                ps = (u + 1) % NB
+                live = [(u - HW + k) % NS for k in range(NB)]
+                ps = live[0]
                 if fl & BF_PIVOT_X:
                     off = st[BS_LX] // 8
                     x = blk[:, off + 5].copy()
-                    k = 0
-                    for s in range(NB):
-                        if s != ps:
-                            x = x - blk[:, off + k] * xs[s]
-                            k += 1
-                    x = x - blk[:, off + 4] * xs[5]
+                    for k in range(1, NB):
+                        x = x - blk[:, off + k - 1] * xs[live[k]]
+                    x = x - blk[:, off + 4] * xs[NS]
                     xs[ps] = x
                     blk[:, st[BS_DX] // 8] = -x
                 if fl & BF_PIVOT_B:
                     off = st[BS_LB] // 8
                     x = blk[:, off + NB].copy()
-                    for s in range(NB):
-                        x = x - blk[:, off + s] * xs[s]
-                    xs[5] = x
+                    for k in range(NB):
+                        x = x - blk[:, off + k] * xs[live[k]]
+                    xs[NS] = x
                     d[:, P["borders"][st[BS_BORDER]][2]] = -x
                 for i in range(nrows):
                     rb = ops[o + SW + RW * i: o + SW + RW * (i + 1)]
                     acc = -v(rb[BR_RR])
-                    for s in range(NB):
-                        acc = acc + v(rb[BR_J0 + s]) * xs[s]
+                    for k in range(NB):
+                        acc = acc + v(rb[BR_J0 + k]) * xs[live[k]]
                     blk[:, rb[BR_DR] // 8] = acc / v(rb[BR_DI])
                 if fl & BF_ENTER_B:
-                    xs[5] = 0.0
+                    xs[NS] = 0.0
                 o += SW + RW * nrows
                 if u == starts[ep_of[u]]:
                     E = P["epochs"][ep_of[u]]
