@@ -19,6 +19,15 @@
 #include "band.h"
 #include "kernels.h"
 
+// timing probes (results wrong or missing): 1 no backward sweep, 2 no arithmetic in the forward steps, 4 none in the backward steps,
+// 8 no operand loads after the first epoch, 16 no factor / solution stores
+#ifndef BAND_DBG
+#define BAND_DBG 0
+#endif
+#if BAND_DBG && !defined(CNL_EXPERIMENT)
+#error "BAND_DBG needs -DCNL_EXPERIMENT=1"
+#endif
+
 namespace cnl {
 
 namespace {
@@ -244,16 +253,14 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   const double* rbase = has_rhs ? grhs + (long long)prob0 * N : gvals;
   double* lbase_g = gL + (long long)prob0 * lsize + P.loff[part];
   double* dbase = gd ? gd + (long long)prob0 * N : nullptr;
-  unsigned voffb[NI], roffb[NI], loffb[NI], ldsb[NI];
+  unsigned movp[NI], ldsb[NI];   // problem of the lane inside the workgroup (clamped to the batch), LDS byte offset of its element
   bool movok[NI];
 #pragma unroll
   for (int i = 0; i < NI; i++) {
     int pl = i * 8 + lq;
     movok[i] = prob0 + pl < batch;
     if (!movok[i]) pl = batch - 1 - prob0;
-    voffb[i] = ((unsigned)pl * (unsigned)nnz + (unsigned)le) << 3;
-    roffb[i] = ((unsigned)pl * (unsigned)N + (unsigned)le) << 3;
-    loffb[i] = ((unsigned)pl * (unsigned)lsize + (unsigned)le) << 3;
+    movp[i] = (unsigned)pl;
     ldsb[i] = ((unsigned)(i * 8 + lq) * (unsigned)LANE_D + (unsigned)le) << 3;
   }
   // compute lanes
@@ -272,49 +279,55 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   int nfact = 0;
   bool done = !valid, success = false, ovr = false;
 
+  static_assert(NI <= 4, "at most four problem groups per mover lane");
   double stg[NPC][NI];   // operand pieces in flight
-  int4 rstg[2];          // step blocks in flight (two 16-byte words per lane: 512 ints)
+  int4 rstg0, rstg1;     // step blocks in flight (two 16-byte words per lane: 512 ints)
   unsigned pmask = 0;    // pieces of the epoch whose operands are in flight
   static_assert(BAND_REC_MAX <= 512, "record buffer: two dwordx4 per lane");
-  auto issue = [&](cptr E, int ofs, const int* ops_g, int opoff) {
-    pmask = 0;
-#pragma unroll
-    for (int k = 0; k < NPC; k++) {
-      const int pc = E[ofs + k];
-      if (pc >= 0) {
-        pmask |= 1u << k;
-        const int arr = pc >> 28;
-        const long long base = (long long)(pc & ((1 << 28) - 1)) << 3;
-        if (arr == 0) {
-          const char* pb = reinterpret_cast<const char*>(vbase) + base;
-#pragma unroll
-          for (int i = 0; i < NI; i++) stg[k][i] = *reinterpret_cast<const double*>(pb + voffb[i]);
-        } else if (arr == 1) {
-          const char* pb = reinterpret_cast<const char*>(rbase) + base;
-#pragma unroll
-          for (int i = 0; i < NI; i++) stg[k][i] = has_rhs ? *reinterpret_cast<const double*>(pb + roffb[i]) : 0.0;
-        } else {
-          const char* pb = reinterpret_cast<const char*>(lbase_g) + base;
-#pragma unroll
-          for (int i = 0; i < NI; i++) stg[k][i] = *reinterpret_cast<const double*>(pb + loffb[i]);
-        }
-      }
-    }
-    // the epoch's step / row blocks (the streams are padded: reading past the epoch's blocks is harmless)
-    const int4* rp = reinterpret_cast<const int4*>(ops_g + opoff) + lane;
-    rstg[0] = rp[0];
-    if (BAND_REC_MAX > 256) rstg[1] = rp[64];
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < NPC; k++)
-      if (pmask & (1u << k)) {
-#pragma unroll
-        for (int i = 0; i < NI; i++) *reinterpret_cast<double*>(wblk + ldsb[i] + (BAND_IN_OFF + 8 * k) * 8) = stg[k][i];
-      }
-    reinterpret_cast<int4*>(recb)[lane] = rstg[0];
-    if (BAND_REC_MAX > 256 && lane < (BAND_REC_MAX - 256) / 4) reinterpret_cast<int4*>(recb)[64 + lane] = rstg[1];
-  };
+  // One load per piece and problem group: the array's base pointer and stride are selected with scalar instructions, the lane's
+  // offset is problem * stride + element.  (Three guarded loads made the compiler form all three 64-bit addresses of every piece
+  // up front — 96 NI VGPRs; selecting among per-array offset arrays made it index them in scratch memory.)  The pieces are
+  // spelled out one by one: every index into the staging registers is a literal.
+#define BAND_ISSUE1(K, I) if constexpr (I < NI) stg[K][I] = *reinterpret_cast<const double*>(pb + ((movp[I] * strd + (unsigned)le) << 3));
+#define BAND_COMMIT1(K, I) if constexpr (I < NI) *reinterpret_cast<double*>(wblk + ldsb[I] + (BAND_IN_OFF + 8 * K) * 8) = stg[K][I];
+#define BAND_ISSUE(K)                                                                                                         \
+  {                                                                                                                           \
+    const int pc = E[ofs + K];                                                                                                \
+    if (pc >= 0) {                                                                                                            \
+      pmask |= 1u << K;                                                                                                       \
+      const int arr = pc >> 28;                                                                                               \
+      const char* pb = (arr == 0 ? reinterpret_cast<const char*>(vbase) : arr == 1 ? reinterpret_cast<const char*>(rbase)     \
+                                                                                   : reinterpret_cast<const char*>(lbase_g)) + \
+                       ((long long)(pc & ((1 << 28) - 1)) << 3);                                                              \
+      const unsigned strd = arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : (unsigned)lsize;                              \
+      BAND_ISSUE1(K, 0) BAND_ISSUE1(K, 1) BAND_ISSUE1(K, 2) BAND_ISSUE1(K, 3)                                                 \
+    }                                                                                                                         \
+  }
+#define BAND_COMMIT(K)                                                                                                        \
+  if (pmask & (1u << K)) {                                                                                                    \
+    BAND_COMMIT1(K, 0) BAND_COMMIT1(K, 1) BAND_COMMIT1(K, 2) BAND_COMMIT1(K, 3)                                               \
+  }
+  // (macros, not lambdas: a closure made the compiler keep every captured variable — the staging registers included — in scratch memory)
+#define BAND_ISSUE_ALL(EP, OFS, OPS, OPOFF)                                                                                   \
+  {                                                                                                                           \
+    cptr E = (EP);                                                                                                            \
+    const int ofs = (OFS);                                                                                                    \
+    pmask = 0;                                                                                                                \
+    BAND_ISSUE(0) BAND_ISSUE(1) BAND_ISSUE(2) BAND_ISSUE(3) BAND_ISSUE(4) BAND_ISSUE(5) BAND_ISSUE(6) BAND_ISSUE(7)           \
+    BAND_ISSUE(8) BAND_ISSUE(9) BAND_ISSUE(10) BAND_ISSUE(11) BAND_ISSUE(12) BAND_ISSUE(13) BAND_ISSUE(14) BAND_ISSUE(15)     \
+    /* the epoch's step / row blocks (the streams are padded: reading past the epoch's blocks is harmless) */                 \
+    const int4* rp = reinterpret_cast<const int4*>((OPS) + (OPOFF)) + lane;                                                   \
+    rstg0 = rp[0];                                                                                                            \
+    if (BAND_REC_MAX > 256) rstg1 = rp[64];                                                                                   \
+  }
+#define BAND_COMMIT_ALL()                                                                                                     \
+  {                                                                                                                           \
+    BAND_COMMIT(0) BAND_COMMIT(1) BAND_COMMIT(2) BAND_COMMIT(3) BAND_COMMIT(4) BAND_COMMIT(5) BAND_COMMIT(6) BAND_COMMIT(7)   \
+    BAND_COMMIT(8) BAND_COMMIT(9) BAND_COMMIT(10) BAND_COMMIT(11) BAND_COMMIT(12) BAND_COMMIT(13) BAND_COMMIT(14) BAND_COMMIT(15) \
+    reinterpret_cast<int4*>(recb)[lane] = rstg0;                                                                              \
+    if (BAND_REC_MAX > 256 && lane < (BAND_REC_MAX - 256) / 4) reinterpret_cast<int4*>(recb)[64 + lane] = rstg1;              \
+  }
+  static_assert(NPC == 16, "sixteen operand pieces");
 
   Win W;
   int npos = 0, nzer = 0;
@@ -329,11 +342,11 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     for (int q = 0; q < NS; q++) { W.X[q] = 0.0; W.c[q] = 0.0; }
     W.S55 = 0.0; W.c5 = 0.0;
     npos = 0; nzer = 0;
-    issue(epochs, BE_FP, fops_g, 0);
+    BAND_ISSUE_ALL(epochs, BE_FP, fops_g, 0)
     for (int e = 0; e < nepochs; e++) {
       cptr E = epochs + e * BAND_EW;
-      commit();
-      if (e + 1 < nepochs) issue(E + BAND_EW, BE_FP, fops_g, E[BAND_EW + BE_FOFF]);
+      BAND_COMMIT_ALL()
+      if (e + 1 < nepochs && !(BAND_DBG & 8)) BAND_ISSUE_ALL(epochs + (e + 1) * BAND_EW, BE_FP, fops_g, epochs[(e + 1) * BAND_EW + BE_FOFF])
       // The steps of the epoch: step t works on the slots of phase t (every epoch but the last has BAND_EPOCH steps), so the eight
       // instantiations follow each other in straight-line code and the window keeps its registers from step to step.
       const int nst = E[BE_NSTEP];
@@ -343,7 +356,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
         Rec st;                                                                                                             \
         load_rec(st, recb, o);                                                                                              \
         const int fl = __builtin_amdgcn_readfirstlane(st.v[BS_FLAGS]);                                                      \
-        if (clane) fstep<PHV>(W, st, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer);   \
+        if (clane && !(BAND_DBG & 2)) fstep<PHV>(W, st, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer);   \
         o += BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                                         \
       }
       BAND_FSTEP(0) BAND_FSTEP(1) BAND_FSTEP(2) BAND_FSTEP(3) BAND_FSTEP(4) BAND_FSTEP(5) BAND_FSTEP(6) BAND_FSTEP(7)
@@ -357,7 +370,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 #pragma unroll
           for (int i = 0; i < NI; i++) {
             const double x = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_LOUT_OFF + 8 * cpc) * 8);
-            if (movok[i] && cpc * 8 + le < lc) *reinterpret_cast<double*>(lout + loffb[i] + 64 * cpc) = x;
+            if (movok[i] && cpc * 8 + le < lc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(lout + (((movp[i] * (unsigned)lsize + (unsigned)le) << 3) + 64 * cpc)) = x;
           }
         }
       }
@@ -448,7 +461,10 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     }
     if (alldone) break;
   }
-  if (mode == MODE_FACTOR) return;
+  if (mode == MODE_FACTOR || (BAND_DBG & 1)) {
+    if (mode != MODE_FACTOR && part == 0 && valid) as_global(Ain.success)[cprob] = 1;
+    return;
+  }
   // ================= backward: d = -K^-1 rhs where the factorisation succeeded =================
   {
     double xs[NS + 1];
@@ -489,11 +505,11 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     for (int i = 0; i < NI; i++) movst[i] = movok[i] && ctrl[NL + i * 8 + lq] != 0.0;
     const bool okme = valid && ctrl[NL + lane % NL] != 0.0 && clane;
     const long long pd = (long long)(prob0 + cpl) * N;
-    issue(epochs + (nepochs - 1) * BAND_EW, BE_BP, bops_g, 0);
+    BAND_ISSUE_ALL(epochs + (nepochs - 1) * BAND_EW, BE_BP, bops_g, 0)
     for (int e = nepochs - 1; e >= 0; e--) {
       cptr E = epochs + e * BAND_EW;
-      commit();
-      if (e > 0) issue(E - BAND_EW, BE_BP, bops_g, E[BE_BOFF - BAND_EW]);
+      BAND_COMMIT_ALL()
+      if (e > 0 && !(BAND_DBG & 8)) BAND_ISSUE_ALL(epochs + (e - 1) * BAND_EW, BE_BP, bops_g, epochs[(e - 1) * BAND_EW + BE_BOFF])
       const int nst = E[BE_NSTEP];
       int o = 0;
 #define BAND_BSTEP(PHV)                                                                              \
@@ -501,7 +517,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
         Rec st;                                                                                      \
         load_rec(st, recb, o);                                                                       \
         const int fl = __builtin_amdgcn_readfirstlane(st.v[BS_FLAGS]);                               \
-        if (clane) bstep<PHV>(xs, st, fl, recb, o, myb, borders, gd, pd, okme);                      \
+        if (clane && !(BAND_DBG & 4)) bstep<PHV>(xs, st, fl, recb, o, myb, borders, gd, pd, okme);                      \
         o += BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                  \
       }
       BAND_BSTEP(7) BAND_BSTEP(6) BAND_BSTEP(5) BAND_BSTEP(4) BAND_BSTEP(3) BAND_BSTEP(2) BAND_BSTEP(1) BAND_BSTEP(0)
@@ -515,11 +531,11 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
         for (int i = 0; i < NI; i++) {
           if (cpc * 8 < xc) {
             const double x = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_DX_OFF + 8 * cpc) * 8);
-            if (movst[i] && cpc * 8 + le < xc) *reinterpret_cast<double*>(dxo + roffb[i] + 64 * cpc) = x;
+            if (movst[i] && cpc * 8 + le < xc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(dxo + (((movp[i] * (unsigned)N + (unsigned)le) << 3) + 64 * cpc)) = x;
           }
           if (cpc * 8 < rc) {
             const double x = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_DR_OFF + 8 * cpc) * 8);
-            if (movst[i] && cpc * 8 + le < rc) *reinterpret_cast<double*>(dro + roffb[i] + 64 * cpc) = x;
+            if (movst[i] && cpc * 8 + le < rc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(dro + (((movp[i] * (unsigned)N + (unsigned)le) << 3) + 64 * cpc)) = x;
           }
         }
       }
