@@ -95,35 +95,55 @@ __device__ __forceinline__ void load_row(RowRec& R, const char* recb, int o) {
 // one forward step of phase PH = step number % 8: enter slot PH, pivot slot PH - 4; fl = flags word (wave-uniform), o = int
 // offset of the step block in the record buffer
 template <int PH>
-__device__ __forceinline__ void fstep(Win& W, const Rec& st, const int fl, const char* recb, const int o, char* myb, const double* __restrict__ gvals,
-                                      const double* __restrict__ grhs, cptr borders, long long pv, long long pr, bool has_rhs, double rho, bool ovr,
-                                      double tol, int& npos, int& nzer) {
+__device__ __forceinline__ void fstep(Win& W, const Rec& st, const RowRec& row0, const int fl, const char* recb, const int o, char* myb,
+                                      const double* __restrict__ gvals, const double* __restrict__ grhs, cptr borders, long long pv, long long pr,
+                                      bool has_rhs, double rho, bool ovr, double tol, int& npos, int& nzer) {
   constexpr int es = PH, ps = lslot(PH, 0);
+  const int nrows = (fl >> 8) & 255;
+  // every operand of the entering variable and of the first residual row is read before anything is computed: ONE LDS round trip
+  // per step instead of one per dependent pair (the block of the step and of its first row were prefetched a step ahead)
+  double eo[15];
+#pragma unroll
+  for (int q = 0; q < 15; q++) eo[q] = LDSD(st.v[BS_DG0 + q]);
+  static_assert(BS_RX == BS_DG0 + 14, "the fifteen operands of an entering variable are consecutive words of the step block");
+  double rj[BAND_NB], rdr = 1.0, rrr = 0.0;
+  if (nrows > 0) {
+#pragma unroll
+    for (int k = 0; k < BAND_NB; k++) rj[k] = LDSD(row0.v[BR_J0 + k]);
+    rdr = LDSD(row0.v[BR_DI]);
+    rrr = LDSD(row0.v[BR_RR]);
+  }
   // ---- enter ----
   {
-    double dg = (LDSD(st.v[BS_DG0]) + LDSD(st.v[BS_DG1])) + LDSD(st.v[BS_DG2]);
-    double rv = LDSD(st.v[BS_RHO]);
+    const double dg = (eo[0] + eo[1]) + eo[2];
+    double rv = eo[BS_RHO - BS_DG0];
     if (!(fl & (1 << 16))) rv = ovr ? rho : rv;
     W.S[sidx(es, es)] = dg + rv;
 #pragma unroll
-    for (int k = 1; k <= BAND_HW; k++) W.S[sidx(es, lslot(PH, BAND_HW - k))] = LDSD(st.v[BS_OD + 2 * (k - 1)]) + LDSD(st.v[BS_OD + 2 * (k - 1) + 1]);
-    W.X[es] = LDSD(st.v[BS_BC0]) + LDSD(st.v[BS_BC1]);
-    W.c[es] = LDSD(st.v[BS_RX]);
+    for (int k = 1; k <= BAND_HW; k++) W.S[sidx(es, lslot(PH, BAND_HW - k))] = eo[BS_OD - BS_DG0 + 2 * (k - 1)] + eo[BS_OD - BS_DG0 + 2 * (k - 1) + 1];
+    W.X[es] = eo[BS_BC0 - BS_DG0] + eo[BS_BC1 - BS_DG0];
+    W.c[es] = eo[BS_RX - BS_DG0];
   }
   // ---- residual rows completed by the entering variable: products -J_a J_b / d_r, counted in the inertia ----
-  const int nrows = (fl >> 8) & 255;
   for (int i = 0; i < nrows; i++) {
-    RowRec rb;
-    load_row(rb, recb, o + BAND_SW + BAND_RW * i);
-    const double dr = LDSD(rb.v[BR_DI]);
+    double J[BAND_NB], dr, rr;
+    if (i == 0) {
+#pragma unroll
+      for (int k = 0; k < BAND_NB; k++) J[k] = rj[k];
+      dr = rdr; rr = rrr;
+    } else {
+      RowRec rb;
+      load_row(rb, recb, o + BAND_SW + BAND_RW * i);
+#pragma unroll
+      for (int k = 0; k < BAND_NB; k++) J[k] = LDSD(rb.v[BR_J0 + k]);
+      dr = LDSD(rb.v[BR_DI]);
+      rr = LDSD(rb.v[BR_RR]);
+    }
     npos += dr > tol;
     nzer += fabs(dr) <= tol;
     const double r = rrcp(dr);
     const double w = rdiv(-1.0, dr, r);
-    double J[BAND_NB];
-#pragma unroll
-    for (int k = 0; k < BAND_NB; k++) J[k] = LDSD(rb.v[BR_J0 + k]);
-    const double tr = LDSD(rb.v[BR_RR]) * w;
+    const double tr = rr * w;
 #pragma unroll
     for (int ka = 0; ka < BAND_NB; ka++) {
       const double ta = J[ka] * w;
@@ -188,35 +208,61 @@ __device__ __forceinline__ void fstep(Win& W, const Rec& st, const int fl, const
 
 // one backward step of phase PH: x of the band pivot, then of the border pivot, then the residual components
 template <int PH>
-__device__ __forceinline__ void bstep(double (&xs)[NS + 1], const Rec& st, const int fl, const char* recb, const int o, char* myb, cptr borders,
-                                      double* __restrict__ gd, long long pd, bool okme) {
+__device__ __forceinline__ void bstep(double (&xs)[NS + 1], const Rec& st, const RowRec& row0, const int fl, const char* recb, const int o, char* myb,
+                                      cptr borders, double* __restrict__ gd, long long pd, bool okme) {
   constexpr int ps = lslot(PH, 0);
+  const int nrows = (fl >> 8) & 255;
+  // factor records and the first row's operands: read up front (one LDS round trip)
+  double lx[BAND_LREC], lb[BAND_LREC], rj[BAND_NB], rdr = 1.0, rrr = 0.0;
   if (fl & BF_PIVOT_X) {
     const double* lo = reinterpret_cast<const double*>(myb + st.v[BS_LX]);
-    double x = lo[5];
 #pragma unroll
-    for (int k = 1; k < BAND_NB; k++) x = fma(-lo[k - 1], xs[lslot(PH, k)], x);
-    x = fma(-lo[4], xs[NS], x);
+    for (int q = 0; q < BAND_LREC; q++) lx[q] = lo[q];
+  }
+  if (fl & BF_PIVOT_B) {
+    const double* lo = reinterpret_cast<const double*>(myb + st.v[BS_LB]);
+#pragma unroll
+    for (int q = 0; q < BAND_LREC; q++) lb[q] = lo[q];
+  }
+  if (nrows > 0) {
+#pragma unroll
+    for (int k = 0; k < BAND_NB; k++) rj[k] = LDSD(row0.v[BR_J0 + k]);
+    rdr = LDSD(row0.v[BR_DI]);
+    rrr = LDSD(row0.v[BR_RR]);
+  }
+  if (fl & BF_PIVOT_X) {
+    double x = lx[5];
+#pragma unroll
+    for (int k = 1; k < BAND_NB; k++) x = fma(-lx[k - 1], xs[lslot(PH, k)], x);
+    x = fma(-lx[4], xs[NS], x);
     xs[ps] = x;
     LDSW(st.v[BS_DX]) = -x;
   }
   if (fl & BF_PIVOT_B) {
-    const double* lo = reinterpret_cast<const double*>(myb + st.v[BS_LB]);
-    double x = lo[BAND_NB];
+    double x = lb[BAND_NB];
 #pragma unroll
-    for (int k = 0; k < BAND_NB; k++) x = fma(-lo[k], xs[lslot(PH, k)], x);
+    for (int k = 0; k < BAND_NB; k++) x = fma(-lb[k], xs[lslot(PH, k)], x);
     xs[NS] = x;
     if (okme) gd[pd + borders[BAND_BW * __builtin_amdgcn_readfirstlane(st.v[BS_BORDER]) + BB_DOUT]] = -x;
   }
-  const int nrows = (fl >> 8) & 255;
   for (int i = 0; i < nrows; i++) {
-    RowRec rb;
-    load_row(rb, recb, o + BAND_SW + BAND_RW * i);
-    double acc = -LDSD(rb.v[BR_RR]);
+    double J[BAND_NB], dr, rr;
+    int dro;
+    if (i == 0) {
 #pragma unroll
-    for (int k = 0; k < BAND_NB; k++) acc = fma(LDSD(rb.v[BR_J0 + k]), xs[lslot(PH, k)], acc);
-    const double dr = LDSD(rb.v[BR_DI]);
-    LDSW(rb.v[BR_DR]) = rdiv(acc, dr, rrcp(dr));
+      for (int k = 0; k < BAND_NB; k++) J[k] = rj[k];
+      dr = rdr; rr = rrr; dro = row0.v[BR_DR];
+    } else {
+      RowRec rb;
+      load_row(rb, recb, o + BAND_SW + BAND_RW * i);
+#pragma unroll
+      for (int k = 0; k < BAND_NB; k++) J[k] = LDSD(rb.v[BR_J0 + k]);
+      dr = LDSD(rb.v[BR_DI]); rr = LDSD(rb.v[BR_RR]); dro = rb.v[BR_DR];
+    }
+    double acc = -rr;
+#pragma unroll
+    for (int k = 0; k < BAND_NB; k++) acc = fma(J[k], xs[lslot(PH, k)], acc);
+    LDSW(dro) = rdiv(acc, dr, rrcp(dr));
   }
   if (fl & BF_ENTER_B) xs[NS] = 0.0;
 }
@@ -351,16 +397,33 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       // instantiations follow each other in straight-line code and the window keeps its registers from step to step.
       const int nst = E[BE_NSTEP];
       int o = 0;
+      // the blocks of step t + 1 (step block + first row block) are read while step t computes
+      Rec stC, stN;
+      RowRec rwC, rwN;
+      load_rec(stC, recb, 0);
+      load_row(rwC, recb, BAND_SW);
 #define BAND_FSTEP(PHV)                                                                                                     \
       if (PHV < nst) {                                                                                                      \
-        Rec st;                                                                                                             \
-        load_rec(st, recb, o);                                                                                              \
-        const int fl = __builtin_amdgcn_readfirstlane(st.v[BS_FLAGS]);                                                      \
-        if (clane && !(BAND_DBG & 2)) fstep<PHV>(W, st, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer);   \
-        o += BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                                         \
+        const int fl = __builtin_amdgcn_readfirstlane(stC.v[BS_FLAGS]);                                                     \
+        const int onext = o + BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                        \
+        if (PHV + 1 < nst) { load_rec(stN, recb, onext); load_row(rwN, recb, onext + BAND_SW); }                            \
+        if (clane && !(BAND_DBG & 2)) fstep<PHV>(W, stC, rwC, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer); \
+        o = onext; stC = stN; rwC = rwN;                                                                                    \
       }
       BAND_FSTEP(0) BAND_FSTEP(1) BAND_FSTEP(2) BAND_FSTEP(3) BAND_FSTEP(4) BAND_FSTEP(5) BAND_FSTEP(6) BAND_FSTEP(7)
       static_assert(BAND_EPOCH == 8, "eight step instantiations per epoch");
+      if (nst == BAND_EPOCH) {
+        // behind a full epoch the slots 0 .. 3 are dead (pivoted in phases 4 .. 7): give them a constant, so that only the ten
+        // entries among the live slots, their border row and right-hand side are carried from epoch to epoch (the junction
+        // behind the loop reads every entry, which would otherwise keep all 52 in registers through the whole sweep)
+#pragma unroll
+        for (int a = 0; a < NS; a++)
+#pragma unroll
+          for (int b = 0; b <= a; b++)
+            if (b < 4) W.S[sidx(a, b)] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) { W.X[a] = 0.0; W.c[a] = 0.0; }
+      }
       // factor records of the epoch: 64-byte pieces from the out ring
       const int lb = E[BE_LBASE], lc = E[BE_LCNT];
       char* lout = reinterpret_cast<char*>(lbase_g) + ((long long)lb << 3);
@@ -512,13 +575,17 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       if (e > 0 && !(BAND_DBG & 8)) BAND_ISSUE_ALL(epochs + (e - 1) * BAND_EW, BE_BP, bops_g, epochs[(e - 1) * BAND_EW + BE_BOFF])
       const int nst = E[BE_NSTEP];
       int o = 0;
-#define BAND_BSTEP(PHV)                                                                              \
-      if (PHV < nst) {                                                                               \
-        Rec st;                                                                                      \
-        load_rec(st, recb, o);                                                                       \
-        const int fl = __builtin_amdgcn_readfirstlane(st.v[BS_FLAGS]);                               \
-        if (clane && !(BAND_DBG & 4)) bstep<PHV>(xs, st, fl, recb, o, myb, borders, gd, pd, okme);                      \
-        o += BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                  \
+      Rec stC, stN;
+      RowRec rwC, rwN;
+      load_rec(stC, recb, 0);
+      load_row(rwC, recb, BAND_SW);
+#define BAND_BSTEP(PHV)                                                                                                     \
+      if (PHV < nst) {                                                                                                      \
+        const int fl = __builtin_amdgcn_readfirstlane(stC.v[BS_FLAGS]);                                                     \
+        const int onext = o + BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                        \
+        if (PHV > 0) { load_rec(stN, recb, onext); load_row(rwN, recb, onext + BAND_SW); }                                  \
+        if (clane && !(BAND_DBG & 4)) bstep<PHV>(xs, stC, rwC, fl, recb, o, myb, borders, gd, pd, okme);                    \
+        o = onext; stC = stN; rwC = rwN;                                                                                    \
       }
       BAND_BSTEP(7) BAND_BSTEP(6) BAND_BSTEP(5) BAND_BSTEP(4) BAND_BSTEP(3) BAND_BSTEP(2) BAND_BSTEP(1) BAND_BSTEP(0)
       // solution components of the epoch
