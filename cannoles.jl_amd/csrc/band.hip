@@ -24,8 +24,16 @@
 #ifndef BAND_DBG
 #define BAND_DBG 0
 #endif
-#if BAND_DBG && !defined(CNL_EXPERIMENT)
+#if (BAND_DBG || defined(BAND_STAMPS)) && !defined(CNL_EXPERIMENT)
 #error "BAND_DBG needs -DCNL_EXPERIMENT=1"
+#endif
+
+#ifdef BAND_STAMPS   // diagnostic: time per phase of an epoch (s_memtime ticks, summed), written over d[0 .. 15] of the workgroup's first problem
+#define BSTAMP_DECL unsigned long long bst_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, bst_t = __builtin_amdgcn_s_memtime();
+#define BSTAMP(K) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); bst_[K] += t_ - bst_t; bst_t = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define BSTAMP_DECL
+#define BSTAMP(K)
 #endif
 
 namespace cnl {
@@ -92,27 +100,34 @@ __device__ __forceinline__ void load_row(RowRec& R, const char* recb, int o) {
   for (int k = 0; k < BAND_RW / 4; k++) { const int4 t = q[k]; R.v[4 * k] = t.x; R.v[4 * k + 1] = t.y; R.v[4 * k + 2] = t.z; R.v[4 * k + 3] = t.w; }
 }
 
+// operands of one forward step: the entering variable's fifteen entries and the first residual row
+struct FOps { double eo[15]; double rj[BAND_NB]; double rdr, rrr; };
+__device__ __forceinline__ void fload(FOps& P, const Rec& st, const RowRec& row0, const int fl, char* myb) {
+#pragma unroll
+  for (int q = 0; q < 15; q++) P.eo[q] = LDSD(st.v[BS_DG0 + q]);
+  static_assert(BS_RX == BS_DG0 + 14, "the fifteen operands of an entering variable are consecutive words of the step block");
+  P.rdr = 1.0; P.rrr = 0.0;
+#pragma unroll
+  for (int k = 0; k < BAND_NB; k++) P.rj[k] = 0.0;
+  if ((fl >> 8) & 255) {
+#pragma unroll
+    for (int k = 0; k < BAND_NB; k++) P.rj[k] = LDSD(row0.v[BR_J0 + k]);
+    P.rdr = LDSD(row0.v[BR_DI]);
+    P.rrr = LDSD(row0.v[BR_RR]);
+  }
+}
+
 // one forward step of phase PH = step number % 8: enter slot PH, pivot slot PH - 4; fl = flags word (wave-uniform), o = int
-// offset of the step block in the record buffer
+// offset of the step block in the record buffer.  The operands were read (fload) while the previous step computed.
 template <int PH>
-__device__ __forceinline__ void fstep(Win& W, const Rec& st, const RowRec& row0, const int fl, const char* recb, const int o, char* myb,
+__device__ __forceinline__ void fstep(Win& W, const FOps& OP, const Rec& st, const int fl, const char* recb, const int o, char* myb,
                                       const double* __restrict__ gvals, const double* __restrict__ grhs, cptr borders, long long pv, long long pr,
                                       bool has_rhs, double rho, bool ovr, double tol, int& npos, int& nzer) {
   constexpr int es = PH, ps = lslot(PH, 0);
   const int nrows = (fl >> 8) & 255;
-  // every operand of the entering variable and of the first residual row is read before anything is computed: ONE LDS round trip
-  // per step instead of one per dependent pair (the block of the step and of its first row were prefetched a step ahead)
-  double eo[15];
-#pragma unroll
-  for (int q = 0; q < 15; q++) eo[q] = LDSD(st.v[BS_DG0 + q]);
-  static_assert(BS_RX == BS_DG0 + 14, "the fifteen operands of an entering variable are consecutive words of the step block");
-  double rj[BAND_NB], rdr = 1.0, rrr = 0.0;
-  if (nrows > 0) {
-#pragma unroll
-    for (int k = 0; k < BAND_NB; k++) rj[k] = LDSD(row0.v[BR_J0 + k]);
-    rdr = LDSD(row0.v[BR_DI]);
-    rrr = LDSD(row0.v[BR_RR]);
-  }
+  const double (&eo)[15] = OP.eo;
+  const double (&rj)[BAND_NB] = OP.rj;
+  const double rdr = OP.rdr, rrr = OP.rrr;
   // ---- enter ----
   {
     const double dg = (eo[0] + eo[1]) + eo[2];
@@ -207,29 +222,39 @@ __device__ __forceinline__ void fstep(Win& W, const Rec& st, const RowRec& row0,
 }
 
 // one backward step of phase PH: x of the band pivot, then of the border pivot, then the residual components
-template <int PH>
-__device__ __forceinline__ void bstep(double (&xs)[NS + 1], const Rec& st, const RowRec& row0, const int fl, const char* recb, const int o, char* myb,
-                                      cptr borders, double* __restrict__ gd, long long pd, bool okme) {
-  constexpr int ps = lslot(PH, 0);
-  const int nrows = (fl >> 8) & 255;
-  // factor records and the first row's operands: read up front (one LDS round trip)
-  double lx[BAND_LREC], lb[BAND_LREC], rj[BAND_NB], rdr = 1.0, rrr = 0.0;
+struct BOps { double lx[BAND_LREC], lb[BAND_LREC], rj[BAND_NB]; double rdr, rrr; };
+__device__ __forceinline__ void bload(BOps& P, const Rec& st, const RowRec& row0, const int fl, char* myb) {
+#pragma unroll
+  for (int q = 0; q < BAND_LREC; q++) { P.lx[q] = 0.0; P.lb[q] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < BAND_NB; k++) P.rj[k] = 0.0;
+  P.rdr = 1.0; P.rrr = 0.0;
   if (fl & BF_PIVOT_X) {
     const double* lo = reinterpret_cast<const double*>(myb + st.v[BS_LX]);
 #pragma unroll
-    for (int q = 0; q < BAND_LREC; q++) lx[q] = lo[q];
+    for (int q = 0; q < BAND_LREC; q++) P.lx[q] = lo[q];
   }
   if (fl & BF_PIVOT_B) {
     const double* lo = reinterpret_cast<const double*>(myb + st.v[BS_LB]);
 #pragma unroll
-    for (int q = 0; q < BAND_LREC; q++) lb[q] = lo[q];
+    for (int q = 0; q < BAND_LREC; q++) P.lb[q] = lo[q];
   }
-  if (nrows > 0) {
+  if ((fl >> 8) & 255) {
 #pragma unroll
-    for (int k = 0; k < BAND_NB; k++) rj[k] = LDSD(row0.v[BR_J0 + k]);
-    rdr = LDSD(row0.v[BR_DI]);
-    rrr = LDSD(row0.v[BR_RR]);
+    for (int k = 0; k < BAND_NB; k++) P.rj[k] = LDSD(row0.v[BR_J0 + k]);
+    P.rdr = LDSD(row0.v[BR_DI]);
+    P.rrr = LDSD(row0.v[BR_RR]);
   }
+}
+template <int PH>
+__device__ __forceinline__ void bstep(double (&xs)[NS + 1], const BOps& OP, const Rec& st, const RowRec& row0, const int fl, const char* recb,
+                                      const int o, char* myb, cptr borders, double* __restrict__ gd, long long pd, bool okme) {
+  constexpr int ps = lslot(PH, 0);
+  const int nrows = (fl >> 8) & 255;
+  const double (&lx)[BAND_LREC] = OP.lx;
+  const double (&lb)[BAND_LREC] = OP.lb;
+  const double (&rj)[BAND_NB] = OP.rj;
+  const double rdr = OP.rdr, rrr = OP.rrr;
   if (fl & BF_PIVOT_X) {
     double x = lx[5];
 #pragma unroll
@@ -328,37 +353,32 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   static_assert(NI <= 4, "at most four problem groups per mover lane");
   double stg[NPC][NI];   // operand pieces in flight
   int4 rstg0, rstg1;     // step blocks in flight (two 16-byte words per lane: 512 ints)
-  unsigned pmask = 0;    // pieces of the epoch whose operands are in flight
   static_assert(BAND_REC_MAX <= 512, "record buffer: two dwordx4 per lane");
-  // One load per piece and problem group: the array's base pointer and stride are selected with scalar instructions, the lane's
-  // offset is problem * stride + element.  (Three guarded loads made the compiler form all three 64-bit addresses of every piece
-  // up front — 96 NI VGPRs; selecting among per-array offset arrays made it index them in scratch memory.)  The pieces are
-  // spelled out one by one: every index into the staging registers is a literal.
+  // The mover is written for back-to-back issue: the sixteen piece descriptors of an epoch come with one scalar load, every
+  // piece is loaded whether the epoch uses it or not (an unused descriptor reads the first elements of vals: a cache hit), every
+  // staged piece is written to LDS — no branch per piece.  One load per piece and problem group: base pointer and stride of the
+  // piece's array are selected with scalar instructions, the lane's offset is problem * stride + element.  (Three guarded loads
+  // made the compiler form all three 64-bit addresses of every piece up front — 96 NI VGPRs; selecting among per-array offset
+  // arrays made it index them in scratch memory; lambdas instead of macros put every captured variable into scratch.)
 #define BAND_ISSUE1(K, I) if constexpr (I < NI) stg[K][I] = *reinterpret_cast<const double*>(pb + ((movp[I] * strd + (unsigned)le) << 3));
 #define BAND_COMMIT1(K, I) if constexpr (I < NI) *reinterpret_cast<double*>(wblk + ldsb[I] + (BAND_IN_OFF + 8 * K) * 8) = stg[K][I];
 #define BAND_ISSUE(K)                                                                                                         \
   {                                                                                                                           \
-    const int pc = E[ofs + K];                                                                                                \
-    if (pc >= 0) {                                                                                                            \
-      pmask |= 1u << K;                                                                                                       \
-      const int arr = pc >> 28;                                                                                               \
-      const char* pb = (arr == 0 ? reinterpret_cast<const char*>(vbase) : arr == 1 ? reinterpret_cast<const char*>(rbase)     \
-                                                                                   : reinterpret_cast<const char*>(lbase_g)) + \
-                       ((long long)(pc & ((1 << 28) - 1)) << 3);                                                              \
-      const unsigned strd = arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : (unsigned)lsize;                              \
-      BAND_ISSUE1(K, 0) BAND_ISSUE1(K, 1) BAND_ISSUE1(K, 2) BAND_ISSUE1(K, 3)                                                 \
-    }                                                                                                                         \
+    const int pc = pcs[K] < 0 ? 0 : pcs[K];                                                                                   \
+    const int arr = pc >> 28;                                                                                                 \
+    const char* pb = (arr == 0 ? reinterpret_cast<const char*>(vbase) : arr == 1 ? reinterpret_cast<const char*>(rbase)       \
+                                                                                 : reinterpret_cast<const char*>(lbase_g)) +   \
+                     ((long long)(pc & ((1 << 28) - 1)) << 3);                                                                \
+    const unsigned strd = arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : (unsigned)lsize;                                \
+    BAND_ISSUE1(K, 0) BAND_ISSUE1(K, 1) BAND_ISSUE1(K, 2) BAND_ISSUE1(K, 3)                                                   \
   }
-#define BAND_COMMIT(K)                                                                                                        \
-  if (pmask & (1u << K)) {                                                                                                    \
-    BAND_COMMIT1(K, 0) BAND_COMMIT1(K, 1) BAND_COMMIT1(K, 2) BAND_COMMIT1(K, 3)                                               \
-  }
+#define BAND_COMMIT(K) { BAND_COMMIT1(K, 0) BAND_COMMIT1(K, 1) BAND_COMMIT1(K, 2) BAND_COMMIT1(K, 3) }
   // (macros, not lambdas: a closure made the compiler keep every captured variable — the staging registers included — in scratch memory)
 #define BAND_ISSUE_ALL(EP, OFS, OPS, OPOFF)                                                                                   \
   {                                                                                                                           \
-    cptr E = (EP);                                                                                                            \
-    const int ofs = (OFS);                                                                                                    \
-    pmask = 0;                                                                                                                \
+    cptr E_ = (EP) + (OFS);                                                                                                   \
+    int pcs[NPC];                                                                                                             \
+    _Pragma("unroll") for (int k_ = 0; k_ < NPC; k_++) pcs[k_] = E_[k_];                                                      \
     BAND_ISSUE(0) BAND_ISSUE(1) BAND_ISSUE(2) BAND_ISSUE(3) BAND_ISSUE(4) BAND_ISSUE(5) BAND_ISSUE(6) BAND_ISSUE(7)           \
     BAND_ISSUE(8) BAND_ISSUE(9) BAND_ISSUE(10) BAND_ISSUE(11) BAND_ISSUE(12) BAND_ISSUE(13) BAND_ISSUE(14) BAND_ISSUE(15)     \
     /* the epoch's step / row blocks (the streams are padded: reading past the epoch's blocks is harmless) */                 \
@@ -375,6 +395,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   }
   static_assert(NPC == 16, "sixteen operand pieces");
 
+  BSTAMP_DECL
   Win W;
   int npos = 0, nzer = 0;
   double lj[6], zj[4];   // junction factor (first wavefront)
@@ -391,26 +412,49 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     BAND_ISSUE_ALL(epochs, BE_FP, fops_g, 0)
     for (int e = 0; e < nepochs; e++) {
       cptr E = epochs + e * BAND_EW;
+      BSTAMP(0)
       BAND_COMMIT_ALL()
+      BSTAMP(1)
       if (e + 1 < nepochs && !(BAND_DBG & 8)) BAND_ISSUE_ALL(epochs + (e + 1) * BAND_EW, BE_FP, fops_g, epochs[(e + 1) * BAND_EW + BE_FOFF])
       // The steps of the epoch: step t works on the slots of phase t (every epoch but the last has BAND_EPOCH steps), so the eight
       // instantiations follow each other in straight-line code and the window keeps its registers from step to step.
       const int nst = E[BE_NSTEP];
       int o = 0;
-      // the blocks of step t + 1 (step block + first row block) are read while step t computes
-      Rec stC, stN;
-      RowRec rwC, rwN;
-      load_rec(stC, recb, 0);
-      load_row(rwC, recb, BAND_SW);
-#define BAND_FSTEP(PHV)                                                                                                     \
-      if (PHV < nst) {                                                                                                      \
-        const int fl = __builtin_amdgcn_readfirstlane(stC.v[BS_FLAGS]);                                                     \
-        const int onext = o + BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                        \
-        if (PHV + 1 < nst) { load_rec(stN, recb, onext); load_row(rwN, recb, onext + BAND_SW); }                            \
-        if (clane && !(BAND_DBG & 2)) fstep<PHV>(W, stC, rwC, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer); \
-        o = onext; stC = stN; rwC = rwN;                                                                                    \
+      BSTAMP(2)
+      // Three-stage pipeline over the steps of the epoch: while step t computes, the operands of step t + 1 are on their way from
+      // LDS (their block was read a step earlier) and the block of step t + 2 is being read.  Register sets rotate by name.
+      Rec st0, st1, st2;
+      RowRec rw0, rw1, rw2;
+      FOps opA, opB;
+      int o0 = 0, o1 = 0, o2 = 0;
+      load_rec(st0, recb, 0);
+      load_row(rw0, recb, BAND_SW);
+      {
+        const int f0 = __builtin_amdgcn_readfirstlane(st0.v[BS_FLAGS]);
+        o1 = BAND_SW + BAND_RW * ((f0 >> 8) & 255);
+        if (nst > 1) { load_rec(st1, recb, o1); load_row(rw1, recb, o1 + BAND_SW); }
+        if (clane) fload(opA, st0, rw0, f0, myb);
       }
-      BAND_FSTEP(0) BAND_FSTEP(1) BAND_FSTEP(2) BAND_FSTEP(3) BAND_FSTEP(4) BAND_FSTEP(5) BAND_FSTEP(6) BAND_FSTEP(7)
+#define BAND_FSTEP(PHV, SC, RC, OC, OPC, SN, RN, ON, OPN, SNN, RNN, ONN)                                                     \
+      if (PHV < nst) {                                                                                                      \
+        const int fl = __builtin_amdgcn_readfirstlane(SC.v[BS_FLAGS]);                                                      \
+        if (PHV + 1 < nst) {                                                                                                \
+          const int fn = __builtin_amdgcn_readfirstlane(SN.v[BS_FLAGS]);                                                    \
+          ONN = ON + BAND_SW + BAND_RW * ((fn >> 8) & 255);                                                                 \
+          if (PHV + 2 < nst) { load_rec(SNN, recb, ONN); load_row(RNN, recb, ONN + BAND_SW); }                              \
+          if (clane) fload(OPN, SN, RN, fn, myb);                                                                           \
+        }                                                                                                                   \
+        if (clane && !(BAND_DBG & 2)) fstep<PHV>(W, OPC, SC, fl, recb, OC, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer); \
+      }
+      BAND_FSTEP(0, st0, rw0, o0, opA, st1, rw1, o1, opB, st2, rw2, o2)
+      BAND_FSTEP(1, st1, rw1, o1, opB, st2, rw2, o2, opA, st0, rw0, o0)
+      BAND_FSTEP(2, st2, rw2, o2, opA, st0, rw0, o0, opB, st1, rw1, o1)
+      BAND_FSTEP(3, st0, rw0, o0, opB, st1, rw1, o1, opA, st2, rw2, o2)
+      BAND_FSTEP(4, st1, rw1, o1, opA, st2, rw2, o2, opB, st0, rw0, o0)
+      BAND_FSTEP(5, st2, rw2, o2, opB, st0, rw0, o0, opA, st1, rw1, o1)
+      BAND_FSTEP(6, st0, rw0, o0, opA, st1, rw1, o1, opB, st2, rw2, o2)
+      BAND_FSTEP(7, st1, rw1, o1, opB, st2, rw2, o2, opA, st0, rw0, o0)
+      BSTAMP(3)
       static_assert(BAND_EPOCH == 8, "eight step instantiations per epoch");
       if (nst == BAND_EPOCH) {
         // behind a full epoch the slots 0 .. 3 are dead (pivoted in phases 4 .. 7): give them a constant, so that only the ten
@@ -427,17 +471,21 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       // factor records of the epoch: 64-byte pieces from the out ring
       const int lb = E[BE_LBASE], lc = E[BE_LCNT];
       char* lout = reinterpret_cast<char*>(lbase_g) + ((long long)lb << 3);
+      {
+        // all reads of the ring first, then the stores (whole pieces are read; lanes past the records do not store)
+        double lx_[BAND_LOUT_MAX / 8][NI];
 #pragma unroll
-      for (int cpc = 0; cpc < BAND_LOUT_MAX / 8; cpc++) {
-        if (cpc * 8 < lc) {
+        for (int cpc = 0; cpc < BAND_LOUT_MAX / 8; cpc++)
 #pragma unroll
-          for (int i = 0; i < NI; i++) {
-            const double x = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_LOUT_OFF + 8 * cpc) * 8);
-            if (movok[i] && cpc * 8 + le < lc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(lout + (((movp[i] * (unsigned)lsize + (unsigned)le) << 3) + 64 * cpc)) = x;
-          }
-        }
+          for (int i = 0; i < NI; i++) lx_[cpc][i] = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_LOUT_OFF + 8 * cpc) * 8);
+#pragma unroll
+        for (int cpc = 0; cpc < BAND_LOUT_MAX / 8; cpc++)
+#pragma unroll
+          for (int i = 0; i < NI; i++)
+            if (movok[i] && cpc * 8 + le < lc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(lout + (((movp[i] * (unsigned)lsize + (unsigned)le) << 3) + 64 * cpc)) = lx_[cpc][i];
       }
     }
+    BSTAMP(4)
     // ================= junction + inertia rule + rho ladder (src/solver_types.jl:90-97, src/CaNNOLeS.jl:1023-1047) ==========
     int tpos = npos, tzer = nzer;
     if (P.nparts == 2) {
@@ -571,23 +619,73 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     BAND_ISSUE_ALL(epochs + (nepochs - 1) * BAND_EW, BE_BP, bops_g, 0)
     for (int e = nepochs - 1; e >= 0; e--) {
       cptr E = epochs + e * BAND_EW;
+      BSTAMP(5)
       BAND_COMMIT_ALL()
+      BSTAMP(6)
       if (e > 0 && !(BAND_DBG & 8)) BAND_ISSUE_ALL(epochs + (e - 1) * BAND_EW, BE_BP, bops_g, epochs[(e - 1) * BAND_EW + BE_BOFF])
       const int nst = E[BE_NSTEP];
       int o = 0;
-      Rec stC, stN;
-      RowRec rwC, rwN;
-      load_rec(stC, recb, 0);
-      load_row(rwC, recb, BAND_SW);
-#define BAND_BSTEP(PHV)                                                                                                     \
-      if (PHV < nst) {                                                                                                      \
-        const int fl = __builtin_amdgcn_readfirstlane(stC.v[BS_FLAGS]);                                                     \
-        const int onext = o + BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                        \
-        if (PHV > 0) { load_rec(stN, recb, onext); load_row(rwN, recb, onext + BAND_SW); }                                  \
-        if (clane && !(BAND_DBG & 4)) bstep<PHV>(xs, stC, rwC, fl, recb, o, myb, borders, gd, pd, okme);                    \
-        o = onext; stC = stN; rwC = rwN;                                                                                    \
+      BSTAMP(7)
+      Rec st0, st1, st2;
+      RowRec rw0, rw1, rw2;
+      BOps opA, opB;
+      int o0 = 0, o1 = 0, o2 = 0;
+      load_rec(st0, recb, 0);
+      load_row(rw0, recb, BAND_SW);
+      {
+        const int f0 = __builtin_amdgcn_readfirstlane(st0.v[BS_FLAGS]);
+        o1 = BAND_SW + BAND_RW * ((f0 >> 8) & 255);
+        if (nst > 1) { load_rec(st1, recb, o1); load_row(rw1, recb, o1 + BAND_SW); }
+        if (clane) bload(opA, st0, rw0, f0, myb);
       }
-      BAND_BSTEP(7) BAND_BSTEP(6) BAND_BSTEP(5) BAND_BSTEP(4) BAND_BSTEP(3) BAND_BSTEP(2) BAND_BSTEP(1) BAND_BSTEP(0)
+      // (position Q in the epoch's backward order: 0 = the epoch's last step; phase = nst - 1 - Q)
+#define BAND_BSTEP(Q, PHV, SC, RC, OC, OPC, SN, RN, ON, OPN, SNN, RNN, ONN)                                                  \
+      {                                                                                                                     \
+        const int fl = __builtin_amdgcn_readfirstlane(SC.v[BS_FLAGS]);                                                      \
+        if (Q + 1 < nst) {                                                                                                  \
+          const int fn = __builtin_amdgcn_readfirstlane(SN.v[BS_FLAGS]);                                                    \
+          ONN = ON + BAND_SW + BAND_RW * ((fn >> 8) & 255);                                                                 \
+          if (Q + 2 < nst) { load_rec(SNN, recb, ONN); load_row(RNN, recb, ONN + BAND_SW); }                                \
+          if (clane) bload(OPN, SN, RN, fn, myb);                                                                           \
+        }                                                                                                                   \
+        if (clane && !(BAND_DBG & 4)) bstep<PHV>(xs, OPC, SC, RC, fl, recb, OC, myb, borders, gd, pd, okme);                \
+      }
+#define BAND_BSTEPS(Q, PHV)                                                                                                 \
+      if (Q % 6 == 0) BAND_BSTEP(Q, PHV, st0, rw0, o0, opA, st1, rw1, o1, opB, st2, rw2, o2)                               \
+      else if (Q % 6 == 1) BAND_BSTEP(Q, PHV, st1, rw1, o1, opB, st2, rw2, o2, opA, st0, rw0, o0)                          \
+      else if (Q % 6 == 2) BAND_BSTEP(Q, PHV, st2, rw2, o2, opA, st0, rw0, o0, opB, st1, rw1, o1)                          \
+      else if (Q % 6 == 3) BAND_BSTEP(Q, PHV, st0, rw0, o0, opB, st1, rw1, o1, opA, st2, rw2, o2)                          \
+      else if (Q % 6 == 4) BAND_BSTEP(Q, PHV, st1, rw1, o1, opA, st2, rw2, o2, opB, st0, rw0, o0)                          \
+      else BAND_BSTEP(Q, PHV, st2, rw2, o2, opB, st0, rw0, o0, opA, st1, rw1, o1)
+      if (nst == BAND_EPOCH) {
+        BAND_BSTEPS(0, 7) BAND_BSTEPS(1, 6) BAND_BSTEPS(2, 5) BAND_BSTEPS(3, 4) BAND_BSTEPS(4, 3) BAND_BSTEPS(5, 2) BAND_BSTEPS(6, 1) BAND_BSTEPS(7, 0)
+      } else {
+        // the last (short) epoch of a part is the first of the backward sweep: position Q has phase nst - 1 - Q, known at run time only
+        int q = 0;
+        for (int ph = nst - 1; ph >= 0; ph--, q++) {
+          Rec sc; RowRec rc; BOps oc;
+          // (plain: block, operands, step — a handful of steps per sweep)
+          int oo = 0;
+          for (int t = 0; t < q; t++) { load_rec(sc, recb, oo); oo += BAND_SW + BAND_RW * ((__builtin_amdgcn_readfirstlane(sc.v[BS_FLAGS]) >> 8) & 255); }
+          load_rec(sc, recb, oo); load_row(rc, recb, oo + BAND_SW);
+          const int fl = __builtin_amdgcn_readfirstlane(sc.v[BS_FLAGS]);
+          if (clane) {
+            bload(oc, sc, rc, fl, myb);
+            if (!(BAND_DBG & 4)) {
+              switch (ph) {
+                case 0: bstep<0>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
+                case 1: bstep<1>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
+                case 2: bstep<2>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
+                case 3: bstep<3>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
+                case 4: bstep<4>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
+                case 5: bstep<5>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
+                default: bstep<6>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
+              }
+            }
+          }
+        }
+      }
+      BSTAMP(8)
       // solution components of the epoch
       const int xlo = E[BE_DXLO], xc = E[BE_DXCNT], rlo = E[BE_DRLO], rc = E[BE_DRCNT];
       char* dxo = reinterpret_cast<char*>(dbase) + ((long long)xlo << 3);
@@ -608,6 +706,10 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       }
     }
   }
+#ifdef BAND_STAMPS
+  BSTAMP(9)
+  if (blockIdx.x == 0 && lane == 0) for (int k = 0; k < 12; k++) gd[(long long)prob0 * N + part * 12 + k] = (double)bst_[k];
+#endif
   // ================= outputs of newton_system! =================
   if (part == 0) {
     if (nfact > 1 && rho <= rhomax) rho_old = rho;
