@@ -282,11 +282,22 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
       if (oplen > BAND_REC_MAX) return no("the blocks of an epoch do not fit the record buffer");
       E[BE_OPLEN] = oplen;
       const int32_t lbase = ev_hi >= 0 ? ev_lo * BAND_LREC : 0, lcnt = ev_hi >= 0 ? (ev_hi - ev_lo + 1) * BAND_LREC : 0;
-      if (lcnt > BAND_LOUT_MAX) return no("more factor records in an epoch than the ring holds");
+      // the out ring takes the factor records of half an epoch (steps 0 .. 3, then 4 .. 7)
+      const int32_t uh = std::min(u1, u0 + BAND_EPOCH / 2);
+      int32_t evh_lo = 1 << 30, evh_hi = -1, evg_lo = 1 << 30, evg_hi = -1;
+      for (int32_t u = u0; u < u1; u++)
+        for (int32_t ev : {S[u].lev_b, S[u].lev_x})
+          if (ev >= 0) {
+            if (u < uh) { evh_lo = std::min(evh_lo, ev); evh_hi = std::max(evh_hi, ev); }
+            else { evg_lo = std::min(evg_lo, ev); evg_hi = std::max(evg_hi, ev); }
+          }
+      const int32_t lbase1 = evh_hi >= 0 ? evh_lo * BAND_LREC : 0, lcnt1 = evh_hi >= 0 ? (evh_hi - evh_lo + 1) * BAND_LREC : 0;
+      const int32_t lbase2 = evg_hi >= 0 ? evg_lo * BAND_LREC : 0, lcnt2 = evg_hi >= 0 ? (evg_hi - evg_lo + 1) * BAND_LREC : 0;
+      if (lcnt1 > BAND_LOUT_MAX || lcnt2 > BAND_LOUT_MAX) return no("more factor records in half an epoch than the ring holds");
       if (x_cnt && x_hi - x_lo + 1 != x_cnt) return no("pivots of an epoch are not consecutive variables");
       if (r_cnt && r_hi - r_lo + 1 != r_cnt) return no("rows of an epoch are not consecutive");
       if (x_cnt > BAND_DX_MAX || r_cnt > BAND_DR_MAX) return no("more outputs in an epoch than the rings hold");
-      E[BE_LBASE] = lbase; E[BE_LCNT] = lcnt;
+      E[BE_LBASE] = lbase1; E[BE_LCNT] = lcnt1; E[BE_LBASE2] = lbase2; E[BE_LCNT2] = lcnt2;
       E[BE_DXLO] = x_cnt ? x_lo : 0; E[BE_DXCNT] = x_cnt;
       E[BE_DRLO] = r_cnt ? (int32_t)(n + r_lo) : 0; E[BE_DRCNT] = r_cnt;
       // forward operands
@@ -335,8 +346,9 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
           blk[BS_BC0] = dir == 0 ? off(st.bc[0]) : ZB; blk[BS_BC1] = dir == 0 ? off(st.bc[1]) : ZB;
           blk[BS_RX] = dir == 0 ? off(st.rx) : ZB;
           if (dir == 0) {
-            blk[BS_LB] = st.lev_b >= 0 ? (BAND_LOUT_OFF + st.lev_b * BAND_LREC - lbase) * 8 : ZB;
-            blk[BS_LX] = st.lev_x >= 0 ? (BAND_LOUT_OFF + st.lev_x * BAND_LREC - lbase) * 8 : ZB;
+            const int32_t lbh = u < uh ? lbase1 : lbase2;
+            blk[BS_LB] = st.lev_b >= 0 ? (BAND_LOUT_OFF + st.lev_b * BAND_LREC - lbh) * 8 : ZB;
+            blk[BS_LX] = st.lev_x >= 0 ? (BAND_LOUT_OFF + st.lev_x * BAND_LREC - lbh) * 8 : ZB;
             blk[BS_DX] = ZB;
           } else {
             blk[BS_LB] = st.lev_b >= 0 ? pk.off(2, st.lev_b * BAND_LREC) : ZB;

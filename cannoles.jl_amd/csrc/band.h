@@ -29,20 +29,23 @@ constexpr int BAND_NB = BAND_HW + 1;
 constexpr int BAND_EPOCH = 8;       // steps per epoch (one round of operand pieces) = window slots: variable number t of a part lives in
                                     // slot t % 8 (five consecutive slots are live at a time), so step u of an epoch always works on the same slots
 constexpr int BAND_NS = BAND_EPOCH;
-constexpr int BAND_NPIECE = 16;     // 64-byte operand pieces per epoch and lane
-constexpr int BAND_REC_MAX = 320;    // ints of step + row blocks per epoch (LDS record buffer of a wavefront)
+constexpr int BAND_NPIECE = 15;     // 64-byte operand pieces per epoch and lane (BASELINE config 3 needs 15 in the forward sweep)
+constexpr int BAND_REC_MAX = 256;    // ints of step + row blocks per epoch (LDS record buffer of a wavefront)
 constexpr int BAND_LREC = 6;        // factor doubles per pivot: band multipliers, border multiplier, z  (see band.hip)
 
-// LDS block of one lane, in doubles: [operand pieces | factor-out ring | dx-out ring | dr-out ring | zero cell]
+// LDS block of one lane, in doubles: [operand pieces | out ring | zero cell].  The out ring holds the factor records of HALF an
+// epoch in the forward sweep (flushed behind steps 3 and 7) and the solution components of an epoch in the backward sweep.
+// 153 doubles = 1224 bytes per lane: 128 lanes (two workgroups of 32 problems) fit the 160 KB of a CU.
 constexpr int BAND_IN_OFF = 0;
-constexpr int BAND_LOUT_OFF = BAND_NPIECE * 8;                       // forward: factor records of the epoch
-constexpr int BAND_LOUT_MAX = 64;
-constexpr int BAND_DX_OFF = BAND_LOUT_OFF + BAND_LOUT_MAX;           // backward: solution components of the epoch's pivots
-constexpr int BAND_DX_MAX = 16;
+constexpr int BAND_LOUT_OFF = BAND_NPIECE * 8;                       // forward: factor records of half an epoch
+constexpr int BAND_LOUT_MAX = 32;
+constexpr int BAND_DX_OFF = BAND_LOUT_OFF;                           // backward: solution components of the epoch's pivots
+constexpr int BAND_DX_MAX = 8;
 constexpr int BAND_DR_OFF = BAND_DX_OFF + BAND_DX_MAX;               // backward: residual components of the epoch's rows
-constexpr int BAND_DR_MAX = 16;
-constexpr int BAND_ZERO_OFF = BAND_DR_OFF + BAND_DR_MAX;             // holds 0.0: every absent operand reads it
-constexpr int BAND_LANE_DOUBLES = BAND_ZERO_OFF + 1;                 // 225: odd, so that 32 lanes reading one offset hit 32 bank pairs
+constexpr int BAND_DR_MAX = 24;
+constexpr int BAND_ZERO_OFF = BAND_LOUT_OFF + BAND_LOUT_MAX;         // holds 0.0: every absent operand reads it
+constexpr int BAND_LANE_DOUBLES = BAND_ZERO_OFF + 1;                 // 153: odd, so that 32 lanes reading one offset hit 32 bank pairs
+static_assert(BAND_DR_OFF + BAND_DR_MAX <= BAND_ZERO_OFF && BAND_LANE_DOUBLES % 2 == 1, "lane block layout");
 
 // step block (BAND_SW ints); LDS offsets are BYTES inside the lane block
 enum {
@@ -66,8 +69,8 @@ enum { BR_DI = 0, BR_J0 /* + live position: 0 = the step's pivot .. HW = the ent
 enum {
   BE_FP = 0,                       // forward operand pieces: element index | array << 28 (0 vals, 1 rhs), -1 unused
   BE_BP = BE_FP + BAND_NPIECE,     // backward operand pieces (array 2: the factor)
-  BE_LBASE = BE_BP + BAND_NPIECE,  // first factor double of the epoch, and their number
-  BE_LCNT,
+  BE_LBASE = BE_BP + BAND_NPIECE,  // first factor double of the epoch's steps 0 .. 3 and their number, then of its steps 4 .. 7
+  BE_LCNT, BE_LBASE2, BE_LCNT2,
   BE_DXLO, BE_DXCNT,               // solution components of the epoch's band pivots: d[lo .. lo + cnt)
   BE_DRLO, BE_DRCNT,               // ... of its residual rows
   BE_NSTEP,                        // steps of the epoch

@@ -50,8 +50,8 @@ __device__ __forceinline__ cptr as_const(const int* p) { return (cptr)(const __a
 
 constexpr int NPC = BAND_NPIECE;
 constexpr int LANE_D = BAND_LANE_DOUBLES;
-constexpr int EXCH_OFF = BAND_ZERO_OFF - 48;   // junction exchange (46 doubles) in a lane block: over the out rings, idle between the sweeps
-static_assert(EXCH_OFF >= BAND_LOUT_OFF, "exchange area inside the out rings");
+constexpr int EXCH_OFF = BAND_IN_OFF;   // junction exchange (46 doubles) in a lane block: over the operand pieces, idle between the sweeps
+static_assert(48 <= BAND_NPIECE * 8, "exchange area inside the operand pieces");
 
 __device__ __forceinline__ constexpr int sidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   double stg[NPC][NI];   // operand pieces in flight
   int4 rstg0, rstg1;     // step blocks in flight (two 16-byte words per lane: 512 ints)
   static_assert(BAND_REC_MAX <= 512, "record buffer: two dwordx4 per lane");
-  // The mover is written for back-to-back issue: the sixteen piece descriptors of an epoch come with one scalar load, every
+  // The mover is written for back-to-back issue: the fifteen piece descriptors of an epoch come with one scalar load, every
   // piece is loaded whether the epoch uses it or not (an unused descriptor reads the first elements of vals: a cache hit), every
   // staged piece is written to LDS — no branch per piece.  One load per piece and problem group: base pointer and stride of the
   // piece's array are selected with scalar instructions, the lane's offset is problem * stride + element.  (Three guarded loads
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     int pcs[NPC];                                                                                                             \
     _Pragma("unroll") for (int k_ = 0; k_ < NPC; k_++) pcs[k_] = E_[k_];                                                      \
     BAND_ISSUE(0) BAND_ISSUE(1) BAND_ISSUE(2) BAND_ISSUE(3) BAND_ISSUE(4) BAND_ISSUE(5) BAND_ISSUE(6) BAND_ISSUE(7)           \
-    BAND_ISSUE(8) BAND_ISSUE(9) BAND_ISSUE(10) BAND_ISSUE(11) BAND_ISSUE(12) BAND_ISSUE(13) BAND_ISSUE(14) BAND_ISSUE(15)     \
+    BAND_ISSUE(8) BAND_ISSUE(9) BAND_ISSUE(10) BAND_ISSUE(11) BAND_ISSUE(12) BAND_ISSUE(13) BAND_ISSUE(14)                    \
     /* the epoch's step / row blocks (the streams are padded: reading past the epoch's blocks is harmless) */                 \
     const int4* rp = reinterpret_cast<const int4*>((OPS) + (OPOFF)) + lane;                                                   \
     rstg0 = rp[0];                                                                                                            \
@@ -389,11 +389,11 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 #define BAND_COMMIT_ALL()                                                                                                     \
   {                                                                                                                           \
     BAND_COMMIT(0) BAND_COMMIT(1) BAND_COMMIT(2) BAND_COMMIT(3) BAND_COMMIT(4) BAND_COMMIT(5) BAND_COMMIT(6) BAND_COMMIT(7)   \
-    BAND_COMMIT(8) BAND_COMMIT(9) BAND_COMMIT(10) BAND_COMMIT(11) BAND_COMMIT(12) BAND_COMMIT(13) BAND_COMMIT(14) BAND_COMMIT(15) \
+    BAND_COMMIT(8) BAND_COMMIT(9) BAND_COMMIT(10) BAND_COMMIT(11) BAND_COMMIT(12) BAND_COMMIT(13) BAND_COMMIT(14)             \
     reinterpret_cast<int4*>(recb)[lane] = rstg0;                                                                              \
     if (BAND_REC_MAX > 256 && lane < (BAND_REC_MAX - 256) / 4) reinterpret_cast<int4*>(recb)[64 + lane] = rstg1;              \
   }
-  static_assert(NPC == 16, "sixteen operand pieces");
+  static_assert(NPC == 15, "fifteen operand pieces");
 
   BSTAMP_DECL
   Win W;
@@ -421,39 +421,42 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       const int nst = E[BE_NSTEP];
       int o = 0;
       BSTAMP(2)
-      // Three-stage pipeline over the steps of the epoch: while step t computes, the operands of step t + 1 are on their way from
-      // LDS (their block was read a step earlier) and the block of step t + 2 is being read.  Register sets rotate by name.
-      Rec st0, st1, st2;
-      RowRec rw0, rw1, rw2;
-      FOps opA, opB;
-      int o0 = 0, o1 = 0, o2 = 0;
-      load_rec(st0, recb, 0);
-      load_row(rw0, recb, BAND_SW);
-      {
-        const int f0 = __builtin_amdgcn_readfirstlane(st0.v[BS_FLAGS]);
-        o1 = BAND_SW + BAND_RW * ((f0 >> 8) & 255);
-        if (nst > 1) { load_rec(st1, recb, o1); load_row(rw1, recb, o1 + BAND_SW); }
-        if (clane) fload(opA, st0, rw0, f0, myb);
-      }
-#define BAND_FSTEP(PHV, SC, RC, OC, OPC, SN, RN, ON, OPN, SNN, RNN, ONN)                                                     \
+      // the blocks of step t + 1 (step block + first row block) are read from the record buffer while step t computes; the step
+      // reads all its operands at its top (one LDS round trip).  (A third stage — operands a step ahead — was measured: no gain,
+      // 170 more registers.)
+      Rec stC, stN;
+      RowRec rwC, rwN;
+      load_rec(stC, recb, 0);
+      load_row(rwC, recb, BAND_SW);
+#define BAND_FSTEP(PHV)                                                                                                     \
       if (PHV < nst) {                                                                                                      \
-        const int fl = __builtin_amdgcn_readfirstlane(SC.v[BS_FLAGS]);                                                      \
-        if (PHV + 1 < nst) {                                                                                                \
-          const int fn = __builtin_amdgcn_readfirstlane(SN.v[BS_FLAGS]);                                                    \
-          ONN = ON + BAND_SW + BAND_RW * ((fn >> 8) & 255);                                                                 \
-          if (PHV + 2 < nst) { load_rec(SNN, recb, ONN); load_row(RNN, recb, ONN + BAND_SW); }                              \
-          if (clane) fload(OPN, SN, RN, fn, myb);                                                                           \
+        const int fl = __builtin_amdgcn_readfirstlane(stC.v[BS_FLAGS]);                                                     \
+        const int onext = o + BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                        \
+        if (PHV + 1 < nst) { load_rec(stN, recb, onext); load_row(rwN, recb, onext + BAND_SW); }                            \
+        if (clane && !(BAND_DBG & 2)) {                                                                                     \
+          FOps op_;                                                                                                         \
+          fload(op_, stC, rwC, fl, myb);                                                                                    \
+          fstep<PHV>(W, op_, stC, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer);      \
         }                                                                                                                   \
-        if (clane && !(BAND_DBG & 2)) fstep<PHV>(W, OPC, SC, fl, recb, OC, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer); \
+        o = onext; stC = stN; rwC = rwN;                                                                                    \
       }
-      BAND_FSTEP(0, st0, rw0, o0, opA, st1, rw1, o1, opB, st2, rw2, o2)
-      BAND_FSTEP(1, st1, rw1, o1, opB, st2, rw2, o2, opA, st0, rw0, o0)
-      BAND_FSTEP(2, st2, rw2, o2, opA, st0, rw0, o0, opB, st1, rw1, o1)
-      BAND_FSTEP(3, st0, rw0, o0, opB, st1, rw1, o1, opA, st2, rw2, o2)
-      BAND_FSTEP(4, st1, rw1, o1, opA, st2, rw2, o2, opB, st0, rw0, o0)
-      BAND_FSTEP(5, st2, rw2, o2, opB, st0, rw0, o0, opA, st1, rw1, o1)
-      BAND_FSTEP(6, st0, rw0, o0, opA, st1, rw1, o1, opB, st2, rw2, o2)
-      BAND_FSTEP(7, st1, rw1, o1, opB, st2, rw2, o2, opA, st0, rw0, o0)
+      // factor records: the out ring holds those of half an epoch; whole 64-byte pieces are read from it (all reads first), lanes
+      // past the records do not store
+#define BAND_LFLUSH(LB, LC)                                                                                                 \
+      {                                                                                                                     \
+        const int lc_ = (LC);                                                                                               \
+        char* lout = reinterpret_cast<char*>(lbase_g) + ((long long)(LB) << 3);                                             \
+        double lx_[BAND_LOUT_MAX / 8][NI];                                                                                  \
+        _Pragma("unroll") for (int cpc = 0; cpc < BAND_LOUT_MAX / 8; cpc++)                                                 \
+          _Pragma("unroll") for (int i = 0; i < NI; i++) lx_[cpc][i] = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_LOUT_OFF + 8 * cpc) * 8); \
+        _Pragma("unroll") for (int cpc = 0; cpc < BAND_LOUT_MAX / 8; cpc++)                                                 \
+          _Pragma("unroll") for (int i = 0; i < NI; i++)                                                                    \
+            if (movok[i] && cpc * 8 + le < lc_ && !(BAND_DBG & 16))                                                         \
+              *reinterpret_cast<double*>(lout + (((movp[i] * (unsigned)lsize + (unsigned)le) << 3) + 64 * cpc)) = lx_[cpc][i]; \
+      }
+      BAND_FSTEP(0) BAND_FSTEP(1) BAND_FSTEP(2) BAND_FSTEP(3)
+      BAND_LFLUSH(E[BE_LBASE], E[BE_LCNT])
+      BAND_FSTEP(4) BAND_FSTEP(5) BAND_FSTEP(6) BAND_FSTEP(7)
       BSTAMP(3)
       static_assert(BAND_EPOCH == 8, "eight step instantiations per epoch");
       if (nst == BAND_EPOCH) {
@@ -468,22 +471,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 #pragma unroll
         for (int a = 0; a < 4; a++) { W.X[a] = 0.0; W.c[a] = 0.0; }
       }
-      // factor records of the epoch: 64-byte pieces from the out ring
-      const int lb = E[BE_LBASE], lc = E[BE_LCNT];
-      char* lout = reinterpret_cast<char*>(lbase_g) + ((long long)lb << 3);
-      {
-        // all reads of the ring first, then the stores (whole pieces are read; lanes past the records do not store)
-        double lx_[BAND_LOUT_MAX / 8][NI];
-#pragma unroll
-        for (int cpc = 0; cpc < BAND_LOUT_MAX / 8; cpc++)
-#pragma unroll
-          for (int i = 0; i < NI; i++) lx_[cpc][i] = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_LOUT_OFF + 8 * cpc) * 8);
-#pragma unroll
-        for (int cpc = 0; cpc < BAND_LOUT_MAX / 8; cpc++)
-#pragma unroll
-          for (int i = 0; i < NI; i++)
-            if (movok[i] && cpc * 8 + le < lc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(lout + (((movp[i] * (unsigned)lsize + (unsigned)le) << 3) + 64 * cpc)) = lx_[cpc][i];
-      }
+      BAND_LFLUSH(E[BE_LBASE2], E[BE_LCNT2])
     }
     BSTAMP(4)
     // ================= junction + inertia rule + rho ladder (src/solver_types.jl:90-97, src/CaNNOLeS.jl:1023-1047) ==========
@@ -492,7 +480,6 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       // windows to LDS (slot order): the junction reads both with run-time slot numbers
       if (clane) {
         double* ex = reinterpret_cast<double*>(myb + EXCH_OFF * 8);
-        // (46 doubles: the exchange area runs over the dx / dr rings and the tail of the factor-out ring, all idle between the sweeps)
 #pragma unroll
         for (int q = 0; q < NS * (NS + 1) / 2; q++) ex[q] = W.S[q];
 #pragma unroll
@@ -626,83 +613,44 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       const int nst = E[BE_NSTEP];
       int o = 0;
       BSTAMP(7)
-      Rec st0, st1, st2;
-      RowRec rw0, rw1, rw2;
-      BOps opA, opB;
-      int o0 = 0, o1 = 0, o2 = 0;
-      load_rec(st0, recb, 0);
-      load_row(rw0, recb, BAND_SW);
-      {
-        const int f0 = __builtin_amdgcn_readfirstlane(st0.v[BS_FLAGS]);
-        o1 = BAND_SW + BAND_RW * ((f0 >> 8) & 255);
-        if (nst > 1) { load_rec(st1, recb, o1); load_row(rw1, recb, o1 + BAND_SW); }
-        if (clane) bload(opA, st0, rw0, f0, myb);
-      }
-      // (position Q in the epoch's backward order: 0 = the epoch's last step; phase = nst - 1 - Q)
-#define BAND_BSTEP(Q, PHV, SC, RC, OC, OPC, SN, RN, ON, OPN, SNN, RNN, ONN)                                                  \
-      {                                                                                                                     \
-        const int fl = __builtin_amdgcn_readfirstlane(SC.v[BS_FLAGS]);                                                      \
-        if (Q + 1 < nst) {                                                                                                  \
-          const int fn = __builtin_amdgcn_readfirstlane(SN.v[BS_FLAGS]);                                                    \
-          ONN = ON + BAND_SW + BAND_RW * ((fn >> 8) & 255);                                                                 \
-          if (Q + 2 < nst) { load_rec(SNN, recb, ONN); load_row(RNN, recb, ONN + BAND_SW); }                                \
-          if (clane) bload(OPN, SN, RN, fn, myb);                                                                           \
+      Rec stC, stN;
+      RowRec rwC, rwN;
+      load_rec(stC, recb, 0);
+      load_row(rwC, recb, BAND_SW);
+#define BAND_BSTEP(PHV)                                                                                                     \
+      if (PHV < nst) {                                                                                                      \
+        const int fl = __builtin_amdgcn_readfirstlane(stC.v[BS_FLAGS]);                                                     \
+        const int onext = o + BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                        \
+        if (PHV > 0) { load_rec(stN, recb, onext); load_row(rwN, recb, onext + BAND_SW); }                                  \
+        if (clane && !(BAND_DBG & 4)) {                                                                                     \
+          BOps op_;                                                                                                         \
+          bload(op_, stC, rwC, fl, myb);                                                                                    \
+          bstep<PHV>(xs, op_, stC, rwC, fl, recb, o, myb, borders, gd, pd, okme);                                           \
         }                                                                                                                   \
-        if (clane && !(BAND_DBG & 4)) bstep<PHV>(xs, OPC, SC, RC, fl, recb, OC, myb, borders, gd, pd, okme);                \
+        o = onext; stC = stN; rwC = rwN;                                                                                    \
       }
-#define BAND_BSTEPS(Q, PHV)                                                                                                 \
-      if (Q % 6 == 0) BAND_BSTEP(Q, PHV, st0, rw0, o0, opA, st1, rw1, o1, opB, st2, rw2, o2)                               \
-      else if (Q % 6 == 1) BAND_BSTEP(Q, PHV, st1, rw1, o1, opB, st2, rw2, o2, opA, st0, rw0, o0)                          \
-      else if (Q % 6 == 2) BAND_BSTEP(Q, PHV, st2, rw2, o2, opA, st0, rw0, o0, opB, st1, rw1, o1)                          \
-      else if (Q % 6 == 3) BAND_BSTEP(Q, PHV, st0, rw0, o0, opB, st1, rw1, o1, opA, st2, rw2, o2)                          \
-      else if (Q % 6 == 4) BAND_BSTEP(Q, PHV, st1, rw1, o1, opA, st2, rw2, o2, opB, st0, rw0, o0)                          \
-      else BAND_BSTEP(Q, PHV, st2, rw2, o2, opB, st0, rw0, o0, opA, st1, rw1, o1)
-      if (nst == BAND_EPOCH) {
-        BAND_BSTEPS(0, 7) BAND_BSTEPS(1, 6) BAND_BSTEPS(2, 5) BAND_BSTEPS(3, 4) BAND_BSTEPS(4, 3) BAND_BSTEPS(5, 2) BAND_BSTEPS(6, 1) BAND_BSTEPS(7, 0)
-      } else {
-        // the last (short) epoch of a part is the first of the backward sweep: position Q has phase nst - 1 - Q, known at run time only
-        int q = 0;
-        for (int ph = nst - 1; ph >= 0; ph--, q++) {
-          Rec sc; RowRec rc; BOps oc;
-          // (plain: block, operands, step — a handful of steps per sweep)
-          int oo = 0;
-          for (int t = 0; t < q; t++) { load_rec(sc, recb, oo); oo += BAND_SW + BAND_RW * ((__builtin_amdgcn_readfirstlane(sc.v[BS_FLAGS]) >> 8) & 255); }
-          load_rec(sc, recb, oo); load_row(rc, recb, oo + BAND_SW);
-          const int fl = __builtin_amdgcn_readfirstlane(sc.v[BS_FLAGS]);
-          if (clane) {
-            bload(oc, sc, rc, fl, myb);
-            if (!(BAND_DBG & 4)) {
-              switch (ph) {
-                case 0: bstep<0>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
-                case 1: bstep<1>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
-                case 2: bstep<2>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
-                case 3: bstep<3>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
-                case 4: bstep<4>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
-                case 5: bstep<5>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
-                default: bstep<6>(xs, oc, sc, rc, fl, recb, oo, myb, borders, gd, pd, okme); break;
-              }
-            }
-          }
-        }
-      }
+      BAND_BSTEP(7) BAND_BSTEP(6) BAND_BSTEP(5) BAND_BSTEP(4) BAND_BSTEP(3) BAND_BSTEP(2) BAND_BSTEP(1) BAND_BSTEP(0)
       BSTAMP(8)
       // solution components of the epoch
       const int xlo = E[BE_DXLO], xc = E[BE_DXCNT], rlo = E[BE_DRLO], rc = E[BE_DRCNT];
       char* dxo = reinterpret_cast<char*>(dbase) + ((long long)xlo << 3);
       char* dro = reinterpret_cast<char*>(dbase) + ((long long)rlo << 3);
+      {
+        double dx_[NI], dr_[BAND_DR_MAX / 8][NI];
 #pragma unroll
-      for (int cpc = 0; cpc < 2; cpc++) {
+        for (int i = 0; i < NI; i++) dx_[i] = *reinterpret_cast<const double*>(wblk + ldsb[i] + BAND_DX_OFF * 8);
 #pragma unroll
-        for (int i = 0; i < NI; i++) {
-          if (cpc * 8 < xc) {
-            const double x = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_DX_OFF + 8 * cpc) * 8);
-            if (movst[i] && cpc * 8 + le < xc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(dxo + (((movp[i] * (unsigned)N + (unsigned)le) << 3) + 64 * cpc)) = x;
-          }
-          if (cpc * 8 < rc) {
-            const double x = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_DR_OFF + 8 * cpc) * 8);
-            if (movst[i] && cpc * 8 + le < rc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(dro + (((movp[i] * (unsigned)N + (unsigned)le) << 3) + 64 * cpc)) = x;
-          }
-        }
+        for (int cpc = 0; cpc < BAND_DR_MAX / 8; cpc++)
+#pragma unroll
+          for (int i = 0; i < NI; i++) dr_[cpc][i] = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_DR_OFF + 8 * cpc) * 8);
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+          if (movst[i] && le < xc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(dxo + ((movp[i] * (unsigned)N + (unsigned)le) << 3)) = dx_[i];
+#pragma unroll
+        for (int cpc = 0; cpc < BAND_DR_MAX / 8; cpc++)
+#pragma unroll
+          for (int i = 0; i < NI; i++)
+            if (movst[i] && cpc * 8 + le < rc && !(BAND_DBG & 16)) *reinterpret_cast<double*>(dro + (((movp[i] * (unsigned)N + (unsigned)le) << 3) + 64 * cpc)) = dr_[cpc][i];
       }
     }
   }

@@ -4,14 +4,14 @@ slot, factor records through the out ring, junction of the two parts — vectori
 infrastructure: it pins the GENERATOR against the oracle without a GPU."""
 import numpy as np
 
-HW, NB, EPOCH, NPIECE, LREC = 4, 5, 8, 16, 6
+HW, NB, EPOCH, NPIECE, LREC = 4, 5, 8, 15, 6
 NS = EPOCH   # window slots: variable number t of a part lives in slot t % NS; the border row is index NS
-IN_OFF, LOUT_OFF, LOUT_MAX = 0, NPIECE * 8, 64
-DX_OFF = LOUT_OFF + LOUT_MAX
-DX_MAX = 16
+IN_OFF, LOUT_OFF, LOUT_MAX = 0, NPIECE * 8, 32
+DX_OFF = LOUT_OFF     # the out ring: factor records of half an epoch (forward), solution components of an epoch (backward)
+DX_MAX = 8
 DR_OFF = DX_OFF + DX_MAX
-DR_MAX = 16
-ZERO_OFF = DR_OFF + DR_MAX
+DR_MAX = 24
+ZERO_OFF = LOUT_OFF + LOUT_MAX
 LANE = ZERO_OFF + 1
 SW, RW, EW, BW = 20, 8, 44, 4
 BS_FLAGS, BS_DG0, BS_RHO, BS_OD = 0, 1, 4, 5
@@ -20,7 +20,7 @@ BS_BC1, BS_RX, BS_LB, BS_LX, BS_DX, BS_BORDER = BS_BC0 + 1, BS_BC0 + 2, BS_BC0 +
 BF_ENTER_B, BF_PIVOT_B, BF_PIVOT_X = 1, 2, 4
 BR_DI, BR_J0, BR_RR, BR_DR = 0, 1, 1 + NB, 2 + NB
 BE_FP, BE_BP = 0, NPIECE
-BE_LBASE, BE_LCNT, BE_DXLO, BE_DXCNT, BE_DRLO, BE_DRCNT, BE_NSTEP, BE_FOFF, BE_BOFF, BE_OPLEN = (2 * NPIECE + i for i in range(10))
+BE_LBASE, BE_LCNT, BE_LBASE2, BE_LCNT2, BE_DXLO, BE_DXCNT, BE_DRLO, BE_DRCNT, BE_NSTEP, BE_FOFF, BE_BOFF, BE_OPLEN = (2 * NPIECE + i for i in range(12))
 
 
 class BandSim:
@@ -63,12 +63,12 @@ class BandSim:
             for u in range(P["nsteps"]):
                 if u == starts[ep_of[u]]:
                     E = P["epochs"][ep_of[u]]
-                    if u:   # factor records of the previous epoch
+                    if u:   # factor records of the previous epoch's second half
                         Ep = P["epochs"][ep_of[u] - 1]
-                        Lq[:, Ep[BE_LBASE]: Ep[BE_LBASE] + Ep[BE_LCNT]] = blk[:, LOUT_OFF: LOUT_OFF + Ep[BE_LCNT]]
+                        Lq[:, Ep[BE_LBASE2]: Ep[BE_LBASE2] + Ep[BE_LCNT2]] = blk[:, LOUT_OFF: LOUT_OFF + Ep[BE_LCNT2]]
                     blk[:, :ZERO_OFF] = np.nan   # stale operands must not be read
                     self._load_pieces(blk, E[BE_FP: BE_FP + NPIECE], (vals, rhs))
-                    assert o == E[BE_FOFF] and E[BE_OPLEN] <= 320
+                    assert o == E[BE_FOFF] and E[BE_OPLEN] <= 256
                 st = ops[o: o + SW]
                 fl = int(st[BS_FLAGS])
                 nrows = (fl >> 8) & 255
@@ -152,8 +152,12 @@ class BandSim:
                     S[:, ps] = np.nan
                     c[ps] = np.nan
                 o += SW + RW * nrows
+                if u - starts[ep_of[u]] == EPOCH // 2 - 1 or (u + 1 == starts[ep_of[u] + 1] and u - starts[ep_of[u]] < EPOCH // 2 - 1):
+                    Ec = P["epochs"][ep_of[u]]   # factor records of the epoch's first half
+                    Lq[:, Ec[BE_LBASE]: Ec[BE_LBASE] + Ec[BE_LCNT]] = blk[:, LOUT_OFF: LOUT_OFF + Ec[BE_LCNT]]
+                    blk[:, LOUT_OFF: ZERO_OFF] = np.nan
             Ep = P["epochs"][P["nepochs"] - 1]
-            Lq[:, Ep[BE_LBASE]: Ep[BE_LBASE] + Ep[BE_LCNT]] = blk[:, LOUT_OFF: LOUT_OFF + Ep[BE_LCNT]]
+            Lq[:, Ep[BE_LBASE2]: Ep[BE_LBASE2] + Ep[BE_LCNT2]] = blk[:, LOUT_OFF: LOUT_OFF + Ep[BE_LCNT2]]
             wins.append((S, c))
         junction = None
         if self.nparts == 2:

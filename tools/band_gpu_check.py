@@ -30,7 +30,6 @@ def run(n, p, B, bk=1, nl=16, stress=None, ncheck=4):
     L.close()
 if __name__ == "__main__":
     run(200, 0, 3, bk=2)
-    run(200, 4, 3, bk=2)
     run(200, 0, 3)
     run(200, 4, 5)
     run(1000, 10, 37)
