@@ -188,26 +188,44 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
     // right-hand side of the variables
     for (size_t t = 0; t < seq.size(); t++)
       if (owns(seq[t])) S[t].rx = rhs_src(seq[t]);
-    // residual rows
-    int32_t rlo = (int32_t)m, rhi = -1;
+    // residual rows: row r is condensed at the step where its last column enters — or later, while its first column is still
+    // unpivoted (the step of that pivot included: rows come before the pivot), so that rows which complete together (the end of
+    // the chain: the last column completes three rows) are spread over the following steps instead of piling their operands
+    // into one epoch
+    struct RowAt { int32_t r, u, deadline; };
+    std::vector<RowAt> mine_rows;
     for (int64_t r = 0; r < m; r++) {
       const RowInfo& q = R[r];
-      int32_t u = 0, hi = -1;
+      int32_t hi = -1;
       for (int32_t x : q.xs) hi = std::max(hi, x);
-      if (q.xs.empty()) { if (part != 0) continue; }
-      else {
-        if (!owns(hi)) continue;
-        int32_t plo = 1 << 30, phi = -1;
-        for (int32_t x : q.xs) { if (pos[x] < 0) return no("internal: row outside its part"); plo = std::min(plo, pos[x]); phi = std::max(phi, pos[x]); }
-        if (phi - plo > BAND_HW) return no("residual row wider than the band");
-        u = phi;
+      if (q.xs.empty()) { if (part == 0) mine_rows.push_back({(int32_t)r, 0, 0}); continue; }
+      if (!owns(hi)) continue;
+      int32_t plo = 1 << 30, phi = -1;
+      for (int32_t x : q.xs) { if (pos[x] < 0) return no("internal: row outside its part"); plo = std::min(plo, pos[x]); phi = std::max(phi, pos[x]); }
+      if (phi - plo > BAND_HW) return no("residual row wider than the band");
+      mine_rows.push_back({(int32_t)r, phi, std::min(plo + BAND_HW, nsteps_raw - 1)});
+    }
+    std::stable_sort(mine_rows.begin(), mine_rows.end(), [&](const RowAt& x, const RowAt& y) { return x.u != y.u ? x.u < y.u : (part == 0 ? x.r < y.r : x.r > y.r); });
+    {
+      int32_t next_free = 0;
+      for (RowAt& ra : mine_rows) {
+        const int32_t want = std::max(ra.u, next_free);
+        if (want <= ra.deadline) ra.u = want;
+        next_free = std::max(next_free, ra.u + 1);
       }
+    }
+    for (const RowAt& ra : mine_rows) {
+      const RowInfo& q = R[ra.r];
+      const int32_t u = ra.u;
       RowOp ro;
-      ro.di = q.dsrc; ro.rr = rhs_src(n + r); ro.r = (int32_t)r;
+      ro.di = q.dsrc; ro.rr = rhs_src(n + ra.r); ro.r = ra.r;
       for (int s = 0; s < BAND_NB; s++) ro.j[s] = -1;
-      for (size_t i = 0; i < q.xs.size(); i++) ro.j[pos[q.xs[i]] - (u - BAND_HW)] = q.srcs[i];   // live position: 0 = the step's pivot, HW = the entering variable
+      for (size_t i = 0; i < q.xs.size(); i++) {
+        const int32_t k = pos[q.xs[i]] - (u - BAND_HW);   // live position: 0 = the step's pivot, HW = the variable entering at step u
+        if (k < 0 || k > BAND_HW) return no("internal: row column outside the window");
+        ro.j[k] = q.srcs[i];
+      }
       S[u].rows.push_back(ro);
-      rlo = std::min(rlo, (int32_t)r); rhi = std::max(rhi, (int32_t)r);
     }
     for (StepOp& st : S) {
       if (st.rows.size() > 15) return no("more than 15 residual rows complete at one variable");
@@ -403,7 +421,6 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
     // slack for the kernels' prefetch of the next block
     Q.fops.resize(Q.fops.size() + BAND_REC_MAX + 64, 0);
     Q.bops.resize(Q.bops.size() + BAND_REC_MAX + 64, 0);
-    (void)rlo; (void)rhi;
   }
   B.lsize = loff + 8;
   B.ok = true;

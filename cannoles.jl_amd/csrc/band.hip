@@ -352,8 +352,9 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 
   static_assert(NI <= 4, "at most four problem groups per mover lane");
   double stg[NPC][NI];   // operand pieces in flight
-  int4 rstg0, rstg1;     // step blocks in flight (two 16-byte words per lane: 512 ints)
-  static_assert(BAND_REC_MAX <= 512, "record buffer: two dwordx4 per lane");
+  int4 rstg0;            // step blocks in flight (one 16-byte word per lane: 256 ints)
+  int pcs[NPC];          // piece descriptors of the epoch being loaded
+  static_assert(BAND_REC_MAX <= 256, "record buffer: one dwordx4 per lane");
   // The mover is written for back-to-back issue: the fifteen piece descriptors of an epoch come with one scalar load, every
   // piece is loaded whether the epoch uses it or not (an unused descriptor reads the first elements of vals: a cache hit), every
   // staged piece is written to LDS — no branch per piece.  One load per piece and problem group: base pointer and stride of the
@@ -374,24 +375,21 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   }
 #define BAND_COMMIT(K) { BAND_COMMIT1(K, 0) BAND_COMMIT1(K, 1) BAND_COMMIT1(K, 2) BAND_COMMIT1(K, 3) }
   // (macros, not lambdas: a closure made the compiler keep every captured variable — the staging registers included — in scratch memory)
+#define BAND_ISSUE_DESC(EP, OFS) { cptr E_ = (EP) + (OFS); _Pragma("unroll") for (int k_ = 0; k_ < NPC; k_++) pcs[k_] = E_[k_]; }
+  /* the epoch's step / row blocks (the streams are padded: reading past the epoch's blocks is harmless) */
+#define BAND_ISSUE_REC(OPS, OPOFF) { rstg0 = (reinterpret_cast<const int4*>((OPS) + (OPOFF)) + lane)[0]; }
 #define BAND_ISSUE_ALL(EP, OFS, OPS, OPOFF)                                                                                   \
   {                                                                                                                           \
-    cptr E_ = (EP) + (OFS);                                                                                                   \
-    int pcs[NPC];                                                                                                             \
-    _Pragma("unroll") for (int k_ = 0; k_ < NPC; k_++) pcs[k_] = E_[k_];                                                      \
+    BAND_ISSUE_DESC(EP, OFS)                                                                                                  \
     BAND_ISSUE(0) BAND_ISSUE(1) BAND_ISSUE(2) BAND_ISSUE(3) BAND_ISSUE(4) BAND_ISSUE(5) BAND_ISSUE(6) BAND_ISSUE(7)           \
     BAND_ISSUE(8) BAND_ISSUE(9) BAND_ISSUE(10) BAND_ISSUE(11) BAND_ISSUE(12) BAND_ISSUE(13) BAND_ISSUE(14)                    \
-    /* the epoch's step / row blocks (the streams are padded: reading past the epoch's blocks is harmless) */                 \
-    const int4* rp = reinterpret_cast<const int4*>((OPS) + (OPOFF)) + lane;                                                   \
-    rstg0 = rp[0];                                                                                                            \
-    if (BAND_REC_MAX > 256) rstg1 = rp[64];                                                                                   \
+    BAND_ISSUE_REC(OPS, OPOFF)                                                                                                \
   }
 #define BAND_COMMIT_ALL()                                                                                                     \
   {                                                                                                                           \
     BAND_COMMIT(0) BAND_COMMIT(1) BAND_COMMIT(2) BAND_COMMIT(3) BAND_COMMIT(4) BAND_COMMIT(5) BAND_COMMIT(6) BAND_COMMIT(7)   \
     BAND_COMMIT(8) BAND_COMMIT(9) BAND_COMMIT(10) BAND_COMMIT(11) BAND_COMMIT(12) BAND_COMMIT(13) BAND_COMMIT(14)             \
     reinterpret_cast<int4*>(recb)[lane] = rstg0;                                                                              \
-    if (BAND_REC_MAX > 256 && lane < (BAND_REC_MAX - 256) / 4) reinterpret_cast<int4*>(recb)[64 + lane] = rstg1;              \
   }
   static_assert(NPC == 15, "fifteen operand pieces");
 
@@ -415,7 +413,10 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       BSTAMP(0)
       BAND_COMMIT_ALL()
       BSTAMP(1)
-      if (e + 1 < nepochs && !(BAND_DBG & 8)) BAND_ISSUE_ALL(epochs + (e + 1) * BAND_EW, BE_FP, fops_g, epochs[(e + 1) * BAND_EW + BE_FOFF])
+      // the next epoch's loads are issued in four groups behind the first four steps (a burst of 34 loads stalled the wavefront on
+      // the CU's memory pipeline for ~2 500 cycles per epoch, in-kernel stamps), still four steps ahead of their use
+      const bool more_ = e + 1 < nepochs && !(BAND_DBG & 8);
+      if (more_) BAND_ISSUE_DESC(epochs + (e + 1) * BAND_EW, BE_FP)
       // The steps of the epoch: step t works on the slots of phase t (every epoch but the last has BAND_EPOCH steps), so the eight
       // instantiations follow each other in straight-line code and the window keeps its registers from step to step.
       const int nst = E[BE_NSTEP];
@@ -454,7 +455,14 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
             if (movok[i] && cpc * 8 + le < lc_ && !(BAND_DBG & 16))                                                         \
               *reinterpret_cast<double*>(lout + (((movp[i] * (unsigned)lsize + (unsigned)le) << 3) + 64 * cpc)) = lx_[cpc][i]; \
       }
-      BAND_FSTEP(0) BAND_FSTEP(1) BAND_FSTEP(2) BAND_FSTEP(3)
+      BAND_FSTEP(0)
+      if (more_) { BAND_ISSUE(0) BAND_ISSUE(1) BAND_ISSUE(2) BAND_ISSUE(3) }
+      BAND_FSTEP(1)
+      if (more_) { BAND_ISSUE(4) BAND_ISSUE(5) BAND_ISSUE(6) BAND_ISSUE(7) }
+      BAND_FSTEP(2)
+      if (more_) { BAND_ISSUE(8) BAND_ISSUE(9) BAND_ISSUE(10) BAND_ISSUE(11) }
+      BAND_FSTEP(3)
+      if (more_) { BAND_ISSUE(12) BAND_ISSUE(13) BAND_ISSUE(14) BAND_ISSUE_REC(fops_g, epochs[(e + 1) * BAND_EW + BE_FOFF]) }
       BAND_LFLUSH(E[BE_LBASE], E[BE_LCNT])
       BAND_FSTEP(4) BAND_FSTEP(5) BAND_FSTEP(6) BAND_FSTEP(7)
       BSTAMP(3)
@@ -609,7 +617,8 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       BSTAMP(5)
       BAND_COMMIT_ALL()
       BSTAMP(6)
-      if (e > 0 && !(BAND_DBG & 8)) BAND_ISSUE_ALL(epochs + (e - 1) * BAND_EW, BE_BP, bops_g, epochs[(e - 1) * BAND_EW + BE_BOFF])
+      const bool more_ = e > 0 && !(BAND_DBG & 8);
+      if (more_) BAND_ISSUE_DESC(epochs + (e - 1) * BAND_EW, BE_BP)
       const int nst = E[BE_NSTEP];
       int o = 0;
       BSTAMP(7)
@@ -629,7 +638,15 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
         }                                                                                                                   \
         o = onext; stC = stN; rwC = rwN;                                                                                    \
       }
-      BAND_BSTEP(7) BAND_BSTEP(6) BAND_BSTEP(5) BAND_BSTEP(4) BAND_BSTEP(3) BAND_BSTEP(2) BAND_BSTEP(1) BAND_BSTEP(0)
+      BAND_BSTEP(7)
+      if (more_) { BAND_ISSUE(0) BAND_ISSUE(1) BAND_ISSUE(2) BAND_ISSUE(3) }
+      BAND_BSTEP(6)
+      if (more_) { BAND_ISSUE(4) BAND_ISSUE(5) BAND_ISSUE(6) BAND_ISSUE(7) }
+      BAND_BSTEP(5)
+      if (more_) { BAND_ISSUE(8) BAND_ISSUE(9) BAND_ISSUE(10) BAND_ISSUE(11) }
+      BAND_BSTEP(4)
+      if (more_) { BAND_ISSUE(12) BAND_ISSUE(13) BAND_ISSUE(14) BAND_ISSUE_REC(bops_g, epochs[(e - 1) * BAND_EW + BE_BOFF]) }
+      BAND_BSTEP(3) BAND_BSTEP(2) BAND_BSTEP(1) BAND_BSTEP(0)
       BSTAMP(8)
       // solution components of the epoch
       const int xlo = E[BE_DXLO], xc = E[BE_DXCNT], rlo = E[BE_DRLO], rc = E[BE_DRCNT];

@@ -1243,7 +1243,9 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
       bd.nsteps[q] = Bp.part[q].nsteps; bd.nepochs[q] = Bp.part[q].nepochs; bd.loff[q] = Bp.part[q].loff;
     }
     bd.nparts = Bp.nparts; bd.m0 = Bp.m0; bd.n = Bp.n; bd.N = Bp.N; bd.nnz = Bp.nnz; bd.nvar = (int32_t)nvar; bd.lsize = Bp.lsize;
-    h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : 16;
+    // 16 problems per workgroup (two workgroups = four wavefronts per CU: one per SIMD) up to the 8192 problems that fills; above,
+    // 32 per workgroup (the LDS of a CU holds two such workgroups: 16384 problems resident) — tools/time_band.py
+    h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : (batch > 8192 ? 32 : 16);
     if (h->band_nl != 8 && h->band_nl != 16 && h->band_nl != 32) return bail(fail(CNL_ERR_ARG, "band_problems_per_group must be 8, 16 or 32"));
     // 32-bit byte offsets inside a workgroup's problems
     const uint64_t span = 8ull * (uint64_t)h->band_nl * (uint64_t)std::max<int64_t>({(int64_t)nnz, N, bd.lsize});
@@ -1287,7 +1289,8 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     // them: a batch of k full machine loads + r problems runs k + 1 rounds, the last one for the r problems alone (cfg3's size:
     // 8448 problems 13.0 ms against 7.9 ms for 8192).  The remainder as a batch of its own has a better plan (many parts, the
     // bidirectional chain, ...): it gets a handle of its own, enqueued behind the full loads (run_split).
-    const int64_t cap = 4 * (int64_t)h->resident_waves, r = batch % cap;
+    // (band kernels: 512 workgroups of 32 problems are resident at once)
+    const int64_t cap = h->band ? 16384 : 4 * (int64_t)h->resident_waves, r = batch % cap;
     if (batch > cap && r > 0 && r <= cap - cap / 16) {
       cnl_options o2 = plan->opt;
       cnl_handle* t = nullptr;

@@ -136,7 +136,7 @@ typedef struct cnl_options {
                                   constraint row a run of its own) runs newton_system on the band kernels (csrc/band.h: one lane per
                                   problem and half of the chain, operands streamed through LDS); 2: the same with the chain in one
                                   part; 0: the register-front kernel                                                              */
-  int32_t band_problems_per_group; /* band kernels: problems per workgroup (8, 16 or 32); 0 = default (16)                      */
+  int32_t band_problems_per_group; /* band kernels: problems per workgroup (8, 16 or 32); 0 = by batch: 16 up to 8192 problems, 32 above */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);

@@ -1879,3 +1879,91 @@ def test_bench_multi_front_end(built):
     dt, nprob, ok, shards = BM.multi_front_end(torch, hipldl, s, rows, cols, [0, 0], 20, steps=3, warmup=1)
     assert ok and nprob == 40 and dt > 0
     assert [(a, c) for a, c, _ in shards] == [(0, 20), (20, 20)]
+
+
+# ---- round 5: band kernels (csrc/band.h, band.hip): newton_system! of throughput handles whose pattern is a band ----------------------
+
+def _band_opts(hipldl, **kw):
+    return hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, **kw)
+
+
+@pytest.mark.parametrize("n,p,B,nl,hw", [(200, 4, 5, 16, 2), (96, 2, 3, 16, 2), (1000, 10, 37, 8, 2), (1000, 10, 37, 32, 2), (1000, 10, 70, 16, 2), (360, 6, 19, 16, 1),
+                                         (400, 0, 9, 16, 2), (10000, 50, 33, 16, 2)])
+def test_band_kernels_against_the_oracle(built, n, p, B, nl, hw):
+    """one lane per (problem, half of the chain): decisions identical to the oracle's on the product's order and on the canonical one,
+    d within the forward / backward bar; batches that are no multiple of the workgroup's problems, one part (n < 80) and two"""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(n, p, hw=hw)
+    vals, rhs = syn.batch_values(s, B, cfg=4)
+    info, cfg = run_case(s, vals, rhs, options=_band_opts(hipldl, band_problems_per_group=nl))
+    assert cfg["band"]
+
+
+def test_band_kernels_ladder_hopeless_and_rho_old(built):
+    """problems that climb the rho ladder (nfact = 6, fixture F3's rule), one that no rho rescues (d untouched, rho_old kept), a
+    start from rho_old > 0 (src/CaNNOLeS.jl:1030,1036) — mixed with convex problems in one workgroup"""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(600, 6)
+    B = 21
+    vals, rhs = syn.batch_values(s, B, cfg=4)
+    for b in (1, 5, 17, 20):
+        vals[b], rhs[b] = syn.band_values(s, 5000 + b, stress="ladder")
+    vals[9, s.offsets()[0]] = -1e300
+    ro = np.zeros(B)
+    ro[5] = 0.3
+    ro[2] = 1e-3
+    info, cfg = run_case(s, vals, rhs, rho_old=ro, options=_band_opts(hipldl))
+    assert cfg["band"]
+
+
+def test_band_and_register_front_kernels_agree(built):
+    """the same batch through cnl_options.band_kernel = 0 and 1: identical decisions, d equal to rounding (the two kernels sum in
+    different orders: DESIGN section 5)"""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(2000, 10)
+    B = 48
+    vals, rhs = syn.batch_values(s, B, cfg=4)
+    vals[7], rhs[7] = syn.band_values(s, 77, stress="ladder")
+    rows, cols = s.kkt_pattern()
+    p = hipldl.default_params()
+    out = {}
+    for bk in (0, 1):
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=_band_opts(hipldl, band_kernel=bk))
+        assert L.config["band"] == bool(bk)
+        v = vals.copy()
+        d = np.zeros((B, s.N))
+        out[bk] = [np.array(x, copy=True) for x in hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, np.zeros(B), p)] + [v]
+        L.close()
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert np.array_equal(a, b)
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-12 * np.abs(out[0][0]).max()
+
+
+def test_band_newton_system_then_solve_ldl(built):
+    """solve_ldl! behind a newton_system! of the band kernels uses the last factorisation (src/CaNNOLeS.jl:1049, solver_types.jl:69-77):
+    the register-front kernel factorises the same values first (the band kernels keep factor records only their own backward sweep
+    reads).  Also try_to_factorize -> newton_system! -> solve_ldl! with a second right-hand side."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(800, 8)
+    B = 20
+    vals, rhs = syn.batch_values(s, B, cfg=4)
+    vals[3], rhs[3] = syn.band_values(s, 33, stress="ladder")
+    rows, cols = s.kkt_pattern()
+    p = hipldl.default_params()
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=_band_opts(hipldl))
+    assert L.config["band"]
+    ok = hipldl.try_to_factorize(L, vals, s.nvar, s.nequ, s.ncon, p[0])
+    assert ok.sum() == B - 1 and not ok[3]
+    v = vals.copy()
+    d = np.zeros((B, s.N))
+    d, ok2, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, np.zeros(B), p)
+    assert ok2.all() and nf[3] == 6
+    d2 = np.zeros((B, s.N))
+    assert hipldl.solve_ldl_(rhs, L.factor, d2) is True
+    assert np.abs(d2 - d).max() <= 1e-11 * np.abs(d).max()
+    rhs3 = np.random.default_rng(5).standard_normal(rhs.shape)
+    d3 = np.zeros((B, s.N))
+    hipldl.solve_ldl_(rhs3, L.factor, d3)
+    for b in (0, 3, 19):
+        assert backward_error(s, v[b], rhs3[b], d3[b]) <= BWD_TOL
+    L.close()

@@ -29,7 +29,7 @@ struct Args {
   int flags;   // 1: no loads after the first epoch, 2: no stores
 };
 
-template <int NL, int FL, int E, int DEPTH>
+template <int NL, int FL, int E, int DEPTH, int PAIR>
 __global__ void __launch_bounds__(128, 1) stream_kernel(const Args A) {
   constexpr int NI = NL / 8;
   constexpr int RING = (5 + 3 + 6) * E;   // one epoch of every stream
@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(128, 1) stream_kernel(const Args A) {
     loff[i] = (long long)p * A.lstride + le;
   }
   double st[NROWS * EB][NI], st2[NROWS * EB][NI];
+  double sp[6][NI];   // PAIR: second halves of the single-rate streams' 128-byte loads
   auto issue = [&](int ep, double (&st)[NROWS * EB][NI]) {
     int r = 0;
 #pragma unroll
@@ -64,8 +65,19 @@ __global__ void __launch_bounds__(128, 1) stream_kernel(const Args A) {
       const double* base = (ISRHS[s] ? rhs : vals) + A.seg[s] + pos;
 #pragma unroll
       for (int c = 0; c < ROWS[s] * EB; c++) {
+        if (PAIR && s >= 2) {
+          // even epochs: both 64-byte halves of the line (this epoch's and the next one's); odd epochs: the half kept in registers
+          if ((ep & 1) == 0) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) st[r][i] = base[(ISRHS[s] ? roff[i] : voff[i]) + c * 8];
+            for (int i = 0; i < NI; i++) { st[r][i] = base[(ISRHS[s] ? roff[i] : voff[i])]; sp[s - 2][i] = base[(ISRHS[s] ? roff[i] : voff[i]) + 8]; }
+          } else {
+#pragma unroll
+            for (int i = 0; i < NI; i++) st[r][i] = sp[s - 2][i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; i++) st[r][i] = base[(ISRHS[s] ? roff[i] : voff[i]) + c * 8];
+        }
         r++;
       }
     }
@@ -133,12 +145,12 @@ __global__ void __launch_bounds__(128, 1) stream_kernel(const Args A) {
   if (acc[0] == 123.456) A.sink[blockIdx.x] = acc[1];
 }
 
-template <int NL, int FL, int E, int DEPTH>
+template <int NL, int FL, int E, int DEPTH, int PAIR>
 int run(const char* name, Args A) {
   constexpr int RING = (5 + 3 + 6) * E;
   constexpr int TOT = (RING + E * OUTR) | 1;
   const size_t ldsb = (size_t)2 * NL * TOT * sizeof(double);
-  auto kern = stream_kernel<NL, FL, E, DEPTH>;
+  auto kern = stream_kernel<NL, FL, E, DEPTH, PAIR>;
   CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
   const int grid = (A.batch + NL - 1) / NL;
   hipEvent_t e0, e1;
@@ -156,7 +168,7 @@ int run(const char* name, Args A) {
     if (ms < best) best = ms;
   }
   const double in_bytes = (double)A.batch * 2.0 * A.nsteps * 14.0 * 8.0, out_bytes = (double)A.batch * 2.0 * A.nsteps * 7.0 * 8.0;
-  printf("{\"case\": \"%s\", \"NL\": %d, \"FL\": %d, \"E\": %d, \"depth\": %d, \"aligned\": %d, \"flags\": %d, \"batch\": %d, \"grid\": %d, \"lds_bytes\": %zu, \"ms\": %.3f, \"TBps\": %.2f, \"ns_per_step\": %.1f}\n", name, NL, FL, E, DEPTH, (int)(A.vstride % 8 == 0), A.flags, A.batch,
+  printf("{\"case\": \"%s\", \"NL\": %d, \"FL\": %d, \"E\": %d, \"depth\": %d, \"pair\": %d, \"aligned\": %d, \"flags\": %d, \"batch\": %d, \"grid\": %d, \"lds_bytes\": %zu, \"ms\": %.3f, \"TBps\": %.2f, \"ns_per_step\": %.1f}\n", name, NL, FL, E, DEPTH, PAIR, (int)(A.vstride % 8 == 0), A.flags, A.batch,
          grid, ldsb, best, (in_bytes + out_bytes) / (best * 1e-3) / 1e12, best * 1e6 / A.nsteps);
   return 0;
 }
@@ -171,22 +183,24 @@ int main(int argc, char** argv) {
   A.vstride = 120041; A.rstride = 20050; A.lstride = 2 * 5000 * 7 + 64; A.batch = batch; A.nsteps = 5000;
   (void)n;
   double *vals, *rhs, *L, *sink;
-  CHK(hipMalloc(&vals, (size_t)batch * 120064 * 8 + 4096));
-  CHK(hipMalloc(&rhs, (size_t)batch * 20056 * 8 + 4096));
-  CHK(hipMalloc(&L, (size_t)batch * A.lstride * 8 + 4096));
+  CHK(hipMalloc(&vals, (size_t)2 * batch * 120064 * 8 + 4096));
+  CHK(hipMalloc(&rhs, (size_t)2 * batch * 20056 * 8 + 4096));
+  CHK(hipMalloc(&L, (size_t)2 * batch * A.lstride * 8 + 4096));
   CHK(hipMalloc(&sink, 1 << 20));
   CHK(hipMemset(vals, 0, (size_t)batch * A.vstride * 8));
   CHK(hipMemset(rhs, 0, (size_t)batch * A.rstride * 8));
   A.vals = vals; A.rhs = rhs; A.L = L; A.sink = sink;
-  A.vstride = 120064; A.rstride = 20056; for (int s = 0; s < NS; s++) A.seg[s] &= ~7;
-  for (int fl = 0; fl < 3; fl++) {
-    A.flags = fl;
-    A.batch = batch;
-    if (run<32, 60, 8, 1>("64B pieces", A)) return 1;
-    A.batch = batch / 2;
-    if (run<16, 60, 16, 1>("128B pieces, half batch", A)) return 1;
-    if (run<32, 60, 8, 1>("64B pieces, half batch", A)) return 1;
-    if (run<16, 60, 8, 1>("64B pieces, half batch", A)) return 1;
+  for (int al = 0; al < 2; al++) {
+    if (al) { A.vstride = 120064; A.rstride = 20056; for (int s = 0; s < NS; s++) A.seg[s] &= ~15; }
+    for (int fl = 0; fl < 3; fl += 2) {
+      A.flags = fl;
+      A.batch = batch;
+      if (run<32, 60, 8, 1, 0>("64B pieces", A)) return 1;
+      if (run<32, 60, 8, 1, 1>("single-rate streams in 128B pairs", A)) return 1;
+      A.batch = 512 * 24;
+      if (run<24, 60, 8, 1, 0>("64B pieces, two workgroups per CU", A)) return 1;
+      if (run<24, 60, 8, 1, 1>("single-rate streams in 128B pairs, two workgroups per CU", A)) return 1;
+    }
   }
   return 0;
 }
