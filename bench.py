@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CNL_BENCH_BATCH", 8192)), help="problems per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CNL_BENCH_BATCH", 16384)), help="problems per GPU (weak scaling); 16384 since round 5 (the band kernels hold that many at once), 8192 before — the line carries both")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --total problems split over the ranks")
     ap.add_argument("--total", type=int, default=256, help="total problems with --strong")
     ap.add_argument("--nvar", "--n", dest="n", type=int, default=10000, help="variables = residuals per problem (spelled --nvar under torch.distributed.run, whose own options make --n ambiguous)")
@@ -279,9 +279,10 @@ def main():
     # the forward sweep alone (try_to_factorize: assembly + LDL^T + inertia, no solve), same timing mode: what is left of kern_ms
     # is the backward sweep (the two sweeps are bound by different things)
     fwd_ms = None
+    band = bool(LDLT.config.get("band"))
     try:
-        if args.no_extras:   # (the profiling passes run with --no-extras: only full steps of the kernel in their statistics)
-            raise RuntimeError("skipped")
+        if args.no_extras or band:   # (the profiling passes run with --no-extras: only full steps of the kernel in their statistics;
+            raise RuntimeError("skipped")   #  on a band handle try_to_factorize runs the register-front kernel: not this kernel's forward sweep)
         fms = []
         with torch.cuda.stream(stream):
             for _ in range(3):
@@ -331,9 +332,10 @@ def main():
                      "frac_of_measured_copy_rate": achieved / HBM_MEASURED_GBPS, "peak_measured_copy": HBM_MEASURED_GBPS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "measured_hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                     "bytes_per_system": b_alg, "nnzL_star": nnzL_star, "kernel_ms": kern_ms, "kernel": "newton2_kernel",
+                     "bytes_per_system": b_alg, "nnzL_star": nnzL_star, "kernel_ms": kern_ms, "kernel": "band_newton_kernel" if band else "newton2_kernel",
+                     "units_per_launch": B,
                      "forward_sweep_ms": fwd_ms, "backward_sweep_ms": (kern_ms - fwd_ms) if fwd_ms else None,
-                     "kernel_is_whole_step": bool(LDLT.config.get("lean")) and bool(LDLT.plan_array("brec")[7] & 256),
+                     "kernel_is_whole_step": band or (bool(LDLT.config.get("lean")) and bool(LDLT.plan_array("brec")[7] & 256)),
                      "note": "since round 3 the lean kernel recovers the residual components in its backward sweep: no post-pass, kernel_ms == step_ms; "
                              "rounds 1-2 (and round 3 before that change) priced a kernel that left 1.2 ms of the step to a second kernel on the same algorithmic bytes "
                              "(their step_frac is the comparable figure)",
@@ -344,10 +346,55 @@ def main():
         extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_h, prob, B, dev, local_rank, stream, args)
     if args.cpu_sample != 0 and world == 1:
         cpu_baseline(out, s, rows, cols, vals_h, rhs_h, prob, LDLT, args)
+    # the long line first (every block, for profiles/), then a COMPACT FINAL LINE (<= 1.8 KB) with the mandated keys and one number
+    # per configuration, so that a reader of the tail of this process's output has every config's figure
     print(json.dumps(out))
+    print(json.dumps(compact_line(out)))
     prob.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def compact_line(out):
+    """mandated keys + roofline + cpu_baseline (short) + `summary`: one figure per configuration of the long line"""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    c = {k: out[k] for k in keep}
+    cfg = out["config"]
+    c["config"] = {"workload": cfg["workload"], "batch_per_gpu": cfg["batch_per_gpu"], "kernel": "band" if cfg["kernel"].get("band") else cfg["kernel"].get("kernel"),
+                   "all_success": cfg["all_success"], "backward_error": cfg["backward_error"]}
+    r = out["roofline"]
+    c["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_system", "units_per_launch")}
+    if "cpu_baseline" in out:
+        b = out["cpu_baseline"]
+        c["cpu_baseline"] = {k: b[k] for k in ("value", "unit", "cores", "kind", "sample") if k in b}
+        if isinstance(c["cpu_baseline"].get("sample"), str):
+            c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"][:120]
+    g = lambda blk, *path: _dig(out.get(blk), path)   # noqa: E731
+    s = {
+        "cfg3_B8192_ksys_s": _k(g("small_batch", "B8192", "systems_per_s")), "cfg3_B4096_ksys_s": _k(g("small_batch", "B4096", "systems_per_s")),
+        "cfg3_B256_ksys_s": _k(g("small_batch", "B256", "systems_per_s")), "cfg3_B1_ms": g("small_batch", "B1", "ms_per_call"),
+        "cfg2_B1_ms": g("cfg2_dense", "B1", "ms_per_system"), "cfg2_B1_frac": g("cfg2_dense", "B1", "frac_of_spec"),
+        "cfg2_B8_frac": g("cfg2_dense", "B8", "frac_of_spec"), "cfg2_B32_frac": g("cfg2_dense", "B32", "frac_of_spec"),
+        "cfg4_B256_ms": g("cfg4", "B256", "ms_per_call"), "cfg4_B256_frac": g("cfg4", "B256", "frac"), "cfg4_B32_ms": g("cfg4", "B32", "ms_per_call"),
+        "cfg4_B4096_frac": g("cfg4", "B4096", "frac"), "cfg5_B256_ms": g("cfg5", "B256", "ms_per_call"), "cfg5_B256_frac": g("cfg5", "B256", "frac"),
+        "f1_residual_vectors_ms": g("aux_f1", "residual_vectors", "ms"), "f1_residual_vectors_frac": g("aux_f1", "residual_vectors", "frac"),
+        "f3_ms_per_step": g("aux_f3", "ms_per_step"), "pcie_inclusive_ksys_s": _k(g("pcie_inclusive", "systems_per_s")),
+        "single_system_host_ms": g("call_pattern_single_system", "newton_system_ms"), "multi_front_end_ratio": g("multi_front_end", "ratio_to_single_handle"),
+    }
+    c["summary"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items() if v is not None}
+    return c
+
+
+def _dig(d, path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def _k(v):
+    return None if v is None else v / 1e3
 
 
 def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_h, prob, B, dev, local_rank, stream, args):
@@ -357,7 +404,7 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
     sb = {}
     # 4608: the chain's 4096 + a remainder of 512 on a handle of its own (cnl_options.split_tail); then two large parts (the
     # bidirectional chain), many large parts, and the bushy tree
-    for bs in (4608, 4096, 1024, 256, 1):
+    for bs in (8192, 4608, 4096, 1024, 256, 1):
         if bs > B:
             continue
         p2 = DeviceProblem(torch, hipldl, s, rows, cols, vals[:bs], rhs[:bs], bs, local_rank, stream)

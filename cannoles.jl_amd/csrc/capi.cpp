@@ -125,6 +125,12 @@ struct cnl_handle {
   bool band_fresh = false;     // the last factorisation was made by the band kernels: a later solve_ldl! needs the register-front
                                // kernel's factor of the same values first (launch)
   int32_t* d_band_ok = nullptr;   // [batch] success flags of that refactorisation (not reported)
+  // the same for the WHOLE handle (views of a handle — SubBatch — move the pointers above): the refactorisation in front of a
+  // solve_ldl! always covers every problem of the handle, whatever views the factorisations and the solve came through
+  double *root_L = nullptr, *root_Lband = nullptr;
+  int32_t* root_band_ok = nullptr;
+  int64_t root_batch = 0;
+  const double* band_vals_root = nullptr;   // values (problem 0 of the handle) the band kernels factorised last
 };
 
 namespace {
@@ -342,12 +348,16 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
   a.L = h->d_L;
   a.scratch = h->d_scratch;
   hipError_t e;
-  if (h->band && a.mode == cnl::MODE_SOLVE && h->band_fresh && a.vals) {
+  if (h->band && a.mode == cnl::MODE_SOLVE && h->band_fresh && h->band_vals_root) {
     // solve_ldl! behind a newton_system! of the band kernels: their factor records are not what the solve sweeps read, so the
-    // register-front kernel factorises the same values first (the rho slots hold what the ladder wrote: the same factor)
+    // register-front kernel factorises the same values first (the rho slots hold what the ladder wrote: the same factor) — every
+    // problem of the handle, whichever view of it this call came through
     cnl::LaunchArgs f = a;
-    f.mode = cnl::MODE_FACTOR; f.rhs = nullptr; f.d = nullptr; f.success = h->d_band_ok; f.npos = nullptr; f.nzero = nullptr;
+    f.mode = cnl::MODE_FACTOR; f.rhs = nullptr; f.d = nullptr; f.success = h->root_band_ok; f.npos = nullptr; f.nzero = nullptr;
     f.rho = nullptr; f.rho_old = nullptr; f.nfact = nullptr;
+    f.batch = (int)h->root_batch; f.L = h->root_L; f.vals = const_cast<double*>(h->band_vals_root);
+    f.scratch = h->d_gs ? h->d_gs - (h->d_L - h->root_L) / h->dp.lsize * h->dp2.gs_doubles : nullptr;
+    f.extra_pos = nullptr; f.extra_zer = nullptr;
     e = cnl::launch_newton2(h->dp2, h->wpb2, h->lds2, f, stream);
     if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("refactorisation for solve_ldl!: ") + hipGetErrorString(e));
     h->band_fresh = false;
@@ -358,6 +368,7 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
     b.L = h->d_Lband;
     e = cnl::launch_band(h->bd, h->band_nl, b, stream);
     h->band_fresh = true;
+    h->band_vals_root = a.vals - (h->d_Lband - h->root_Lband) / h->bd.lsize * (int64_t)h->bd.nnz;
   } else if (h->use_v2 && (a.mode != cnl::MODE_SOLVE || h->v2_solve)) {
     if (a.mode == cnl::MODE_FACTOR) h->band_fresh = false;
     a.scratch = h->d_gs;
@@ -1254,6 +1265,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
       if ((rc = dalloc(h, &h->d_band_ok, (size_t)batch))) return bail(rc);
       if (hipMemset(h->d_Lband, 0, ((size_t)batch * (size_t)bd.lsize + 64) * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
       h->band = true;
+      h->root_Lband = h->d_Lband; h->root_band_ok = h->d_band_ok; h->root_batch = batch;
     }
   }
   if (plan->split_mode && h->staged) {
@@ -1321,6 +1333,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     const size_t ldoubles = (size_t)batch * (size_t)dp.lsize + 4096;
     if ((rc = dalloc(h, &h->d_L, ldoubles))) return bail(rc);
     if (hipMemset(h->d_L, 0, ldoubles * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
+    h->root_L = h->d_L;
   }
   if (!h->cfg.lds_work)
     if ((rc = dalloc(h, &h->d_scratch, (size_t)batch * (size_t)dp.work_doubles))) return bail(rc);

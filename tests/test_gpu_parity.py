@@ -721,6 +721,13 @@ def test_near_singular_sweep_decisions(built, plan_kind):
     p = hipldl.default_params()
     L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=opts)
     perm = L.plan_array("perm").astype(np.int64)
+    if L.config.get("band"):
+        # the band kernels (round 5) eliminate the two halves of the chain towards the junction: THEIR last pivot is the junction's
+        # last variable, and the oracle is given an order that ends with it (any order with that variable last has the same last
+        # pivot: the Schur complement of everything else)
+        bi = L.plan_array("band_info")
+        jb = int(bi[2]) + 3 if bi[1] == 2 else s.nvar - 1
+        perm = np.array([v for v in perm if v != jb] + [jb], dtype=np.int64)
     orc = O.Oracle(s.N, rows, cols, perm)
     hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
     rng = np.random.default_rng(11)
@@ -962,7 +969,8 @@ def test_split_tail_remainder_on_its_own_plan(built, nA, kernel, order):
     dev = torch.device("cuda", 0)
     res = {}
     for tail in (1, 0):
-        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(split_tail=tail))
+        # (band_kernel = 0: the machine loads of the register-front single stream; the band kernels' own are in test_band_remainder_handle)
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(split_tail=tail, band_kernel=0))
         assert L.config["kernel"] == kernel and L.info["order"].startswith(order) and L.config["tail"] == bool(tail)
         v = torch.from_numpy(vals).to(dev)
         r = torch.from_numpy(rhs).to(dev)
@@ -1048,7 +1056,7 @@ def test_split_tail_odd_remainders(built, B):
     dg = off[0] + np.nonzero(hF_r == hF_c)[0]
     vals[B - 1, dg[:40]] = -40.0
     p = hipldl.default_params()
-    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(band_kernel=0))
     if B > 8192:
         assert L.config["tail"] and L.config["kernel"] == "v2"
     v = vals.copy()
@@ -1966,4 +1974,43 @@ def test_band_newton_system_then_solve_ldl(built):
     hipldl.solve_ldl_(rhs3, L.factor, d3)
     for b in (0, 3, 19):
         assert backward_error(s, v[b], rhs3[b], d3[b]) <= BWD_TOL
+    L.close()
+
+
+@pytest.mark.parametrize("B", [16384 + 37, 8192 + 5])
+def test_band_remainder_handle(built, B):
+    """band kernels: 512 workgroups of 32 problems are resident at once (16 384 problems); a batch of one such load + r problems gives
+    the remainder a handle of its own (csrc/capi.cpp, run_split), a batch below it runs in one launch.  Decisions and a sample of
+    solutions against the oracle; a ladder climber sits in the last problem (in the remainder), solve_ldl! behind it finds each
+    part's factor."""
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(240, 4)
+    rows, cols = s.kkt_pattern()
+    v8, r8 = syn.batch_values(s, 8, cfg=3)
+    rng = np.random.default_rng(B)
+    vals = np.tile(v8, (B // 8 + 1, 1))[:B] * (1.0 + 1e-3 * rng.standard_normal((B, 1)))
+    rhs = np.tile(r8, (B // 8 + 1, 1))[:B] + 1e-3 * np.arange(B)[:, None]
+    off = s.offsets()
+    vals[:, off[4]:off[5]] = -1.0
+    hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
+    dg = off[0] + np.nonzero(hF_r == hF_c)[0]
+    vals[B - 1, dg[:40]] = -40.0
+    p = hipldl.default_params()
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    assert L.config["band"] and L.config["tail"] == (B > 16384)
+    v = vals.copy()
+    d = np.full((B, s.N), 7.0)
+    d, ok, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, np.zeros(B), p)
+    assert ok.all() and nf[B - 1] > 1 and (nf[:B - 1] == 1).all()
+    d2 = np.zeros((B, s.N))
+    hipldl.solve_ldl_(2.0 * rhs, L.factor, d2)
+    orc = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
+    po = O.default_params()
+    for b in sorted({0, 31, 32, 8191, 8192, 16383 % B, 16384 % B, B - 2, B - 1}):
+        vv = vals[b].copy()
+        d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs[b], vv, 0.0, po)
+        assert ok0 and (nf0, rho0, ro0) == (int(nf[b]), float(rho[b]), float(ro[b])), b
+        assert np.array_equal(v[b, -s.nvar:], vv[-s.nvar:])
+        assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+        assert np.abs(d2[b] - 2.0 * d0).max() <= FWD_TOL * 2.0 * np.abs(d0).max()
     L.close()
