@@ -355,17 +355,17 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   int4 rstg0;            // step blocks in flight (one 16-byte word per lane: 256 ints)
   int pcs[NPC];          // piece descriptors of the epoch being loaded
   static_assert(BAND_REC_MAX <= 256, "record buffer: one dwordx4 per lane");
-  // The mover is written for back-to-back issue: the fifteen piece descriptors of an epoch come with one scalar load, every
-  // piece is loaded whether the epoch uses it or not (an unused descriptor reads the first elements of vals: a cache hit), every
-  // staged piece is written to LDS — no branch per piece.  One load per piece and problem group: base pointer and stride of the
+  // The mover is written for back-to-back issue: the fifteen piece descriptors of an epoch come with one scalar load, unused
+  // pieces are skipped with a wave-uniform branch (a load that hits in cache costs the CU's memory pipeline what any other costs),
+  // every staged piece is written to LDS whether used or not.  One load per piece and problem group: base pointer and stride of the
   // piece's array are selected with scalar instructions, the lane's offset is problem * stride + element.  (Three guarded loads
   // made the compiler form all three 64-bit addresses of every piece up front — 96 NI VGPRs; selecting among per-array offset
   // arrays made it index them in scratch memory; lambdas instead of macros put every captured variable into scratch.)
 #define BAND_ISSUE1(K, I) if constexpr (I < NI) stg[K][I] = *reinterpret_cast<const double*>(pb + ((movp[I] * strd + (unsigned)le) << 3));
 #define BAND_COMMIT1(K, I) if constexpr (I < NI) *reinterpret_cast<double*>(wblk + ldsb[I] + (BAND_IN_OFF + 8 * K) * 8) = stg[K][I];
 #define BAND_ISSUE(K)                                                                                                         \
-  {                                                                                                                           \
-    const int pc = pcs[K] < 0 ? 0 : pcs[K];                                                                                   \
+  if (pcs[K] >= 0) {   /* (wave-uniform: an unused piece costs the memory pipeline what a used one does) */                   \
+    const int pc = pcs[K];                                                                                                    \
     const int arr = pc >> 28;                                                                                                 \
     const char* pb = (arr == 0 ? reinterpret_cast<const char*>(vbase) : arr == 1 ? reinterpret_cast<const char*>(rbase)       \
                                                                                  : reinterpret_cast<const char*>(lbase_g)) +   \
