@@ -98,6 +98,8 @@ struct cnl_handle {
   // problems [0, split_staged) run on this handle's chain plan, the REMAINDER on a handle of its own with the many-part latency
   // plan cnl_create picks for that small batch, one behind the other on the caller's stream (run_split)
   cnl_handle* tail = nullptr;
+  bool tail_redone = false;   // (per call) a dataflow wait of the remainder handle gave up: its redo launch has been through the whole device
+                              // ladder for those problems — the host ladder must leave them alone
   bool tail_fresh = false;    // the factors of the remainder live in the tail handle (false: in this handle's storage — chunked host calls)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1782,7 +1784,7 @@ static int host_ladder_run(cnl_handle* h, const double params[9], const double* 
   std::vector<double> ro_in(B);
   // split handles: only the chain part [0, split_staged) ran the first attempt alone; the single-stream part has been through the
   // whole device ladder already (a problem that exhausted it there must not climb again: nfact would count twice)
-  const size_t first_only = (h->split_staged > 0 && (size_t)h->split_staged < B && !h->split_halves && !h->tail) ? (size_t)h->split_staged : B;
+  const size_t first_only = (h->split_staged > 0 && (size_t)h->split_staged < B && !h->split_halves && (!h->tail || h->tail_redone)) ? (size_t)h->split_staged : B;
   bool any_act = false;
   for (size_t b = 0; b < B; b++) {
     ro_in[b] = rho_old ? rho_old[b] : 0.0;
@@ -1938,7 +1940,12 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     // fashion on the whole handle can set it (split handles run through views: one launch per stage, nothing waits)
     if (host_ladder && h->d_dep && h->d_stat && h->split_staged == 0)
       HIPCHK(hipMemcpyAsync(up_status, h->d_stat, 4, hipMemcpyDeviceToHost, h->stream));
+    //  ... and of the remainder handle's call, which does run in dataflow fashion on a handle of its own
+    int32_t tail_status = 0;
+    if (host_ladder && h->tail && h->tail->d_dep && h->tail->d_stat)
+      HIPCHK(hipMemcpyAsync(&tail_status, h->tail->d_stat, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->tail_redone = tail_status != 0;
     std::memcpy(rho, pb + o_rho, B * 8);
     std::memcpy(rho_old_out, pb + o_ro, B * 8);
     std::memcpy(nfact, pb + o_nf, B * 4);
@@ -1980,7 +1987,11 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
   int32_t status_word = 0;
   if (host_ladder && h->d_dep && h->d_stat && h->split_staged == 0)
     HIPCHK(hipMemcpyAsync(&status_word, h->d_stat, 4, hipMemcpyDeviceToHost, h->stream));
+  int32_t tail_status2 = 0;
+  if (host_ladder && h->tail && h->tail->d_dep && h->tail->d_stat)
+    HIPCHK(hipMemcpyAsync(&tail_status2, h->tail->d_stat, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->tail_redone = tail_status2 != 0;
   bool laddered = false;
   if (host_ladder && status_word == 0) {
     bool any_failed = false;

@@ -260,11 +260,27 @@ __global__ void __launch_bounds__(256) outer_end_kernel(const cnl_outer_state S)
   const double ds = S.p > 0 ? tmax(sl / (double)S.p, S.smax) / S.smax : 1.0;
   const bool first_order = tmax(S.normdual[b] / ds, S.normprimal[b]) <= S.epstol[b];
   S.it[b] += 1;
-  S.status[b] = first_order ? 1 : (S.small_res[b] ? 2 : (S.brk[b] ? 3 : (S.tired[b] ? 4 : 0)));
+  // tired = inner > max_inner: the reference hands that to get_status as `stalled` (src/CaNNOLeS.jl:846) -> 5; 4 (max_eval) is an
+  // evaluation-count limit, which this loop does not have
+  S.status[b] = first_order ? 1 : (S.small_res[b] ? 2 : (S.brk[b] ? 3 : (S.tired[b] ? 5 : 0)));
   S.phase0[b] = 1;
 }
 
-int check(const cnl_outer_state* st) { return st && st->B > 0 && st->status && st->flags ? 0 : CNL_ERR_ARG; }
+// every array of the state the kernels dereference must be there (the header promises CNL_ERR_ARG for a missing array, not an
+// asynchronous fault): the block of pointers from `status` to `lamt_e`; the line-search entries also need theirs (check_ls)
+int check(const cnl_outer_state* st) {
+  if (!st || st->B <= 0) return CNL_ERR_ARG;
+  static_assert(sizeof(void*) == 8, "pointer block of cnl_outer_state");
+  const void* const* p0 = reinterpret_cast<const void* const*>(&st->status);
+  const void* const* p1 = reinterpret_cast<const void* const*>(&st->lamt_e);
+  for (const void* const* q = p0; q <= p1; q++)
+    if (!*q) return CNL_ERR_ARG;
+  return 0;
+}
+int check_ls(const cnl_outer_state* st) {
+  if (check(st)) return CNL_ERR_ARG;
+  return st->ls_g && st->xl && st->Fl && st->cl && st->lam_ls && st->alpha && st->Dphi && st->phix && st->eta && st->nbk && st->bt ? 0 : CNL_ERR_ARG;
+}
 int done() { return hipGetLastError() == hipSuccess ? CNL_OK : CNL_ERR_HIP; }
 
 }  // namespace
@@ -297,26 +313,26 @@ int cnl_outer_trial_done_dev(const cnl_outer_state* st, void* stream) {
 }
 
 int cnl_outer_ls_begin_dev(const cnl_outer_state* st, void* stream) {
-  if (check(st) || !st->ls_g || !st->xl) return CNL_ERR_ARG;
+  if (check_ls(st)) return CNL_ERR_ARG;
   hipLaunchKernelGGL(outer_ls_begin_kernel, dim3((unsigned)st->B), dim3(256), 0, (hipStream_t)stream, *st);
   return done();
 }
 
 int cnl_outer_ls_test_dev(const cnl_outer_state* st, int first, void* stream) {
-  if (check(st) || !st->Fl) return CNL_ERR_ARG;
+  if (check_ls(st)) return CNL_ERR_ARG;
   if (hipMemsetAsync(st->flags + 6, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return CNL_ERR_HIP;
   hipLaunchKernelGGL(outer_ls_test_kernel, dim3((unsigned)st->B), dim3(256), 0, (hipStream_t)stream, *st, first);
   return done();
 }
 
 int cnl_outer_ls_step_dev(const cnl_outer_state* st, void* stream) {
-  if (check(st) || !st->xl) return CNL_ERR_ARG;
+  if (check_ls(st)) return CNL_ERR_ARG;
   hipLaunchKernelGGL(outer_ls_step_kernel, dim3((unsigned)st->B), dim3(256), 0, (hipStream_t)stream, *st);
   return done();
 }
 
 int cnl_outer_ls_take_dev(const cnl_outer_state* st, void* stream) {
-  if (check(st) || !st->xl) return CNL_ERR_ARG;
+  if (check_ls(st)) return CNL_ERR_ARG;
   hipLaunchKernelGGL(outer_ls_take_kernel, dim3((unsigned)st->B), dim3(256), 0, (hipStream_t)stream, *st);
   return done();
 }

@@ -594,7 +594,7 @@ def solve_batch_device_framework(fam, params=None, max_steps=400, max_inner=1000
             lam, rhs_cur, normdual, normprimal, r = small_res_check(chk, lam, rhs_cur, normdual, normprimal, r)
             first_order = t.maximum(normdual / dual_scaling(lam), normprimal) <= epstol
         it = it + done_in.to(t.int32)
-        new_status = t.where(first_order, FIRST, t.where(small_residual, SMALL, t.where(brk, EXC, t.where(tired, TIRED, UNKNOWN))))
+        new_status = t.where(first_order, FIRST, t.where(small_residual, SMALL, t.where(brk, EXC, t.where(tired, STALL, UNKNOWN))))   # inner > max_inner: `stalled` (src/CaNNOLeS.jl:846)
         status = t.where(done_in, new_status.to(t.int32), status)
         phase0 = phase0 | done_in
     t.cuda.synchronize(dev)

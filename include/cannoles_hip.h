@@ -293,7 +293,7 @@ int cnl_multi_synchronize(cnl_multi* m, void* const* streams);
  * arrays in HBM and every branch as a per-problem mask (cannoles.jl_amd/device_loop.py).  The four entry points below do the
  * masks and the masked state updates of one global step IN PLACE on that state, one launch each (the reference's tests in the
  * reference's operation order; minimum / maximum propagate NaN).  `cnl_outer_state` is plain device pointers and sizes; every
- * array is problem-major.  Status codes: 0 unknown (active), 1 first_order, 2 small_residual, 3 exception, 4 max_eval.  The entry points
+ * array is problem-major.  Status codes: 0 unknown (active), 1 first_order, 2 small_residual, 3 exception, 4 max_eval (never produced: this loop has no evaluation counter), 5 stalled (inner > max_inner, src/CaNNOLeS.jl:846).  The entry points
  * take no handle: they launch on the calling thread's CURRENT device, which must be the one the arrays live on, and are asynchronous on
  * `stream`; they return CNL_ERR_ARG for a null state / missing array and CNL_ERR_HIP when the launch fails.
  *   cnl_outer_begin_dev        :612-626  start of an outer iteration for the problems in phase0; act, need (a Newton system is due);

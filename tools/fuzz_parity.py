@@ -132,6 +132,7 @@ for case in range(ncases):
         v0 = vals.copy()
         d0, ok0, rho0, ro0, nf0 = O.newton_system_batch(orc, B, s.nvar, s.nequ, s.ncon, rhs, v0, ro_in, po)
         bad = []
+        skip = set()   # problems whose first pivot is below the rounding noise and was decided differently: no further comparison
         if not (np.array_equal(ok.astype(bool), np.atleast_1d(ok0).astype(bool)) and np.array_equal(nf, np.atleast_1d(nf0))
                 and np.array_equal(rho, np.atleast_1d(rho0)) and np.array_equal(ro, np.atleast_1d(ro0))):
             # a first factorisation with a pivot below the rounding noise of the matrix has no determined inertia (DESIGN section 5,
@@ -148,25 +149,32 @@ for case in range(ncases):
                     vv[-s.nvar:] = rho_t
                 orc.try_to_factorize(vv, s.nvar, s.nequ, s.ncon, po[0])
                 Dab = np.abs(orc.D)
-                if Dab.min() <= 1e-11 * Dab.max():
+                #  the threshold follows the rounding noise a non-pivoting LDL^T of these matrices accumulates — a few
+                # thousand eps of the largest pivot (entries are O(1); condensation, division and summation order differ from the
+                # oracle's) — instead of a fixed 1e-11; every reclassified problem is printed, and the remaining checks still run for
+                # the problems whose decisions agree
+                if Dab.min() <= 4096.0 * np.finfo(float).eps * Dab.max():
                     noise.append(b)
+                    print(f"   sub-noise: {tag} problem {b}: min|D| / max|D| = {Dab.min() / Dab.max():.2e} at rho = {rho_t:.3e}; "
+                          f"hip (ok, nf, rho) = ({bool(ok[b])}, {int(nf[b])}, {float(rho[b]):.3e}), oracle ({bool(ok0a[b])}, {int(nf0a[b])}, {float(np.atleast_1d(rho0)[b]):.3e})", flush=True)
             if len(noise) == len(differ):
                 subnoise += 1
-                L.close()
-                continue
-            bad.append("decisions")
+                skip = set(noise)
+            else:
+                bad.append("decisions")
             if os.environ.get("FUZZ_VERBOSE"):
                 print("    hip   ok", ok.astype(int), "nf", nf, "rho", rho, "ro", ro, flush=True)
                 print("    orcl  ok", np.atleast_1d(ok0).astype(int), "nf", np.atleast_1d(nf0), "rho", np.atleast_1d(rho0), "ro", np.atleast_1d(ro0), flush=True)
                 print("    rho_old in", ro_in, flush=True)
-        if not np.array_equal(v.reshape(B, -1)[:, -s.nvar:], v0[:, -s.nvar:], equal_nan=True):
+        keep = [b for b in range(B) if b not in skip]
+        if not np.array_equal(v.reshape(B, -1)[keep, -s.nvar:], v0[keep, -s.nvar:], equal_nan=True):
             bad.append("rho slots")
         def berr(vv, rr, dd):   # normwise backward error of K d = -rhs with the values (rho slots included) the call left
             import scipy.sparse as sp
             Kl = sp.coo_matrix((vv, (rows - 1, cols - 1)), shape=(s.N, s.N)).tocsr()
             K = Kl + sp.tril(Kl, -1).T
             return np.abs(K @ dd + rr).max() / (abs(K).sum(axis=1).max() * np.abs(dd).max() + np.abs(rr).max())
-        for b in range(B):
+        for b in keep:
             if np.atleast_1d(ok0)[b]:
                 if not np.abs(d[b] - d0[b]).max() <= 1e-8 * max(1e-300, np.abs(d0[b]).max()):
                     # ill-conditioned systems (rank-deficient blocks held up by a small rho): the solution is only as good as the
@@ -178,9 +186,9 @@ for case in range(ncases):
                 bad.append(f"d[{b}] touched")
         # the two-call sequence with the rho the ladder left
         okf = np.atleast_1d(hipldl.try_to_factorize(L, v, s.nvar, s.nequ, s.ncon, p[0]))
-        if not np.array_equal(okf.astype(bool), np.atleast_1d(ok0).astype(bool)):
+        if not np.array_equal(okf.astype(bool)[keep], np.atleast_1d(ok0).astype(bool)[keep]):
             bad.append("try_to_factorize with the final rho")
-        elif okf.all():
+        elif okf.all() and not skip:
             d2 = np.zeros((B, s.N))
             hipldl.solve_ldl_(2.0 * rhs, L.factor, d2)
             for b in range(B):
@@ -189,7 +197,7 @@ for case in range(ncases):
                     if not be <= max(1e-13, 10.0 * be0):
                         bad.append(f"solve d[{b}] backward error {be:.1e} (oracle {be0:.1e})")
         # the same handle again, other values (state left by the first round must not matter): problems swapped round, another rho_old
-        if not bad and B > 1 and os.environ.get("FUZZ_WIDE"):
+        if not bad and not skip and B > 1 and os.environ.get("FUZZ_WIDE"):
             permb = rng.permutation(B)
             vals2, rhs2, ro2 = vals[permb].copy(), rhs[permb] * 0.5, ro_in[permb[::-1]].copy()
             vb = vals2.copy()
@@ -221,5 +229,5 @@ for case in range(ncases):
     except Exception as e:  # noqa: BLE001
         fails += 1
         print("ERROR", tag, repr(e)[:300], flush=True)
-print(f"{ncases} cases, {fails} failures, kernels {kinds}" + (f", {subnoise} case(s) with sub-noise pivots decided differently (not failures: a pivot below 1e-11 of the largest at the rung where the sides part)" if subnoise else ""), flush=True)
+print(f"{ncases} cases, {fails} failures, kernels {kinds}" + (f", {subnoise} case(s) with sub-noise pivots decided differently (not failures: a pivot below 4096 eps of the largest at the rung where the sides part; each is printed above)" if subnoise else ""), flush=True)
 sys.exit(1 if fails else 0)
