@@ -243,7 +243,10 @@ int setup_v2(cnl_handle* h) {
   d.breccap = (P.brec_maxlen + 3) & ~3;
   d.recwords = std::max(d.reccap, 2 * d.breccap);
   d.u2_peak = P.u2_peak;
-  d.jraw_off = (int32_t)((P.u2_peak + std::max<int64_t>(P.fs2_max, 64) + 1) & ~(int64_t)1);
+  // (round 5, found by the randomised run with lds_pad = 0: the out-of-line elimination of a class-64 front publishes its pivot row at
+  //  lb[0 .. 65] of the staging area — lanes beyond the pivot park their value at index TE + 1 —, two doubles more than the 64 reserved
+  //  here; without padding between the problems they landed in the next problem's update stack)
+  d.jraw_off = (int32_t)((P.u2_peak + std::max<int64_t>(P.fs2_max, 72) + 1) & ~(int64_t)1);
   d.bpanel_off = (int32_t)((P.bwd_peak + 2 + 1) & ~(int64_t)1);  // end of the backward sweep's x stack
   // the raw-value area (128 doubles per problem) is needed only by fast fronts whose products come as lists (plan.h: RF_ROWS)
   int64_t prob = std::max<int64_t>((int64_t)d.jraw_off + (P.rec_direct && P.listprod_fronts > 0 ? 128 : 0), (int64_t)d.bpanel_off);
@@ -289,14 +292,19 @@ int setup_v2(cnl_handle* h) {
       h->resident_waves = (int)std::min<long long>(resident, 1 << 20);
     }
   }
-  // Staged execution only for plans made of fast-class fronts with row-form (or no) products — what the lean instantiation takes.
-  // (Round 4, tools/fuzz_parity.py: on plans with out-of-line front classes or product lists the STAGED instantiations, which
-  //  spill to scratch around those calls, gave results that depended on what earlier kernels of the process had left in scratch
-  //  memory — wrong rho-ladder decisions, memory faults — reproducibly so with CNL_DBG_SCRATCHFILL; the single-stream
-  //  instantiations run the same 300 cases clean with scratch full of garbage.  Such plans keep the single stream until the cause
-  //  is found; every BASELINE configuration is of the fast class.)
+  // Plans with out-of-line front classes (order 17 .. 64) or product lists run staged too, WITHOUT the in-kernel (fused) rho ladder.
+  // History: round 4's randomised run found wrong rho-ladder decisions and memory faults on such plans that depended on what earlier
+  // kernels had left in scratch / LDS / registers, and fenced the whole staged execution off.  Round 5 found two real overflows with
+  // the same tool — the update-matrix slots of the global scratch were padded for 16-lane rows whatever the class of the front
+  // (analysis.cpp: up to 47 doubles of the next slot overwritten, a slot another wavefront uses at the same time), and the class-64
+  // elimination publishes its pivot row two doubles past the LDS staging area (setup above) — and narrowed what is left: with both
+  // fixed, 12 000 cases with garbage everywhere are clean on the staged first attempt, try_to_factorize and solve_ldl!
+  // (gpurun_out/fuzz_slf1_noladder.txt), while the FUSED ladder instantiation on such plans still faults (a spin limit, the
+  // register budget and the commit launch are ruled out: DESIGN 4c).  So the restriction is now the ladder alone: problems that
+  // fail the staged attempt take the sequential launch (device pointers) or the host-driven ladder (host pointers).
+  // cnl_options.staged_large_fronts = 1 (experiment builds only) turns the fused ladder on there, for the hunt.
   const bool fast_class_only = P.ncls[1] == 0 && P.ncls[2] == 0 && P.listprod_fronts == 0;
-  if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && o.staged && (fast_class_only || o.staged_large_fronts != 0)) {
+  if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && o.staged) {
     std::vector<int32_t> tk;
     for (const cnl::Task& t : P.tasks) { tk.push_back(t.rec_off); tk.push_back(t.f1 - t.f0); tk.push_back(t.brec_off); tk.push_back(t.is_root); tk.push_back(t.parent); tk.push_back(t.nchild); }
     if ((rc = upload(h, tk, &h->d_tasks))) return rc;
@@ -331,7 +339,7 @@ int setup_v2(cnl_handle* h) {
     // Plans of a few LARGE tasks (the bidirectional chain of mid-size batches) keep the sequential launch when one fused launch
     // cannot hold the batch: a rung there is the same chain of fronts either way, and two fused launches of two wavefronts per SIMD
     // lose to one sequential launch of one (cfg5 at 4096 problems: 3.9 against 2.9 ms).
-    if (o.device_ladder && h->resident_waves >= h->ntasks) {
+    if (o.device_ladder && h->resident_waves >= h->ntasks && (fast_class_only || o.staged_large_fronts != 0)) {
       const long long slots = h->resident_waves / h->ntasks, nq = (h->batch + 3) / 4;
       const long long launches = (nq + slots - 1) / slots;
       if (launches == 1 || (launches <= 4 && h->ntasks >= 16)) h->lad_mode = o.device_ladder_fused ? 2 : 1;

@@ -1256,14 +1256,16 @@ def test_multi_device_shards_with_remainder_handles(built):
         assert np.abs(d2[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
 
 
-@pytest.mark.parametrize("fill,wide,seed0", [(None, False, 0), ("0x3f800001", False, 0), ("0xffffffff", False, 300), ("0x3f800001", True, 9000)])
+@pytest.mark.parametrize("fill,wide,seed0", [(None, False, 0), ("0x3f800001", False, 0), ("0xffffffff", False, 300), ("0x3f800001", True, 9000), ("0xffffffff", True, 9200),
+                                             ("0x7fc00000", True, 9400)])
 def test_randomised_parity_is_independent_of_what_earlier_kernels_left(built, fill, wide, seed0):
     """tools/fuzz_parity.py (120 small irregular and band structures, batches that are not multiples of four, every plan kind, ladder
     climbers; every decision bit for bit and d to 1e-8 against the oracle on an order the product had no part in) — in a process
     of its own, once as it is and twice with every launch preceded by kernels that leave a byte pattern in the LDS, the scratch
     memory and the vector registers of the device (CNL_DBG_SCRATCHFILL / CNL_DBG_LDSFILL).  Round 4: the staged instantiations with
     out-of-line front classes took decisions that depended on the scratch contents of earlier kernels — invisible to a test-suite
-    whose processes start with zeroed scratch."""
+    whose processes start with zeroed scratch.  Round 5: six runs of 120 cases (600 with garbage fills), the wide ones with random settings
+    of every remaining execution option (the band kernels' included)."""
     import subprocess, sys
     env = dict(os.environ)
     if fill:

@@ -111,7 +111,9 @@ for case in range(ncases):
             ropt["split_batch"] = 2
     if os.environ.get("FUZZ_WIDE"):   # random execution switches on top
         for k, vs in (("dataflow", (1, 0)), ("band_form", (1, 0)), ("host_ladder", (1, 0)), ("device_ladder", (1, 0)), ("device_ladder_fused", (0, 1)),
-                      ("lean_kernel", (1, 0)), ("rows_in_backward", (1, 0)), ("row_products", (1, 0)), ("dense_graph", (1, 0))):
+                      ("lean_kernel", (1, 0)), ("rows_in_backward", (1, 0)), ("row_products", (1, 0)), ("dense_graph", (1, 0)),
+                      ("band_kernel", (1, 0)), ("band_kernel", (1, 2)), ("band_problems_per_group", (0, 8)), ("band_problems_per_group", (0, 32)),
+                      ("dense_panel_blocks", (1, 0)), ("dense_panel_blocks", (1, 2)), ("lds_pad", (1, 0)), ("waves_per_block", (0, 2)), ("multipliers_early", (1, 0))):
             if rng.integers(4) == 0:
                 ropt[k] = vs[1]
     tag = f"case {seed} fam {fam} n {s.nvar} m {s.nequ} p {s.ncon} B {B} kind {kind} posdef {posdef} {ropt}"
@@ -119,7 +121,7 @@ for case in range(ncases):
         print("RUN", tag, flush=True)
     try:
         L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(plan_kind=kind, **{**ropt, **extra}))
-        kk = L.config["kernel"] + ("+tail" if L.config["tail"] else "") + ("+split" if fam == 5 and L.info["order"].startswith("ndc2") and not L.config["tail"] else "")
+        kk = L.config["kernel"] + ("+band" if L.config.get("band") else "") + ("+tail" if L.config["tail"] else "") + ("+split" if fam == 5 and L.info["order"].startswith("ndc2") and not L.config["tail"] else "")
         kinds[kk] = kinds.get(kk, 0) + 1
         if os.environ.get("FUZZ_VERBOSE"):
             print("   ", L.config["kernel"], L.info["order"], "tail" if L.config["tail"] else "", flush=True)

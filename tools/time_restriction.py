@@ -26,7 +26,7 @@ for name, seed in {"case7": 7, "case15": 15, "case176": 176, "case225": 225}.ite
         vals = np.stack([syn.random_values(s, 100 + b)[0] for b in range(B)]); rhs = np.stack([syn.random_values(s, 100 + b)[1] for b in range(B)])
         print(name, "n", s.nvar, "m", s.nequ, "p", s.ncon, flush=True) if B == 1 else None
         out = {}
-        for tag, opt in (("single_stream", {}), ("staged", {"staged_large_fronts": 1, "device_ladder": 0})):
+        for tag, opt in (("single_stream", {"staged": 0}), ("staged", {})):   # (round 5: the staged execution is the default again — without the fused ladder)
             L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(**opt))
             tv, tr = torch.tensor(vals, device=dev), torch.tensor(rhs, device=dev)
             td = torch.zeros((B, s.N), dtype=torch.float64, device=dev); ro = torch.zeros(B, dtype=torch.float64, device=dev); rho = torch.zeros_like(ro)
