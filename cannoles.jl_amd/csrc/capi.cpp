@@ -32,6 +32,7 @@ struct cnl_plan {
   int64_t N = 0, nnz = 0, nvar = 0, nequ = 0, ncon = 0;  // outer dimensions, as the reference sees them
   std::vector<int32_t> perm_outer;
   bool latency = false;  // ordered and cut into tasks for small batches (staged execution, csrc/plan.h)
+  bool prefer_dense = false;  // latency plan with fronts of the 64 class on a small condensed system: small batches go the dense route
   cnl::DensePlan D;  // dense residual block (BASELINE config 2): served by the dense backend, csrc/dense.h
   std::vector<int32_t> gpos;  // non-empty: the condensed system may be treated as ONE dense matrix (position of every K2 slot)
   cnl_options opt{};          // the options the plan was built with (the handle reads its execution switches from here)
@@ -229,6 +230,7 @@ int setup_v2(cnl_handle* h) {
   h->use_v2 = false;
   const cnl_options& o = h->plan->opt;
   if (!P.v2_ok || !o.register_front) return CNL_OK;
+  if (!h->plan->gpos.empty() && (o.general_dense == 2 || (h->plan->prefer_dense && h->batch <= 16))) return CNL_OK;  // the dense route (plan_create_impl); 2: wherever it is possible
   cnl::DevPlan2& d = h->dp2;
   // streams are over-read by the prefetcher: pad with zeros
   std::vector<int32_t> rec(P.rec), brec(P.brec);
@@ -880,7 +882,7 @@ void cnl_options_init(cnl_options* o) {
   o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
   // (fused: measured slower than the separate launches on one system of cfg3's size, 0.140 against 0.118 ms — the rung loop costs
   //  the kernel 50 VGPRs and 45 spilled SGPRs — so it is off by default)
-  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0; o->band_kernel = 1; o->band_problems_per_group = 0;
+  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0; o->band_kernel = 1; o->band_problems_per_group = 0; o->f1_tiles = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -894,10 +896,10 @@ static int resolve_options(const cnl_options* in, cnl_options& out) {
   out = *in;
   out.force_order[sizeof(out.force_order) - 1] = 0;
 #ifndef CNL_EXPERIMENT
-  // (round 5) known to give wrong results — scratch-history-dependent decisions and memory faults, DESIGN 4b item 8 — and still
-  // un-root-caused: not selectable in a product build
+  // (round 5) the in-kernel ladder on plans with out-of-line front classes still faults (the staged execution itself
+  // is fixed and back): not selectable in a product build
   if (out.staged_large_fronts != 0)
-    return fail(CNL_ERR_ARG, "cnl_options.staged_large_fronts needs an experiment build (-DCNL_EXPERIMENT=1): the staged execution of plans with large fronts is known to be wrong");
+    return fail(CNL_ERR_ARG, "cnl_options.staged_large_fronts needs an experiment build (-DCNL_EXPERIMENT=1): the in-kernel ladder on plans with large fronts is known to be wrong");
 #endif
   return CNL_OK;
 }
@@ -1072,7 +1074,11 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
   // Irregular sparsity: when the fill makes fronts larger than the register-front kernel takes and the condensed system is of
   // moderate order, one dense LDL^T of the whole condensed matrix beats the general multifrontal kernel by far
   // (csrc/dense.h; chosen at handle creation for small batches; CNL_NO_GDENSE=1 disables)
-  if (p->C.active && !p->D.active && !p->P.v2_ok && p->C.N2 >= 96 && p->C.N2 <= 4096 && o.general_dense) {
+  // (round 5) ... and so does a latency plan whose fronts reach the 64 class while the whole condensed system is of order <= 512: the
+  // dense route costs 0.075 ms + 0.28 us per unit of order for one system (tools/time_dense_route.py), the staged walk over fronts of
+  // that size 0.2 ms and more (n = 133, fronts up to 59: 0.215 against 0.106 ms).  The handle takes it for batches up to 16.
+  p->prefer_dense = latency && p->P.v2_ok && p->P.ncls[2] > 0 && p->C.N2 <= 512;
+  if (p->C.active && !p->D.active && (!p->P.v2_ok || p->prefer_dense || o.general_dense == 2) && p->C.N2 >= 96 && p->C.N2 <= 4096 && o.general_dense) {
     p->gpos.resize(p->C.ncs);
     for (int64_t s2 = 0; s2 < p->C.ncs; s2++) p->gpos[s2] = (int32_t)((p->C.rows2[s2] - 1) + p->C.N2 * (p->C.cols2[s2] - 1));
   }
@@ -1386,6 +1392,60 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
       if ((rc = upload(h, rcol, &J.rcolC))) return bail(rc);
     }
     J.nvar = (int32_t)nvar; J.nequ = (int32_t)nequ; J.ncon = (int32_t)ncon; J.N = (int32_t)N; J.nnz = (int32_t)nnz;
+    // (round 5) column tiles of row f1 (kernels.h: DevJt::rv_*): the slot / index ranges of every tile of RVT_COLS columns
+    if (plan->opt.f1_tiles && nvar > 0) {
+      const int32_t nt = (int32_t)((nvar + cnl::RVT_COLS - 1) / cnl::RVT_COLS);
+      std::vector<int32_t> tiles((size_t)nt * cnl::RVT_TW, 0);
+      std::vector<uint32_t> table((size_t)nt * (cnl::RVT_KF + cnl::RVT_KC + 1) * cnl::RVT_COLS, 0u);
+      bool ok = true;
+      int32_t lds_max = 0;
+      for (int32_t t = 0; t < nt && ok; t++) {
+        const int64_t c0 = (int64_t)t * cnl::RVT_COLS, c1 = std::min<int64_t>(nvar, c0 + cnl::RVT_COLS);
+        int32_t fslo = INT32_MAX, fshi = -1, rlo = INT32_MAX, rhi = -1, cslo = INT32_MAX, cshi = -1, llo = INT32_MAX, lhi = -1;
+        for (int32_t q = ptrF[c0]; q < ptrF[c1]; q++) { fslo = std::min(fslo, slotF[q]); fshi = std::max(fshi, slotF[q]); rlo = std::min(rlo, idxF[q]); rhi = std::max(rhi, idxF[q]); }
+        for (int32_t q = ptrC[c0]; q < ptrC[c1]; q++) { cslo = std::min(cslo, slotC[q]); cshi = std::max(cshi, slotC[q]); llo = std::min(llo, idxC[q]); lhi = std::max(lhi, idxC[q]); }
+        int32_t* T = &tiles[(size_t)t * cnl::RVT_TW];
+        T[cnl::RVT_FSLO] = fshi < 0 ? 0 : fslo; T[cnl::RVT_WF] = fshi < 0 ? 0 : fshi - fslo + 1;
+        T[cnl::RVT_RLO] = rhi < 0 ? 0 : rlo;   T[cnl::RVT_WR] = rhi < 0 ? 0 : rhi - rlo + 1;
+        T[cnl::RVT_CSLO] = cshi < 0 ? 0 : cslo; T[cnl::RVT_WC] = cshi < 0 ? 0 : cshi - cslo + 1;
+        T[cnl::RVT_LLO] = lhi < 0 ? 0 : llo;   T[cnl::RVT_WL] = lhi < 0 ? 0 : lhi - llo + 1;
+        if (T[cnl::RVT_WF] > cnl::RVT_MAXF || T[cnl::RVT_WR] > cnl::RVT_MAXR || T[cnl::RVT_WC] > cnl::RVT_MAXC || T[cnl::RVT_WL] > cnl::RVT_MAXL) { ok = false; break; }
+        auto even = [](int32_t w) { return (w + 3) & ~1; };   // a window and the double its 16-byte alignment may put in front
+        lds_max = std::max(lds_max, even(T[cnl::RVT_WF]) + even(T[cnl::RVT_WR]) + even(T[cnl::RVT_WC]) + even(T[cnl::RVT_WL]));
+        uint32_t* tab = &table[(size_t)t * (cnl::RVT_KF + cnl::RVT_KC + 1) * cnl::RVT_COLS];
+        for (int64_t c = c0; c < c1; c++) {
+          const int32_t nF = ptrF[c + 1] - ptrF[c], nC = ptrC[c + 1] - ptrC[c];
+          if (nF > 255 || nC > 255) { ok = false; break; }
+          for (int32_t u = 0; u < std::min(nF, cnl::RVT_KF); u++)
+            tab[(size_t)u * cnl::RVT_COLS + (c - c0)] = (uint32_t)(slotF[ptrF[c] + u] - T[cnl::RVT_FSLO]) | (uint32_t)(idxF[ptrF[c] + u] - T[cnl::RVT_RLO]) << 16;
+          for (int32_t u = 0; u < std::min(nC, cnl::RVT_KC); u++)
+            tab[(size_t)(cnl::RVT_KF + u) * cnl::RVT_COLS + (c - c0)] = (uint32_t)(slotC[ptrC[c] + u] - T[cnl::RVT_CSLO]) | (uint32_t)(idxC[ptrC[c] + u] - T[cnl::RVT_LLO]) << 16;
+          tab[(size_t)(cnl::RVT_KF + cnl::RVT_KC) * cnl::RVT_COLS + (c - c0)] = (uint32_t)nF | (uint32_t)nC << 8;
+        }
+      }
+      if (ok) {
+        // the residual rows a tile has in LDS anyway are the rows whose primal entry F - r it writes: possible when the tiles' row
+        // ranges are ordered and cover 0 .. nequ without gaps (a band); otherwise tiles of rows of their own follow the column tiles
+        bool own = nequ > 0;
+        int32_t prev = 0;
+        for (int32_t t = 0; t < nt && own; t++) {
+          int32_t* T = &tiles[(size_t)t * cnl::RVT_TW];
+          const int32_t lo = T[cnl::RVT_RLO], hi = lo + T[cnl::RVT_WR];
+          const int32_t next_lo = t + 1 < nt ? tiles[(size_t)(t + 1) * cnl::RVT_TW + cnl::RVT_RLO] : (int32_t)nequ;
+          const int32_t own_hi = t + 1 < nt ? std::min(hi, std::max(next_lo, prev)) : (int32_t)nequ;
+          if (prev < lo || own_hi > hi || own_hi < prev) { own = false; break; }
+          T[cnl::RVT_OWNLO] = prev; T[cnl::RVT_OWNHI] = own_hi;
+          prev = own_hi;
+        }
+        if (own && prev != nequ) own = false;
+        if (!own) for (int32_t t = 0; t < nt; t++) tiles[(size_t)t * cnl::RVT_TW + cnl::RVT_OWNLO] = tiles[(size_t)t * cnl::RVT_TW + cnl::RVT_OWNHI] = 0;
+        if ((rc = upload(h, tiles, &J.rv_tiles))) return bail(rc);
+        if ((rc = upload(h, table, &J.rv_table))) return bail(rc);
+        J.rv_ntiles = nt; J.rv_lds_doubles = lds_max;
+        J.rv_primal_tiles = own ? 0 : (int32_t)((nequ + cnl::RVT_PROWS - 1) / cnl::RVT_PROWS);
+      }
+      if (std::getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] row f1: %s\n", ok ? "column tiles" : "gather kernel (a tile's windows exceed the limits)");
+    }
   }
   *hout = h;
   return CNL_OK;
@@ -1510,6 +1570,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   if (h->lean && !h->dense && !h->gdense) cfg[5] |= 16;  // newton_system / factorize run the kernels' LEAN instantiation
   if (h->tail) cfg[5] |= 32;                             // the remainder of the batch runs on a handle of its own (split_tail)
   if (h->band) cfg[5] |= 64;                             // newton_system runs on the band kernels (csrc/band.h)
+  if (h->djt.rv_ntiles > 0) cfg[5] |= 128;               // row f1 runs on column tiles (kernels.h: DevJt::rv_*)
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;
   return CNL_OK;

@@ -71,7 +71,18 @@ struct DevJt {
   const int32_t *ptrC, *slotC, *idxC;  // [nvar + 1], [nnz(J_c)] x 2
   const int32_t *rptrC, *rslotC, *rcolC;  // J_c by rows: [ncon + 1], [nnz(J_c)] x 2 (slot in vals, variable) — CGLS (row f4)
   int32_t nvar, nequ, ncon, N, nnz;
+  // (round 5) column tiles of row f1: when the entries of RVT_COLS consecutive columns lie in short slot / index ranges (band
+  // and block patterns in COO order do), a workgroup streams those ranges of `vals`, r and lambda coalesced into LDS and forms the
+  // column sums from there (residual_vectors_tiled_kernel).  rv_ntiles == 0: the gather kernel serves the pattern.
+  const int32_t* rv_tiles;    // [rv_ntiles][RVT_TW]
+  const uint32_t* rv_table;   // [rv_ntiles][RVT_KF + RVT_KC + 1][RVT_COLS]: window offsets of a column's first entries, counts
+  int32_t rv_ntiles, rv_lds_doubles, rv_primal_tiles;
 };
+constexpr int RVT_COLS = 256;   // columns per tile: one per thread of a 256-thread workgroup (two per thread: 190 registers)
+constexpr int RVT_KF = 6, RVT_KC = 2;   // entries of a column held in the table (the rest of a longer column: index lists)
+constexpr int RVT_MAXF = 2046, RVT_MAXR = 510, RVT_MAXC = 510, RVT_MAXL = 510;   // window limits (doubles): 4 + 1 + 1 + 1 chunks of 16 bytes per thread
+constexpr int RVT_PROWS = 2048;  // rows per primal tile when the dual tiles cannot own the primal rows
+enum { RVT_FSLO = 0, RVT_WF, RVT_RLO, RVT_WR, RVT_CSLO, RVT_WC, RVT_LLO, RVT_WL, RVT_OWNLO, RVT_OWNHI, RVT_TW = 12 };
 
 enum { MODE_NEWTON = 0, MODE_FACTOR = 1, MODE_SOLVE = 2 };
 

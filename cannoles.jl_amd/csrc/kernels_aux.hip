@@ -409,6 +409,198 @@ __global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// (round 5) Row f1 through COLUMN TILES.  The gather kernel above spends its time in the texture-address unit: a wavefront's load of
+// "entry u of 64 consecutive columns" touches 64 addresses 40 bytes apart (a band Jacobian in row-major COO order), i.e. 20 cache
+// lines per instruction for 512 useful bytes, and every line is touched by five such instructions.  Here a workgroup serves RVT_COLS
+// consecutive columns: the slot range of `vals` that holds their J_F entries, the range of r they multiply, and the same for J_c /
+// lambda are CONTIGUOUS ranges for band and block patterns (DevJt::rv_tiles, found at handle creation), so they are streamed with
+// 16-byte loads per lane — one problem ahead, through registers — into LDS, and each thread forms the sums of its column from LDS
+// with the offsets of its entries held in registers for all the problems of the workgroup.  Same arithmetic as above: per-column
+// sums in COO order, multiply and add rounded separately, the two products subtracted afterwards (bit-identical results; the
+// parity tests compare the two kernels bit for bit).  The residual rows a tile has in LDS are also the rows whose primal entry
+// F - r it writes (r is read once).
+//
+// A window of w doubles at g (8-byte aligned) is loaded in 16-byte chunks from the 16-byte boundary at or below g: the chunk may
+// start one double before the window and end one double behind it — inside the 16-byte granule of a valid address, never across
+// a page — and element k of the window lands in lds[par + k], par = the parity of g.
+typedef double rvt_d2 __attribute__((ext_vector_type(2)));   // (HIP's double2 class keeps arrays of it out of registers)
+template <int NCH>
+__device__ __forceinline__ void rvt_issue(const double* __restrict__ g, int w, int t, rvt_d2 (&v)[NCH]) {
+  const int par = (int)((reinterpret_cast<uintptr_t>(g) >> 3) & 1);
+  const rvt_d2* g2 = reinterpret_cast<const rvt_d2*>(g - par);
+  const int nch = (w + par + 1) >> 1;
+#pragma unroll
+  for (int u = 0; u < NCH; u++)
+    if (u * 256 < nch) {                      // wavefront-uniform
+      const int i = u * 256 + t;
+      if (i < nch) v[u] = g2[i];
+    }
+}
+template <int NCH>
+__device__ __forceinline__ void rvt_commit(double* lds, int w, int par, int t, const rvt_d2 (&v)[NCH]) {
+  const int nch = (w + par + 1) >> 1;
+  rvt_d2* l2 = reinterpret_cast<rvt_d2*>(lds);
+#pragma unroll
+  for (int u = 0; u < NCH; u++)
+    if (u * 256 < nch) {
+      const int i = u * 256 + t;
+      if (i < nch) l2[i] = v[u];
+    }
+}
+__device__ __forceinline__ int rvt_par(const double* g) { return (int)((reinterpret_cast<uintptr_t>(g) >> 3) & 1); }
+__device__ __forceinline__ int rvt_even(int w) { return (w + 3) & ~1; }
+constexpr int RVT_NFX = (RVT_MAXR + 255) / 256;   // primal rows of a tile per thread
+
+__global__ void __launch_bounds__(256) residual_vectors_tiled_kernel(const DevJt Jin, const double* __restrict__ vals,
+                                                                     const double* __restrict__ r, const double* __restrict__ lambda,
+                                                                     const double* __restrict__ Fx, const double* __restrict__ cx,
+                                                                     double* __restrict__ rhs, double* __restrict__ norms, int batch, int pb) {
+#pragma clang fp contract(off)
+  extern __shared__ rvt_d2 rvt_lds2[];
+  double* lds = reinterpret_cast<double*>(rvt_lds2);
+  __shared__ unsigned long long red[2];
+  DevJt J = Jin;
+  J.ptrF = as_global(Jin.ptrF); J.slotF = as_global(Jin.slotF); J.idxF = as_global(Jin.idxF);
+  J.ptrC = as_global(Jin.ptrC); J.slotC = as_global(Jin.slotC); J.idxC = as_global(Jin.idxC);
+  J.rv_tiles = as_global(Jin.rv_tiles); J.rv_table = as_global(Jin.rv_table);
+  const int t = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int b_begin = blockIdx.y * pb, b_end = min(batch, b_begin + pb);
+  if (t < 2) red[t] = 0ull;
+  if (tile >= J.rv_ntiles) {
+    // rows of the primal part that no column tile owns (the column tiles' row ranges are not an ordered cover of 0 .. nequ)
+    const int i0 = (tile - J.rv_ntiles) * RVT_PROWS;
+    for (int b = b_begin; b < b_end; b++) {
+      unsigned long long up = 0ull;
+#pragma unroll
+      for (int k = 0; k < RVT_PROWS / 256; k++) {
+        const int i = i0 + k * 256 + t;
+        if (i < J.nequ) {
+          const double o = Fx[(long long)b * J.nequ + i] - r[(long long)b * J.nequ + i];
+          rhs[(long long)b * J.N + J.nvar + i] = o;
+          const unsigned long long a = (unsigned long long)__double_as_longlong(fabs(o));
+          up = a > up ? a : up;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(up, o, 64); up = x > up ? x : up; }
+      if ((t & 63) == 0 && up) atomicMax(reinterpret_cast<unsigned long long*>(norms + 2 * (long long)b + 1), up);
+    }
+    return;
+  }
+  const int32_t* T = J.rv_tiles + tile * RVT_TW;
+  const int fslo = T[RVT_FSLO], wF = T[RVT_WF], rlo = T[RVT_RLO], wR = T[RVT_WR], cslo = T[RVT_CSLO], wC = T[RVT_WC], llo = T[RVT_LLO],
+            wL = T[RVT_WL], own_lo = T[RVT_OWNLO], own_hi = T[RVT_OWNHI];
+  const int oF = 0, oR = rvt_even(wF), oC = oR + rvt_even(wR), oL = oC + rvt_even(wC);
+  // the column(s) of this thread: window offsets of their first entries, counts
+  constexpr int CPT = RVT_COLS / 256;
+  uint32_t tab[CPT][RVT_KF + RVT_KC + 1];
+#pragma unroll
+  for (int j = 0; j < CPT; j++)
+#pragma unroll
+    for (int w = 0; w < RVT_KF + RVT_KC + 1; w++)
+      tab[j][w] = J.rv_table[((size_t)tile * (RVT_KF + RVT_KC + 1) + w) * RVT_COLS + j * 256 + t];
+  rvt_d2 pF[(RVT_MAXF + 2 + 511) / 512], pR[(RVT_MAXR + 2 + 511) / 512], pC[(RVT_MAXC + 2 + 511) / 512], pL[(RVT_MAXL + 2 + 511) / 512];
+  double pX[RVT_NFX];
+  // (a macro: a lambda that captures the register arrays by reference puts them in scratch memory)
+#define RVT_ISSUE(B_)                                                                              \
+  {                                                                                                \
+    const long long b_ = (B_);                                                                     \
+    rvt_issue(vals + b_ * J.nnz + fslo, wF, t, pF);                                                \
+    rvt_issue(r + b_ * J.nequ + rlo, wR, t, pR);                                                   \
+    if (wC) {                                                                                      \
+      rvt_issue(vals + b_ * J.nnz + cslo, wC, t, pC);                                              \
+      rvt_issue(lambda + b_ * J.ncon + llo, wL, t, pL);                                            \
+    }                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < RVT_NFX; k++) {                                          \
+      const int i = own_lo + k * 256 + t;                                                          \
+      if (i < own_hi) pX[k] = __builtin_nontemporal_load(Fx + b_ * J.nequ + i);                    \
+    }                                                                                              \
+  }
+  RVT_ISSUE(b_begin)
+  for (int b = b_begin; b < b_end; b++) {
+    const int parF = rvt_par(vals + (long long)b * J.nnz + fslo), parR = rvt_par(r + (long long)b * J.nequ + rlo);
+    const int parC = wC ? rvt_par(vals + (long long)b * J.nnz + cslo) : 0, parL = wC ? rvt_par(lambda + (long long)b * J.ncon + llo) : 0;
+    rvt_commit(lds + oF, wF, parF, t, pF);
+    rvt_commit(lds + oR, wR, parR, t, pR);
+    if (wC) { rvt_commit(lds + oC, wC, parC, t, pC); rvt_commit(lds + oL, wL, parL, t, pL); }
+    double fx[RVT_NFX];
+#pragma unroll
+    for (int k = 0; k < RVT_NFX; k++) fx[k] = pX[k];
+    __syncthreads();
+    if (b + 1 < b_end) RVT_ISSUE(b + 1)
+    unsigned long long ud = 0ull, up = 0ull;
+    const double* lF = lds + oF + parF; const double* lR = lds + oR + parR; const double* lC = lds + oC + parC; const double* lL = lds + oL + parL;
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+      const int col = tile * RVT_COLS + j * 256 + t;
+      const int nF = (int)(tab[j][RVT_KF + RVT_KC] & 255u), nC = (int)((tab[j][RVT_KF + RVT_KC] >> 8) & 255u);
+      double jv[RVT_KF], xv[RVT_KF], cv[RVT_KC], lv[RVT_KC];
+#pragma unroll
+      for (int u = 0; u < RVT_KF; u++) { jv[u] = lF[tab[j][u] & 0xffffu]; xv[u] = lR[tab[j][u] >> 16]; }
+      if (wC) {
+#pragma unroll
+        for (int u = 0; u < RVT_KC; u++) { cv[u] = lC[tab[j][RVT_KF + u] & 0xffffu]; lv[u] = lL[tab[j][RVT_KF + u] >> 16]; }
+      }
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int u = 0; u < RVT_KF; u++)
+        if (u < nF) { const double t_ = jv[u] * xv[u]; s1 = s1 + t_; }
+      if (nF > RVT_KF) {
+        const int q0 = J.ptrF[col];
+        for (int k = RVT_KF; k < nF; k++) { const double t_ = vals[(long long)b * J.nnz + J.slotF[q0 + k]] * r[(long long)b * J.nequ + J.idxF[q0 + k]]; s1 = s1 + t_; }
+      }
+      if (wC) {
+#pragma unroll
+        for (int u = 0; u < RVT_KC; u++)
+          if (u < nC) { const double t_ = cv[u] * lv[u]; s2 = s2 + t_; }
+        if (nC > RVT_KC) {
+          const int q0 = J.ptrC[col];
+          for (int k = RVT_KC; k < nC; k++) { const double t_ = vals[(long long)b * J.nnz + J.slotC[q0 + k]] * lambda[(long long)b * J.ncon + J.idxC[q0 + k]]; s2 = s2 + t_; }
+        }
+      }
+      if (col < J.nvar) {
+        const double o = s1 - s2;
+        rhs[(long long)b * J.N + col] = o;
+        const unsigned long long a = (unsigned long long)__double_as_longlong(fabs(o));
+        ud = a > ud ? a : ud;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RVT_NFX; k++) {
+      const int i = own_lo + k * 256 + t;
+      if (i < own_hi) {
+        const double o = fx[k] - lR[i - rlo];
+        rhs[(long long)b * J.N + J.nvar + i] = o;
+        const unsigned long long a = (unsigned long long)__double_as_longlong(fabs(o));
+        up = a > up ? a : up;
+      }
+    }
+    if (tile == 0)
+      for (int k = t; k < J.ncon; k += 256) {
+        const double o = cx[(long long)b * J.ncon + k];
+        rhs[(long long)b * J.N + J.nvar + J.nequ + k] = o;
+        const unsigned long long a = (unsigned long long)__double_as_longlong(fabs(o));
+        up = a > up ? a : up;
+      }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long xd = __shfl_xor(ud, o, 64), xp = __shfl_xor(up, o, 64);
+      ud = xd > ud ? xd : ud;
+      up = xp > up ? xp : up;
+    }
+    if ((t & 63) == 0) {
+      if (ud) atomicMax(&red[0], ud);
+      if (up) atomicMax(&red[1], up);
+    }
+    __syncthreads();
+    if (t < 2) {
+      const unsigned long long v = red[t];
+      if (v) atomicMax(reinterpret_cast<unsigned long long*>(norms + 2 * (long long)b + t), v);
+      red[t] = 0ull;
+    }
+  }
+}
+
 // Trial point of the extrapolation step, /root/reference/src/CaNNOLeS.jl:661-668 with dlambda = -d[n+m+1:N] (:654):
 //   xt = x + dx, rt = r + dr, dlambda capped at ||dlambda||_2 <= max_dlambda (1e4), lambdat = lambda + dlambda.
 // One workgroup per problem.
@@ -573,6 +765,13 @@ hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const dou
                                    const double* cx, double* rhs, double* norms, int batch, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(norms, 0, sizeof(double) * 2 * (size_t)batch, stream);
   if (e != hipSuccess) return e;
+  if (J.rv_ntiles > 0) {
+    // problems per workgroup: the table of a tile is read once per workgroup, and a workgroup streams one problem ahead
+    const int pb = batch >= 4096 ? 16 : batch >= 512 ? 4 : batch >= 64 ? 2 : 1;
+    hipLaunchKernelGGL(residual_vectors_tiled_kernel, dim3(J.rv_ntiles + J.rv_primal_tiles, (batch + pb - 1) / pb), dim3(256),
+                       (size_t)J.rv_lds_doubles * sizeof(double), stream, J, vals, r, lambda, Fx, cx, rhs, norms, batch, pb);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(residual_vectors_kernel, dim3((J.N + 255) / 256, (batch + RPT - 1) / RPT), dim3(256), 0, stream, J, vals, r, lambda, Fx, cx, rhs,
                      norms, batch);
   return hipGetLastError();

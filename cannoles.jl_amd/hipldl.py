@@ -54,7 +54,7 @@ class cnl_options(C.Structure):
             "order_mode", "nd_leaf", "relax", "task_cap", "multipliers_early", "condense", "direct_records", "register_front",
             "dense_backend", "general_dense", "staged", "dataflow", "dataflow_waves", "dataflow_spin_limit", "waves_per_block",
             "v1_tpp", "v1_ppb", "v1_lds", "v1_solve", "lds_pad", "ubig", "wait_thr", "dense_graph", "dense_syrk_wgs", "verbose",
-            "multi_share_plan", "row_products", "split_batch", "lean_kernel", "rows_in_backward", "dense_panel_blocks", "host_ladder", "device_ladder", "device_ladder_fused", "band_form", "split_tail", "staged_large_fronts", "band_kernel", "band_problems_per_group")] + [("force_order", C.c_char * 32)]
+            "multi_share_plan", "row_products", "split_batch", "lean_kernel", "rows_in_backward", "dense_panel_blocks", "host_ladder", "device_ladder", "device_ladder_fused", "band_form", "split_tail", "staged_large_fronts", "band_kernel", "band_problems_per_group", "f1_tiles")] + [("force_order", C.c_char * 32)]
 
 
 class cnl_outer_state(C.Structure):
@@ -309,7 +309,7 @@ class HIPLDLStruct:
         _check(lib().cnl_get_config(h, cfg))
         self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4]),
                        "kernel": {2: "v2", 3: "dense", 4: "v2-staged"}.get(int(cfg[5]) & 15, "v1"), "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7]),
-                       "lean": bool(int(cfg[5]) & 16), "tail": bool(int(cfg[5]) & 32), "band": bool(int(cfg[5]) & 64)}
+                       "lean": bool(int(cfg[5]) & 16), "tail": bool(int(cfg[5]) & 32), "band": bool(int(cfg[5]) & 64), "f1_tiles": bool(int(cfg[5]) & 128)}
 
     def plan_array(self, name):
         return _plan_array(lib().cnl_get_plan(self._h), name)

@@ -83,7 +83,7 @@ typedef struct cnl_options {
   int32_t direct_records;      /* 1: the register-front kernel condenses on the fly (no separate condense pass)                 */
   int32_t register_front;      /* 1: the register-front kernel may serve the plan (fronts of order <= 64)                       */
   int32_t dense_backend;       /* 1: dense residual blocks go to the dense backend                                              */
-  int32_t general_dense;       /* 1: small batches of irregular plans with fronts > 64 are factorised as ONE dense matrix       */
+  int32_t general_dense;       /* 1: small batches of irregular plans with fronts > 64 (up to 16 problems: > 32 when the condensed order is <= 512) are factorised as ONE dense matrix; 2: wherever possible (measurements) */
   int32_t staged;              /* 1: latency plans run their first attempt stage by stage                                       */
   int32_t dataflow;            /* 1: smallest batches run all tasks in one launch per phase, waiting on device counters         */
   int32_t dataflow_waves;      /* at most this many wavefronts run in dataflow fashion (default 1024; clamped to what the device
@@ -137,6 +137,7 @@ typedef struct cnl_options {
                                   problem and half of the chain, operands streamed through LDS); 2: the same with the chain in one
                                   part; 0: the register-front kernel                                                              */
   int32_t band_problems_per_group; /* band kernels: problems per workgroup (8, 16 or 32); 0 = by batch: 16 up to 8192 problems, 32 above */
+  int32_t f1_tiles;            /* 1: row f1 (cnl_residual_vectors_dev) streams column tiles through LDS where the pattern allows; 0: gather kernel */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);
@@ -347,7 +348,8 @@ int cnl_last_kernel_ms(cnl_handle* h, float* ms);
  * [4]=grid size (those five describe the general kernel, kernels.hip), [5]=2 if the register-front
  * kernel (kernels2.hip) serves newton_system/factorize (4: with staged execution of the first attempt), 3 dense backend, else 1;
  * + 16 when newton_system / factorize run the LEAN instantiation (fast-class fronts with row-form products only), [6]=its wavefronts per workgroup,
- * [7]=its LDS bytes per workgroup; [5] + 32 when the remainder of the batch runs on a handle of its own (cnl_options.split_tail). */
+ * [7]=its LDS bytes per workgroup; [5] + 32 when the remainder of the batch runs on a handle of its own (cnl_options.split_tail),
+ * + 64 when cnl_newton_system runs on the band kernels, + 128 when cnl_residual_vectors_dev runs on column tiles. */
 int cnl_get_config(const cnl_handle* h, int64_t cfg[8]);
 
 #ifdef __cplusplus

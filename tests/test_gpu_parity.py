@@ -255,24 +255,34 @@ def _f1_inputs(s, B, seed):
     return np.ascontiguousarray(vals), r, np.ascontiguousarray(lam), Fx, np.ascontiguousarray(cx)
 
 
-@pytest.mark.parametrize("kind", ["band", "random", "nocon"])
-def test_f1_residual_vectors_bit_exact(built, kind):
+@pytest.mark.parametrize("tiles", [1, 0])
+@pytest.mark.parametrize("kind", ["band", "band_odd", "cfg3_slice", "random", "nocon", "scattered"])
+def test_f1_residual_vectors_bit_exact(built, kind, tiles):
     """rhs = [Jx'r - Jc'λ; F - r; c] and the two infinity norms: per-column COO-order sums, bit-identical to the
-    restated COO mul! (src/CaNNOLeS.jl:507-508,519-524,528-529,631-632)."""
+    restated COO mul! (src/CaNNOLeS.jl:507-508,519-524,528-529,631-632).  Both kernels of the row: the column tiles streamed
+    through LDS (round 5; band and block patterns) and the gather kernel (`f1_tiles = 0`, and every pattern whose tiles' slot
+    ranges exceed the windows)."""
     import torch
     hipldl, syn, O = _mods()
     B = 6
     if kind == "band":
         s = syn.band_structure(1000, 10)
+    elif kind == "band_odd":
+        s, B = syn.band_structure(777, 7), 67       # odd sizes: every alignment of the 16-byte chunks; two problems per workgroup + a rest
+    elif kind == "cfg3_slice":
+        s, B = syn.band_structure(3000, 15), 3
     elif kind == "random":
         s = syn.random_structure(40, 55, 7, 0.15, seed=3)
+    elif kind == "scattered":
+        s = syn.random_structure(700, 900, 3, 0.01, seed=9)   # a tile's entries lie anywhere in vals: gather kernel whatever the option says
     else:
         s = syn.random_structure(30, 45, 0, 0.15, seed=5)
     vals, r, lam, Fx, cx = _f1_inputs(s, B, 11)
-    if kind == "random":
+    if kind in ("random", "band_odd"):
         r[2, 3] = np.nan  # NaN must reach dual and its norm, as in norm(., Inf)
     rows, cols = s.kkt_pattern()
-    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    LDLT = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(f1_tiles=tiles))
+    assert LDLT.config["f1_tiles"] == (bool(tiles) and kind != "scattered")
     dev = torch.device("cuda", 0)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     tv, tr, tl, tF, tc = t(vals), t(r), t(lam), t(Fx), t(cx)
@@ -286,6 +296,7 @@ def test_f1_residual_vectors_bit_exact(built, kind):
         rhs0, (nd0, np0) = O.residual_vectors(rows, cols, vals[b], s.nvar, s.nequ, s.ncon, r[b], lam[b], Fx[b], cx[b])
         assert np.array_equal(rhs[b], rhs0, equal_nan=True)
         assert np.array_equal(nrm[b], np.array([nd0, np0]), equal_nan=True)
+    LDLT.close()
 
 
 def test_f1_trial_point(built):
