@@ -37,40 +37,66 @@ inline int32_t rhs_src(int64_t i) { return (int32_t)(-(i + 2)); }
 // packs the sources of one epoch into 64-byte pieces; returns false when more than BAND_NPIECE are needed
 struct Packer {
   int32_t len[3];
-  std::vector<int32_t> base[3];   // piece bases per array
-  std::vector<std::pair<int32_t, int32_t>> pieces;   // (array, base) in piece order
+  struct Piece { int32_t arr, base, slot, width; };   // width 8: one slot; 16: a WIDE piece, two consecutive slots loaded by one instruction
+  std::vector<Piece> pieces;
+  // wide layout (band.h: BAND_WIDE_POS): the slot pairs (0,1) .. (6,7) take 128-byte pieces — 16 bytes per lane, one instruction —
+  // and the slots 8 .. 14 take 64-byte pieces: which instruction loads a slot is fixed, the kernels' mover has no case distinction.
+  // Narrow layout: fifteen 64-byte pieces.
+  bool wide = true;
   bool pack(std::vector<int32_t> (&need)[3]) {
     pieces.clear();
+    std::vector<Piece> W, S;   // wide, single
     for (int a = 0; a < 3; a++) {
-      base[a].clear();
       std::vector<int32_t>& v = need[a];
       std::sort(v.begin(), v.end());
       v.erase(std::unique(v.begin(), v.end()), v.end());
       size_t i = 0;
       while (i < v.size()) {
         int32_t b = v[i];
-        if (b > len[a] - 8) b = len[a] - 8;   // the piece must stay inside the array
+        size_t i2 = i;
+        while (i2 < v.size() && v[i2] < b + 8) i2++;
+        int32_t w = 8;
+        // a second run of eight right behind this one is wanted too: one wide piece instead of two
+        if (wide && (int)W.size() < BAND_WIDE_POS && i2 < v.size() && v[i2] < b + 16 && b <= len[a] - 16) w = 16;
+        if (b > len[a] - w) b = len[a] - w;   // the piece must stay inside the array
         if (b < 0) return false;
-        base[a].push_back(b);
-        pieces.push_back({a, b});
-        while (i < v.size() && v[i] < b + 8) i++;
+        (w == 16 ? W : S).push_back({a, b, 0, w});
+        while (i < v.size() && v[i] < b + w) i++;
       }
     }
-    return (int)pieces.size() <= BAND_NPIECE;
+    if (!wide) {
+      if ((int)S.size() > BAND_NPIECE) return false;
+      for (size_t k = 0; k < S.size(); k++) { S[k].slot = (int32_t)k; pieces.push_back(S[k]); }
+      return true;
+    }
+    // more singles than single slots: the free pair positions take them (loaded wide: eight more elements come along)
+    while ((int)S.size() > BAND_NPIECE - 2 * BAND_WIDE_POS && (int)W.size() < BAND_WIDE_POS) {
+      Piece q = S.back();
+      S.pop_back();
+      if (len[q.arr] < 16) return false;
+      q.base = std::min(q.base, len[q.arr] - 16);
+      q.width = 16;
+      W.push_back(q);
+    }
+    if ((int)S.size() > BAND_NPIECE - 2 * BAND_WIDE_POS) return false;
+    for (size_t k = 0; k < W.size(); k++) { W[k].slot = (int32_t)(2 * k); pieces.push_back(W[k]); }
+    for (size_t k = 0; k < S.size(); k++) { S[k].slot = (int32_t)(2 * BAND_WIDE_POS + k); pieces.push_back(S[k]); }
+    return true;
   }
   // LDS byte offset of element e of array a
   int32_t off(int a, int32_t e) const {
-    for (size_t k = 0; k < pieces.size(); k++)
-      if (pieces[k].first == a && e >= pieces[k].second && e < pieces[k].second + 8) return (int32_t)((BAND_IN_OFF + 8 * k + (e - pieces[k].second)) * 8);
+    for (const Piece& pc : pieces)
+      if (pc.arr == a && e >= pc.base && e < pc.base + pc.width) return (int32_t)((BAND_IN_OFF + 8 * pc.slot + (e - pc.base)) * 8);
     return -1;
   }
 };
 
 }  // namespace
 
-void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
-                     int64_t ncon, int nparts_wanted) {
+static void build_band_plan_impl(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
+                                 int64_t ncon, int nparts_wanted, bool wide_pieces) {
   B = BandPlan();
+  B.wide = wide_pieces;
   auto no = [&](const std::string& w) { B.ok = false; B.why = w; };
   const int64_t n = nvar, m = nequ, p = ncon;
   if (N != n + m + p) return no("N != nvar + nequ + ncon");
@@ -282,6 +308,8 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
     std::vector<std::vector<int32_t>> fblocks(nsteps), bblocks(nsteps);
     Packer pk;
     pk.len[0] = (int32_t)nnz; pk.len[1] = (int32_t)N; pk.len[2] = (int32_t)(lpart + 8);
+    pk.wide = wide_pieces;
+    if (lpart + 8 >= (1 << 27)) return no("factor too long");
     const int32_t ZB = BAND_ZERO_OFF * 8;
     // An epoch is a run of BAND_EPOCH steps whose operands must fit the pieces and whose outputs the rings.
     std::string why_not;
@@ -341,12 +369,15 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
         if (dir == 1) for (int32_t i = 0; i < lcnt; i++) need[2].push_back(lbase + i);
         if (!pk.pack(need)) {
           std::string w = "an epoch needs more operand pieces than a lane holds (part " + std::to_string(part) + ", steps " + std::to_string(u0) + ".." + std::to_string(u1) + (dir ? ", backward" : ", forward") + ":";
-          for (auto& pc : pk.pieces) w += " " + std::to_string(pc.first) + ":" + std::to_string(pc.second);
+          for (auto& pc : pk.pieces) w += " " + std::to_string(pc.arr) + ":" + std::to_string(pc.base) + (pc.width == 16 ? "w" : "");
           return no(w + ")");
         }
         int32_t* PP = E + (dir == 0 ? BE_FP : BE_BP);
         for (int k = 0; k < BAND_NPIECE; k++) PP[k] = -1;
-        for (size_t k = 0; k < pk.pieces.size(); k++) PP[k] = pk.pieces[k].second | (pk.pieces[k].first << 28);
+        for (const Packer::Piece& pc : pk.pieces) {
+          PP[pc.slot] = pc.base | (pc.arr << 28) | (pc.width == 16 ? BAND_PIECE_WIDE : 0);
+          if (pc.width == 16) PP[pc.slot + 1] = -2;   // second half of a wide piece
+        }
         auto off = [&](int32_t s) -> int32_t {
           if (s == -1) return ZB;
           return s >= 0 ? pk.off(0, s) : pk.off(1, -(s + 2));
@@ -424,6 +455,13 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
   }
   B.lsize = loff + 8;
   B.ok = true;
+}
+
+void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
+                     int64_t ncon, int nparts_wanted, bool wide_pieces) {
+  build_band_plan_impl(B, N, nnz, rows1, cols1, nvar, nequ, ncon, nparts_wanted, wide_pieces);
+  // an epoch whose operands do not fit four wide and seven 64-byte pieces may still fit fifteen 64-byte ones
+  if (!B.ok && wide_pieces) build_band_plan_impl(B, N, nnz, rows1, cols1, nvar, nequ, ncon, nparts_wanted, false);
 }
 
 }  // namespace cnl

@@ -295,7 +295,7 @@ __device__ __forceinline__ void bstep(double (&xs)[NS + 1], const BOps& OP, cons
 }  // namespace
 
 // LDS of a workgroup: [part][NL] lane blocks | [part] record buffers | control block: per problem [rho | flags], one word "all done"
-template <int NL>
+template <int NL, bool WIDE>
 __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(const BandDev P, const LaunchArgs Ain) {
   constexpr int NI = NL / 8;
   extern __shared__ double lds[];
@@ -351,6 +351,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   bool done = !valid, success = false, ovr = false;
 
   static_assert(NI <= 4, "at most four problem groups per mover lane");
+  typedef double band_d2 __attribute__((ext_vector_type(2), aligned(8)));
   double stg[NPC][NI];   // operand pieces in flight
   int4 rstg0;            // step blocks in flight (one 16-byte word per lane: 256 ints)
   int pcs[NPC];          // piece descriptors of the epoch being loaded
@@ -362,18 +363,37 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   // made the compiler form all three 64-bit addresses of every piece up front — 96 NI VGPRs; selecting among per-array offset
   // arrays made it index them in scratch memory; lambdas instead of macros put every captured variable into scratch.)
 #define BAND_ISSUE1(K, I) if constexpr (I < NI) stg[K][I] = *reinterpret_cast<const double*>(pb + ((movp[I] * strd + (unsigned)le) << 3));
-#define BAND_COMMIT1(K, I) if constexpr (I < NI) *reinterpret_cast<double*>(wblk + ldsb[I] + (BAND_IN_OFF + 8 * K) * 8) = stg[K][I];
-#define BAND_ISSUE(K)                                                                                                         \
-  if (pcs[K] >= 0) {   /* (wave-uniform: an unused piece costs the memory pipeline what a used one does) */                   \
-    const int pc = pcs[K];                                                                                                    \
-    const int arr = pc >> 28;                                                                                                 \
-    const char* pb = (arr == 0 ? reinterpret_cast<const char*>(vbase) : arr == 1 ? reinterpret_cast<const char*>(rbase)       \
-                                                                                 : reinterpret_cast<const char*>(lbase_g)) +   \
-                     ((long long)(pc & ((1 << 28) - 1)) << 3);                                                                \
-    const unsigned strd = arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : (unsigned)lsize;                                \
-    BAND_ISSUE1(K, 0) BAND_ISSUE1(K, 1) BAND_ISSUE1(K, 2) BAND_ISSUE1(K, 3)                                                   \
+  // WIDE layout (band.h: BAND_WIDE_POS): the slot pairs (0,1) .. (6,7) are loaded as 128-byte pieces, 16 bytes per lane, into the
+  // staging registers of both slots — which instruction loads a slot is fixed per instantiation (a first version chose per piece
+  // at run time: two code paths per piece, 30 % slower than without wide pieces)
+#define BAND_ISSUE1W(K, I)                                                                                                    \
+  if constexpr (I < NI) {                                                                                                     \
+    const band_d2 w_ = *reinterpret_cast<const band_d2*>(pb + ((movp[I] * strd + 2u * (unsigned)le) << 3));                   \
+    stg[K][I] = w_.x; stg[K + 1 < NPC ? K + 1 : K][I] = w_.y;                                                                 \
   }
-#define BAND_COMMIT(K) { BAND_COMMIT1(K, 0) BAND_COMMIT1(K, 1) BAND_COMMIT1(K, 2) BAND_COMMIT1(K, 3) }
+#define BAND_COMMIT1(K, I) if constexpr (I < NI) *reinterpret_cast<double*>(wblk + ldsb[I] + (BAND_IN_OFF + 8 * K) * 8) = stg[K][I];
+#define BAND_COMMIT1W(K, I)                                                                                                   \
+  if constexpr (I < NI) {                                                                                                     \
+    double* l_ = reinterpret_cast<double*>(wblk + ldsb[I] + (BAND_IN_OFF + 8 * K) * 8 + le * 8);                              \
+    l_[0] = stg[K][I]; l_[1] = stg[K + 1 < NPC ? K + 1 : K][I];                                                               \
+  }
+#define BAND_ISSUE(K)                                                                                                         \
+  if constexpr (!(WIDE && K < 2 * BAND_WIDE_POS && (K & 1))) {                                                                \
+    if (pcs[K] >= 0) {   /* (wave-uniform: an unused piece costs the memory pipeline what a used one does) */                 \
+      const int pc = pcs[K];                                                                                                  \
+      const int arr = pc >> 28;                                                                                               \
+      const char* pb = (arr == 0 ? reinterpret_cast<const char*>(vbase) : arr == 1 ? reinterpret_cast<const char*>(rbase)     \
+                                                                                   : reinterpret_cast<const char*>(lbase_g)) + \
+                       ((long long)(pc & (BAND_PIECE_WIDE - 1)) << 3);                                                        \
+      const unsigned strd = arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : (unsigned)lsize;                              \
+      if constexpr (WIDE && K < 2 * BAND_WIDE_POS) { BAND_ISSUE1W(K, 0) BAND_ISSUE1W(K, 1) BAND_ISSUE1W(K, 2) BAND_ISSUE1W(K, 3) } \
+      else { BAND_ISSUE1(K, 0) BAND_ISSUE1(K, 1) BAND_ISSUE1(K, 2) BAND_ISSUE1(K, 3) }                                        \
+    }                                                                                                                         \
+  }
+#define BAND_COMMIT(K)                                                                                                        \
+  if constexpr (WIDE && K < 2 * BAND_WIDE_POS) {                                                                              \
+    if constexpr (!(K & 1)) { BAND_COMMIT1W(K, 0) BAND_COMMIT1W(K, 1) BAND_COMMIT1W(K, 2) BAND_COMMIT1W(K, 3) }               \
+  } else { BAND_COMMIT1(K, 0) BAND_COMMIT1(K, 1) BAND_COMMIT1(K, 2) BAND_COMMIT1(K, 3) }
   // (macros, not lambdas: a closure made the compiler keep every captured variable — the staging registers included — in scratch memory)
 #define BAND_ISSUE_DESC(EP, OFS) { cptr E_ = (EP) + (OFS); _Pragma("unroll") for (int k_ = 0; k_ < NPC; k_++) pcs[k_] = E_[k_]; }
   /* the epoch's step / row blocks (the streams are padded: reading past the epoch's blocks is harmless) */
@@ -708,9 +728,15 @@ hipError_t launch_band(const BandDev& P, int nl, const LaunchArgs& a, hipStream_
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * P.nparts), ldsb, stream, P, a);
     return hipGetLastError();
   };
-  if (nl == 32) return go(band_newton_kernel<32>);
-  if (nl == 16) return go(band_newton_kernel<16>);
-  if (nl == 8) return go(band_newton_kernel<8>);
+  if (P.wide) {
+    if (nl == 32) return go(band_newton_kernel<32, true>);
+    if (nl == 16) return go(band_newton_kernel<16, true>);
+    if (nl == 8) return go(band_newton_kernel<8, true>);
+  } else {
+    if (nl == 32) return go(band_newton_kernel<32, false>);
+    if (nl == 16) return go(band_newton_kernel<16, false>);
+    if (nl == 8) return go(band_newton_kernel<8, false>);
+  }
   return hipErrorInvalidConfiguration;
 }
 

@@ -882,7 +882,7 @@ void cnl_options_init(cnl_options* o) {
   o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
   // (fused: measured slower than the separate launches on one system of cfg3's size, 0.140 against 0.118 ms — the rung loop costs
   //  the kernel 50 VGPRs and 45 spilled SGPRs — so it is off by default)
-  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0; o->band_kernel = 1; o->band_problems_per_group = 0; o->f1_tiles = 1;
+  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0; o->band_kernel = 1; o->band_problems_per_group = 0; o->f1_tiles = 1; o->band_wide_pieces = 1;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -1063,12 +1063,12 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
   if (o.dense_backend) cnl::detect_dense(p->D, N, nnz, rows1, cols1, nvar, nequ, ncon);
   // (round 5) large batches of band-structured problems: the sliding-window elimination with one lane per (problem, part)
   if (!latency && o.band_kernel && p->C.active && !p->D.active) {
-    cnl::build_band_plan(p->band, N, nnz, rows1, cols1, nvar, nequ, ncon, o.band_kernel == 2 ? 1 : 2);
+    cnl::build_band_plan(p->band, N, nnz, rows1, cols1, nvar, nequ, ncon, o.band_kernel == 2 ? 1 : 2, o.band_wide_pieces != 0);
     if (verbose) fprintf(stderr, "[cnl] band program: %s%s\n", p->band.ok ? "ok" : "no: ", p->band.ok ? "" : p->band.why.c_str());
   }
   {
     const cnl::BandPlan& Bp = p->band;
-    p->band_info = {Bp.ok ? 1 : 0, Bp.nparts, Bp.m0, Bp.n, Bp.N, Bp.nnz, (int32_t)Bp.lsize};
+    p->band_info = {Bp.ok ? 1 : 0, Bp.nparts, Bp.m0, Bp.n, Bp.N, Bp.nnz, (int32_t)Bp.lsize, Bp.wide ? 1 : 0};
     for (int q = 0; q < 2; q++) p->band_pinfo[q] = {Bp.part[q].nsteps, Bp.part[q].nepochs, Bp.part[q].npiv, Bp.part[q].nevents, (int32_t)Bp.part[q].loff};
   }
   // Irregular sparsity: when the fill makes fronts larger than the register-front kernel takes and the condensed system is of
@@ -1269,7 +1269,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
       if ((rc = upload(h, Bp.part[q].borders, &bd.borders[q]))) return bail(rc);
       bd.nsteps[q] = Bp.part[q].nsteps; bd.nepochs[q] = Bp.part[q].nepochs; bd.loff[q] = Bp.part[q].loff;
     }
-    bd.nparts = Bp.nparts; bd.m0 = Bp.m0; bd.n = Bp.n; bd.N = Bp.N; bd.nnz = Bp.nnz; bd.nvar = (int32_t)nvar; bd.lsize = Bp.lsize;
+    bd.nparts = Bp.nparts; bd.m0 = Bp.m0; bd.n = Bp.n; bd.N = Bp.N; bd.nnz = Bp.nnz; bd.nvar = (int32_t)nvar; bd.lsize = Bp.lsize; bd.wide = Bp.wide ? 1 : 0;
     // 16 problems per workgroup (two workgroups = four wavefronts per CU: one per SIMD) up to the 8192 problems that fills; above,
     // 32 per workgroup (the LDS of a CU holds two such workgroups: 16384 problems resident) — tools/time_band.py
     h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : (batch > 8192 ? 32 : 16);

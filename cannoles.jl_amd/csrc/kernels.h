@@ -158,6 +158,7 @@ struct BandDev {
   int32_t nsteps[2], nepochs[2];
   long long loff[2];
   int32_t nparts, m0, n, N, nnz, nvar;
+  int32_t wide;   // the program uses the wide layout (band.h: BAND_WIDE_POS)
   long long lsize;
 };
 // newton_system! / try_to_factorize of a.batch problems on the band kernels, nl problems per workgroup (8, 16 or 32); a.L = the

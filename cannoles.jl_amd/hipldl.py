@@ -54,7 +54,7 @@ class cnl_options(C.Structure):
             "order_mode", "nd_leaf", "relax", "task_cap", "multipliers_early", "condense", "direct_records", "register_front",
             "dense_backend", "general_dense", "staged", "dataflow", "dataflow_waves", "dataflow_spin_limit", "waves_per_block",
             "v1_tpp", "v1_ppb", "v1_lds", "v1_solve", "lds_pad", "ubig", "wait_thr", "dense_graph", "dense_syrk_wgs", "verbose",
-            "multi_share_plan", "row_products", "split_batch", "lean_kernel", "rows_in_backward", "dense_panel_blocks", "host_ladder", "device_ladder", "device_ladder_fused", "band_form", "split_tail", "staged_large_fronts", "band_kernel", "band_problems_per_group", "f1_tiles")] + [("force_order", C.c_char * 32)]
+            "multi_share_plan", "row_products", "split_batch", "lean_kernel", "rows_in_backward", "dense_panel_blocks", "host_ladder", "device_ladder", "device_ladder_fused", "band_form", "split_tail", "staged_large_fronts", "band_kernel", "band_problems_per_group", "f1_tiles", "band_wide_pieces")] + [("force_order", C.c_char * 32)]
 
 
 class cnl_outer_state(C.Structure):

@@ -40,11 +40,15 @@ class BandSim:
     # ---- one factorisation attempt (+ forward substitution) of every problem -------------------------------------------
     def _load_pieces(self, blk, pieces, arrays):
         for k, pc in enumerate(pieces):
-            if pc < 0:
+            if pc < 0:              # -1 unused, -2 second half of a wide piece
                 continue
-            arr, base = arrays[pc >> 28], pc & ((1 << 28) - 1)
-            assert base + 8 <= arr.shape[1], (base, arr.shape)
-            blk[:, IN_OFF + 8 * k: IN_OFF + 8 * k + 8] = arr[:, base: base + 8]
+            wide = (pc >> 27) & 1   # BAND_PIECE_WIDE: 16 elements into this slot and the next, loaded by one instruction
+            arr, base = arrays[pc >> 28], pc & ((1 << 27) - 1)
+            w = 16 if wide else 8
+            if wide:
+                assert k + 1 < len(pieces) and pieces[k + 1] == -2, "wide piece without its second slot"
+            assert base + w <= arr.shape[1], (base, arr.shape)
+            blk[:, IN_OFF + 8 * k: IN_OFF + 8 * k + w] = arr[:, base: base + w]
 
     def forward(self, vals, rhs, rho, ovr, tol, Lst):
         B = vals.shape[0]
