@@ -22,15 +22,19 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda", 0)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
 fails = 0
+tiled = 0
 for case in range(ncases):
     seed = seed0 + case
     rng = np.random.default_rng(200000 + seed)
-    fam = int(rng.integers(3))
+    fam = int(rng.integers(4))
     if fam == 0:
         n = int(rng.integers(3, 90)); m = int(rng.integers(2, 2 * n + 2)); pc = int(rng.integers(0, min(6, n) + 1))
         s = syn.random_structure(n, m, pc, float(rng.uniform(0.05, 0.4)), seed, hess=bool(rng.integers(4)))
     elif fam == 1:
         pc = int(rng.integers(0, 5)); blocks = int(rng.integers(4, 70)); n = (pc if pc else 1) * blocks
+        s = syn.band_structure(n, pc, hw=int(rng.integers(1, 5)))
+    elif fam == 3:   # (round 5) several column tiles of row f1 (256 columns each), odd sizes
+        pc = int(rng.integers(0, 6)); blocks = int(rng.integers(60, 700)); n = (pc if pc else 1) * blocks
         s = syn.band_structure(n, pc, hw=int(rng.integers(1, 5)))
     else:
         n = int(rng.integers(100, 600)); m = int(rng.integers(n // 2, n + 80)); pc = int(rng.integers(0, 9))
@@ -41,6 +45,7 @@ for case in range(ncases):
     bad = []
     try:
         L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+        tiled += bool(L.config["f1_tiles"])
         vals = np.stack([syn.random_values(s, seed * 100 + b)[0] if s.name != "band" else syn.band_values(s, seed * 100 + b)[0] for b in range(B)])
         r = rng.standard_normal((B, s.nequ)); lam = rng.standard_normal((B, max(s.ncon, 1)))[:, :s.ncon]
         Fx = rng.standard_normal((B, s.nequ)); cx = rng.standard_normal((B, max(s.ncon, 1)))[:, :s.ncon]
@@ -120,5 +125,5 @@ for case in range(ncases):
     if bad:
         fails += 1
         print("FAIL", tag, bad[:5], flush=True)
-print(f"{ncases} cases, {fails} failures", flush=True)
+print(f"{ncases} cases ({tiled} with row f1 on column tiles), {fails} failures", flush=True)
 sys.exit(1 if fails else 0)
