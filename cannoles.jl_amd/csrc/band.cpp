@@ -69,18 +69,33 @@ struct Packer {
       for (size_t k = 0; k < S.size(); k++) { S[k].slot = (int32_t)k; pieces.push_back(S[k]); }
       return true;
     }
-    // more singles than single slots: the free pair positions take them (loaded wide: eight more elements come along)
-    while ((int)S.size() > BAND_NPIECE - 2 * BAND_WIDE_POS && (int)W.size() < BAND_WIDE_POS) {
-      Piece q = S.back();
-      S.pop_back();
+    // The factor stream (array 2) must be CONTIGUOUS in LDS (a record of six doubles may straddle two pieces): its wide pieces take
+    // the top pair positions, its singles the first single slots right behind them; the other arrays' wides fill the pair positions
+    // from the bottom, their singles the remaining single slots.  More singles than single slots: the free pair positions take
+    // singles of the other arrays (loaded wide: eight more elements come along).
+    std::vector<Piece> Wf, Wo, Sf, So;
+    for (const Piece& q : W) (q.arr == 2 ? Wf : Wo).push_back(q);
+    for (const Piece& q : S) (q.arr == 2 ? Sf : So).push_back(q);
+    for (size_t k = 1; k < Sf.size() + Wf.size(); k++) {   // wides first, ascending and adjacent: what contiguity needs
+      const Piece& a = k - 1 < Wf.size() ? Wf[k - 1] : Sf[k - 1 - Wf.size()];
+      const Piece& b = k < Wf.size() ? Wf[k] : Sf[k - Wf.size()];
+      if (b.base != a.base + a.width) return false;
+    }
+    for (const Piece& q : Sf) if (!Wf.empty() && q.base < Wf.back().base) return false;
+    const int nsingle = BAND_NPIECE - 2 * BAND_WIDE_POS;
+    while ((int)(Sf.size() + So.size()) > nsingle && (int)(Wf.size() + Wo.size()) < BAND_WIDE_POS && !So.empty()) {
+      Piece q = So.back();
+      So.pop_back();
       if (len[q.arr] < 16) return false;
       q.base = std::min(q.base, len[q.arr] - 16);
       q.width = 16;
-      W.push_back(q);
+      Wo.push_back(q);
     }
-    if ((int)S.size() > BAND_NPIECE - 2 * BAND_WIDE_POS) return false;
-    for (size_t k = 0; k < W.size(); k++) { W[k].slot = (int32_t)(2 * k); pieces.push_back(W[k]); }
-    for (size_t k = 0; k < S.size(); k++) { S[k].slot = (int32_t)(2 * BAND_WIDE_POS + k); pieces.push_back(S[k]); }
+    if ((int)(Sf.size() + So.size()) > nsingle) return false;
+    for (size_t k = 0; k < Wo.size(); k++) { Wo[k].slot = (int32_t)(2 * k); pieces.push_back(Wo[k]); }
+    for (size_t k = 0; k < Wf.size(); k++) { Wf[k].slot = (int32_t)(2 * (BAND_WIDE_POS - Wf.size() + k)); pieces.push_back(Wf[k]); }
+    for (size_t k = 0; k < Sf.size(); k++) { Sf[k].slot = (int32_t)(2 * BAND_WIDE_POS + k); pieces.push_back(Sf[k]); }
+    for (size_t k = 0; k < So.size(); k++) { So[k].slot = (int32_t)(2 * BAND_WIDE_POS + Sf.size() + k); pieces.push_back(So[k]); }
     return true;
   }
   // LDS byte offset of element e of array a
@@ -301,15 +316,15 @@ static void build_band_plan_impl(BandPlan& B, int64_t N, int64_t nnz, const int6
     Q.nevents = nev;
     Q.loff = loff;
     const int64_t lpart = (int64_t)nev * BAND_LREC;
-    loff += (lpart + 8 + 7) & ~(int64_t)7;   // + 8: the last piece of a part may over-read
+    loff += (lpart + 16 + 7) & ~(int64_t)7;   // + 16: the last (wide) piece of a part may over-read
     // ---- epochs: pack the operands into pieces, turn sources into LDS offsets ------------------------------------------
     Q.epochs.clear();
     Q.fops.clear(); Q.bops.clear();
     std::vector<std::vector<int32_t>> fblocks(nsteps), bblocks(nsteps);
     Packer pk;
-    pk.len[0] = (int32_t)nnz; pk.len[1] = (int32_t)N; pk.len[2] = (int32_t)(lpart + 8);
+    pk.len[0] = (int32_t)nnz; pk.len[1] = (int32_t)N; pk.len[2] = (int32_t)(lpart + 16);
     pk.wide = wide_pieces;
-    if (lpart + 8 >= (1 << 27)) return no("factor too long");
+    if (lpart + 16 >= (1 << 27)) return no("factor too long");
     const int32_t ZB = BAND_ZERO_OFF * 8;
     // An epoch is a run of BAND_EPOCH steps whose operands must fit the pieces and whose outputs the rings.
     std::string why_not;
@@ -461,7 +476,10 @@ void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, 
                      int64_t ncon, int nparts_wanted, bool wide_pieces) {
   build_band_plan_impl(B, N, nnz, rows1, cols1, nvar, nequ, ncon, nparts_wanted, wide_pieces);
   // an epoch whose operands do not fit four wide and seven 64-byte pieces may still fit fifteen 64-byte ones
-  if (!B.ok && wide_pieces) build_band_plan_impl(B, N, nnz, rows1, cols1, nvar, nequ, ncon, nparts_wanted, false);
+  if (!B.ok && wide_pieces) {
+    if (std::getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] band program: wide layout not possible (%s)\n", B.why.c_str());
+    build_band_plan_impl(B, N, nnz, rows1, cols1, nvar, nequ, ncon, nparts_wanted, false);
+  }
 }
 
 }  // namespace cnl

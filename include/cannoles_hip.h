@@ -138,7 +138,7 @@ typedef struct cnl_options {
                                   part; 0: the register-front kernel                                                              */
   int32_t band_problems_per_group; /* band kernels: problems per workgroup (8, 16 or 32); 0 = by batch: 16 up to 8192 problems, 32 above */
   int32_t f1_tiles;            /* 1: row f1 (cnl_residual_vectors_dev) streams column tiles through LDS where the pattern allows; 0: gather kernel */
-  int32_t band_wide_pieces;    /* 1: the band program loads contiguous operand runs in 128-byte pieces (16 bytes per lane); 0: 64-byte pieces only */
+  int32_t band_wide_pieces;    /* 1: the band program loads contiguous operand runs in 128-byte pieces (16 bytes per lane; four per epoch); 0 (default): 64-byte pieces only — measured equal */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);

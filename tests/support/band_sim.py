@@ -30,6 +30,7 @@ class BandSim:
         if not self.ok:
             return
         self.nparts, self.m0, self.n, self.N, self.nnz, self.lsize = (int(v) for v in info[1:7])
+        self.wide = bool(info[7]) if len(info) > 7 else False
         self.parts = []
         for q in range(self.nparts):
             pi = plan.array(f"band_part{q}")

@@ -34,12 +34,15 @@ def _check(s, vals, rhs, params, rho_old=0.0, **opt):
     return sim
 
 
+@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("n,p,hw,kernel", [(200, 4, 2, 1), (200, 0, 2, 1), (200, 0, 2, 2), (360, 6, 1, 1), (1000, 10, 2, 1), (96, 2, 2, 1)])
-def test_band_program_reproduces_the_oracle(built, params, n, p, hw, kernel):
+def test_band_program_reproduces_the_oracle(built, params, n, p, hw, kernel, wide):
+    """both layouts of the program: fifteen 64-byte pieces per epoch, and four 128-byte + seven 64-byte pieces (band_wide_pieces)"""
     s = syn.band_structure(n, p, hw=hw)
     vals, rhs = syn.batch_values(s, 3, cfg=4)
-    sim = _check(s, vals, rhs, params, band_kernel=kernel)
+    sim = _check(s, vals, rhs, params, band_kernel=kernel, band_wide_pieces=wide)
     assert sim.nparts == (1 if kernel == 2 or n < 80 else 2)
+    assert sim.wide == bool(wide)
 
 
 def test_band_program_ladder_and_hopeless(built, params):
@@ -58,6 +61,7 @@ def test_band_program_full_size_headline_pattern(built, params):
     s = syn.band_structure(10000, 50)
     vals, rhs = syn.batch_values(s, 2, cfg=3)
     sim = _check(s, vals, rhs, params)
+    _check(s, vals, rhs, params, band_wide_pieces=1)
     assert sim.nparts == 2 and sim.parts[0]["nsteps"] == sim.parts[1]["nsteps"] == 5002
     assert sim.lsize * 8 < 0.5e6   # factor records: six doubles per pivot
 

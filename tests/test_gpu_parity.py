@@ -1930,15 +1930,16 @@ def _band_opts(hipldl, **kw):
     return hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, **kw)
 
 
+@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("n,p,B,nl,hw", [(200, 4, 5, 16, 2), (96, 2, 3, 16, 2), (1000, 10, 37, 8, 2), (1000, 10, 37, 32, 2), (1000, 10, 70, 16, 2), (360, 6, 19, 16, 1),
                                          (400, 0, 9, 16, 2), (10000, 50, 33, 16, 2)])
-def test_band_kernels_against_the_oracle(built, n, p, B, nl, hw):
+def test_band_kernels_against_the_oracle(built, n, p, B, nl, hw, wide):
     """one lane per (problem, half of the chain): decisions identical to the oracle's on the product's order and on the canonical one,
     d within the forward / backward bar; batches that are no multiple of the workgroup's problems, one part (n < 80) and two"""
     hipldl, syn, O = _mods()
     s = syn.band_structure(n, p, hw=hw)
     vals, rhs = syn.batch_values(s, B, cfg=4)
-    info, cfg = run_case(s, vals, rhs, options=_band_opts(hipldl, band_problems_per_group=nl))
+    info, cfg = run_case(s, vals, rhs, options=_band_opts(hipldl, band_problems_per_group=nl, band_wide_pieces=wide))
     assert cfg["band"]
 
 
