@@ -322,7 +322,17 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   // mover: wave-uniform base pointers + 32-bit per-lane byte offsets (NL problems span < 4 GB)
   const double* vbase = gvals + (long long)prob0 * nnz;
   const double* rbase = has_rhs ? grhs + (long long)prob0 * N : gvals;
-  double* lbase_g = gL + (long long)prob0 * lsize + P.loff[part];
+  // The factor records are private to the launch (written by the forward sweep, read by the backward sweep of the SAME workgroup), so
+  // their layout is the kernel's choice: INTERLEAVED over the NL problems of the workgroup in blocks of eight doubles — element e of
+  // problem p of the workgroup lives at ((e >> 3) * NL + p) * 8 + (e & 7) of the workgroup's region — so that the eight 64-byte runs one
+  // store / load instruction touches are 512 contiguous bytes (tools/seg_bench.hip: this memory system gives scattered 64-byte
+  // segments 3.4 ... 4.5 TB/s, runs of 256 bytes and more 6.0).
+  // Measured on one box (tools/ab_lib.py): 16 384 problems, 32 per workgroup: 12.41 -> 12.22 ms; 8 192 problems, 16 per workgroup:
+  // 7.40 -> 7.75 ms (the address arithmetic costs the latency-bound case more than the layout gives) — so only the 32-problem
+  // instantiation interleaves.
+  constexpr bool LINT = NL >= 32;
+  double* lbase_g = gL + (long long)prob0 * lsize + (LINT ? 0 : P.loff[part]);
+  const int loff8 = LINT ? (int)P.loff[part] : 0;   // a multiple of 8
   double* dbase = gd ? gd + (long long)prob0 * N : nullptr;
   unsigned movp[NI], ldsb[NI];   // problem of the lane inside the workgroup (clamped to the batch), LDS byte offset of its element
   bool movok[NI];
@@ -362,13 +372,13 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   // piece's array are selected with scalar instructions, the lane's offset is problem * stride + element.  (Three guarded loads
   // made the compiler form all three 64-bit addresses of every piece up front — 96 NI VGPRs; selecting among per-array offset
   // arrays made it index them in scratch memory; lambdas instead of macros put every captured variable into scratch.)
-#define BAND_ISSUE1(K, I) if constexpr (I < NI) stg[K][I] = *reinterpret_cast<const double*>(pb + ((movp[I] * strd + (unsigned)le) << 3));
+#define BAND_ISSUE1(K, I) if constexpr (I < NI) stg[K][I] = *reinterpret_cast<const double*>(pb + ((movp[I] * strd + tl) << 3));
   // WIDE layout (band.h: BAND_WIDE_POS): the slot pairs (0,1) .. (6,7) are loaded as 128-byte pieces, 16 bytes per lane, into the
   // staging registers of both slots — which instruction loads a slot is fixed per instantiation (a first version chose per piece
   // at run time: two code paths per piece, 30 % slower than without wide pieces)
 #define BAND_ISSUE1W(K, I)                                                                                                    \
   if constexpr (I < NI) {                                                                                                     \
-    const band_d2 w_ = *reinterpret_cast<const band_d2*>(pb + ((movp[I] * strd + 2u * (unsigned)le) << 3));                   \
+    const band_d2 w_ = *reinterpret_cast<const band_d2*>(pb + ((movp[I] * strd + tl) << 3));                   \
     stg[K][I] = w_.x; stg[K + 1 < NPC ? K + 1 : K][I] = w_.y;                                                                 \
   }
 #define BAND_COMMIT1(K, I) if constexpr (I < NI) *reinterpret_cast<double*>(wblk + ldsb[I] + (BAND_IN_OFF + 8 * K) * 8) = stg[K][I];
@@ -382,12 +392,24 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     if (pcs[K] >= 0) {   /* (wave-uniform: an unused piece costs the memory pipeline what a used one does) */                 \
       const int pc = pcs[K];                                                                                                  \
       const int arr = pc >> 28;                                                                                               \
+      const int el_ = (pc & (BAND_PIECE_WIDE - 1)) + (arr == 2 ? loff8 : 0);                                                  \
+      /* lane offset (doubles) = problem * strd + tl, tl = t + (t >> 3) * gap with t = m + element of the lane: the caller's arrays  \
+         are problem-major (m = 0, t < 8 ... 16: gap = 0), the factor is interleaved in blocks of eight (see lbase_g) */       \
+      const int m_ = (LINT && arr == 2) ? (el_ & 7) : 0;                                                                                \
+      const unsigned gap_ = (LINT && arr == 2) ? (unsigned)(NL * 8 - 8) : 0u;                                                           \
       const char* pb = (arr == 0 ? reinterpret_cast<const char*>(vbase) : arr == 1 ? reinterpret_cast<const char*>(rbase)     \
                                                                                    : reinterpret_cast<const char*>(lbase_g)) + \
-                       ((long long)(pc & (BAND_PIECE_WIDE - 1)) << 3);                                                        \
-      const unsigned strd = arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : (unsigned)lsize;                              \
-      if constexpr (WIDE && K < 2 * BAND_WIDE_POS) { BAND_ISSUE1W(K, 0) BAND_ISSUE1W(K, 1) BAND_ISSUE1W(K, 2) BAND_ISSUE1W(K, 3) } \
-      else { BAND_ISSUE1(K, 0) BAND_ISSUE1(K, 1) BAND_ISSUE1(K, 2) BAND_ISSUE1(K, 3) }                                        \
+                       (((LINT && arr == 2) ? (long long)(el_ >> 3) * (NL * 8) : (long long)el_) << 3);                                 \
+      const unsigned strd = arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : LINT ? 8u : (unsigned)lsize;                                           \
+      if constexpr (WIDE && K < 2 * BAND_WIDE_POS) {                                                                          \
+        const unsigned t_ = (unsigned)m_ + 2u * (unsigned)le;                                                                 \
+        const unsigned tl = t_ + (t_ >> 3) * gap_;                                                                            \
+        BAND_ISSUE1W(K, 0) BAND_ISSUE1W(K, 1) BAND_ISSUE1W(K, 2) BAND_ISSUE1W(K, 3)                                           \
+      } else {                                                                                                                \
+        const unsigned t_ = (unsigned)m_ + (unsigned)le;                                                                      \
+        const unsigned tl = t_ + (t_ >> 3) * gap_;                                                                            \
+        BAND_ISSUE1(K, 0) BAND_ISSUE1(K, 1) BAND_ISSUE1(K, 2) BAND_ISSUE1(K, 3)                                               \
+      }                                                                                                                       \
     }                                                                                                                         \
   }
 #define BAND_COMMIT(K)                                                                                                        \
@@ -466,14 +488,19 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 #define BAND_LFLUSH(LB, LC)                                                                                                 \
       {                                                                                                                     \
         const int lc_ = (LC);                                                                                               \
-        char* lout = reinterpret_cast<char*>(lbase_g) + ((long long)(LB) << 3);                                             \
+        const int lb_ = (LB) + loff8;                                                                                       \
+        char* lout = reinterpret_cast<char*>(lbase_g) + ((LINT ? (long long)(lb_ >> 3) * (NL * 8) : (long long)lb_) << 3);  \
+        const unsigned t_ = (LINT ? (unsigned)(lb_ & 7) : 0u) + (unsigned)le;                                               \
+        const unsigned tl = t_ + (LINT ? (t_ >> 3) * (unsigned)(NL * 8 - 8) : 0u);                                          \
+        const unsigned lstr_ = LINT ? 8u : (unsigned)lsize;                                                                 \
+        constexpr int lcp_ = LINT ? NL * 64 : 64;                                                                           \
         double lx_[BAND_LOUT_MAX / 8][NI];                                                                                  \
         _Pragma("unroll") for (int cpc = 0; cpc < BAND_LOUT_MAX / 8; cpc++)                                                 \
           _Pragma("unroll") for (int i = 0; i < NI; i++) lx_[cpc][i] = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_LOUT_OFF + 8 * cpc) * 8); \
         _Pragma("unroll") for (int cpc = 0; cpc < BAND_LOUT_MAX / 8; cpc++)                                                 \
           _Pragma("unroll") for (int i = 0; i < NI; i++)                                                                    \
             if (movok[i] && cpc * 8 + le < lc_ && !(BAND_DBG & 16))                                                         \
-              *reinterpret_cast<double*>(lout + (((movp[i] * (unsigned)lsize + (unsigned)le) << 3) + 64 * cpc)) = lx_[cpc][i]; \
+              *reinterpret_cast<double*>(lout + (((movp[i] * lstr_ + tl) << 3) + lcp_ * cpc)) = lx_[cpc][i];                 \
       }
       BAND_FSTEP(0)
       if (more_) { BAND_ISSUE(0) BAND_ISSUE(1) BAND_ISSUE(2) BAND_ISSUE(3) }

@@ -1277,9 +1277,10 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     // 32-bit byte offsets inside a workgroup's problems
     const uint64_t span = 8ull * (uint64_t)h->band_nl * (uint64_t)std::max<int64_t>({(int64_t)nnz, N, bd.lsize});
     if (span < (1ull << 32) && cnl::band_lds_bytes(bd.nparts, h->band_nl) <= std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024)) {
-      if ((rc = dalloc(h, &h->d_Lband, (size_t)batch * (size_t)bd.lsize + 64))) return bail(rc);
+      // (+ 32 problems: the band kernels interleave the records of a workgroup's problems, the last workgroup's region is a whole one)
+      if ((rc = dalloc(h, &h->d_Lband, ((size_t)batch + 32) * (size_t)bd.lsize + 64))) return bail(rc);
       if ((rc = dalloc(h, &h->d_band_ok, (size_t)batch))) return bail(rc);
-      if (hipMemset(h->d_Lband, 0, ((size_t)batch * (size_t)bd.lsize + 64) * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
+      if (hipMemset(h->d_Lband, 0, (((size_t)batch + 32) * (size_t)bd.lsize + 64) * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
       h->band = true;
       h->root_Lband = h->d_Lband; h->root_band_ok = h->d_band_ok; h->root_batch = batch;
     }
@@ -1905,6 +1906,9 @@ int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d,
     size_t chunk = std::max<size_t>(16, ((B / 8) + 3) & ~(size_t)3);
     const size_t per = (size_t)(P.nnz + P.N) * sizeof(double);
     while (chunk * per < ((size_t)16 << 20) && chunk < B) chunk += 4;
+    // band kernels: the factor records of a workgroup's problems (8, 16 or 32) are interleaved in ONE region of the factor storage;
+    // chunks run concurrently on different streams, so their regions must not share a workgroup
+    if (h->band) chunk = (chunk + 31) & ~(size_t)31;
     if (chunk < B) return newton_system_pipelined(h, vals, rhs, d, rho_old, params, rho, rho_old_out, nfact, success, chunk);
   }
   HIPCHK(hipMemcpyAsync(h->d_vals, vals, B * P.nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
