@@ -26,7 +26,7 @@ struct Args {
   int len[NS];      // doubles of the stream
   int nsteps;       // steps per part
   int batch;
-  int flags;   // 1: no loads after the first epoch, 2: no stores
+  int flags;   // 1: no loads after the first epoch, 2: no stores, 4: INTERLEAVED layout (blocks of eight doubles of the workgroup's problems side by side: every instruction moves 512 contiguous bytes)
 };
 
 template <int NL, int FL, int E, int DEPTH, int PAIR, int W16 = 0>
@@ -79,6 +79,11 @@ __global__ void __launch_bounds__(128, 1) stream_kernel(const Args A) {
         } else if (W16) {
 #pragma unroll
           for (int i = 0; i < NI; i++) { const d2 v = *reinterpret_cast<const d2*>(base + (ISRHS[s] ? roff[i] : voff[i]) + c * 8); st[r][i] = v.x; stb[r][i] = v.y; }
+        } else if (A.flags & 4) {
+          const long long e0 = (long long)A.seg[s] + pos + c * 8 + le;          // element of the lane inside a problem's array
+          const double* wb = (ISRHS[s] ? rhs + (long long)prob0 * A.rstride : vals + (long long)prob0 * A.vstride);
+#pragma unroll
+          for (int i = 0; i < NI; i++) st[r][i] = wb[((e0 >> 3) * NL + (i * PPI + lq)) * 8 + (e0 & 7)];
         } else {
 #pragma unroll
           for (int i = 0; i < NI; i++) st[r][i] = base[(ISRHS[s] ? roff[i] : voff[i]) + c * 8];
@@ -130,7 +135,10 @@ __global__ void __launch_bounds__(128, 1) stream_kernel(const Args A) {
         const double x = blk[(i * PPI + lq) * TOT + RING + c * 8 + le];
         if (prob0 + i * PPI + lq < A.batch && !(A.flags & 2)) {
           if (W16) { d2 v; v.x = x; v.y = blk[(i * PPI + lq) * TOT + RING + c * 8 + le + 1]; *reinterpret_cast<d2*>(outbase + loff[i] + (long long)ep * (E * OUTR) + c * 8) = v; }
-          else outbase[loff[i] + (long long)ep * (E * OUTR) + c * 8] = x;
+          else if (A.flags & 4) {
+            const long long e0 = (long long)part * (A.lstride / 2) + (long long)ep * (E * OUTR) + c * 8 + le;
+            (A.L + (long long)prob0 * A.lstride)[((e0 >> 3) * NL + (i * PPI + lq)) * 8 + (e0 & 7)] = x;
+          } else outbase[loff[i] + (long long)ep * (E * OUTR) + c * 8] = x;
         }
       }
   };
@@ -201,7 +209,8 @@ int main(int argc, char** argv) {
   // what bounds the skeleton: every problem aliased onto problem 0 (cache hits), loads only, stores only
   for (int alias = 0; alias < 2; alias++) {
     if (alias) { A.vstride = 0; A.rstride = 0; }
-    for (int fl = 0; fl < 3; fl++) {
+    for (int fl : {0, 1, 2, 4, 6}) {
+      if (alias && fl >= 4) continue;
       A.flags = fl;
       A.batch = 512 * 24;
       if (run<24, 60, 8, 1, 0, 0>(alias ? "two workgroups per CU, ALL PROBLEMS READ PROBLEM 0" : "two workgroups per CU", A)) return 1;
