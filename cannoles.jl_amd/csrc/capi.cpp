@@ -294,18 +294,14 @@ int setup_v2(cnl_handle* h) {
       h->resident_waves = (int)std::min<long long>(resident, 1 << 20);
     }
   }
-  // Plans with out-of-line front classes (order 17 .. 64) or product lists run staged too, WITHOUT the in-kernel (fused) rho ladder.
-  // History: round 4's randomised run found wrong rho-ladder decisions and memory faults on such plans that depended on what earlier
-  // kernels had left in scratch / LDS / registers, and fenced the whole staged execution off.  Round 5 found two real overflows with
-  // the same tool — the update-matrix slots of the global scratch were padded for 16-lane rows whatever the class of the front
-  // (analysis.cpp: up to 47 doubles of the next slot overwritten, a slot another wavefront uses at the same time), and the class-64
-  // elimination publishes its pivot row two doubles past the LDS staging area (setup above) — and narrowed what is left: with both
-  // fixed, 12 000 cases with garbage everywhere are clean on the staged first attempt, try_to_factorize and solve_ldl!
-  // (gpurun_out/fuzz_slf1_noladder.txt), while the FUSED ladder instantiation on such plans still faults (a spin limit, the
-  // register budget and the commit launch are ruled out: DESIGN 4c).  So the restriction is now the ladder alone: problems that
-  // fail the staged attempt take the sequential launch (device pointers) or the host-driven ladder (host pointers).
-  // cnl_options.staged_large_fronts = 1 (experiment builds only) turns the fused ladder on there, for the hunt.
-  const bool fast_class_only = P.ncls[1] == 0 && P.ncls[2] == 0 && P.listprod_fronts == 0;
+  // Rounds 4 - 5, for the record: staged handles on plans with out-of-line front classes (order 17 .. 64) gave
+  // history-dependent wrong decisions and memory faults.  Three causes, all found with garbage left in LDS / scratch / registers in
+  // front of every launch (CNL_DBG_SCRATCHFILL, CNL_DBG_LDSFILL) and tools/fuzz_parity.py: the update-matrix slots of the global scratch
+  // were padded for 16-lane rows whatever the class of the front (analysis.cpp); the class-64 elimination publishes its pivot row two
+  // doubles past the LDS staging area (setup above); and — the one that survived both — the compiler placed the register spills of the
+  // call to the out-of-line front path IN FRONT of the EXEC restore of the join block behind the lane-divergent `if (dep_wait)`, so a
+  // task with nothing to wait for stored no spills and reloaded garbage (kernels2.hip: DEP_WAITING; tools/check_spill_exec.py checks the
+  // ISA of every build for the pattern).  No restriction is left: every stageable plan runs staged, with the in-kernel ladder.
   if (!P.tasks.empty() && P.rec_direct && P.d_outer && d.count_d && o.staged) {
     std::vector<int32_t> tk;
     for (const cnl::Task& t : P.tasks) { tk.push_back(t.rec_off); tk.push_back(t.f1 - t.f0); tk.push_back(t.brec_off); tk.push_back(t.is_root); tk.push_back(t.parent); tk.push_back(t.nchild); }
@@ -341,7 +337,7 @@ int setup_v2(cnl_handle* h) {
     // Plans of a few LARGE tasks (the bidirectional chain of mid-size batches) keep the sequential launch when one fused launch
     // cannot hold the batch: a rung there is the same chain of fronts either way, and two fused launches of two wavefronts per SIMD
     // lose to one sequential launch of one (cfg5 at 4096 problems: 3.9 against 2.9 ms).
-    if (o.device_ladder && h->resident_waves >= h->ntasks && (fast_class_only || o.staged_large_fronts != 0)) {
+    if (o.device_ladder && h->resident_waves >= h->ntasks) {
       const long long slots = h->resident_waves / h->ntasks, nq = (h->batch + 3) / 4;
       const long long launches = (nq + slots - 1) / slots;
       if (launches == 1 || (launches <= 4 && h->ntasks >= 16)) h->lad_mode = o.device_ladder_fused ? 2 : 1;
@@ -895,12 +891,6 @@ static int resolve_options(const cnl_options* in, cnl_options& out) {
   if (in->struct_size != (int32_t)sizeof(cnl_options)) return fail(CNL_ERR_ARG, "cnl_options.struct_size does not match this library (use cnl_options_init)");
   out = *in;
   out.force_order[sizeof(out.force_order) - 1] = 0;
-#ifndef CNL_EXPERIMENT
-  // (round 5) the in-kernel ladder on plans with out-of-line front classes still faults (the staged execution itself
-  // is fixed and back): not selectable in a product build
-  if (out.staged_large_fronts != 0)
-    return fail(CNL_ERR_ARG, "cnl_options.staged_large_fronts needs an experiment build (-DCNL_EXPERIMENT=1): the in-kernel ladder on plans with large fronts is known to be wrong");
-#endif
   return CNL_OK;
 }
 

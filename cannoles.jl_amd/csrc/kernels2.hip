@@ -736,16 +736,34 @@ static_assert(PVR == ROWS_KM + 1, "the raw-value prefetch registers double as th
 // index order, a time-sliced device — must not hang the device): a wait that gives up is COUNTED in status_total / status_call,
 // and the classic launch that follows every staged attempt then redoes the whole batch sequentially, so a timeout costs time,
 // never a wrong result.  Once one wait of the call has given up the others stop waiting at once.
-__device__ __forceinline__ void spin_until(const int* p, int target, int limit, int* status_total, int* status_call) {
-  bool ok = false;
+#ifdef CNL_DBG_TRACE   // experiment builds: records of four ints in a device buffer, printed by the launcher behind the ladder launch
+__device__ int cnl_trace_buf[1 << 16];
+__device__ int cnl_trace_n;
+#define CNL_TRACE(TAG, A_, B_, C_) do { if ((threadIdx.x & 63) == 0) { const int i_ = atomicAdd(&cnl_trace_n, 4); if (i_ < (1 << 16) - 4) { cnl_trace_buf[i_] = (TAG) | ((int)blockIdx.x << 8); cnl_trace_buf[i_ + 1] = (A_); cnl_trace_buf[i_ + 2] = (B_); cnl_trace_buf[i_ + 3] = (C_); } } } while (0)
+#else
+#define CNL_TRACE(TAG, A_, B_, C_) do { } while (0)
+#endif
+// Every branch of the wait is WAVE-UNIFORM by construction (the polled values go through readfirstlane, the give-up bookkeeping is
+// done by all lanes, 63 of which add zero).  Round 5, the root of the staged-execution fault of round 4 on plans with out-of-line
+// front classes: with the natural form — `if (!ok && lane == 0) { atomics }` — the region is lane-divergent for the compiler, and
+// in the instantiations that CALL slow_front right behind a wait it placed the register spills that belong in front of the call
+// into the tail of that region, i.e. on a path the regular case never takes: the reloads behind the call then returned whatever
+// earlier kernels had left in scratch memory (pointers among them).  Garbage-filled scratch made it deterministic, zeroed scratch
+// hid it; ending the wavefront in the give-up branch (a tracing build) made it disappear.  
+__device__ __forceinline__ void spin_until(const int* p, int target, int limit, int* status_total, int* status_call, [[maybe_unused]] int site = 0) {
+  int ok = 0;
   for (int it = 0; it < limit; it++) {
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
-    if ((it & 255) == 255 && __hip_atomic_load(status_call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= target) { ok = 1; break; }
+    if ((it & 255) == 255 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(status_call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
     __builtin_amdgcn_s_sleep(4);
   }
-  if (!ok && (threadIdx.x & 63) == 0) {
-    __hip_atomic_fetch_add(status_total, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(status_call, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CNL_DBG_TRACE
+  if (!ok) { CNL_TRACE(9, target, __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), site); __builtin_amdgcn_endpgm(); }
+#endif
+  if (!ok) {   // scalar branch
+    const int one = (threadIdx.x & 63) == 0 ? 1 : 0;
+    __hip_atomic_fetch_add(status_total, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(status_call, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #ifndef CNL_DF_NOFENCE   // (timing probe: -DCNL_DF_NOFENCE drops both fences; results are then not guaranteed)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -812,6 +830,11 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   // deep, and the start-up latency of a task, not its fronts, is most of its critical path.
   const int* dep_wait = nullptr;
   int dep_target = 0;
+  // A wave-uniform test BY CONSTRUCTION (readfirstlane): the pointer is the same in all lanes, but the compiler cannot know (it derives
+  // from the wavefront's index), and a lane-divergent `if (dep_wait)` in front of a call made it place the register spills of the call
+  // in front of the EXEC restore of the join block — reached with EXEC = 0 whenever there was nothing to wait for, so the spills stored
+  // nothing (tools/check_spill_exec.py finds the pattern in the ISA)
+#define DEP_WAITING (__builtin_amdgcn_readfirstlane(dep_wait != nullptr ? 1 : 0) != 0)
   int t_nchild_l = 0, t_parent_l = -1, tix_l = 0;   // fused ladder launch (phase 2): the task's links, kept for every rung
   [[maybe_unused]] int* lad = nullptr;              // ... and the control block of its group of problems
   if constexpr (STAGED) {
@@ -971,7 +994,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       PREFETCH_ROWS(lr, lp0, HDRW(hv0, R_NUPD), HDRW(hv0, R_NPIV))
     }
     for (int s = 0; s < nfr; s++) {
-      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }  // children's update vectors are read below
+      if constexpr (STAGED) if (DEP_WAITING) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }  // children's update vectors are read below
       const int* rec = recw;
       const int hv = rec[lane & 15];
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM), nasmv = HDRW(hv, R_NASMV);
@@ -1164,7 +1187,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         const bool fast0 = (fw0 >> 8) == 16 && !(fw0 & RF_FS_GLOBAL);
         if (!CNL_LEAN && !fast0) {
           // rare: large or globally staged front, handled out of line
-          if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }
+          if constexpr (STAGED) if (DEP_WAITING) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call), 1); dep_wait = nullptr; }
           if (!(CNL_ABL & 2048)) slow_front(P.rec, A.vals, has_rhs ? A.rhs : nullptr, A.L, A.scratch, A.batch, lane, prob0, recw, roff, pbase0, cnt, eig_tol, rho, ovr, P.count_d != 0);
           gsync();
           roff = nxt_off;
@@ -1182,7 +1205,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
       bool more = true;
       bool img_clean = false;  // the staging image is known to be all zeros
       while (more) {
-      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }  // children's update matrices are read below
+      if constexpr (STAGED) if (DEP_WAITING) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call), 2); dep_wait = nullptr; }  // children's update matrices are read below
       const int* rec = recw;
       const int hv = rec[lane & 15];
       const int npiv = HDRW(hv, R_NPIV), nupd = HDRW(hv, R_NUPD), nasm = HDRW(hv, R_NASM);
@@ -1475,7 +1498,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) __hip_atomic_store(lad + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        spin_until(lad + 1, 2 * rung, A.spin_limit, as_global(A.status_total), as_global(A.status_call));
+        spin_until(lad + 1, 2 * rung, A.spin_limit, as_global(A.status_total), as_global(A.status_call), 3);
         epoch = rfl(__hip_atomic_load(lad + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       }
       // a wait that gave up anywhere: the sequential launch behind this one redoes the call; leave
@@ -1577,7 +1600,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
         PREFETCH_ROWS(lr, lp0, nupd0, npiv0)
         primed = true;
       }
-      if constexpr (STAGED) if (dep_wait) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call)); dep_wait = nullptr; }  // the parent's x is read below
+      if constexpr (STAGED) if (DEP_WAITING) { spin_until(dep_wait, dep_target, A.spin_limit, as_global(A.status_total), as_global(A.status_call), 4); dep_wait = nullptr; }  // the parent's x is read below
       const int* rec = recw;
       const int hb = rec[lane & 7];
       const int npiv = HDRW(hb, B_NPIV), nupd = HDRW(hb, B_NUPD), xoff = HDRW(hb, B_XOFF), pxoff = HDRW(hb, B_PXOFF);
@@ -1824,6 +1847,26 @@ hipError_t launch_newton2_staged(const DevPlan2& P, int wpb, size_t lds_bytes, L
     for (int q = s_df - 1; q >= 0; q--) launch_range(1, stage_ptr[q], stage_ptr[q + 1]);
   }
   if (ladder) launch_ladder(0);  // the problems that failed the attempt climb the rho ladder here (the other groups' wavefronts exit at once)
+#ifdef CNL_DBG_TRACE
+  if (ladder) {
+    (void)hipStreamSynchronize(stream);
+    static int hb[1 << 16];
+    int n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(cnl_trace_n), sizeof(int));
+    (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(cnl_trace_buf), sizeof(hb));
+    fprintf(stderr, "[trace] ladder launch: ntasks_all %d nquads %d batch %d, %d records\n", ntasks_all, a.nquads, a.batch, n / 4);
+    for (int i = 0; i + 3 < n && i < (1 << 16) - 4; i += 4) {
+      const int tag = hb[i] & 255, wg = hb[i] >> 8;
+      if (tag == 1) fprintf(stderr, "[trace] wg %d START task %d widx %d nchild %d nfr %d parent %d\n", wg, hb[i + 1] & 0xffff, hb[i + 1] >> 16, hb[i + 2] & 0xffff, hb[i + 2] >> 16, hb[i + 3]);
+      else if (tag == 2) fprintf(stderr, "[trace] wg %d task %d END OF RUNG %d tpos %d tzer %d\n", wg, hb[i + 1] & 0xffff, hb[i + 1] >> 16, hb[i + 2], hb[i + 3]);
+      else if (tag == 3) fprintf(stderr, "[trace] wg %d task %d rung %d fin %d epoch %d\n", wg, hb[i + 1] & 0xffff, hb[i + 1] >> 16, hb[i + 2], hb[i + 3]);
+      else if (tag == 9) fprintf(stderr, "[trace] wg %d GIVE UP at site %d: wants %d has %d\n", wg, hb[i + 3], hb[i + 1], hb[i + 2]);
+      else fprintf(stderr, "[trace] wg %d tag %d: %d %d %d\n", wg, tag, hb[i + 1], hb[i + 2], hb[i + 3]);
+    }
+    n = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(cnl_trace_n), &n, sizeof(int));
+  }
+#endif
   if (a.mode == MODE_FACTOR)
     hipLaunchKernelGGL(staged_decide_kernel, dim3((a.batch + 255) / 256), dim3(256), 0, stream, a.gcnt, P.nvar, a.batch, a.success, a.npos, a.nzero);
   return hipGetLastError();

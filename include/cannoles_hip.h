@@ -126,11 +126,10 @@ typedef struct cnl_options {
                                   staged_max_batch + r problems, r <= staged_max_batch / 4 (first part on the bidirectional
                                   chain), and k full loads of the single stream (four problems per resident wavefront: 8192 at
                                   cfg3's size) + r problems; 0: split_batch's two halves / the single stream's extra round        */
-  int32_t staged_large_fronts; /* 0 (default): on plans with out-of-line front classes (order 17 .. 64) or product lists the staged
-                                  execution runs WITHOUT the in-kernel rho ladder (failed problems take the sequential launch / the
-                                  host-driven ladder): that instantiation is KNOWN TO BE WRONG there (memory faults).  1 turns
-                                  it on all the same and is accepted only by an experiment build of the library
-                                  (-DCNL_EXPERIMENT=1, cnl_version() < 0); a product build answers CNL_ERR_ARG                    */
+  int32_t staged_large_fronts; /* no effect since round 5 (kept for the layout of the structure): rounds 4 - 5 fenced the staged
+                                  execution / the in-kernel ladder off on plans with fronts of order 17 .. 64 while a fault there
+                                  was hunted; its cause — register spills the compiler placed in front of an EXEC restore — is
+                                  removed, every stageable plan runs staged with the in-kernel ladder               */
   int32_t band_kernel;         /* (round 5) 1 (default): a throughput handle whose pattern is a band in the natural order of the
                                   variables (every residual row and Hessian entry within five consecutive variables, every
                                   constraint row a run of its own) runs newton_system on the band kernels (csrc/band.h: one lane per
