@@ -329,6 +329,39 @@ def test_f1_trial_point(built):
     assert np.linalg.norm(tdl[1].cpu().numpy()) <= 1e4 * (1 + 1e-14)
 
 
+def test_aux_kernels_beyond_the_grid_limit(built):
+    """prepare_newton_system! and the trial point for MORE problems than a grid dimension holds (65 535): the kernels walk the
+    problems with a clamped second grid dimension; first, last and the problems either side of the limit against the oracle"""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(24, 2)
+    B = 66000
+    rows, cols = s.kkt_pattern()
+    nnz = len(rows)
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(band_kernel=0))
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    mk = lambda n: torch.randn((B, n), dtype=torch.float64, device=dev, generator=g)
+    nhF, nhc, njF, njc = len(s.hF[0]), len(s.hc[0]), len(s.jF[0]), len(s.jc[0])
+    hF, hc, Jx, Jc, de = mk(nhF), mk(nhc), mk(njF), mk(njc), mk(1).abs().reshape(B).contiguous()
+    vals = torch.full((B, nnz), 7.0, dtype=torch.float64, device=dev)
+    hipldl.prepare_newton_system_dev(L, nhF, nhc, njF, njc, hF.data_ptr(), hc.data_ptr(), Jx.data_ptr(), Jc.data_ptr(), de.data_ptr(), vals.data_ptr(), 0)
+    x, r, lam, d = mk(s.nvar), mk(s.nequ), mk(s.ncon), mk(s.N)
+    xt, rt, lt, dl = torch.zeros_like(x), torch.zeros_like(r), torch.zeros_like(lam), torch.zeros_like(lam)
+    hipldl.trial_point_dev(L, x.data_ptr(), r.data_ptr(), lam.data_ptr(), d.data_ptr(), 1e4, xt.data_ptr(), rt.data_ptr(), lt.data_ptr(), dl.data_ptr(), 0)
+    torch.cuda.synchronize()
+    c = lambda a, b: a[b].cpu().numpy()
+    for b in (0, 65534, 65535, 65536, B - 1):
+        v0 = np.full(nnz, 7.0)
+        O.prepare(v0, s.nvar, s.nequ, s.ncon, nhF, nhc, njF, njc, c(hF, b), c(hc, b), c(Jx, b), c(Jc, b), float(de[b]))
+        assert np.array_equal(c(vals, b), v0), b
+        xt0, rt0, lt0, dl0 = O.trial_point(s.nvar, s.nequ, s.ncon, c(x, b), c(r, b), c(lam, b), c(d, b), 1e4)
+        assert np.array_equal(c(xt, b), xt0) and np.array_equal(c(rt, b), rt0), b
+        np.testing.assert_allclose(c(dl, b), dl0, rtol=4e-15, atol=0)
+        np.testing.assert_allclose(c(lt, b), lt0, rtol=4e-15, atol=1e-300)
+    L.close()
+
+
 @pytest.mark.parametrize("hw", [1, 3, 4])
 def test_band_halfwidths_general_residual_pivots(built, hw):
     """Band families with other Jacobian half-widths: longer raw-value / product lists (several product rounds, raw
