@@ -614,14 +614,17 @@ __global__ void __launch_bounds__(256) trial_point_kernel(const DevJt J, const d
                                                           double* __restrict__ lambdat, double* __restrict__ dlambda, int batch) {
   const int t = threadIdx.x;
   __shared__ double part[4];
-  for (long long b = blockIdx.y; b < batch; b += gridDim.y) {   // (gridDim.y is clamped to the launch limit of 65535)
+  // one grid dimension (a second one ends at 65 535 problems): workgroup = (problem, chunk)
+  const int nch_ = (J.nvar + J.nequ + 256 * TP_UNROLL - 1) / (256 * TP_UNROLL) > 0 ? (J.nvar + J.nequ + 256 * TP_UNROLL - 1) / (256 * TP_UNROLL) : 1;
+  const long long b = blockIdx.x / nch_;
+  const int chunk = blockIdx.x % nch_;
   const double* db = d + b * J.N;
   {
     const int nxr = J.nvar + J.nequ;   // d[0 .. nvar + nequ) = [dx | dr] lines up with [x | r]
     double a[TP_UNROLL], c[TP_UNROLL];
 #pragma unroll
     for (int j = 0; j < TP_UNROLL; j++) {
-      const int k = blockIdx.x * (256 * TP_UNROLL) + j * 256 + t;
+      const int k = chunk * (256 * TP_UNROLL) + j * 256 + t;
       a[j] = 0.0; c[j] = 0.0;
       if (k < nxr) {
         a[j] = __builtin_nontemporal_load(k < J.nvar ? x + b * J.nvar + k : r + b * J.nequ + (k - J.nvar));
@@ -630,12 +633,11 @@ __global__ void __launch_bounds__(256) trial_point_kernel(const DevJt J, const d
     }
 #pragma unroll
     for (int j = 0; j < TP_UNROLL; j++) {
-      const int k = blockIdx.x * (256 * TP_UNROLL) + j * 256 + t;
+      const int k = chunk * (256 * TP_UNROLL) + j * 256 + t;
       if (k < nxr) __builtin_nontemporal_store(a[j] + c[j], k < J.nvar ? xt + b * J.nvar + k : rt + b * J.nequ + (k - J.nvar));
     }
   }
-  if (blockIdx.x != 0) continue;
-  __syncthreads();   // (part is reused by the next problem of this workgroup)
+  if (chunk != 0) return;
   double ss = 0.0;
   for (int k = t; k < J.ncon; k += 256) { const double v = db[J.nvar + J.nequ + k]; ss += v * v; }
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -647,7 +649,6 @@ __global__ void __launch_bounds__(256) trial_point_kernel(const DevJt J, const d
     if (nrm > max_dlambda) dl = dl * max_dlambda / nrm;  // same operation order as dλ .= dλ .* Mdλ ./ norm(dλ)
     dlambda[b * J.ncon + k] = dl;
     lambdat[b * J.ncon + k] = lambda[b * J.ncon + k] + dl;
-  }
   }
 }
 
@@ -664,13 +665,16 @@ __global__ void __launch_bounds__(256) prepare_kernel(int nnzhF, int nnzhc, int 
   // four slots per thread, 256 apart (coalesced 8-byte accesses), every load issued before the first store; the data are touched
   // once: non-temporal.  (One slot per thread: 0.62 of the HBM rate on 1.68 MB per system, bound by the number of workgroups.)
   const int o1 = nnzhF, o2 = o1 + nnzhc, o3 = o2 + nnzjF, o4 = o3 + nnzjc, o5 = o4 + nequ, o6 = o5 + ncon, nnz = o6 + nvar;
-  for (long long b = blockIdx.y; b < batch; b += gridDim.y) {   // (gridDim.y is clamped to the launch limit of 65535)
+  // one grid dimension (a second one ends at 65 535 problems): workgroup = (problem, chunk of 1 024 slots)
+  const int nch_ = (nnz + 256 * PREP_UNROLL - 1) / (256 * PREP_UNROLL);
+  const long long b = blockIdx.x / nch_;
+  const int chunk = blockIdx.x % nch_;
   double* v = vals + b * nnz;
   double x[PREP_UNROLL];
   bool st[PREP_UNROLL];
 #pragma unroll
   for (int j = 0; j < PREP_UNROLL; j++) {
-    const int k = blockIdx.x * (256 * PREP_UNROLL) + j * 256 + threadIdx.x;
+    const int k = chunk * (256 * PREP_UNROLL) + j * 256 + threadIdx.x;
     x[j] = 0.0; st[j] = false;
     if (k >= nnz) continue;
     if (k < o1) { if (hF) { x[j] = __builtin_nontemporal_load(hF + b * nnzhF + k); st[j] = true; } }
@@ -683,9 +687,8 @@ __global__ void __launch_bounds__(256) prepare_kernel(int nnzhF, int nnzhc, int 
   }
 #pragma unroll
   for (int j = 0; j < PREP_UNROLL; j++) {
-    const int k = blockIdx.x * (256 * PREP_UNROLL) + j * 256 + threadIdx.x;
+    const int k = chunk * (256 * PREP_UNROLL) + j * 256 + threadIdx.x;
     if (st[j]) __builtin_nontemporal_store(x[j], v + k);
-  }
   }
 }
 
@@ -792,7 +795,7 @@ hipError_t launch_cgls(const DevJt& J, const double* vals, const double* r, doub
 hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon, const double* hF, const double* hc,
                           const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, hipStream_t stream) {
   const int nnz = nnzhF + nnzhc + nnzjF + nnzjc + nequ + ncon + nvar;
-  hipLaunchKernelGGL(prepare_kernel, dim3((nnz + 256 * PREP_UNROLL - 1) / (256 * PREP_UNROLL), std::min(batch, 65535)), dim3(256), 0, stream, nnzhF, nnzhc, nnzjF, nnzjc, nvar, nequ, ncon,
+  hipLaunchKernelGGL(prepare_kernel, dim3((unsigned)((long long)((nnz + 256 * PREP_UNROLL - 1) / (256 * PREP_UNROLL)) * batch)), dim3(256), 0, stream, nnzhF, nnzhc, nnzjF, nnzjc, nvar, nequ, ncon,
                      hF, hc, Jx, Jcx, delta, vals, batch);
   return hipGetLastError();
 }
@@ -818,7 +821,7 @@ hipError_t launch_trial_point(const DevJt& J, const double* x, const double* r, 
                               double max_dlambda, double* xt, double* rt, double* lambdat, double* dlambda, int batch,
                               hipStream_t stream) {
   const int nch = std::max(1, (J.nvar + J.nequ + 256 * TP_UNROLL - 1) / (256 * TP_UNROLL));
-  hipLaunchKernelGGL(trial_point_kernel, dim3(nch, std::min(batch, 65535)), dim3(256), 0, stream, J, x, r, lambda, d, max_dlambda, xt, rt, lambdat, dlambda,
+  hipLaunchKernelGGL(trial_point_kernel, dim3((unsigned)((long long)nch * batch)), dim3(256), 0, stream, J, x, r, lambda, d, max_dlambda, xt, rt, lambdat, dlambda,
                      batch);
   return hipGetLastError();
 }
