@@ -31,7 +31,21 @@ FP64_MFMA_SPEC_TFLOPS = 78.6       # datasheet fp64 matrix peak
 FP64_MFMA_MEASURED_TFLOPS = 47.8   # v_mfma_f64_16x16x4_f64 loop, 4 waves/SIMD x 8 accumulators (profiles/r02_microbench.json)
 CANONICAL_NNZL_CFG3 = 346209  # nnz(L) of the order "r, x natural, lambda" at n=1e4, p=50
 CANONICAL_NNZL_CFG4 = 14529   # the same order at n=1e3, p=10 (BASELINE config 4 / 5)
-TRAFFIC_FILE = "r04_traffic.json"
+PARITY_TOL = 1e-9   # bench.py FAILS (exit 3) when the timed kernel's solutions differ from the oracle's by more than this (relative, max norm)
+
+
+def traffic_record(root, batch, workload, kernel):
+    """newest profiles/r*_traffic.json whose batch, workload and kernel family match this run (HBM bytes per launch of the dominant
+    kernel from separate rocprofv3 --pmc passes of the same command; tools/summarize_profiles.py writes it)"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(root, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+        except Exception:
+            continue
+        if tj.get("batch") == batch and tj.get("workload") == list(workload) and kernel.split("_kernel")[0] in str(tj.get("kernel", "")):
+            return tj, os.path.basename(path)
+    return None, None
 
 
 def band_batch(s, B, seed):
@@ -310,13 +324,16 @@ def main():
     nnzL_star = min(info["nnzL_exact"], CANONICAL_NNZL_CFG3) if headline else info["nnzL_exact"]
     b_alg = 12 * s.nnzNS + 24 * s.N + 32 * nnzL_star
     achieved = b_alg * B / (kern_ms * 1e-3) / 1e9
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-    if os.path.exists(tpath):  # HBM bytes per launch of the dominant kernel from separate rocprofv3 PMC passes of this command
-        tj = json.load(open(tpath))
-        if tj.get("batch") == B and tj.get("workload") == [args.n, args.ncon]:
-            traffic = tj.get("hbm_bytes_per_launch")
-            traffic_src = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, not measured by this run)"
+    traffic, traffic_src, traffic_raw = None, None, None
+    kname = "band_newton_kernel" if band else "newton2_kernel"
+    tj, tfile = traffic_record(ROOT, B, (args.n, args.ncon), kname)
+    if tj:  # HBM bytes per launch of the dominant kernel from separate rocprofv3 PMC passes of this command
+        traffic, traffic_raw = tj.get("hbm_bytes_per_launch"), tj.get("raw_sum_bytes")
+        traffic_src = f"profiles/{tfile} (rocprofv3 --pmc passes of this command, not measured by this run)"
+    # what the kernel itself has to move: the band kernels keep no L for the condensed rows (they re-read J in the
+    # backward sweep) — per pivot 15 doubles read + 6 written forward, 13 read + 2 written backward; B_alg above is the CONTRACT figure
+    #  and no bound on this kernel's traffic, so the fraction on the kernel's own bytes is printed beside it
+    kernel_bytes = band_kernel_bytes(LDLT, s) if band else None
     out = {
         "metric": "Newton systems/sec (fp64), batched n=1e4 NLS; achieved HBM GB/s vs peak",
         "value": value, "unit": "systems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -332,7 +349,11 @@ def main():
                      "frac_of_measured_copy_rate": achieved / HBM_MEASURED_GBPS, "peak_measured_copy": HBM_MEASURED_GBPS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "measured_hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                     "bytes_per_system": b_alg, "nnzL_star": nnzL_star, "kernel_ms": kern_ms, "kernel": "band_newton_kernel" if band else "newton2_kernel",
+                     "traffic_raw_counters": traffic_raw,
+                     "kernel_bytes_per_system": kernel_bytes,
+                     "frac_on_kernel_bytes": (kernel_bytes * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kernel_bytes else None,
+                     "traffic_over_kernel_bytes": (traffic / (kernel_bytes * B)) if (traffic and kernel_bytes) else None,
+                     "bytes_per_system": b_alg, "nnzL_star": nnzL_star, "kernel_ms": kern_ms, "kernel": kname,
                      "units_per_launch": B,
                      "forward_sweep_ms": fwd_ms, "backward_sweep_ms": (kern_ms - fwd_ms) if fwd_ms else None,
                      "kernel_is_whole_step": band or (bool(LDLT.config.get("lean")) and bool(LDLT.plan_array("brec")[7] & 256)),
@@ -344,15 +365,42 @@ def main():
     extras = (not args.no_extras) and world == 1 and not args.strong
     if extras:
         extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_h, prob, B, dev, local_rank, stream, args)
+    out["value_batch_per_gpu"] = B
+    if _dig(out.get("small_batch"), ("B8192", "systems_per_s")) is not None:
+        out["value_at_batch_8192"] = out["small_batch"]["B8192"]["systems_per_s"]   # rounds 1-4 quoted `value` at this batch
     if args.cpu_sample != 0 and world == 1:
         cpu_baseline(out, s, rows, cols, vals_h, rhs_h, prob, LDLT, args)
     # the long line first (every block, for profiles/), then a COMPACT FINAL LINE (<= 1.8 KB) with the mandated keys and one number
     # per configuration, so that a reader of the tail of this process's output has every config's figure
+    # parity guard of the TIMED configuration: the solutions the timed kernel left in HBM against the oracle's
+    # (max_rel_diff_vs_gpu of the cpu_baseline leg) and the backward errors of the first problems; a miss fails the bench
+    perr = out.get("cpu_baseline", {}).get("max_rel_diff_vs_gpu")
+    guard = {"all_success": bool(ok), "backward_error": berr, "backward_tol": 1e-12, "max_rel_diff_vs_oracle": perr, "oracle_tol": PARITY_TOL}
+    guard["ok"] = bool(ok) and berr <= 1e-12 and (perr is None or perr <= PARITY_TOL)
+    out["parity_guard"] = guard
     print(json.dumps(out))
     print(json.dumps(compact_line(out)))
     prob.close()
     if dist is not None:
         dist.destroy_process_group()
+    if not guard["ok"]:
+        print(f"bench.py: parity guard FAILED: {guard}", file=sys.stderr)
+        sys.exit(3)
+
+
+def band_kernel_bytes(LDLT, s):
+    """bytes one band_newton_kernel launch necessarily moves per system: every COO value and right-hand-side entry once in the forward
+    sweep, the factor records written once and read once, the Jacobian / -I entries of the condensed rows and their right-hand sides
+    a second time in the backward sweep, d written once"""
+    bi = LDLT.plan_array("band_info")
+    lsz = 0
+    for q in range(int(bi[1])):
+        lsz += int(LDLT.plan_array(f"band_part{q}")[3]) * 6   # factor events x BAND_LREC doubles
+    nnzj = len(s.jF[0]) + len(s.jc[0])
+    fwd = 8 * (s.nnzNS + s.N) + 8 * lsz
+    bwd = 8 * lsz + 8 * (len(s.jF[0]) + 2 * s.nequ) + 8 * s.N
+    del nnzj
+    return fwd + bwd
 
 
 def compact_line(out):
@@ -363,7 +411,8 @@ def compact_line(out):
     c["config"] = {"workload": cfg["workload"], "batch_per_gpu": cfg["batch_per_gpu"], "kernel": "band" if cfg["kernel"].get("band") else cfg["kernel"].get("kernel"),
                    "all_success": cfg["all_success"], "backward_error": cfg["backward_error"]}
     r = out["roofline"]
-    c["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_system", "units_per_launch")}
+    c["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_system", "units_per_launch",
+                                       "kernel_bytes_per_system", "frac_on_kernel_bytes", "traffic_over_kernel_bytes")}
     if "cpu_baseline" in out:
         b = out["cpu_baseline"]
         c["cpu_baseline"] = {k: b[k] for k in ("value", "unit", "cores", "kind", "sample") if k in b}
@@ -383,6 +432,14 @@ def compact_line(out):
         "single_system_host_ms": g("call_pattern_single_system", "newton_system_ms"), "multi_front_end_ratio": g("multi_front_end", "ratio_to_single_handle"),
     }
     c["summary"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items() if v is not None}
+    if "parity_guard" in out:
+        c["parity_guard"] = {k: out["parity_guard"][k] for k in ("ok", "max_rel_diff_vs_oracle", "backward_error")}
+    # the default batch moved from 8192 (rounds 1-4) to 16384 in round 5 — say which batch `value` is measured on, and
+    # carry the 8192-problem figure as a top-level key whenever this run measured it
+    c["value_batch_per_gpu"] = cfg["batch_per_gpu"]
+    b8 = g("small_batch", "B8192", "systems_per_s")
+    if b8 is not None:
+        c["value_at_batch_8192"] = b8
     return c
 
 

@@ -308,7 +308,11 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lq = lane >> 3, le = lane & 7;
   const int prob0 = blockIdx.x * NL;
-  const bool has_rhs = mode == MODE_NEWTON && grhs != nullptr;
+  // MODE_SOLVE = solve_ldl! behind a factorisation of this handle (src/solver_types.jl:69-77): the band kernels keep no factor a later
+  // right-hand side could be run through (their six-double records hold z = c / d of the ONE right-hand side they were computed with),
+  // so the solve factorises the same values again — the rho slots hold what the ladder left — and sweeps the new right-hand side
+  // in the same launch: the arithmetic of the first attempt of newton_system!, no ladder, no outputs but d.
+  const bool has_rhs = mode != MODE_FACTOR && grhs != nullptr;
   char* wblk = reinterpret_cast<char*>(lds + (size_t)part * NL * LANE_D);
   char* recb = reinterpret_cast<char*>(lds + (size_t)P.nparts * NL * LANE_D) + (size_t)part * BAND_REC_MAX * 4;
   double* ctrl = reinterpret_cast<double*>(reinterpret_cast<char*>(lds + (size_t)P.nparts * NL * LANE_D) + (size_t)P.nparts * BAND_REC_MAX * 4);
@@ -485,8 +489,9 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       }
       // factor records: the out ring holds those of half an epoch; whole 64-byte pieces are read from it (all reads first), lanes
       // past the records do not store
+      // (try_to_factorize keeps no records: a later solve_ldl! factorises again, see MODE_SOLVE above)
 #define BAND_LFLUSH(LB, LC)                                                                                                 \
-      {                                                                                                                     \
+      if (mode != MODE_FACTOR) {                                                                                            \
         const int lc_ = (LC);                                                                                               \
         const int lb_ = (LB) + loff8;                                                                                       \
         char* lout = reinterpret_cast<char*>(lbase_g) + ((LINT ? (long long)(lb_ >> 3) * (NL * 8) : (long long)lb_) << 3);  \
@@ -589,6 +594,9 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
           if (Ain.nzero) as_global(Ain.nzero)[cprob] = tzer;
         }
         done = true;
+      } else if (mode == MODE_SOLVE) {
+        success = ok;   // (a problem whose factorisation fails the inertia rule has no factor: its rows of d stay untouched)
+        done = true;
       } else if (!done) {
         nfact++;
         if (ok) { done = true; success = true; }
@@ -615,7 +623,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     if (alldone) break;
   }
   if (mode == MODE_FACTOR || (BAND_DBG & 1)) {
-    if (mode != MODE_FACTOR && part == 0 && valid) as_global(Ain.success)[cprob] = 1;
+    if (mode == MODE_NEWTON && part == 0 && valid) as_global(Ain.success)[cprob] = 1;
     return;
   }
   // ================= backward: d = -K^-1 rhs where the factorisation succeeded =================
@@ -723,7 +731,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   if (blockIdx.x == 0 && lane == 0) for (int k = 0; k < 12; k++) gd[(long long)prob0 * N + part * 12 + k] = (double)bst_[k];
 #endif
   // ================= outputs of newton_system! =================
-  if (part == 0) {
+  if (part == 0 && mode == MODE_NEWTON) {
     if (nfact > 1 && rho <= rhomax) rho_old = rho;
     if (valid) {
       as_global(Ain.rho)[cprob] = rho;

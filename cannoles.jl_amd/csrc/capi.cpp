@@ -1560,7 +1560,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   cfg[5] = (h->dense || h->gdense) ? 3 : (h->use_v2 ? (h->staged ? 4 : 2) : 1);
   if (h->lean && !h->dense && !h->gdense) cfg[5] |= 16;  // newton_system / factorize run the kernels' LEAN instantiation
   if (h->tail) cfg[5] |= 32;                             // the remainder of the batch runs on a handle of its own (split_tail)
-  if (h->band) cfg[5] |= 64;                             // newton_system runs on the band kernels (csrc/band.h)
+  if (h->band) cfg[5] |= 64 | ((int64_t)h->band_nl << 8) | ((int64_t)h->bd.nparts << 16);   // newton_system runs on the band kernels (csrc/band.h): problems per workgroup, parts
   if (h->djt.rv_ntiles > 0) cfg[5] |= 128;               // row f1 runs on column tiles (kernels.h: DevJt::rv_*)
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;

@@ -792,10 +792,15 @@ hipError_t launch_cgls(const DevJt& J, const double* vals, const double* r, doub
   return hipGetLastError();
 }
 
+// one linear grid dimension (problem, chunk): the product must fit a 31-bit grid (a larger one would truncate silently)
+static inline bool linear_grid_ok(long long nch, long long batch) { return nch > 0 && batch > 0 && nch * batch <= 0x7fffffffLL; }
+
 hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon, const double* hF, const double* hc,
                           const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, hipStream_t stream) {
   const int nnz = nnzhF + nnzhc + nnzjF + nnzjc + nequ + ncon + nvar;
-  hipLaunchKernelGGL(prepare_kernel, dim3((unsigned)((long long)((nnz + 256 * PREP_UNROLL - 1) / (256 * PREP_UNROLL)) * batch)), dim3(256), 0, stream, nnzhF, nnzhc, nnzjF, nnzjc, nvar, nequ, ncon,
+  const long long nch = (nnz + 256 * PREP_UNROLL - 1) / (256 * PREP_UNROLL);   // (0 when nnz == 0: the kernel divides by it)
+  if (!linear_grid_ok(nch, batch)) return hipErrorInvalidConfiguration;
+  hipLaunchKernelGGL(prepare_kernel, dim3((unsigned)(nch * batch)), dim3(256), 0, stream, nnzhF, nnzhc, nnzjF, nnzjc, nvar, nequ, ncon,
                      hF, hc, Jx, Jcx, delta, vals, batch);
   return hipGetLastError();
 }
@@ -804,23 +809,36 @@ hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const dou
                                    const double* cx, double* rhs, double* norms, int batch, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(norms, 0, sizeof(double) * 2 * (size_t)batch, stream);
   if (e != hipSuccess) return e;
-  if (J.rv_ntiles > 0) {
-    // problems per workgroup: the table of a tile is read once per workgroup, and a workgroup streams one problem ahead
-    // (measured at 8192 systems of cfg3's pattern: 1 -> 1.40 ms, 2 -> 1.30, 4 -> 1.27, 16 -> 1.32)
-    const int pb = batch >= 512 ? 4 : batch >= 64 ? 2 : 1;
-    hipLaunchKernelGGL(residual_vectors_tiled_kernel, dim3(J.rv_ntiles + J.rv_primal_tiles, (batch + pb - 1) / pb), dim3(256),
-                       (size_t)J.rv_lds_doubles * sizeof(double), stream, J, vals, r, lambda, Fx, cx, rhs, norms, batch, pb);
-    return hipGetLastError();
+  // problems per workgroup of the tiled kernel: the table of a tile is read once per workgroup, and a workgroup streams one problem
+  // ahead (measured at 8192 systems of cfg3's pattern: 1 -> 1.40 ms, 2 -> 1.30, 4 -> 1.27, 16 -> 1.32)
+  const int pb = J.rv_ntiles > 0 ? (batch >= 512 ? 4 : batch >= 64 ? 2 : 1) : RPT;
+  // the second grid dimension holds at most 65535 groups of problems: larger batches go in slices of that many groups, every
+  // per-problem pointer advanced to the slice's first problem (row strides: nnz, nequ, ncon, N, 2)
+  const long long slice = 65535LL * pb;
+  for (long long b0 = 0; b0 < batch; b0 += slice) {
+    const int nb = (int)std::min<long long>(slice, batch - b0);
+    const double* v_ = vals + b0 * J.nnz;
+    const double* r_ = r + b0 * J.nequ;
+    const double* l_ = lambda ? lambda + b0 * J.ncon : nullptr;
+    const double* f_ = Fx + b0 * J.nequ;
+    const double* c_ = cx ? cx + b0 * J.ncon : nullptr;
+    double* o_ = rhs + b0 * J.N;
+    double* n_ = norms + 2 * b0;
+    if (J.rv_ntiles > 0)
+      hipLaunchKernelGGL(residual_vectors_tiled_kernel, dim3(J.rv_ntiles + J.rv_primal_tiles, (nb + pb - 1) / pb), dim3(256),
+                         (size_t)J.rv_lds_doubles * sizeof(double), stream, J, v_, r_, l_, f_, c_, o_, n_, nb, pb);
+    else
+      hipLaunchKernelGGL(residual_vectors_kernel, dim3((J.N + 255) / 256, (nb + RPT - 1) / RPT), dim3(256), 0, stream, J, v_, r_, l_, f_, c_, o_, n_, nb);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(residual_vectors_kernel, dim3((J.N + 255) / 256, (batch + RPT - 1) / RPT), dim3(256), 0, stream, J, vals, r, lambda, Fx, cx, rhs,
-                     norms, batch);
-  return hipGetLastError();
+  return hipSuccess;
 }
 
 hipError_t launch_trial_point(const DevJt& J, const double* x, const double* r, const double* lambda, const double* d,
                               double max_dlambda, double* xt, double* rt, double* lambdat, double* dlambda, int batch,
                               hipStream_t stream) {
   const int nch = std::max(1, (J.nvar + J.nequ + 256 * TP_UNROLL - 1) / (256 * TP_UNROLL));
+  if (!linear_grid_ok(nch, batch)) return hipErrorInvalidConfiguration;
   hipLaunchKernelGGL(trial_point_kernel, dim3((unsigned)((long long)nch * batch)), dim3(256), 0, stream, J, x, r, lambda, d, max_dlambda, xt, rt, lambdat, dlambda,
                      batch);
   return hipGetLastError();

@@ -267,19 +267,31 @@ __global__ void __launch_bounds__(256) outer_end_kernel(const cnl_outer_state S)
 }
 
 // every array of the state the kernels dereference must be there (the header promises CNL_ERR_ARG for a missing array, not an
-// asynchronous fault): the block of pointers from `status` to `lamt_e`; the line-search entries also need theirs (check_ls)
+// asynchronous fault).  The members are named one by one (walking the struct as an array of pointers would read a scalar
+// member added later as a pointer).  The multiplier / constraint arrays (lam, cx, ct, lamt, lamt_e, cl, lam_ls) have rows of
+// P = max(p, 1) entries and are walked over P: they are required also when p == 0 (include/cannoles_hip.h says so); only the
+// constraint-Jacobian value arrays Jcv / Jct may be NULL when nnzjc == 0.  The line-search entries also need theirs (check_ls).
 int check(const cnl_outer_state* st) {
   if (!st || st->B <= 0) return CNL_ERR_ARG;
-  static_assert(sizeof(void*) == 8, "pointer block of cnl_outer_state");
-  const void* const* p0 = reinterpret_cast<const void* const*>(&st->status);
-  const void* const* p1 = reinterpret_cast<const void* const*>(&st->lamt_e);
-  for (const void* const* q = p0; q <= p1; q++)
-    if (!*q) return CNL_ERR_ARG;
+#define CNL_NEED(m) if (!st->m) return CNL_ERR_ARG;
+  CNL_NEED(status) CNL_NEED(it) CNL_NEED(flags) CNL_NEED(nf_new) CNL_NEED(ok_new)
+  CNL_NEED(inner) CNL_NEED(nfact) CNL_NEED(nlin)
+  CNL_NEED(phase0) CNL_NEED(act) CNL_NEED(need) CNL_NEED(brk) CNL_NEED(ext) CNL_NEED(lsm) CNL_NEED(rej) CNL_NEED(chk) CNL_NEED(done_in) CNL_NEED(tired) CNL_NEED(small_res)
+  CNL_NEED(normdual) CNL_NEED(normprimal) CNL_NEED(combined) CNL_NEED(combined_hat) CNL_NEED(delta) CNL_NEED(ndh) CNL_NEED(nph) CNL_NEED(fx)
+  CNL_NEED(epsk) CNL_NEED(epstol) CNL_NEED(epsF) CNL_NEED(epsc) CNL_NEED(rho_old)
+  CNL_NEED(d) CNL_NEED(d_new) CNL_NEED(ro_tmp) CNL_NEED(rho_new)
+  CNL_NEED(x) CNL_NEED(r) CNL_NEED(Fx) CNL_NEED(Jv) CNL_NEED(rhs_cur)
+  CNL_NEED(xt) CNL_NEED(rt) CNL_NEED(Ft) CNL_NEED(Jt) CNL_NEED(rhs_t) CNL_NEED(nrm_t)
+  CNL_NEED(xt_e) CNL_NEED(rt_e)
+  CNL_NEED(cx) CNL_NEED(lam) CNL_NEED(ct) CNL_NEED(lamt) CNL_NEED(lamt_e)
+  if (st->nnzjc > 0) { CNL_NEED(Jcv) CNL_NEED(Jct) }
   return 0;
 }
 int check_ls(const cnl_outer_state* st) {
   if (check(st)) return CNL_ERR_ARG;
-  return st->ls_g && st->xl && st->Fl && st->cl && st->lam_ls && st->alpha && st->Dphi && st->phix && st->eta && st->nbk && st->bt ? 0 : CNL_ERR_ARG;
+  CNL_NEED(ls_g) CNL_NEED(xl) CNL_NEED(Fl) CNL_NEED(cl) CNL_NEED(lam_ls) CNL_NEED(alpha) CNL_NEED(Dphi) CNL_NEED(phix) CNL_NEED(eta) CNL_NEED(nbk) CNL_NEED(bt)
+#undef CNL_NEED
+  return 0;
 }
 int done() { return hipGetLastError() == hipSuccess ? CNL_OK : CNL_ERR_HIP; }
 

@@ -296,7 +296,9 @@ int cnl_multi_synchronize(cnl_multi* m, void* const* streams);
  * reference's operation order; minimum / maximum propagate NaN).  `cnl_outer_state` is plain device pointers and sizes; every
  * array is problem-major.  Status codes: 0 unknown (active), 1 first_order, 2 small_residual, 3 exception, 4 max_eval (never produced: this loop has no evaluation counter), 5 stalled (inner > max_inner, src/CaNNOLeS.jl:846).  The entry points
  * take no handle: they launch on the calling thread's CURRENT device, which must be the one the arrays live on, and are asynchronous on
- * `stream`; they return CNL_ERR_ARG for a null state / missing array and CNL_ERR_HIP when the launch fails.
+ * `stream`; they return CNL_ERR_ARG for a null state / missing array and CNL_ERR_HIP when the launch fails.  Every array is required
+ * — the multiplier / constraint arrays lam, cx, ct, lamt, lamt_e (cl, lam_ls for the line search) have rows of P = max(p, 1) entries and
+ * are required also when p == 0 —; only Jcv / Jct may be NULL when nnzjc == 0.
  *   cnl_outer_begin_dev        :612-626  start of an outer iteration for the problems in phase0; act, need (a Newton system is due);
  *                                        flags[0..3] = any active / any need / any extrapolation step / any line-search step
  *   cnl_outer_newton_done_dev  :633-659  did_newton != 0: d, rho_old, nfact, nlin from the Newton call's outputs (d_new, ro_tmp,
@@ -349,7 +351,8 @@ int cnl_last_kernel_ms(cnl_handle* h, float* ms);
  * kernel (kernels2.hip) serves newton_system/factorize (4: with staged execution of the first attempt), 3 dense backend, else 1;
  * + 16 when newton_system / factorize run the LEAN instantiation (fast-class fronts with row-form products only), [6]=its wavefronts per workgroup,
  * [7]=its LDS bytes per workgroup; [5] + 32 when the remainder of the batch runs on a handle of its own (cnl_options.split_tail),
- * + 64 when cnl_newton_system runs on the band kernels, + 128 when cnl_residual_vectors_dev runs on column tiles. */
+ * + 64 when cnl_newton_system runs on the band kernels (then bits 8-15 = problems per workgroup, bits 16-23 = parts of the chain),
+ * + 128 when cnl_residual_vectors_dev runs on column tiles. */
 int cnl_get_config(const cnl_handle* h, int64_t cfg[8]);
 
 #ifdef __cplusplus

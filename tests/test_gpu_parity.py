@@ -330,36 +330,51 @@ def test_f1_trial_point(built):
 
 
 def test_aux_kernels_beyond_the_grid_limit(built):
-    """prepare_newton_system! and the trial point for MORE problems than a grid dimension holds (65 535): the kernels walk the
-    problems with a clamped second grid dimension; first, last and the problems either side of the limit against the oracle"""
+    """prepare_newton_system! and the trial point for MORE problems than a grid dimension holds (65 535): ONE linear grid dimension
+    (problem, chunk) — refused with an error, not truncated, when the product leaves 31 bits —; row f1 for more problems than its
+    second grid dimension holds (65 535 groups of four: 262 140 problems): launched in slices.  First, last and the problems either
+    side of each limit against the oracle."""
     import torch
     hipldl, syn, O = _mods()
     s = syn.band_structure(24, 2)
-    B = 66000
+    B = 263000
     rows, cols = s.kkt_pattern()
     nnz = len(rows)
-    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(band_kernel=0))
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev); g.manual_seed(3)
     mk = lambda n: torch.randn((B, n), dtype=torch.float64, device=dev, generator=g)
     nhF, nhc, njF, njc = len(s.hF[0]), len(s.hc[0]), len(s.jF[0]), len(s.jc[0])
     hF, hc, Jx, Jc, de = mk(nhF), mk(nhc), mk(njF), mk(njc), mk(1).abs().reshape(B).contiguous()
     vals = torch.full((B, nnz), 7.0, dtype=torch.float64, device=dev)
-    hipldl.prepare_newton_system_dev(L, nhF, nhc, njF, njc, hF.data_ptr(), hc.data_ptr(), Jx.data_ptr(), Jc.data_ptr(), de.data_ptr(), vals.data_ptr(), 0)
     x, r, lam, d = mk(s.nvar), mk(s.nequ), mk(s.ncon), mk(s.N)
-    xt, rt, lt, dl = torch.zeros_like(x), torch.zeros_like(r), torch.zeros_like(lam), torch.zeros_like(lam)
-    hipldl.trial_point_dev(L, x.data_ptr(), r.data_ptr(), lam.data_ptr(), d.data_ptr(), 1e4, xt.data_ptr(), rt.data_ptr(), lt.data_ptr(), dl.data_ptr(), 0)
-    torch.cuda.synchronize()
+    Fx, cx = mk(s.nequ), mk(s.ncon)
     c = lambda a, b: a[b].cpu().numpy()
-    for b in (0, 65534, 65535, 65536, B - 1):
-        v0 = np.full(nnz, 7.0)
-        O.prepare(v0, s.nvar, s.nequ, s.ncon, nhF, nhc, njF, njc, c(hF, b), c(hc, b), c(Jx, b), c(Jc, b), float(de[b]))
-        assert np.array_equal(c(vals, b), v0), b
-        xt0, rt0, lt0, dl0 = O.trial_point(s.nvar, s.nequ, s.ncon, c(x, b), c(r, b), c(lam, b), c(d, b), 1e4)
-        assert np.array_equal(c(xt, b), xt0) and np.array_equal(c(rt, b), rt0), b
-        np.testing.assert_allclose(c(dl, b), dl0, rtol=4e-15, atol=0)
-        np.testing.assert_allclose(c(lt, b), lt0, rtol=4e-15, atol=1e-300)
-    L.close()
+    probe = (0, 65534, 65535, 65536, 262139, 262140, 262141, B - 1)
+    for tiles in (1, 0):
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(band_kernel=0, f1_tiles=tiles))
+        assert tiles or not L.config["f1_tiles"]
+        if tiles:
+            hipldl.prepare_newton_system_dev(L, nhF, nhc, njF, njc, hF.data_ptr(), hc.data_ptr(), Jx.data_ptr(), Jc.data_ptr(), de.data_ptr(), vals.data_ptr(), 0)
+            xt, rt, lt, dl = torch.zeros_like(x), torch.zeros_like(r), torch.zeros_like(lam), torch.zeros_like(lam)
+            hipldl.trial_point_dev(L, x.data_ptr(), r.data_ptr(), lam.data_ptr(), d.data_ptr(), 1e4, xt.data_ptr(), rt.data_ptr(), lt.data_ptr(), dl.data_ptr(), 0)
+            torch.cuda.synchronize()
+            for b in probe:
+                v0 = np.full(nnz, 7.0)
+                O.prepare(v0, s.nvar, s.nequ, s.ncon, nhF, nhc, njF, njc, c(hF, b), c(hc, b), c(Jx, b), c(Jc, b), float(de[b]))
+                assert np.array_equal(c(vals, b), v0), b
+                xt0, rt0, lt0, dl0 = O.trial_point(s.nvar, s.nequ, s.ncon, c(x, b), c(r, b), c(lam, b), c(d, b), 1e4)
+                assert np.array_equal(c(xt, b), xt0) and np.array_equal(c(rt, b), rt0), b
+                np.testing.assert_allclose(c(dl, b), dl0, rtol=4e-15, atol=0)
+                np.testing.assert_allclose(c(lt, b), lt0, rtol=4e-15, atol=1e-300)
+        rhs = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
+        nrm = torch.full((B, 2), -1.0, dtype=torch.float64, device=dev)
+        hipldl.residual_vectors_dev(L, vals.data_ptr(), r.data_ptr(), lam.data_ptr(), Fx.data_ptr(), cx.data_ptr(), rhs.data_ptr(), nrm.data_ptr(), 0)
+        torch.cuda.synchronize()
+        for b in probe:
+            rhs0, (nd0, np0) = O.residual_vectors(rows, cols, c(vals, b), s.nvar, s.nequ, s.ncon, c(r, b), c(lam, b), c(Fx, b), c(cx, b))
+            assert np.array_equal(c(rhs, b), rhs0), (tiles, b)
+            assert np.array_equal(c(nrm, b), np.array([nd0, np0])), (tiles, b)
+        L.close()
 
 
 @pytest.mark.parametrize("hw", [1, 3, 4])
@@ -667,17 +682,21 @@ def test_fixtures_f2_f3_through_the_hip_path(built):
     L.close()
 
 
-@pytest.mark.parametrize("B,kernel,order,forced", [(8192, "v2", "canonical", False),   # THE headline plan of bench.py, as cnl_create picks it
-                                                   (4608, "v2", "canonical", True), (4608, "v2-staged", "ndc2", False),
-                                                   (3584, "v2-staged", "ndc2", False), (1536, "v2-staged", "ndc", False)])
-def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, forced):
-    """The headline shape (cfg3 pattern, n = nequ = 1e4, ncon = 50): the headline batch itself (8192 problems, the plan cnl_create
-    picks: canonical+early on the single stream — what bench.py times), on the throughput kernel (single stream, forced here with
-    cnl_options.plan_kind: it is what cnl_create picks from 7681 problems on), at a batch between one and two wavefronts per SIMD
-    (B = 4608: the first 4096 problems on the bidirectional chain, the remaining 512 behind them on a handle of their own with a
-    many-part plan — csrc/capi.cpp, run_split, cnl_options.split_tail), at one the bidirectional chain serves alone (B = 3584) and
-    at one with many large parts (B = 1536): the whole batch through cnl_newton_system_dev, a random sample of 32 problems
-    against the oracle; in the split batch one problem of each part also climbs the rho ladder."""
+@pytest.mark.parametrize("B,kernel,order,forced,band_nl", [
+    (9216, "v2", "canonical", False, 32),   # what bench.py TIMES: band_newton_kernel<32, false> with interleaved factor records (any batch above 8192)
+    (8192, "v2", "canonical", False, 16),   # rounds 1-4's headline batch: band_newton_kernel<16, false>, problem-major factor records
+    (4608, "v2", "canonical", True, 16), (4608, "v2-staged", "ndc2", False, 0),
+    (3584, "v2-staged", "ndc2", False, 0), (1536, "v2-staged", "ndc", False, 0)])
+def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, forced, band_nl):
+    """The headline shape (cfg3 pattern, n = nequ = 1e4, ncon = 50).  B = 9216: the INSTANTIATION bench.py times (every batch above
+    8192 problems runs band_newton_kernel<32, false>: 32 problems per workgroup, factor records interleaved over the workgroup —
+    csrc/band.hip LINT; bench.py's 16 384 problems differ only in the grid size), with one problem that climbs the rho ladder inside a
+    workgroup of convex ones; B = 8192: the band kernels with 16 problems per workgroup; B = 4608 forced onto the throughput plan;
+    then a batch between one and two wavefronts per SIMD (B = 4608: the first 4096 problems on the bidirectional chain, the remaining
+    512 behind them on a handle of their own with a many-part plan — csrc/capi.cpp, run_split, cnl_options.split_tail), one the
+    bidirectional chain serves alone (B = 3584) and one with many large parts (B = 1536): the whole batch through
+    cnl_newton_system_dev, a random sample of 32 problems against the oracle; in the split batch one problem of each part also
+    climbs the rho ladder.  config["band"] / ["band_nl"] are asserted: which kernel ran is part of what the test pins."""
     import torch
     hipldl, syn, O = _mods()
     import bench as BM
@@ -696,17 +715,19 @@ def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, 
             host[int(b)] = (vh[b - b0].copy(), rh[b - b0].copy())
     p = hipldl.default_params()
     split = B == 4608 and not forced
-    if split:   # one problem in the chain part and one in the remainder need rho > 0
+    climbers = (int(pick[0]), int(pick[-1])) if split else ((int(pick[7]),) if band_nl == 32 else ())
+    if climbers:   # split: one problem in the chain part and one in the remainder need rho > 0; band<32>: one inside a workgroup
         off = s.offsets()
         hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
         dg = torch.from_numpy(off[0] + np.nonzero(hF_r == hF_c)[0][:400]).to(dev)
-        for b in (int(pick[0]), int(pick[-1])):
+        for b in climbers:
             vals[b, dg] = -30.0
             host[b][0][dg.cpu().numpy()] = -30.0
-        assert pick[0] < 4096 <= pick[-1]
+        assert not split or pick[0] < 4096 <= pick[-1]
     L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B,
                             options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT) if forced else None)
     assert L.config["kernel"] == kernel and L.info["order"].startswith(order) and L.config["tail"] == split
+    assert L.config["band"] == (band_nl > 0) and L.config["band_nl"] == band_nl
     d = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
     ro = torch.zeros(B, dtype=torch.float64, device=dev)
     rho = torch.ones(B, dtype=torch.float64, device=dev)
@@ -716,8 +737,10 @@ def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, 
     torch.cuda.synchronize()
     nfh, rhoh = nf.cpu().numpy(), rho.cpu().numpy()
     assert bool((ok == 1).all())
-    if not split:
+    if not climbers:
         assert (nfh == 1).all() and (rhoh == 0).all()
+    else:
+        assert int((nfh > 1).sum()) == len(climbers)
     orc = O.Oracle(s.N, rows, cols, L.plan_array("perm").astype(np.int64))
     dh = d[torch.from_numpy(pick).to(dev)].cpu().numpy()
     vend = vals[torch.from_numpy(pick).to(dev)].cpu().numpy()
@@ -726,7 +749,7 @@ def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, 
         vv = v0.copy()
         d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, r0, vv, 0.0, O.default_params())
         assert ok0 and (nf0, rho0) == (int(nfh[b]), float(rhoh[b]))
-        assert (nf0 > 1) == (split and k in (0, 31))
+        assert (nf0 > 1) == (int(b) in climbers)
         assert np.array_equal(vend[k, -s.nvar:], vv[-s.nvar:])
         assert np.abs(dh[k] - d0).max() <= FWD_TOL * np.abs(d0).max()
         assert backward_error(s, vv, r0, dh[k]) <= BWD_TOL
