@@ -292,20 +292,28 @@ def main():
     kern_ms = float(np.mean(kms))
     # the forward sweep alone (try_to_factorize: assembly + LDL^T + inertia, no solve), same timing mode: what is left of kern_ms
     # is the backward sweep (the two sweeps are bound by different things)
-    fwd_ms = None
+    fwd_ms, solve_ms = None, None
     band = bool(LDLT.config.get("band"))
     try:
-        if args.no_extras or band:   # (the profiling passes run with --no-extras: only full steps of the kernel in their statistics;
-            raise RuntimeError("skipped")   #  on a band handle try_to_factorize runs the register-front kernel: not this kernel's forward sweep)
-        fms = []
+        if args.no_extras:   # (the profiling passes run with --no-extras: only full steps of the kernel in their statistics)
+            raise RuntimeError("skipped")
+        # the reference's own two-call sequence on the same handle (src/CaNNOLeS.jl:1023,1049): try_to_factorize = the forward sweep
+        # (band handles: without the factor-record stores), solve_ldl! = (band handles) factorisation + both sweeps of a right-hand side
+        fms, sms = [], []
+        d_two = torch.zeros_like(prob.d)
         with torch.cuda.stream(stream):
             for _ in range(3):
                 hipldl._check(hipldl.lib().cnl_factorize_dev(LDLT._h, prob.vals.data_ptr(), 2.220446049250313e-16, prob.succ.data_ptr(), stream.cuda_stream))
                 torch.cuda.synchronize()
                 fms.append(LDLT.last_kernel_ms())
+                hipldl._check(hipldl.lib().cnl_solve_dev(LDLT._h, prob.rhs.data_ptr(), d_two.data_ptr(), stream.cuda_stream))
+                torch.cuda.synchronize()
+                sms.append(LDLT.last_kernel_ms())
             prob.step()   # leaves the handle and `succ` as the timed loop left them
             torch.cuda.synchronize()
-        fwd_ms = float(np.mean(fms[1:]))
+        fwd_ms, solve_ms = float(np.mean(fms[1:])), float(np.mean(sms[1:]))
+        two_call_equal = bool(torch.equal(d_two, prob.d))
+        del d_two
     except Exception:
         fwd_ms = None
     LDLT.set_timing(False)
@@ -356,6 +364,10 @@ def main():
                      "bytes_per_system": b_alg, "nnzL_star": nnzL_star, "kernel_ms": kern_ms, "kernel": kname,
                      "units_per_launch": B,
                      "forward_sweep_ms": fwd_ms, "backward_sweep_ms": (kern_ms - fwd_ms) if fwd_ms else None,
+                     "two_call_sequence": ({"try_to_factorize_ms": fwd_ms, "solve_ldl_ms": solve_ms, "total_over_newton_system": (fwd_ms + solve_ms) / kern_ms,
+                                            "d_bit_equal_to_newton_system": two_call_equal,
+                                            "note": "same handle, same kernel family (cnl_factorize_dev + cnl_solve_dev); band handles: the solve factorises again and sweeps in one launch"}
+                                           if (fwd_ms and solve_ms) else None),
                      "kernel_is_whole_step": band or (bool(LDLT.config.get("lean")) and bool(LDLT.plan_array("brec")[7] & 256)),
                      "note": "since round 3 the lean kernel recovers the residual components in its backward sweep: no post-pass, kernel_ms == step_ms; "
                              "rounds 1-2 (and round 3 before that change) priced a kernel that left 1.2 ms of the step to a second kernel on the same algorithmic bytes "
@@ -428,7 +440,8 @@ def compact_line(out):
         "cfg4_B4096_frac": g("cfg4", "B4096", "frac"), "cfg5_B256_ms": g("cfg5", "B256", "ms_per_call"), "cfg5_B256_frac": g("cfg5", "B256", "frac"),
         "f1_residual_vectors_ms": g("aux_f1", "residual_vectors", "ms"), "f1_residual_vectors_frac": g("aux_f1", "residual_vectors", "frac"),
         "f1_trial_point_frac": g("aux_f1", "trial_point", "frac"), "f2_prepare_frac": g("aux_f1", "f2_prepare", "frac"),
-        "f3_ms_per_step": g("aux_f3", "ms_per_step"), "pcie_inclusive_ksys_s": _k(g("pcie_inclusive", "systems_per_s")),
+        "f3_ms_per_step": g("aux_f3", "ms_per_step"), "two_call_over_newton": _dig(out.get("roofline"), ("two_call_sequence", "total_over_newton_system")),
+        "pcie_inclusive_ksys_s": _k(g("pcie_inclusive", "systems_per_s")),
         "single_system_host_ms": g("call_pattern_single_system", "newton_system_ms"), "multi_front_end_ratio": g("multi_front_end", "ratio_to_single_handle"),
     }
     c["summary"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items() if v is not None}

@@ -34,18 +34,14 @@ struct StepOp {
 };
 inline int32_t rhs_src(int64_t i) { return (int32_t)(-(i + 2)); }
 
-// packs the sources of one epoch into 64-byte pieces; returns false when more than BAND_NPIECE are needed
+// packs the sources of one epoch into 64-byte pieces (eight consecutive elements of one array); returns false when more than
+// BAND_NPIECE are needed.  (Round 5 also had a layout with four 128-byte pieces per epoch: measured equal, removed in round 6.)
 struct Packer {
   int32_t len[3];
-  struct Piece { int32_t arr, base, slot, width; };   // width 8: one slot; 16: a WIDE piece, two consecutive slots loaded by one instruction
+  struct Piece { int32_t arr, base, slot; };
   std::vector<Piece> pieces;
-  // wide layout (band.h: BAND_WIDE_POS): the slot pairs (0,1) .. (6,7) take 128-byte pieces — 16 bytes per lane, one instruction —
-  // and the slots 8 .. 14 take 64-byte pieces: which instruction loads a slot is fixed, the kernels' mover has no case distinction.
-  // Narrow layout: fifteen 64-byte pieces.
-  bool wide = true;
   bool pack(std::vector<int32_t> (&need)[3]) {
     pieces.clear();
-    std::vector<Piece> W, S;   // wide, single
     for (int a = 0; a < 3; a++) {
       std::vector<int32_t>& v = need[a];
       std::sort(v.begin(), v.end());
@@ -53,65 +49,27 @@ struct Packer {
       size_t i = 0;
       while (i < v.size()) {
         int32_t b = v[i];
-        size_t i2 = i;
-        while (i2 < v.size() && v[i2] < b + 8) i2++;
-        int32_t w = 8;
-        // a second run of eight right behind this one is wanted too: one wide piece instead of two
-        if (wide && (int)W.size() < BAND_WIDE_POS && i2 < v.size() && v[i2] < b + 16 && b <= len[a] - 16) w = 16;
-        if (b > len[a] - w) b = len[a] - w;   // the piece must stay inside the array
+        if (b > len[a] - 8) b = len[a] - 8;   // the piece must stay inside the array
         if (b < 0) return false;
-        (w == 16 ? W : S).push_back({a, b, 0, w});
-        while (i < v.size() && v[i] < b + w) i++;
+        pieces.push_back({a, b, (int32_t)pieces.size()});
+        while (i < v.size() && v[i] < b + 8) i++;
       }
     }
-    if (!wide) {
-      if ((int)S.size() > BAND_NPIECE) return false;
-      for (size_t k = 0; k < S.size(); k++) { S[k].slot = (int32_t)k; pieces.push_back(S[k]); }
-      return true;
-    }
-    // The factor stream (array 2) must be CONTIGUOUS in LDS (a record of six doubles may straddle two pieces): its wide pieces take
-    // the top pair positions, its singles the first single slots right behind them; the other arrays' wides fill the pair positions
-    // from the bottom, their singles the remaining single slots.  More singles than single slots: the free pair positions take
-    // singles of the other arrays (loaded wide: eight more elements come along).
-    std::vector<Piece> Wf, Wo, Sf, So;
-    for (const Piece& q : W) (q.arr == 2 ? Wf : Wo).push_back(q);
-    for (const Piece& q : S) (q.arr == 2 ? Sf : So).push_back(q);
-    for (size_t k = 1; k < Sf.size() + Wf.size(); k++) {   // wides first, ascending and adjacent: what contiguity needs
-      const Piece& a = k - 1 < Wf.size() ? Wf[k - 1] : Sf[k - 1 - Wf.size()];
-      const Piece& b = k < Wf.size() ? Wf[k] : Sf[k - Wf.size()];
-      if (b.base != a.base + a.width) return false;
-    }
-    for (const Piece& q : Sf) if (!Wf.empty() && q.base < Wf.back().base) return false;
-    const int nsingle = BAND_NPIECE - 2 * BAND_WIDE_POS;
-    while ((int)(Sf.size() + So.size()) > nsingle && (int)(Wf.size() + Wo.size()) < BAND_WIDE_POS && !So.empty()) {
-      Piece q = So.back();
-      So.pop_back();
-      if (len[q.arr] < 16) return false;
-      q.base = std::min(q.base, len[q.arr] - 16);
-      q.width = 16;
-      Wo.push_back(q);
-    }
-    if ((int)(Sf.size() + So.size()) > nsingle) return false;
-    for (size_t k = 0; k < Wo.size(); k++) { Wo[k].slot = (int32_t)(2 * k); pieces.push_back(Wo[k]); }
-    for (size_t k = 0; k < Wf.size(); k++) { Wf[k].slot = (int32_t)(2 * (BAND_WIDE_POS - Wf.size() + k)); pieces.push_back(Wf[k]); }
-    for (size_t k = 0; k < Sf.size(); k++) { Sf[k].slot = (int32_t)(2 * BAND_WIDE_POS + k); pieces.push_back(Sf[k]); }
-    for (size_t k = 0; k < So.size(); k++) { So[k].slot = (int32_t)(2 * BAND_WIDE_POS + Sf.size() + k); pieces.push_back(So[k]); }
-    return true;
+    return (int)pieces.size() <= BAND_NPIECE;
   }
   // LDS byte offset of element e of array a
   int32_t off(int a, int32_t e) const {
     for (const Piece& pc : pieces)
-      if (pc.arr == a && e >= pc.base && e < pc.base + pc.width) return (int32_t)((BAND_IN_OFF + 8 * pc.slot + (e - pc.base)) * 8);
+      if (pc.arr == a && e >= pc.base && e < pc.base + 8) return (int32_t)((BAND_IN_OFF + 8 * pc.slot + (e - pc.base)) * 8);
     return -1;
   }
 };
 
 }  // namespace
 
-static void build_band_plan_impl(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
-                                 int64_t ncon, int nparts_wanted, bool wide_pieces) {
+void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
+                     int64_t ncon, int nparts_wanted) {
   B = BandPlan();
-  B.wide = wide_pieces;
   auto no = [&](const std::string& w) { B.ok = false; B.why = w; };
   const int64_t n = nvar, m = nequ, p = ncon;
   if (N != n + m + p) return no("N != nvar + nequ + ncon");
@@ -316,14 +274,13 @@ static void build_band_plan_impl(BandPlan& B, int64_t N, int64_t nnz, const int6
     Q.nevents = nev;
     Q.loff = loff;
     const int64_t lpart = (int64_t)nev * BAND_LREC;
-    loff += (lpart + 16 + 7) & ~(int64_t)7;   // + 16: the last (wide) piece of a part may over-read
+    loff += (lpart + 16 + 7) & ~(int64_t)7;   // + 16: slack behind a part's records
     // ---- epochs: pack the operands into pieces, turn sources into LDS offsets ------------------------------------------
     Q.epochs.clear();
     Q.fops.clear(); Q.bops.clear();
     std::vector<std::vector<int32_t>> fblocks(nsteps), bblocks(nsteps);
     Packer pk;
     pk.len[0] = (int32_t)nnz; pk.len[1] = (int32_t)N; pk.len[2] = (int32_t)(lpart + 16);
-    pk.wide = wide_pieces;
     if (lpart + 16 >= (1 << 27)) return no("factor too long");
     const int32_t ZB = BAND_ZERO_OFF * 8;
     // An epoch is a run of BAND_EPOCH steps whose operands must fit the pieces and whose outputs the rings.
@@ -384,15 +341,12 @@ static void build_band_plan_impl(BandPlan& B, int64_t N, int64_t nnz, const int6
         if (dir == 1) for (int32_t i = 0; i < lcnt; i++) need[2].push_back(lbase + i);
         if (!pk.pack(need)) {
           std::string w = "an epoch needs more operand pieces than a lane holds (part " + std::to_string(part) + ", steps " + std::to_string(u0) + ".." + std::to_string(u1) + (dir ? ", backward" : ", forward") + ":";
-          for (auto& pc : pk.pieces) w += " " + std::to_string(pc.arr) + ":" + std::to_string(pc.base) + (pc.width == 16 ? "w" : "");
+          for (auto& pc : pk.pieces) w += " " + std::to_string(pc.arr) + ":" + std::to_string(pc.base);
           return no(w + ")");
         }
         int32_t* PP = E + (dir == 0 ? BE_FP : BE_BP);
         for (int k = 0; k < BAND_NPIECE; k++) PP[k] = -1;
-        for (const Packer::Piece& pc : pk.pieces) {
-          PP[pc.slot] = pc.base | (pc.arr << 28) | (pc.width == 16 ? BAND_PIECE_WIDE : 0);
-          if (pc.width == 16) PP[pc.slot + 1] = -2;   // second half of a wide piece
-        }
+        for (const Packer::Piece& pc : pk.pieces) PP[pc.slot] = pc.base | (pc.arr << 28);
         auto off = [&](int32_t s) -> int32_t {
           if (s == -1) return ZB;
           return s >= 0 ? pk.off(0, s) : pk.off(1, -(s + 2));
@@ -470,16 +424,6 @@ static void build_band_plan_impl(BandPlan& B, int64_t N, int64_t nnz, const int6
   }
   B.lsize = loff + 8;
   B.ok = true;
-}
-
-void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
-                     int64_t ncon, int nparts_wanted, bool wide_pieces) {
-  build_band_plan_impl(B, N, nnz, rows1, cols1, nvar, nequ, ncon, nparts_wanted, wide_pieces);
-  // an epoch whose operands do not fit four wide and seven 64-byte pieces may still fit fifteen 64-byte ones
-  if (!B.ok && wide_pieces) {
-    if (std::getenv("CNL_VERBOSE")) fprintf(stderr, "[cnl] band program: wide layout not possible (%s)\n", B.why.c_str());
-    build_band_plan_impl(B, N, nnz, rows1, cols1, nvar, nequ, ncon, nparts_wanted, false);
-  }
 }
 
 }  // namespace cnl

@@ -31,8 +31,6 @@ constexpr int BAND_EPOCH = 8;       // steps per epoch (one round of operand pie
 constexpr int BAND_NS = BAND_EPOCH;
 constexpr int BAND_NPIECE = 15;     // 64-byte operand pieces per epoch and lane (BASELINE config 3 needs 15 in the forward sweep)
 constexpr int BAND_REC_MAX = 256;    // ints of step + row blocks per epoch (LDS record buffer of a wavefront)
-constexpr int BAND_PIECE_WIDE = 1 << 27;   // piece descriptor: 128 bytes (16 per lane) into this slot and the next
-constexpr int BAND_WIDE_POS = 4;           // wide layout of a program: the slot pairs (0,1) .. (6,7) hold wide pieces, the slots 8 .. 14 64-byte pieces
 constexpr int BAND_LREC = 6;        // factor doubles per pivot: band multipliers, border multiplier, z  (see band.hip)
 
 // LDS block of one lane, in doubles: [operand pieces | out ring | zero cell].  The out ring holds the factor records of HALF an
@@ -69,7 +67,7 @@ enum { BF_ENTER_B = 1, BF_PIVOT_B = 2, BF_PIVOT_X = 4, BF_ENTER_X = 8 };
 enum { BR_DI = 0, BR_J0 /* + live position: 0 = the step's pivot .. HW = the entering variable */, BR_RR = BR_J0 + BAND_NB, BR_DR, BAND_RW = 8 };
 // epoch block
 enum {
-  BE_FP = 0,                       // forward operand pieces: element index | BAND_PIECE_WIDE | array << 28 (0 vals, 1 rhs); -1 unused, -2 second half of a wide piece
+  BE_FP = 0,                       // forward operand pieces: element index | array << 28 (0 vals, 1 rhs); -1 unused
   BE_BP = BE_FP + BAND_NPIECE,     // backward operand pieces (array 2: the factor)
   BE_LBASE = BE_BP + BAND_NPIECE,  // first factor double of the epoch's steps 0 .. 3 and their number, then of its steps 4 .. 7
   BE_LCNT, BE_LBASE2, BE_LCNT2,
@@ -96,7 +94,6 @@ struct BandPlan {
   bool ok = false;
   std::string why;            // why not, when !ok
   int32_t nparts = 0;
-  bool wide = false;          // the program uses the wide layout (BAND_WIDE_POS)
   int32_t m0 = 0;             // part 0 pivots variables [0, m0), part 1 pivots [m0 + BAND_HW, n) downwards (nparts == 2)
   int32_t n = 0, N = 0, nnz = 0;
   int64_t lsize = 0;          // factor doubles per problem
@@ -105,6 +102,6 @@ struct BandPlan {
 
 // rows1/cols1: the reference's 1-based COO pattern (src/CaNNOLeS.jl:256-315).  Fills B (B.ok, B.why); nparts_wanted: 1 or 2.
 void build_band_plan(BandPlan& B, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar, int64_t nequ,
-                     int64_t ncon, int nparts_wanted, bool wide_pieces = true);
+                     int64_t ncon, int nparts_wanted);
 
 }  // namespace cnl

@@ -24,6 +24,7 @@
 #include "condense.h"
 #include "dense.h"
 #include "kernels.h"
+#include "options.h"
 #include "plan.h"
 
 struct cnl_plan {
@@ -35,7 +36,7 @@ struct cnl_plan {
   bool prefer_dense = false;  // latency plan with fronts of the 64 class on a small condensed system: small batches go the dense route
   cnl::DensePlan D;  // dense residual block (BASELINE config 2): served by the dense backend, csrc/dense.h
   std::vector<int32_t> gpos;  // non-empty: the condensed system may be treated as ONE dense matrix (position of every K2 slot)
-  cnl_options opt{};          // the options the plan was built with (the handle reads its execution switches from here)
+  cnl::Tuning opt{};          // the switches the plan was built with (options.h; the handle reads its execution switches from here)
   std::atomic<int> refs{1};   // handles of a cnl_multi share one analysis (read-only after creation)
   bool split_mode = false;    // bidirectional-chain plan for a batch between one and two wavefronts per SIMD (capi.cpp, run_split)
   cnl::BandPlan band;         // (round 5) band program of a throughput plan (csrc/band.h); band.ok == false: the pattern is no band
@@ -124,16 +125,8 @@ struct cnl_handle {
   bool band = false;
   cnl::BandDev bd{};
   int band_nl = 16;            // problems per workgroup
+  bool band_mw = false;        // the kernel with dedicated mover wavefronts serves the handle (band.hip, band_newton_mw_kernel)
   double* d_Lband = nullptr;   // [batch][bd.lsize] factor records of the band kernels
-  bool band_fresh = false;     // the last factorisation was made by the band kernels: a later solve_ldl! needs the register-front
-                               // kernel's factor of the same values first (launch)
-  int32_t* d_band_ok = nullptr;   // [batch] success flags of that refactorisation (not reported)
-  // the same for the WHOLE handle (views of a handle — SubBatch — move the pointers above): the refactorisation in front of a
-  // solve_ldl! always covers every problem of the handle, whatever views the factorisations and the solve came through
-  double *root_L = nullptr, *root_Lband = nullptr;
-  int32_t* root_band_ok = nullptr;
-  int64_t root_batch = 0;
-  const double* band_vals_root = nullptr;   // values (problem 0 of the handle) the band kernels factorised last
 };
 
 namespace {
@@ -215,7 +208,7 @@ int choose_config(cnl_handle* h) {
     tpp = P.fmax <= 96 ? 64 : (P.fmax <= 400 ? 256 : 1024);
     ppb = tpp == 64 ? 4 : 1;
   }
-  const cnl_options& o = h->plan->opt;
+  const cnl::Tuning& o = h->plan->opt;
   if (o.v1_tpp > 0) tpp = o.v1_tpp;
   if (o.v1_ppb > 0) ppb = o.v1_ppb;
   if (o.v1_lds >= 0) ldsw = o.v1_lds;
@@ -228,7 +221,7 @@ int choose_config(cnl_handle* h) {
 int setup_v2(cnl_handle* h) {
   const cnl::Plan& P = h->plan->P;
   h->use_v2 = false;
-  const cnl_options& o = h->plan->opt;
+  const cnl::Tuning& o = h->plan->opt;
   if (!P.v2_ok || !o.register_front) return CNL_OK;
   if (!h->plan->gpos.empty() && (o.general_dense == 2 || (h->plan->prefer_dense && h->batch <= 16))) return CNL_OK;  // the dense route (plan_create_impl); 2: wherever it is possible
   cnl::DevPlan2& d = h->dp2;
@@ -348,41 +341,44 @@ int setup_v2(cnl_handle* h) {
   return CNL_OK;
 }
 
+// debugging aid (include/cannoles_hip.h): CNL_DBG_LDSFILL=<byte pattern> — kernels that leave the pattern in LDS, scratch and registers
+// run in front of every launch.  The variable is read ONCE per process (round 6: it was a getenv per launch in the product build).
+const int* dbg_ldsfill() {
+  static const int pat = [] { const char* e = getenv("CNL_DBG_LDSFILL"); return e ? (int)strtol(e, nullptr, 0) : -1; }();
+  static const bool on = getenv("CNL_DBG_LDSFILL") != nullptr;
+  return on ? &pat : nullptr;
+}
+
+// launches per kernel family since the library was loaded (cnl_launch_counts): [band kernels, register-front kernel, general kernel]
+std::atomic<long long> g_launches[3];
+
 int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
-  if (const char* pat = getenv("CNL_DBG_LDSFILL")) (void)cnl::launch_lds_fill((int)strtol(pat, nullptr, 0), stream);
+  if (const int* pat = dbg_ldsfill()) (void)cnl::launch_lds_fill(*pat, stream);
   a.batch = (int)h->batch;
   a.lean = h->lean ? 1 : 0;
   a.back_rows = (h->lean && h->plan->P.back_rows) ? 1 : 0;
   a.L = h->d_L;
   a.scratch = h->d_scratch;
   hipError_t e;
-  if (h->band && a.mode == cnl::MODE_SOLVE && h->band_fresh && h->band_vals_root) {
-    // solve_ldl! behind a newton_system! of the band kernels: their factor records are not what the solve sweeps read, so the
-    // register-front kernel factorises the same values first (the rho slots hold what the ladder wrote: the same factor) — every
-    // problem of the handle, whichever view of it this call came through
-    cnl::LaunchArgs f = a;
-    f.mode = cnl::MODE_FACTOR; f.rhs = nullptr; f.d = nullptr; f.success = h->root_band_ok; f.npos = nullptr; f.nzero = nullptr;
-    f.rho = nullptr; f.rho_old = nullptr; f.nfact = nullptr;
-    f.batch = (int)h->root_batch; f.L = h->root_L; f.vals = const_cast<double*>(h->band_vals_root);
-    f.scratch = h->d_gs ? h->d_gs - (h->d_L - h->root_L) / h->dp.lsize * h->dp2.gs_doubles : nullptr;
-    f.extra_pos = nullptr; f.extra_zer = nullptr;
-    e = cnl::launch_newton2(h->dp2, h->wpb2, h->lds2, f, stream);
-    if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("refactorisation for solve_ldl!: ") + hipGetErrorString(e));
-    h->band_fresh = false;
-  }
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));  // events bracket the multifrontal kernel only
-  if (h->band && a.mode == cnl::MODE_NEWTON && !a.skip_done && !a.only_if_status && a.rhs) {
+  if (h->band && !a.skip_done && !a.only_if_status && (a.mode != cnl::MODE_NEWTON || a.rhs)) {
+    // band handles: all three calls of the plugin surface run on the band kernels (round 6).  try_to_factorize is the forward
+    // sweep alone; solve_ldl! factorises the values of the last factorisation again (a.vals = the handle's last_vals, rho slots as
+    // the ladder left them) and sweeps the new right-hand side in the same launch — the band kernels' six-double records hold
+    // z = c / d of the one right-hand side they were computed with, so there is no stored factor a second right-hand side could use,
+    // and the register-front refactorisation rounds 5 put in front of such a solve (a second, slower kernel whose flags nobody read)
+    // is gone
     cnl::LaunchArgs b = a;
     b.L = h->d_Lband;
-    e = cnl::launch_band(h->bd, h->band_nl, b, stream);
-    h->band_fresh = true;
-    h->band_vals_root = a.vals - (h->d_Lband - h->root_Lband) / h->bd.lsize * (int64_t)h->bd.nnz;
+    e = h->band_mw ? cnl::launch_band_mw(h->bd, h->band_nl, b, stream) : cnl::launch_band(h->bd, h->band_nl, b, stream);
+    g_launches[0]++;
   } else if (h->use_v2 && (a.mode != cnl::MODE_SOLVE || h->v2_solve)) {
-    if (a.mode == cnl::MODE_FACTOR) h->band_fresh = false;
     a.scratch = h->d_gs;
     e = cnl::launch_newton2(h->dp2, h->wpb2, h->lds2, a, stream);
+    g_launches[1]++;
   } else {
     e = cnl::launch_newton(h->dp, h->cfg, a, stream);
+    g_launches[2]++;
   }
   if (e != hipSuccess)
     return fail(CNL_ERR_HIP, std::string("kernel launch (tpp=") + std::to_string(h->cfg.tpp) + " ppb=" + std::to_string(h->cfg.ppb) +
@@ -393,7 +389,7 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
 
 // one staged pass over the tasks of a latency plan (first attempt of newton_system, try_to_factorize, or solve_ldl!)
 int launch_staged(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
-  if (const char* pat = getenv("CNL_DBG_LDSFILL")) (void)cnl::launch_lds_fill((int)strtol(pat, nullptr, 0), stream);
+  if (const int* pat = dbg_ldsfill()) (void)cnl::launch_lds_fill(*pat, stream);
   a.batch = (int)h->batch; a.L = h->d_L; a.scratch = h->d_gs;
   a.tasks = h->d_tasks; a.gcnt = h->d_gcnt; a.skip_done = 0; a.dep = h->d_dep; a.df_waves = h->df_waves;
   a.lean = h->lean ? 1 : 0;
@@ -418,7 +414,6 @@ struct SubBatch {
   cnl_handle* h;
   int64_t batch;
   double *L, *gs, *scratch, *cbuf, *d2, *Lband;
-  int32_t* band_ok;
   int *xpos, *xzer, *gcnt, *dep, *lad, *stat;
   const double* last_vals;
   bool staged;
@@ -428,9 +423,8 @@ struct SubBatch {
     if (!allow_staged) h->staged = false;
     batch = h->batch; L = h->d_L; gs = h->d_gs; scratch = h->d_scratch; cbuf = h->d_cbuf; d2 = h->d_d2;
     xpos = h->d_xpos; xzer = h->d_xzer; gcnt = h->d_gcnt; dep = h->d_dep; lad = h->d_lad; stat = h->d_stat;
-    Lband = h->d_Lband; band_ok = h->d_band_ok;
+    Lband = h->d_Lband;
     if (h->d_Lband) h->d_Lband += b0 * h->bd.lsize;
-    if (h->d_band_ok) h->d_band_ok += b0;
     const cnl::Cond& C = h->plan->C;
     h->batch = nb;
     h->d_L += b0 * h->dp.lsize;
@@ -446,7 +440,7 @@ struct SubBatch {
   ~SubBatch() {
     h->batch = batch; h->d_L = L; h->d_gs = gs; h->d_scratch = scratch; h->d_cbuf = cbuf; h->d_d2 = d2;
     h->d_xpos = xpos; h->d_xzer = xzer; h->d_gcnt = gcnt; h->d_dep = dep; h->d_lad = lad; h->d_stat = stat;
-    h->last_vals = last_vals; h->staged = staged; h->d_Lband = Lband; h->d_band_ok = band_ok;
+    h->last_vals = last_vals; h->staged = staged; h->d_Lband = Lband;
   }
 };
 
@@ -594,7 +588,7 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
   int rc = CNL_OK;
   if (h->split_staged > 0 && !h->in_split && (h->staged || h->tail) && h->split_staged < h->batch) return run_split(h, a, d_vals, d_rhs, d_d, stream);
   if (h->dense || h->gdense)
-    if (const char* pat = getenv("CNL_DBG_LDSFILL")) (void)cnl::launch_lds_fill((int)strtol(pat, nullptr, 0), stream);
+    if (const int* pat = dbg_ldsfill()) (void)cnl::launch_lds_fill(*pat, stream);
   if (h->dense) {
     // dense residual block: J'WJ + tiled dense LDL^T on the fp64 matrix cores (csrc/dense.hip); asynchronous, the rho ladder
     // is decided on the device
@@ -866,39 +860,54 @@ void cnl_default_params(double p[9]) {
 void cnl_options_init(cnl_options* o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));
+  const cnl::Tuning t;   // the defaults live in options.h
   o->struct_size = (int32_t)sizeof(cnl_options);
-  o->plan_kind = CNL_PLAN_AUTO;
+  o->plan_kind = t.plan_kind;
   // measured on MI355X (cfg3 pattern, tools/cmp_staged_threshold.py): latency plans with a few large canonical parts reach
   // 600 k systems/s at 2048 problems and 613 k at 4096 (the single stream: 342 k and 567 k); from 5120 on the single stream wins
-  o->staged_max_batch = 4096;
-  o->order_mode = -1; o->nd_leaf = 0; o->relax = -1; o->task_cap = 0;
-  o->multipliers_early = 1; o->condense = 1; o->direct_records = 1; o->register_front = 1; o->dense_backend = 1; o->general_dense = 1;
-  o->staged = 1; o->dataflow = 1; o->dataflow_waves = 1024; o->dataflow_spin_limit = 1 << 22;
-  o->waves_per_block = 0; o->v1_tpp = -1; o->v1_ppb = -1; o->v1_lds = -1; o->v1_solve = 0; o->lds_pad = 1;
-  o->ubig = 17; o->wait_thr = 2; o->dense_graph = 1; o->dense_syrk_wgs = 0; o->verbose = 0; o->multi_share_plan = 1; o->row_products = 1; o->split_batch = 1; o->lean_kernel = 1; o->rows_in_backward = 1; o->dense_panel_blocks = 1; o->host_ladder = 1;
-  // (fused: measured slower than the separate launches on one system of cfg3's size, 0.140 against 0.118 ms — the rung loop costs
-  //  the kernel 50 VGPRs and 45 spilled SGPRs — so it is off by default)
-  o->device_ladder = 1; o->device_ladder_fused = 0; o->band_form = 1; o->split_tail = 1; o->staged_large_fronts = 0; o->band_kernel = 1; o->band_problems_per_group = 0; o->f1_tiles = 1; o->band_wide_pieces = 0;
+  o->staged_max_batch = t.staged_max_batch;
+  o->verbose = t.verbose; o->band_kernel = t.band_kernel; o->dense_backend = t.dense_backend; o->staged = t.staged; o->dataflow = t.dataflow;
+  o->device_ladder = t.device_ladder; o->host_ladder = t.host_ladder; o->split_tail = t.split_tail; o->multi_share_plan = t.multi_share_plan;
+  o->f1_tiles = t.f1_tiles;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
-                            int64_t nequ, int64_t ncon, int latency, int par, double slots, const cnl_options& o);
+                            int64_t nequ, int64_t ncon, int latency, int par, double slots, const cnl::Tuning& o);
+static int plan_create_tuned(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                             int64_t nequ, int64_t ncon, int64_t batch, const cnl::Tuning& o);
+static int create_tuned(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                        int64_t nequ, int64_t ncon, int64_t batch, int device, const cnl::Tuning& o);
 
-// options as given, or the defaults; rejects a struct of another ABI revision
-static int resolve_options(const cnl_options* in, cnl_options& out) {
-  cnl_options_init(&out);
+// public options -> the internal switch set: the defaults, the public fields, then the `tuning` pairs (which may name any switch of
+// options.h, public ones included); rejects a struct of another ABI revision and unknown keys
+static int resolve_options(const cnl_options* in, cnl::Tuning& out) {
+  out = cnl::Tuning();
   if (!in) return CNL_OK;
   if (in->struct_size != (int32_t)sizeof(cnl_options)) return fail(CNL_ERR_ARG, "cnl_options.struct_size does not match this library (use cnl_options_init)");
-  out = *in;
+  out.plan_kind = in->plan_kind; out.staged_max_batch = in->staged_max_batch; out.verbose = in->verbose; out.band_kernel = in->band_kernel;
+  out.dense_backend = in->dense_backend; out.staged = in->staged; out.dataflow = in->dataflow; out.device_ladder = in->device_ladder;
+  out.host_ladder = in->host_ladder; out.split_tail = in->split_tail; out.multi_share_plan = in->multi_share_plan; out.f1_tiles = in->f1_tiles;
+  std::memcpy(out.force_order, in->force_order, sizeof(out.force_order));
   out.force_order[sizeof(out.force_order) - 1] = 0;
+  char tun[sizeof(in->tuning) + 1];
+  std::memcpy(tun, in->tuning, sizeof(in->tuning));
+  tun[sizeof(in->tuning)] = 0;
+  const std::string err = cnl::tuning_parse(out, tun);
+  if (!err.empty()) return fail(CNL_ERR_ARG, err);
   return CNL_OK;
 }
 
 int cnl_plan_create_ex(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
                        int64_t nequ, int64_t ncon, int64_t batch, const cnl_options* opt) {
-  cnl_options o;
+  cnl::Tuning o;
   int rc = resolve_options(opt, o);
   if (rc) return rc;
+  return plan_create_tuned(plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch, o);
+}
+
+static int plan_create_tuned(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                             int64_t nequ, int64_t ncon, int64_t batch, const cnl::Tuning& o) {
+  int rc = CNL_OK;
   int latency = 0;
   if (o.plan_kind == CNL_PLAN_LATENCY) latency = 1;
   else if (o.plan_kind == CNL_PLAN_AUTO) latency = batch >= 1 && batch <= (o.staged_max_batch > 0 ? o.staged_max_batch : 4096);
@@ -910,7 +919,7 @@ int cnl_plan_create_ex(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* r
     // order's cost, the handle runs part of the batch on it and the rest single-stream, concurrently (run_split).
     const int64_t smb = o.staged_max_batch > 0 ? o.staged_max_batch : 4096;
     if (rc == CNL_OK && o.plan_kind == CNL_PLAN_AUTO && o.split_batch && batch > smb && batch <= 2 * smb - smb / 8 && o.force_order[0] == 0) {
-      cnl_options o2 = o;
+      cnl::Tuning o2 = o;
       std::snprintf(o2.force_order, sizeof(o2.force_order), "ndc2+early");
       cnl_plan* alt = nullptr;
       const int nq = (int)((smb + 3) / 4);
@@ -948,7 +957,7 @@ int cnl_plan_create_for_batch(cnl_plan** plan, int64_t N, int64_t nnz, const int
 // latency != 0: plan for a small batch — order chosen by the critical path, tree cut into tasks (par = wavefront slots per
 // group of four problems)
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
-                            int64_t nequ, int64_t ncon, int latency, int par, double slots, const cnl_options& o) {
+                            int64_t nequ, int64_t ncon, int latency, int par, double slots, const cnl::Tuning& o) {
   if (!plan || !rows1 || !cols1) return fail(CNL_ERR_ARG, "null argument");
   cnl_plan* p = new cnl_plan();
   p->N = N; p->nnz = nnz; p->nvar = nvar; p->nequ = nequ; p->ncon = ncon;
@@ -1053,12 +1062,12 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
   if (o.dense_backend) cnl::detect_dense(p->D, N, nnz, rows1, cols1, nvar, nequ, ncon);
   // (round 5) large batches of band-structured problems: the sliding-window elimination with one lane per (problem, part)
   if (!latency && o.band_kernel && p->C.active && !p->D.active) {
-    cnl::build_band_plan(p->band, N, nnz, rows1, cols1, nvar, nequ, ncon, o.band_kernel == 2 ? 1 : 2, o.band_wide_pieces != 0);
+    cnl::build_band_plan(p->band, N, nnz, rows1, cols1, nvar, nequ, ncon, o.band_kernel == 2 ? 1 : 2);
     if (verbose) fprintf(stderr, "[cnl] band program: %s%s\n", p->band.ok ? "ok" : "no: ", p->band.ok ? "" : p->band.why.c_str());
   }
   {
     const cnl::BandPlan& Bp = p->band;
-    p->band_info = {Bp.ok ? 1 : 0, Bp.nparts, Bp.m0, Bp.n, Bp.N, Bp.nnz, (int32_t)Bp.lsize, Bp.wide ? 1 : 0};
+    p->band_info = {Bp.ok ? 1 : 0, Bp.nparts, Bp.m0, Bp.n, Bp.N, Bp.nnz, (int32_t)Bp.lsize, 0};
     for (int q = 0; q < 2; q++) p->band_pinfo[q] = {Bp.part[q].nsteps, Bp.part[q].nepochs, Bp.part[q].npiv, Bp.part[q].nevents, (int32_t)Bp.part[q].loff};
   }
   // Irregular sparsity: when the fill makes fronts larger than the register-front kernel takes and the condensed system is of
@@ -1167,6 +1176,15 @@ int cnl_create_ex(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows
                   int64_t nequ, int64_t ncon, int64_t batch, int device, const cnl_options* opt) {
   if (!hout) return fail(CNL_ERR_ARG, "null handle pointer");
   *hout = nullptr;
+  cnl::Tuning o;
+  const int rc0 = resolve_options(opt, o);
+  if (rc0) return rc0;
+  return create_tuned(hout, N, nnz, rows1, cols1, nvar, nequ, ncon, batch, device, o);
+}
+
+static int create_tuned(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
+                        int64_t nequ, int64_t ncon, int64_t batch, int device, const cnl::Tuning& o) {
+  *hout = nullptr;
   if (batch < 1 || batch > (1 << 24)) return fail(CNL_ERR_ARG, "batch out of range");
   int ndev = 0;
   const hipError_t ce = hipGetDeviceCount(&ndev);
@@ -1176,7 +1194,7 @@ int cnl_create_ex(cnl_handle** hout, int64_t N, int64_t nnz, const int64_t* rows
   if (device < 0 || device >= ndev) return fail(CNL_ERR_ARG, "device index out of range");
   cnl_plan* plan = nullptr;
   // small batches cannot fill the chip with one wavefront per four problems: plan for latency (bushy order, tasks)
-  int rc = cnl_plan_create_ex(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch, opt);
+  int rc = plan_create_tuned(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon, batch, o);
   if (rc) return rc;
   return create_from_plan(hout, plan, rows1, cols1, batch, device);
 }
@@ -1259,20 +1277,24 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
       if ((rc = upload(h, Bp.part[q].borders, &bd.borders[q]))) return bail(rc);
       bd.nsteps[q] = Bp.part[q].nsteps; bd.nepochs[q] = Bp.part[q].nepochs; bd.loff[q] = Bp.part[q].loff;
     }
-    bd.nparts = Bp.nparts; bd.m0 = Bp.m0; bd.n = Bp.n; bd.N = Bp.N; bd.nnz = Bp.nnz; bd.nvar = (int32_t)nvar; bd.lsize = Bp.lsize; bd.wide = Bp.wide ? 1 : 0;
+    bd.nparts = Bp.nparts; bd.m0 = Bp.m0; bd.n = Bp.n; bd.N = Bp.N; bd.nnz = Bp.nnz; bd.nvar = (int32_t)nvar; bd.lsize = Bp.lsize;
     // 16 problems per workgroup (two workgroups = four wavefronts per CU: one per SIMD) up to the 8192 problems that fills; above,
     // 32 per workgroup (the LDS of a CU holds two such workgroups: 16384 problems resident) — tools/time_band.py
     h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : (batch > 8192 ? 32 : 16);
     if (h->band_nl != 8 && h->band_nl != 16 && h->band_nl != 32) return bail(fail(CNL_ERR_ARG, "band_problems_per_group must be 8, 16 or 32"));
+    // (round 6) dedicated mover wavefronts: two parts, 16 problems per group, two groups per workgroup (band.hip, band_newton_mw_kernel)
+    //  — an experiment, measured slower (profiles/r06_band_movers.jsonl); compiled only into experiment builds
+    if (plan->opt.band_movers > 0 && cnl::band_mw_lds_bytes(16) == (size_t)-1)
+      return bail(fail(CNL_ERR_ARG, "tuning key band_movers needs a library built with -DCNL_EXPERIMENT=1 -DBAND_MW (csrc/band.hip)"));
+    h->band_mw = plan->opt.band_movers > 0 && bd.nparts == 2 && cnl::band_mw_lds_bytes(16) <= std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024);
+    if (h->band_mw) h->band_nl = 16;
     // 32-bit byte offsets inside a workgroup's problems
     const uint64_t span = 8ull * (uint64_t)h->band_nl * (uint64_t)std::max<int64_t>({(int64_t)nnz, N, bd.lsize});
     if (span < (1ull << 32) && cnl::band_lds_bytes(bd.nparts, h->band_nl) <= std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024)) {
       // (+ 32 problems: the band kernels interleave the records of a workgroup's problems, the last workgroup's region is a whole one)
       if ((rc = dalloc(h, &h->d_Lband, ((size_t)batch + 32) * (size_t)bd.lsize + 64))) return bail(rc);
-      if ((rc = dalloc(h, &h->d_band_ok, (size_t)batch))) return bail(rc);
       if (hipMemset(h->d_Lband, 0, (((size_t)batch + 32) * (size_t)bd.lsize + 64) * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
       h->band = true;
-      h->root_Lband = h->d_Lband; h->root_band_ok = h->d_band_ok; h->root_batch = batch;
     }
   }
   if (plan->split_mode && h->staged) {
@@ -1290,9 +1312,8 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     // a remainder of at most a quarter of the machine-filling batch: its own handle with its own (many-part) plan — run_split
     const int64_t smb = ((plan->opt.staged_max_batch > 0 ? plan->opt.staged_max_batch : 4096)) & ~(int64_t)3;
     if (h->staged && plan->opt.split_batch == 1 && plan->opt.split_tail != 0 && batch > smb && batch - smb <= smb / 4) {
-      cnl_options o2 = plan->opt;
       cnl_handle* t = nullptr;
-      if (cnl_create_ex(&t, N, nnz, rows1, cols1, nvar, nequ, ncon, batch - smb, device, &o2) == CNL_OK) {
+      if (create_tuned(&t, N, nnz, rows1, cols1, nvar, nequ, ncon, batch - smb, device, plan->opt) == CNL_OK) {
         if (t->staged && t->use_v2 && !t->dense && !t->gdense && !t->tail && t->split_staged == 0) {
           h->tail = t; h->split_halves = false; h->split_staged = smb;
         } else {
@@ -1311,9 +1332,8 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     // (band kernels: 512 workgroups of 32 problems are resident at once)
     const int64_t cap = h->band ? 16384 : 4 * (int64_t)h->resident_waves, r = batch % cap;
     if (batch > cap && r > 0 && r <= cap - cap / 16) {
-      cnl_options o2 = plan->opt;
       cnl_handle* t = nullptr;
-      if (cnl_create_ex(&t, N, nnz, rows1, cols1, nvar, nequ, ncon, r, device, &o2) == CNL_OK) {
+      if (create_tuned(&t, N, nnz, rows1, cols1, nvar, nequ, ncon, r, device, plan->opt) == CNL_OK) {
         if (t->staged && t->use_v2 && !t->dense && !t->gdense) { h->tail = t; h->split_staged = batch - r; }
         else cnl_destroy(t);
       }
@@ -1340,7 +1360,6 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     const size_t ldoubles = (size_t)batch * (size_t)dp.lsize + 4096;
     if ((rc = dalloc(h, &h->d_L, ldoubles))) return bail(rc);
     if (hipMemset(h->d_L, 0, ldoubles * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
-    h->root_L = h->d_L;
   }
   if (!h->cfg.lds_work)
     if ((rc = dalloc(h, &h->d_scratch, (size_t)batch * (size_t)dp.work_doubles))) return bail(rc);
@@ -1552,6 +1571,12 @@ int cnl_last_kernel_ms(cnl_handle* h, float* ms) {
   return CNL_OK;
 }
 
+int cnl_launch_counts(int64_t counts[3]) {
+  if (!counts) return fail(CNL_ERR_ARG, "null argument");
+  for (int k = 0; k < 3; k++) counts[k] = g_launches[k].load();
+  return CNL_OK;
+}
+
 int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   if (!h || !cfg) return fail(CNL_ERR_ARG, "null argument");
   std::memset(cfg, 0, 8 * sizeof(int64_t));
@@ -1560,7 +1585,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   cfg[5] = (h->dense || h->gdense) ? 3 : (h->use_v2 ? (h->staged ? 4 : 2) : 1);
   if (h->lean && !h->dense && !h->gdense) cfg[5] |= 16;  // newton_system / factorize run the kernels' LEAN instantiation
   if (h->tail) cfg[5] |= 32;                             // the remainder of the batch runs on a handle of its own (split_tail)
-  if (h->band) cfg[5] |= 64 | ((int64_t)h->band_nl << 8) | ((int64_t)h->bd.nparts << 16);   // newton_system runs on the band kernels (csrc/band.h): problems per workgroup, parts
+  if (h->band) cfg[5] |= 64 | ((int64_t)h->band_nl << 8) | ((int64_t)h->bd.nparts << 16) | (h->band_mw ? (int64_t)1 << 24 : 0);   // newton_system runs on the band kernels (csrc/band.h): problems per workgroup, parts
   if (h->djt.rv_ntiles > 0) cfg[5] |= 128;               // row f1 runs on column tiles (kernels.h: DevJt::rv_*)
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;
@@ -2115,7 +2140,7 @@ int cnl_multi_create_ex(cnl_multi** mout, int64_t N, int64_t nnz, const int64_t*
   if (!mout || !devices) return fail(CNL_ERR_ARG, "null argument");
   *mout = nullptr;
   if (ndev < 1 || ndev > 64 || batch < 1) return fail(CNL_ERR_ARG, "need 1 <= ndev <= 64 and batch >= 1");
-  cnl_options o;
+  cnl::Tuning o;
   int rc = resolve_options(opt, o);
   if (rc) return rc;
   int navail = 0;
@@ -2147,10 +2172,10 @@ int cnl_multi_create_ex(cnl_multi** mout, int64_t N, int64_t nnz, const int64_t*
         if (shared[k]) { cnl_plan_destroy(shared[k]); shared[k] = nullptr; }   // (a third size: cannot happen with balanced shards)
         shared_count[k] = m->count[i];
       }
-      if (!shared[k]) rc = cnl_plan_create_ex(&shared[k], N, nnz, rows1, cols1, nvar, nequ, ncon, m->count[i], &o);
+      if (!shared[k]) rc = plan_create_tuned(&shared[k], N, nnz, rows1, cols1, nvar, nequ, ncon, m->count[i], o);
       if (!rc) { plan = shared[k]; plan->refs.fetch_add(1); }
     } else {
-      rc = cnl_plan_create_ex(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon, m->count[i], &o);
+      rc = plan_create_tuned(&plan, N, nnz, rows1, cols1, nvar, nequ, ncon, m->count[i], o);
     }
     cnl_handle* h = nullptr;
     if (!rc) rc = create_from_plan(&h, plan, rows1, cols1, m->count[i], m->device[i]);  // owns one reference, also when it fails

@@ -229,6 +229,12 @@ int build_condensation(Cond& C, int64_t N, int64_t nnz, const int64_t* rows1, co
       C.chunk_nslot_max = std::max(C.chunk_nslot_max, nsl);
     }
     C.ch_region[0] = 0; C.ch_region[1] = C.ch_region[2] = C.ch_region[3] = (int32_t)C.ch_tile.size();
+    // the tiled kernel's whole LDS need (kernels_aux.hip, launch_condense_tiled: four problems' tiles + a chunk's contribution and
+    // slot lists) must fit a workgroup: a dense Jacobian gives every slot of J'J one contribution per residual row, and a chunk of
+    // 256 such slots exceeded the limit (found by the option fuzz of round 6 with dense_backend = 0: the launch failed with
+    // "invalid argument") — such patterns keep the plain slot kernel
+    const size_t lds_need = (size_t)CONDENSE_TILED_PROBLEMS * (size_t)C.tile_max * 8 + (size_t)C.chunk_ncon_max * 8 + ((size_t)C.chunk_nslot_max + 8) * 4;
+    if (lds_need > 144 * 1024) C.tiled_ok = false;
   }
   C.active = true;
   msg.clear();

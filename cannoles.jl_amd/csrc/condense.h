@@ -22,6 +22,9 @@
 
 namespace cnl {
 
+constexpr int CONDENSE_TILED_PROBLEMS = 4;   // problems per workgroup of condense_tiled_kernel (kernels_aux.hip: TPB)
+
+
 struct Cond {
   bool active = false;
   int64_t N = 0, nnz = 0, nvar = 0, nequ = 0, ncon = 0;  // outer (reference) dimensions

@@ -158,13 +158,15 @@ struct BandDev {
   int32_t nsteps[2], nepochs[2];
   long long loff[2];
   int32_t nparts, m0, n, N, nnz, nvar;
-  int32_t wide;   // the program uses the wide layout (band.h: BAND_WIDE_POS)
   long long lsize;
 };
 // newton_system! / try_to_factorize of a.batch problems on the band kernels, nl problems per workgroup (8, 16 or 32); a.L = the
 // band factor storage [batch][P.lsize]
 hipError_t launch_band(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream);
 size_t band_lds_bytes(int nparts, int nl);
+// the same program on the kernel with dedicated mover wavefronts (band.hip, band_newton_mw_kernel): two parts, nl = 16
+hipError_t launch_band_mw(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream);
+size_t band_mw_lds_bytes(int nl);
 
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);

@@ -5,6 +5,7 @@
 // They stream over independent (problem, entry) pairs at full occupancy; no dependency chains.
 #include <hip/hip_runtime.h>
 
+#include "condense.h"
 #include "kernels.h"
 
 namespace cnl {
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) condense_kernel(const DevCond Cin, const 
 // vals is fetched about once per problem), then every thread forms slots for the TPB problems from LDS
 // (contribution indices are read once per slot and reused for every problem).  `mask` selects the slot
 // ranges to produce: 1 matrix, 2 rho, 4 right-hand side.
-constexpr int TPB = 4;
+constexpr int TPB = CONDENSE_TILED_PROBLEMS;
 __global__ void __launch_bounds__(256) condense_tiled_kernel(const DevCond Cin, const double* __restrict__ vals,
                                                              const double* __restrict__ rhs, double* __restrict__ cbuf,
                                                              int mask, int batch) {

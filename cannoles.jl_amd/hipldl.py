@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "cnl_create", "cnl_destroy", "cnl_get_plan",
     "cnl_factorize", "cnl_solve", "cnl_newton_system",
     "cnl_factorize_dev", "cnl_solve_dev", "cnl_newton_system_dev",
-    "cnl_set_timing", "cnl_last_kernel_ms", "cnl_get_config",
+    "cnl_set_timing", "cnl_last_kernel_ms", "cnl_get_config", "cnl_launch_counts",
     "cnl_residual_vectors_dev", "cnl_trial_point_dev", "cnl_prepare_newton_system_dev",
     "cnl_cgls_multipliers_dev",
     "cnl_multi_create_ex", "cnl_multi_factorize_dev", "cnl_multi_solve_dev", "cnl_multi_newton_system_dev", "cnl_multi_synchronize",
@@ -50,11 +50,11 @@ PLAN_AUTO, PLAN_THROUGHPUT, PLAN_LATENCY = 0, 1, 2
 class cnl_options(C.Structure):
     """struct cnl_options of include/cannoles_hip.h (field order and types must match)"""
     _fields_ = [("struct_size", C.c_int32), ("plan_kind", C.c_int32), ("staged_max_batch", C.c_int64)] + [
-        (k, C.c_int32) for k in (
-            "order_mode", "nd_leaf", "relax", "task_cap", "multipliers_early", "condense", "direct_records", "register_front",
-            "dense_backend", "general_dense", "staged", "dataflow", "dataflow_waves", "dataflow_spin_limit", "waves_per_block",
-            "v1_tpp", "v1_ppb", "v1_lds", "v1_solve", "lds_pad", "ubig", "wait_thr", "dense_graph", "dense_syrk_wgs", "verbose",
-            "multi_share_plan", "row_products", "split_batch", "lean_kernel", "rows_in_backward", "dense_panel_blocks", "host_ladder", "device_ladder", "device_ladder_fused", "band_form", "split_tail", "staged_large_fronts", "band_kernel", "band_problems_per_group", "f1_tiles", "band_wide_pieces")] + [("force_order", C.c_char * 32)]
+        (k, C.c_int32) for k in ("verbose", "band_kernel", "dense_backend", "staged", "dataflow", "device_ladder", "host_ladder", "split_tail",
+                                 "multi_share_plan", "f1_tiles")] + [("force_order", C.c_char * 32), ("tuning", C.c_char * 192)]
+
+
+_PUBLIC_OPTIONS = {f[0] for f in cnl_options._fields_} - {"struct_size", "tuning"}
 
 
 class cnl_outer_state(C.Structure):
@@ -75,17 +75,27 @@ class cnl_outer_state(C.Structure):
 
 
 def Options(**kw):
-    """cnl_options with the library's defaults (cnl_options_init), then the given fields: explicit arguments instead of
-    environment variables — e.g. Options(plan_kind=PLAN_THROUGHPUT), Options(dataflow=0), Options(force_order="nd32+early")."""
+    """cnl_options with the library's defaults (cnl_options_init), then the given switches: explicit arguments instead of
+    environment variables — e.g. Options(plan_kind=PLAN_THROUGHPUT), Options(dataflow=0), Options(force_order="nd32+early").
+    Fields of the public structure are set directly; any other switch of csrc/options.h (lean_kernel, band_form,
+    band_problems_per_group, ...) goes into its `tuning` string as key=value — the library rejects an unknown key."""
     o = cnl_options()
     lib().cnl_options_init(C.byref(o))
     assert o.struct_size == C.sizeof(cnl_options), "cnl_options layout differs from the library's"
+    tun = []
     for k, v in kw.items():
         if k == "force_order":
             v = v.encode() if isinstance(v, str) else v
-        if not hasattr(o, k):
-            raise AttributeError(f"cnl_options has no field {k!r}")
-        setattr(o, k, v)
+        if k == "tuning":
+            tun.append(v.decode() if isinstance(v, bytes) else str(v))
+        elif k in _PUBLIC_OPTIONS:
+            setattr(o, k, v)
+        else:
+            tun.append(f"{k}={int(v)}")
+    text = ",".join(t for t in tun if t)
+    if len(text) >= 192:
+        raise ValueError("cnl_options.tuning holds 191 characters")
+    o.tuning = text.encode()
     return o
 
 
@@ -190,6 +200,7 @@ def lib():
         L.cnl_set_timing.argtypes = [vp, C.c_int]
         L.cnl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cnl_get_config.argtypes = [vp, _i64p]
+        L.cnl_launch_counts.argtypes = [_i64p]
         for fn in ("cnl_outer_begin_dev", "cnl_outer_extrapolated_dev", "cnl_outer_trial_done_dev", "cnl_outer_end_dev", "cnl_outer_ls_begin_dev",
                    "cnl_outer_ls_step_dev", "cnl_outer_ls_take_dev"):
             getattr(L, fn).argtypes = [vp, vp]
@@ -310,7 +321,7 @@ class HIPLDLStruct:
         self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4]),
                        "kernel": {2: "v2", 3: "dense", 4: "v2-staged"}.get(int(cfg[5]) & 15, "v1"), "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7]),
                        "lean": bool(int(cfg[5]) & 16), "tail": bool(int(cfg[5]) & 32), "band": bool(int(cfg[5]) & 64), "f1_tiles": bool(int(cfg[5]) & 128),
-                       "band_nl": (int(cfg[5]) >> 8) & 255, "band_parts": (int(cfg[5]) >> 16) & 255}
+                       "band_nl": (int(cfg[5]) >> 8) & 255, "band_parts": (int(cfg[5]) >> 16) & 255, "band_movers": bool((int(cfg[5]) >> 24) & 1)}
 
     def plan_array(self, name):
         return _plan_array(lib().cnl_get_plan(self._h), name)
@@ -344,6 +355,13 @@ class HIPLDLStruct:
         ms = C.c_float(0)
         _check(lib().cnl_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+def launch_counts():
+    """launches per kernel family since the library was loaded: {"band", "register_front", "general"} (cnl_launch_counts)"""
+    c = np.zeros(3, np.int64)
+    _check(lib().cnl_launch_counts(c))
+    return {"band": int(c[0]), "register_front": int(c[1]), "general": int(c[2])}
 
 
 def get_vals(LDLT):

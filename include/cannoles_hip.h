@@ -61,12 +61,15 @@ void cnl_default_params(double params[9]);
 
 /* ---- options ----------------------------------------------------------------------------------------------------------
  * Everything that selects a plan or an execution is an ARGUMENT: the library reads no environment variable that changes what it
- * computes (CNL_VERBOSE only adds log lines on stderr; the debugging aids CNL_DBG_LDSFILL / CNL_DBG_SCRATCHFILL launch kernels that leave
- * a byte pattern in LDS, scratch and registers in front of every launch, CNL_DBG_GUARD surrounds every device allocation with filled guard
- * zones — the library's results must not, and do not, depend on either).  cnl_options_init fills the defaults — the choices cnl_create makes by
- * itself; the `_ex` entry points take a modified copy.  Used by tests and measurement tools to force a plan kind or an execution
- * the automatic choice would not pick for that batch; a drop-in caller never needs it (the reference has no counterpart:
- * `ldl_analyze` takes no options, src/solver_types.jl:63).                                                                       */
+ * computes (CNL_VERBOSE only adds log lines on stderr; the debugging aids CNL_DBG_LDSFILL / CNL_DBG_SCRATCHFILL — read once per process —
+ * launch kernels that leave a byte pattern in LDS, scratch and registers in front of every launch, CNL_DBG_GUARD surrounds every device
+ * allocation with filled guard zones — the library's results must not, and do not, depend on either).  cnl_options_init fills the
+ * defaults — the choices cnl_create makes by itself; the `_ex` entry points take a modified copy.  A drop-in caller never needs it (the
+ * reference has no counterpart: `ldl_analyze` takes no options, src/solver_types.jl:63).
+ * The structure holds the switches that select a plan kind or allow / forbid a kernel family or an execution; everything finer
+ * (orderings, thresholds, ablation switches of single kernels, measured-slower experiments) is reachable through `tuning`, a string of
+ * "key=value" pairs whose keys are listed in cannoles.jl_amd/csrc/options.h — used by the measurement tools and the randomised
+ * option fuzz of the test-suite; an unknown key is CNL_ERR_ARG.                                                                   */
 #define CNL_PLAN_AUTO 0        /* by batch size: latency plan up to staged_max_batch problems, throughput plan above           */
 #define CNL_PLAN_THROUGHPUT 1  /* least total work, one sequential record stream per four problems                             */
 #define CNL_PLAN_LATENCY 2     /* bushy elimination tree cut into tasks (staged execution)                                      */
@@ -74,71 +77,29 @@ typedef struct cnl_options {
   int32_t struct_size;         /* sizeof(cnl_options), set by cnl_options_init (ABI evolution)                                  */
   int32_t plan_kind;           /* CNL_PLAN_*                                                                                    */
   int64_t staged_max_batch;    /* CNL_PLAN_AUTO: largest batch planned for latency (default 4096)                              */
-  int32_t order_mode;          /* -1 auto (cost model over all candidates), 0 canonical, 1 nested dissection, 2 minimum degree  */
-  int32_t nd_leaf;             /* nested-dissection leaf size, 0 = sweep                                                        */
-  int32_t relax;               /* relaxed-amalgamation budget (explicit zeros per merged column), -1 = default                  */
-  int32_t task_cap;            /* fronts per bottom task of a latency plan, 0 = default                                         */
-  int32_t multipliers_early;   /* 1: candidates with every multiplier right behind the last variable it touches are considered  */
-  int32_t condense;            /* 1: static condensation of the -I block                                                        */
-  int32_t direct_records;      /* 1: the register-front kernel condenses on the fly (no separate condense pass)                 */
-  int32_t register_front;      /* 1: the register-front kernel may serve the plan (fronts of order <= 64)                       */
-  int32_t dense_backend;       /* 1: dense residual blocks go to the dense backend                                              */
-  int32_t general_dense;       /* 1: small batches of irregular plans with fronts > 64 (up to 16 problems: > 32 when the condensed order is <= 512) are factorised as ONE dense matrix; 2: wherever possible (measurements) */
-  int32_t staged;              /* 1: latency plans run their first attempt stage by stage                                       */
-  int32_t dataflow;            /* 1: smallest batches run all tasks in one launch per phase, waiting on device counters         */
-  int32_t dataflow_waves;      /* at most this many wavefronts run in dataflow fashion (default 1024; clamped to what the device
-                                  holds at once)                                                                                */
-  int32_t dataflow_spin_limit; /* polls before a dataflow wait gives up (default 1 << 22).  A wait that gives up is counted
-                                  (cnl_dataflow_timeouts) and the call falls back to the sequential execution for the batch      */
-  int32_t waves_per_block;     /* register-front kernel: wavefronts per workgroup, 0 = default (1)                              */
-  int32_t v1_tpp, v1_ppb, v1_lds; /* general kernel: threads per problem, problems per workgroup, work area in LDS; -1 = auto   */
-  int32_t v1_solve;            /* 1: cnl_solve always runs on the general kernel                                                */
-  int32_t lds_pad;             /* 1: per-problem LDS areas 32 banks apart                                                       */
-  int32_t ubig;                /* update matrices of order above this live in global scratch (default 17)                       */
-  int32_t wait_thr;            /* ... and those that wait for more than this many fronts (default 2)                            */
-  int32_t dense_graph;         /* 1: the dense backend replays its launch sequence as a hipGraph                                */
-  int32_t dense_syrk_wgs;      /* workgroups of the J'WJ kernel, 0 = default                                                    */
   int32_t verbose;             /* 1: log plan decisions on stderr                                                               */
-  int32_t multi_share_plan;    /* 1: cnl_multi_create analyses the pattern once for all shards of equal plan kind               */
-  int32_t row_products;        /* 1: condensation products of small fronts organised per residual row (csrc/plan.h, RF_ROWS)    */
-  int32_t split_batch;         /* batches between one and two wavefronts per SIMD (csrc/capi.cpp, run_split): 1 (default) two halves on
-                                  the bidirectional chain one behind the other (up to 6400 problems; above: as 2), 2 partly on the
-                                  chain, partly single-stream, concurrently (round 3's form), 0 the single stream                */
-  int32_t lean_kernel;         /* 1: plans of fast-class row-form fronts run the kernels' instantiation without the cold paths  */
-  int32_t rows_in_backward;    /* 1: the lean kernel recovers the residual components in its backward sweep (no post-pass)      */
-  int32_t dense_panel_blocks;  /* dense backend, panel step with four column-block wavefronts per tile (dn_panel2): 0 never,
-                                  1 while the step is latency-bound (batch x tiles <= 512; default), 2 always                    */
-  int32_t host_ladder;         /* 1: where the in-kernel device ladder is not available (device_ladder = 0, split handles, plans whose
-                                  tasks do not fit the device at once, the dense backend) the host-pointer cnl_newton_system drives
-                                  the rho ladder from the host, every rung a staged try_to_factorize (default); 0: the sequential launch */
-  int32_t device_ladder;       /* 1: device-pointer cnl_newton_system_dev on staged handles climbs the rho ladder inside ONE launch
-                                  in which every task of the elimination tree has a wavefront of its own (per rung the tasks
-                                  factorise in dataflow fashion, the last to finish applies the ladder rule; default); 0: the
-                                  sequential launch (one wavefront per four problems walks all fronts, per rung)                  */
-  int32_t device_ladder_fused; /* 1: on the smallest batches (where the first attempt would run in dataflow fashion) that launch makes
-                                  the first attempt and the backward sweeps too: newton_system is one launch (default 0: measured
-                                  slower than the separate launches, 0.140 against 0.118 ms for one system of cfg3's size)         */
-  int32_t band_form;           /* 1: fast fronts whose pivot rows are structurally zero outside a few fixed columns and the four
-                                  columns below the pivot (the fronts of band problems) run an elimination that does not contain
-                                  the other row updates (csrc/plan.h, band_fronts; default); 0: every pivot updates every row    */
+  int32_t band_kernel;         /* 1 (default): a throughput handle whose pattern is a band in the natural order of the variables
+                                  (every residual row and Hessian entry within five consecutive variables, every constraint row a
+                                  run of its own) runs on the band kernels (csrc/band.h: one lane per problem and half of the chain,
+                                  operands streamed through LDS) — newton_system, try_to_factorize (the forward sweep alone) and
+                                  solve_ldl! (which factorises the values of the last factorisation again and sweeps the new
+                                  right-hand side in the same launch); 2: the same with the chain in one part; 0: the register-front
+                                  kernel                                                                                        */
+  int32_t dense_backend;       /* 1: dense residual blocks (BASELINE config 2) go to the dense backend (fp64 MFMA)              */
+  int32_t staged;              /* 1: latency plans run stage by stage (tasks of the elimination tree on different wavefronts)   */
+  int32_t dataflow;            /* 1: smallest batches run all tasks in one launch per phase, waiting on device counters         */
+  int32_t device_ladder;       /* 1: cnl_newton_system(_dev) on staged handles climbs the rho ladder inside ONE launch in which every
+                                  task of the elimination tree has a wavefront of its own; 0: the sequential launch              */
+  int32_t host_ladder;         /* 1: where the in-kernel ladder is not available (device_ladder = 0, split handles, the dense backend)
+                                  the host-pointer cnl_newton_system drives the rho ladder from the host, every rung a staged
+                                  try_to_factorize; 0: the sequential launch                                                    */
   int32_t split_tail;          /* 1: the remainder of a batch above a machine-filling one runs on a handle of its own, with the plan
-                                  cnl_create picks for a batch of that size, behind the rest on the caller's stream (default):
-                                  staged_max_batch + r problems, r <= staged_max_batch / 4 (first part on the bidirectional
-                                  chain), and k full loads of the single stream (four problems per resident wavefront: 8192 at
-                                  cfg3's size) + r problems; 0: split_batch's two halves / the single stream's extra round        */
-  int32_t staged_large_fronts; /* no effect since round 5 (kept for the layout of the structure): rounds 4 - 5 fenced the staged
-                                  execution / the in-kernel ladder off on plans with fronts of order 17 .. 64 while a fault there
-                                  was hunted; its cause — register spills the compiler placed in front of an EXEC restore — is
-                                  removed, every stageable plan runs staged with the in-kernel ladder               */
-  int32_t band_kernel;         /* (round 5) 1 (default): a throughput handle whose pattern is a band in the natural order of the
-                                  variables (every residual row and Hessian entry within five consecutive variables, every
-                                  constraint row a run of its own) runs newton_system on the band kernels (csrc/band.h: one lane per
-                                  problem and half of the chain, operands streamed through LDS); 2: the same with the chain in one
-                                  part; 0: the register-front kernel                                                              */
-  int32_t band_problems_per_group; /* band kernels: problems per workgroup (8, 16 or 32); 0 = by batch: 16 up to 8192 problems, 32 above */
-  int32_t f1_tiles;            /* 1: row f1 (cnl_residual_vectors_dev) streams column tiles through LDS where the pattern allows; 0: gather kernel */
-  int32_t band_wide_pieces;    /* 1: the band program loads contiguous operand runs in 128-byte pieces (16 bytes per lane; four per epoch); 0 (default): 64-byte pieces only — measured equal */
+                                  cnl_create picks for a batch of that size, behind the rest on the caller's stream             */
+  int32_t multi_share_plan;    /* 1: cnl_multi_create analyses the pattern once for all shards of equal plan kind               */
+  int32_t f1_tiles;            /* 1: row f1 (cnl_residual_vectors_dev) streams column tiles through LDS where the pattern allows;
+                                  0: gather kernel                                                                               */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
+  char tuning[192];            /* "key=value[,key=value...]": any switch of csrc/options.h (measurement / test use)             */
 } cnl_options;
 void cnl_options_init(cnl_options* opt);
 
@@ -354,6 +315,10 @@ int cnl_last_kernel_ms(cnl_handle* h, float* ms);
  * + 64 when cnl_newton_system runs on the band kernels (then bits 8-15 = problems per workgroup, bits 16-23 = parts of the chain),
  * + 128 when cnl_residual_vectors_dev runs on column tiles. */
 int cnl_get_config(const cnl_handle* h, int64_t cfg[8]);
+/* Launches of the Newton-system kernels since the library was loaded, per kernel family: counts[0] band kernels (csrc/band.hip),
+ * [1] register-front kernel (csrc/kernels2.hip, staged launches not included), [2] general kernel (csrc/kernels.hip).  Lets a test
+ * pin WHICH kernel served a call sequence (e.g. that solve_ldl! behind a band factorisation launches no second kernel family). */
+int cnl_launch_counts(int64_t counts[3]);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,6 @@ class BandSim:
         if not self.ok:
             return
         self.nparts, self.m0, self.n, self.N, self.nnz, self.lsize = (int(v) for v in info[1:7])
-        self.wide = bool(info[7]) if len(info) > 7 else False
         self.parts = []
         for q in range(self.nparts):
             pi = plan.array(f"band_part{q}")
@@ -41,13 +40,10 @@ class BandSim:
     # ---- one factorisation attempt (+ forward substitution) of every problem -------------------------------------------
     def _load_pieces(self, blk, pieces, arrays):
         for k, pc in enumerate(pieces):
-            if pc < 0:              # -1 unused, -2 second half of a wide piece
+            if pc < 0:              # -1: unused
                 continue
-            wide = (pc >> 27) & 1   # BAND_PIECE_WIDE: 16 elements into this slot and the next, loaded by one instruction
-            arr, base = arrays[pc >> 28], pc & ((1 << 27) - 1)
-            w = 16 if wide else 8
-            if wide:
-                assert k + 1 < len(pieces) and pieces[k + 1] == -2, "wide piece without its second slot"
+            arr, base = arrays[pc >> 28], pc & ((1 << 28) - 1)
+            w = 8                   # a piece: eight consecutive elements of one array (64 bytes)
             assert base + w <= arr.shape[1], (base, arr.shape)
             blk[:, IN_OFF + 8 * k: IN_OFF + 8 * k + w] = arr[:, base: base + w]
 

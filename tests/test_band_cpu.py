@@ -34,15 +34,14 @@ def _check(s, vals, rhs, params, rho_old=0.0, **opt):
     return sim
 
 
-@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("n,p,hw,kernel", [(200, 4, 2, 1), (200, 0, 2, 1), (200, 0, 2, 2), (360, 6, 1, 1), (1000, 10, 2, 1), (96, 2, 2, 1)])
-def test_band_program_reproduces_the_oracle(built, params, n, p, hw, kernel, wide):
-    """both layouts of the program: fifteen 64-byte pieces per epoch, and four 128-byte + seven 64-byte pieces (band_wide_pieces)"""
+def test_band_program_reproduces_the_oracle(built, params, n, p, hw, kernel):
+    """the generator's program (fifteen 64-byte operand pieces per epoch), interpreted on the CPU, against the oracle: one and two parts,
+    half-widths 1 and 2, with and without constraints"""
     s = syn.band_structure(n, p, hw=hw)
     vals, rhs = syn.batch_values(s, 3, cfg=4)
-    sim = _check(s, vals, rhs, params, band_kernel=kernel, band_wide_pieces=wide)
+    sim = _check(s, vals, rhs, params, band_kernel=kernel)
     assert sim.nparts == (1 if kernel == 2 or n < 80 else 2)
-    assert sim.wide == bool(wide)
 
 
 def test_band_program_ladder_and_hopeless(built, params):
@@ -61,7 +60,6 @@ def test_band_program_full_size_headline_pattern(built, params):
     s = syn.band_structure(10000, 50)
     vals, rhs = syn.batch_values(s, 2, cfg=3)
     sim = _check(s, vals, rhs, params)
-    _check(s, vals, rhs, params, band_wide_pieces=1)
     assert sim.nparts == 2 and sim.parts[0]["nsteps"] == sim.parts[1]["nsteps"] == 5002
     assert sim.lsize * 8 < 0.5e6   # factor records: six doubles per pivot
 
@@ -76,11 +74,18 @@ def test_patterns_that_are_no_band_are_refused(built):
     assert pl.array("band_info")[0] == 0
 
 
-def test_retired_option_is_accepted_and_has_no_effect(built):
-    """cnl_options.staged_large_fronts fenced a faulty execution off in rounds 4 - 5; the fault is root-caused and removed, the
-    field is kept for the layout of the structure and changes nothing"""
-    s = syn.random_structure(140, 170, 2, 0.02, seed=4)
+def test_options_outside_the_public_structure_travel_as_tuning_pairs(built):
+    """round 6: cnl_options holds a dozen switches; every other switch of csrc/options.h is a key=value pair of its `tuning` string.
+    A tuning key changes the plan exactly like the old field did, public fields may be named there too, and an unknown key or a
+    malformed pair is CNL_ERR_ARG (not silently ignored)."""
+    s = syn.band_structure(200, 4)
     rows, cols = s.kkt_pattern()
-    a = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=4, options=hipldl.Options(staged_large_fronts=1))
-    b = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=4)
-    assert a.info == b.info and np.array_equal(a.array("perm"), b.array("perm"))
+    o = hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, band_form=0, lean_kernel=0)
+    assert o.tuning == b"band_form=0,lean_kernel=0" and o.plan_kind == hipldl.PLAN_THROUGHPUT
+    a = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=64, options=hipldl.Options(tuning="plan_kind=1,force_order=canonical"))
+    b = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=64, options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, force_order="canonical"))
+    assert a.info == b.info and np.array_equal(a.array("perm"), b.array("perm")) and a.info["order"].startswith("canonical")
+    for bad in ("no_such_switch=1", "lean_kernel", "lean_kernel=x", "staged_large_fronts=1", "band_wide_pieces=1"):
+        with pytest.raises(hipldl.CnlError) as e:
+            hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=4, options=hipldl.Options(tuning=bad))
+        assert e.value.code == 1

@@ -1988,16 +1988,15 @@ def _band_opts(hipldl, **kw):
     return hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, **kw)
 
 
-@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("n,p,B,nl,hw", [(200, 4, 5, 16, 2), (96, 2, 3, 16, 2), (1000, 10, 37, 8, 2), (1000, 10, 37, 32, 2), (1000, 10, 70, 16, 2), (360, 6, 19, 16, 1),
                                          (400, 0, 9, 16, 2), (10000, 50, 33, 16, 2)])
-def test_band_kernels_against_the_oracle(built, n, p, B, nl, hw, wide):
+def test_band_kernels_against_the_oracle(built, n, p, B, nl, hw):
     """one lane per (problem, half of the chain): decisions identical to the oracle's on the product's order and on the canonical one,
     d within the forward / backward bar; batches that are no multiple of the workgroup's problems, one part (n < 80) and two"""
     hipldl, syn, O = _mods()
     s = syn.band_structure(n, p, hw=hw)
     vals, rhs = syn.batch_values(s, B, cfg=4)
-    info, cfg = run_case(s, vals, rhs, options=_band_opts(hipldl, band_problems_per_group=nl, band_wide_pieces=wide))
+    info, cfg = run_case(s, vals, rhs, options=_band_opts(hipldl, band_problems_per_group=nl))
     assert cfg["band"]
 
 
@@ -2042,9 +2041,12 @@ def test_band_and_register_front_kernels_agree(built):
 
 
 def test_band_newton_system_then_solve_ldl(built):
-    """solve_ldl! behind a newton_system! of the band kernels uses the last factorisation (src/CaNNOLeS.jl:1049, solver_types.jl:69-77):
-    the register-front kernel factorises the same values first (the band kernels keep factor records only their own backward sweep
-    reads).  Also try_to_factorize -> newton_system! -> solve_ldl! with a second right-hand side."""
+    """The reference's own two-call sequence on a band handle (try_to_factorize then solve_ldl!, src/CaNNOLeS.jl:1023,1049,
+    src/solver_types.jl:69-98) and solve_ldl! behind newton_system!: since round 6 every call runs on the band kernels —
+    try_to_factorize is the forward sweep (inertia counts equal to the oracle's), solve_ldl! factorises the values of the last
+    factorisation again and sweeps the new right-hand side in one launch.  No register-front launch happens (cnl_launch_counts), and a
+    solve with the right-hand side of the newton_system! call reproduces its d bit for bit (the same arithmetic on the same values,
+    the rho slots holding what the ladder left)."""
     hipldl, syn, O = _mods()
     s = syn.band_structure(800, 8)
     B = 20
@@ -2054,20 +2056,86 @@ def test_band_newton_system_then_solve_ldl(built):
     p = hipldl.default_params()
     L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=_band_opts(hipldl))
     assert L.config["band"]
-    ok = hipldl.try_to_factorize(L, vals, s.nvar, s.nequ, s.ncon, p[0])
+    c0 = hipldl.launch_counts()
+    ok, npos, nzer = hipldl.try_to_factorize(L, vals, s.nvar, s.nequ, s.ncon, p[0], return_inertia=True)
     assert ok.sum() == B - 1 and not ok[3]
+    orc = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
+    for b in range(B):
+        ok0, np0, nz0 = orc.try_to_factorize(vals[b], s.nvar, s.nequ, s.ncon, O.default_params()[0], return_inertia=True)
+        assert (bool(ok[b]), int(npos[b]), int(nzer[b])) == (ok0, np0, nz0), b
+    # the two-call sequence of the problems that hold a factor: d = -K^-1 rhs
+    d1 = np.full((B, s.N), 7.0)
+    assert hipldl.solve_ldl_(rhs, L.factor, d1) is True
+    assert np.all(d1[3] == 7.0)   # the failed problem's rows stay as the caller passed them
+    for b in (0, 4, 19):
+        assert backward_error(s, vals[b], rhs[b], d1[b]) <= BWD_TOL
     v = vals.copy()
     d = np.zeros((B, s.N))
     d, ok2, rho, ro, nf = hipldl.newton_system_(d, s.nvar, s.nequ, s.ncon, rhs, v, L, np.zeros(B), p)
     assert ok2.all() and nf[3] == 6
+    d = np.array(d, copy=True).reshape(B, s.N)
+    assert np.array_equal(d1[[0, 4, 19]], d[[0, 4, 19]])   # two calls == the fused call where nothing climbed
     d2 = np.zeros((B, s.N))
     assert hipldl.solve_ldl_(rhs, L.factor, d2) is True
-    assert np.abs(d2 - d).max() <= 1e-11 * np.abs(d).max()
+    assert np.array_equal(d2, d)
     rhs3 = np.random.default_rng(5).standard_normal(rhs.shape)
     d3 = np.zeros((B, s.N))
     hipldl.solve_ldl_(rhs3, L.factor, d3)
     for b in (0, 3, 19):
         assert backward_error(s, v[b], rhs3[b], d3[b]) <= BWD_TOL
+    c1 = hipldl.launch_counts()
+    assert c1["band"] - c0["band"] == 5 and c1["register_front"] == c0["register_front"] and c1["general"] == c0["general"]
+    L.close()
+
+
+def test_band_two_call_sequence_device_pointers(built):
+    """cnl_factorize_dev -> cnl_solve_dev on a band handle above 8192 problems (band_newton_kernel<32>, interleaved factor records):
+    success flags as the fused call reports them, d bit-equal to cnl_newton_system_dev's where nothing climbed; the `_dev` twins keep
+    the caller's d_vals pointer for the solve (include/cannoles_hip.h)."""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(240, 4)
+    B = 8192 + 40
+    rows, cols = s.kkt_pattern()
+    v8, r8 = syn.batch_values(s, 8, cfg=3)
+    rng = np.random.default_rng(2)
+    vals = np.tile(v8, (B // 8 + 1, 1))[:B] * (1.0 + 1e-3 * rng.standard_normal((B, 1)))
+    rhs = np.tile(r8, (B // 8 + 1, 1))[:B] + 1e-3 * np.arange(B)[:, None]
+    off = s.offsets()
+    vals[:, off[4]:off[5]] = -1.0
+    hF_r, hF_c = np.asarray(s.hF[0]), np.asarray(s.hF[1])
+    dg = off[0] + np.nonzero(hF_r == hF_c)[0]
+    vals[B - 3, dg[:40]] = -40.0   # fails at rho = 0
+    dev = torch.device("cuda", 0)
+    tv, tr = torch.from_numpy(vals).to(dev), torch.from_numpy(rhs).to(dev)
+    td = torch.full((B, s.N), 7.0, dtype=torch.float64, device=dev)
+    su = torch.zeros(B, dtype=torch.int32, device=dev)
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B)
+    assert L.config["band"] and L.config["band_nl"] == 32
+    p = hipldl.default_params()
+    c0 = hipldl.launch_counts()
+    hipldl._check(hipldl.lib().cnl_factorize_dev(L._h, tv.data_ptr(), float(p[0]), su.data_ptr(), 0))
+    hipldl._check(hipldl.lib().cnl_solve_dev(L._h, tr.data_ptr(), td.data_ptr(), 0))
+    torch.cuda.synchronize()
+    suh = su.cpu().numpy()
+    assert suh.sum() == B - 1 and suh[B - 3] == 0
+    d_two = td.cpu().numpy()
+    assert np.all(d_two[B - 3] == 7.0)
+    td2 = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
+    ro, rho = torch.zeros(B, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.float64, device=dev)
+    nf, ok = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    hipldl.newton_system_dev(L, tv.data_ptr(), tr.data_ptr(), td2.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), ok.data_ptr(), p, 0)
+    torch.cuda.synchronize()
+    d_fused = td2.cpu().numpy()
+    keep = np.arange(B) != B - 3
+    assert np.array_equal(d_two[keep], d_fused[keep])
+    assert bool((ok == 1).all()) and int(nf[B - 3]) > 1
+    c1 = hipldl.launch_counts()
+    assert c1["band"] - c0["band"] == 3 and c1["register_front"] == c0["register_front"]
+    orc = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
+    for b in (0, 31, 32, 8191, 8192, B - 1):
+        d0, ok0, _, _, _ = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs[b], vals[b].copy(), 0.0, O.default_params())
+        assert ok0 and np.abs(d_two[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
     L.close()
 
 

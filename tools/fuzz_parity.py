@@ -110,9 +110,9 @@ for case in range(ncases):
         if rng.integers(4) == 0:
             ropt["split_batch"] = 2
     if os.environ.get("FUZZ_WIDE"):   # random execution switches on top
-        for k, vs in (("dataflow", (1, 0)), ("band_form", (1, 0)), ("host_ladder", (1, 0)), ("device_ladder", (1, 0)), ("device_ladder_fused", (0, 1)),
+        for k, vs in (("dataflow", (1, 0)), ("staged", (1, 0)), ("dense_backend", (1, 0)), ("split_tail", (1, 0)), ("band_form", (1, 0)), ("host_ladder", (1, 0)), ("device_ladder", (1, 0)), ("device_ladder_fused", (0, 1)),
                       ("lean_kernel", (1, 0)), ("rows_in_backward", (1, 0)), ("row_products", (1, 0)), ("dense_graph", (1, 0)),
-                      ("band_kernel", (1, 0)), ("band_kernel", (1, 2)), ("band_problems_per_group", (0, 8)), ("band_problems_per_group", (0, 32)), ("band_wide_pieces", (0, 1)), ("f1_tiles", (1, 0)), ("general_dense", (1, 2)),
+                      ("band_kernel", (1, 0)), ("band_kernel", (1, 2)), ("band_problems_per_group", (0, 8)), ("band_problems_per_group", (0, 32)), ("f1_tiles", (1, 0)), ("general_dense", (1, 2)),
                       ("dense_panel_blocks", (1, 0)), ("dense_panel_blocks", (1, 2)), ("lds_pad", (1, 0)), ("waves_per_block", (0, 2)), ("multipliers_early", (1, 0))):
             if rng.integers(4) == 0:
                 ropt[k] = vs[1]
