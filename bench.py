@@ -442,7 +442,7 @@ def compact_line(out):
         "f1_trial_point_frac": g("aux_f1", "trial_point", "frac"), "f2_prepare_frac": g("aux_f1", "f2_prepare", "frac"),
         "f3_ms_per_step": g("aux_f3", "ms_per_step"), "two_call_over_newton": _dig(out.get("roofline"), ("two_call_sequence", "total_over_newton_system")),
         "pcie_inclusive_ksys_s": _k(g("pcie_inclusive", "systems_per_s")),
-        "single_system_host_ms": g("call_pattern_single_system", "newton_system_ms"), "multi_front_end_ratio": g("multi_front_end", "ratio_to_single_handle"),
+        "single_system_host_ms": g("call_pattern_single_system", "newton_system_ms"), "single_system_analysis_s": g("call_pattern_single_system", "analysis_s"), "multi_front_end_ratio": g("multi_front_end", "ratio_to_single_handle"),
     }
     c["summary"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items() if v is not None}
     if "parity_guard" in out:
@@ -753,6 +753,16 @@ def call_pattern_block(torch, hipldl, s, rows, cols, vals_h, rhs_h, dev, local_r
         return float(np.median(ts) * 1e3)
 
     res = {"entry": "host pointers, pageable numpy arrays, batch 1, cfg3 pattern"}
+    # the one-time cost in front of the first call of a drop-in solver object (the reference: sparse + triu + ldl_analyze,
+    # src/solver_types.jl:61-65): the host-side symbolic analysis cnl_create runs for this batch size (candidate orders on host threads)
+    ta = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pl = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=1)
+        ta.append(time.perf_counter() - t0)
+        del pl
+    res["analysis_s"] = float(np.median(ta))
+    res["analysis_host_threads"] = min(16, os.cpu_count() or 1)
     res["newton_system_ms"] = med(lambda: hipldl.newton_system_(d1, s.nvar, s.nequ, s.ncon, r1, v1, L1, 0.0, params))
     res["try_to_factorize_ms"] = med(lambda: hipldl.try_to_factorize(L1, v1, s.nvar, s.nequ, s.ncon, params[0]))
     res["solve_ldl_ms"] = med(lambda: hipldl.solve_ldl_(r1, L1.factor, d1))

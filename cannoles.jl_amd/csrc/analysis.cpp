@@ -13,6 +13,9 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <functional>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -622,37 +625,32 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     }
   };
 
+  // Candidates = (x order) x (multipliers last | early).  The x orders and their evaluations are independent of each other: they run
+  // on host threads (round 6: the sweep was 0.3 s of a 0.65 s analysis of one cfg3-size system, serial), results land in a fixed
+  // order so that the choice does not depend on the threads.  With opt.force_order only the named candidate is built.
   std::vector<Cand> cands;
   const bool try_early = !stageC.empty() && opt.early;
-  auto add_cand = [&](const std::string& name, const ivec& xorder) {
-    {
-      Cand c; c.name = name;
-      evaluate(assemble_perm(xorder), c);
-      cands.push_back(std::move(c));
-    }
-    if (try_early) {
-      Cand c; c.name = name + "+early";
-      evaluate(assemble_perm_early(xorder), c);
-      cands.push_back(std::move(c));
-    }
+  struct Job { std::string name; std::function<void(ivec&)> make; };
+  std::vector<Job> jobs;
+  auto wanted = [&](const std::string& name) {
+    return opt.force_order.empty() || opt.force_order == name || (try_early && opt.force_order == name + "+early");
   };
+  auto add_job = [&](const std::string& name, std::function<void(ivec&)> make) { if (wanted(name)) jobs.push_back({name, std::move(make)}); };
   int mode = opt.order_mode;
-  if (mode == 0 || mode < 0) add_cand("canonical", xs_all);
+  if (mode == 0 || mode < 0) add_job("canonical", [&](ivec& xo) { xo = xs_all; });
   double sdens = nx_ > 0 ? (double)sg.ptr[nx_] / ((double)nx_ * (double)std::max(1, nx_ - 1)) : 1.0;
   bool sparse_enough = nx_ > 8 && sdens < 0.4;
-  if ((mode == 2 || mode < 0) && sparse_enough) {
-    ivec xo; min_degree(sg, xs_all, xo);
-    add_cand("md", xo);
-  }
+  if ((mode == 2 || mode < 0) && sparse_enough) add_job("md", [&](ivec& xo) { min_degree(sg, xs_all, xo); });
+  ivec body, hubs;
+  Graph bg;
   if ((mode == 1 || mode < 0) && sparse_enough) {
     // hubs: x nodes with degree > 8*median+16 are excluded from ND and go last among x
     ivec dsort(nx_);
     for (int32_t j = 0; j < nx_; j++) dsort[j] = sg.deg(j);
     std::nth_element(dsort.begin(), dsort.begin() + nx_ / 2, dsort.end());
     int32_t hub_thr = 8 * dsort[nx_ / 2] + 16;
-    ivec body, hubs;
     for (int32_t j = 0; j < nx_; j++) (sg.deg(j) > hub_thr ? hubs : body).push_back(j);
-    Graph bg = sg;
+    bg = sg;
     if (!hubs.empty()) {  // drop hub edges from the working graph
       std::vector<char> ish(nx_, 0); for (int32_t h : hubs) ish[h] = 1;
       bg.ptr.assign(nx_ + 1, 0); bg.idx.clear();
@@ -667,11 +665,12 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
     else leaves = {32, 96, 256, 768, 2048};
     for (int32_t leaf : leaves) {
       if (leaf >= (int32_t)body.size() && leaves.size() > 1 && leaf != leaves.front()) break;
-      NDWork w; w.g = &bg; w.part.assign(nx_, -1); w.level.assign(nx_, -1); w.leaf = leaf;
-      ivec xo; xo.reserve(nx_);
-      nd_rec(w, body, xo);
-      xo.insert(xo.end(), hubs.begin(), hubs.end());
-      add_cand("nd" + std::to_string(leaf), xo);
+      add_job("nd" + std::to_string(leaf), [&, leaf](ivec& xo) {
+        NDWork w; w.g = &bg; w.part.assign(nx_, -1); w.level.assign(nx_, -1); w.leaf = leaf;
+        xo.reserve(nx_);
+        nd_rec(w, body, xo);
+        xo.insert(xo.end(), hubs.begin(), hubs.end());
+      });
     }
     // Mid-size batches (latency plans with few wavefront slots per group of problems): a handful of LARGE parts, each kept in
     // the canonical order — inside a part the tree is the chain of full fronts the throughput order has, the parts run as
@@ -680,14 +679,52 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       for (int div : {2, 4, 8, 16, 32, 64, 128}) {
         const int32_t leaf = (int32_t)body.size() / div + 1;
         if (leaf < 64) break;
-        NDWork w; w.g = &bg; w.part.assign(nx_, -1); w.level.assign(nx_, -1); w.leaf = leaf; w.canon_leaves = true;
-        ivec xo; xo.reserve(nx_);
-        nd_rec(w, body, xo);
-        xo.insert(xo.end(), hubs.begin(), hubs.end());
-        add_cand("ndc" + std::to_string(div), xo);
+        add_job("ndc" + std::to_string(div), [&, leaf](ivec& xo) {
+          NDWork w; w.g = &bg; w.part.assign(nx_, -1); w.level.assign(nx_, -1); w.leaf = leaf; w.canon_leaves = true;
+          xo.reserve(nx_);
+          nd_rec(w, body, xo);
+          xo.insert(xo.end(), hubs.begin(), hubs.end());
+        });
       }
   }
-  if (cands.empty()) add_cand("canonical", xs_all);
+  if (jobs.empty()) jobs.push_back({"canonical", [&](ivec& xo) { xo = xs_all; }});
+  {
+    const size_t per = try_early ? 2 : 1;
+    std::vector<Cand> slot(jobs.size() * per);
+    std::vector<char> have(slot.size(), 0);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (size_t k = next.fetch_add(1); k < jobs.size(); k = next.fetch_add(1)) {
+        ivec xo;
+        jobs[k].make(xo);
+        if (opt.force_order.empty() || opt.force_order == jobs[k].name) {
+          Cand& c = slot[k * per]; c.name = jobs[k].name;
+          evaluate(assemble_perm(xo), c);
+          have[k * per] = 1;
+        }
+        if (try_early && (opt.force_order.empty() || opt.force_order == jobs[k].name + "+early")) {
+          Cand& c = slot[k * per + 1]; c.name = jobs[k].name + "+early";
+          evaluate(assemble_perm_early(xo), c);
+          have[k * per + 1] = 1;
+        }
+      }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nthr = std::min<size_t>({jobs.size(), (size_t)hw, (size_t)16});
+    if (nthr <= 1 || N < 2000) work();   // (small systems: a thread start costs more than their candidates)
+    else {
+      std::vector<std::thread> th;
+      for (size_t t = 0; t + 1 < nthr; t++) th.emplace_back(work);
+      work();
+      for (auto& t : th) t.join();
+    }
+    for (size_t k = 0; k < slot.size(); k++) if (have[k]) cands.push_back(std::move(slot[k]));
+  }
+  if (cands.empty()) {   // (a forced name that no candidate carries: the canonical order)
+    Cand c; c.name = "canonical";
+    evaluate(assemble_perm(xs_all), c);
+    cands.push_back(std::move(c));
+  }
   // throughput plans minimise the total work; latency plans the critical path plus the work spread over the wavefront
   // slots a group of four problems can use (only orders the register-front kernel can run are staged)
   // Latency score = the longer of the critical path and the work spread over the wavefront slots of a group of problems.

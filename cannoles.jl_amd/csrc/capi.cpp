@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -970,13 +971,19 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
   opt.order_mode = o.order_mode; opt.nd_leaf = o.nd_leaf; opt.relax = o.relax; opt.task_cap = o.task_cap;
   opt.early = o.multipliers_early; opt.register_front = o.register_front; opt.ubig = o.ubig; opt.wait_thr = o.wait_thr;
   opt.verbose = verbose ? 1 : 0; opt.force_order = o.force_order;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {   // (verbose log: seconds since the analysis started)
+    if (verbose) fprintf(stderr, "[cnl] analysis %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+  };
   int rc = cnl::build_condensation(p->C, N, nnz, rows1, cols1, nvar, nequ, ncon, msg, o.condense != 0);
+  lap("condensation");
   if (!rc) {
     if (p->C.active)
       rc = cnl::build_plan(p->P, p->C.N2, p->C.ncs + nvar, p->C.rows2.data(), p->C.cols2.data(), nvar, p->C.nequ2, ncon, opt, msg);
     else
       rc = cnl::build_plan(p->P, N, nnz, rows1, cols1, nvar, nequ, ncon, opt, msg);
   }
+  lap("ordering + plan");
   if (rc) {
     delete p;
     *plan = nullptr;
@@ -990,19 +997,21 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
     const size_t old_words = p->P.rec.size();
     p->P.row_products = o.row_products != 0;
     p->P.band_form = o.band_form != 0;
-    p->P.row_min_products = 72;
-    int drc = cnl::write_forward_records(p->P, &D);
     // A plan whose fronts are ALL fast-class row-form fronts runs the kernels' lean instantiation and recovers the residual
     // components in its backward sweep (no post-pass): worth more than the few rounds small fronts save with product lists, so
     // every front is given the row form when that makes the whole plan lean.  A front whose residual rows do not fit the row form's
     // sixteen lanes is cut in two (same order, one more front) and the records are written again.
+    // (round 6: such plans are written with the row form at once — the records with the lists' threshold of 72 products were
+    //  written first and thrown away, one of five passes over the records of a latency plan)
     const bool fast_only = p->P.ncls[1] == 0 && p->P.ncls[2] == 0;
-    if (!drc && o.row_products && o.lean_kernel && fast_only && p->P.listprod_fronts > 0) {
-      p->P.row_min_products = 1;
-      drc = cnl::write_forward_records(p->P, &D);
+    const bool want_lean = o.row_products && o.lean_kernel && fast_only;
+    p->P.row_min_products = want_lean ? 1 : 72;
+    int drc = cnl::write_forward_records(p->P, &D);
+    if (!drc && want_lean && p->P.listprod_fronts > 0) {
       if (!drc && p->P.listprod_fronts > 0 && !p->P.rows_overflow.empty() && p->P.rows_overflow.size() <= 64) {
         cnl::Options opt2 = opt;
         opt2.split_positions = p->P.rows_overflow;
+        opt2.force_order = p->P.order_name;   // the same order, one more front: only that candidate is built again
         cnl::Plan P2;
         std::string msg2;
         if (cnl::build_plan(P2, p->C.N2, p->C.ncs + nvar, p->C.rows2.data(), p->C.cols2.data(), nvar, p->C.nequ2, ncon, opt2, msg2) == 0 &&
@@ -1060,6 +1069,7 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
     }
   }
   if (o.dense_backend) cnl::detect_dense(p->D, N, nnz, rows1, cols1, nvar, nequ, ncon);
+  lap("records");
   // (round 5) large batches of band-structured problems: the sliding-window elimination with one lane per (problem, part)
   if (!latency && o.band_kernel && p->C.active && !p->D.active) {
     cnl::build_band_plan(p->band, N, nnz, rows1, cols1, nvar, nequ, ncon, o.band_kernel == 2 ? 1 : 2);
@@ -1090,6 +1100,7 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
   } else {
     p->perm_outer = p->P.perm;
   }
+  lap("band program + done");
   *plan = p;
   return CNL_OK;
 }
