@@ -291,7 +291,7 @@ def main():
             kms.append(LDLT.last_kernel_ms())
     kern_ms = float(np.mean(kms))
     # the forward sweep alone (try_to_factorize: assembly + LDL^T + inertia, no solve), same timing mode: what is left of kern_ms
-    # is the backward sweep (the two sweeps are bound by different things)
+    # is the backward sweep (profiles/HISTORY.md 4a: the two sweeps are bound by different things)
     fwd_ms, solve_ms = None, None
     band = bool(LDLT.config.get("band"))
     try:

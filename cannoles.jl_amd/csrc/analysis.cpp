@@ -1061,7 +1061,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
         // CNL_USTG / CNL_DPP_USTG: all lanes of a row store) —, so the last rows run up to TE - 1 doubles past its end.  (Until round 5 the
         // pad was 16 whatever the class: the out-of-line classes overwrote up to 47 doubles of the NEXT slot — another task's update
         // matrix or staging triangle, in use by another wavefront at the same time — and, from the last slot, memory past the problem's
-        // scratch: the history-dependent wrong decisions and memory faults of DESIGN 4b item 8.)
+        // scratch: the history-dependent wrong decisions and memory faults of profiles/HISTORY.md 4b item 8.)
         if (uglob[s]) { uoff2[s] = (int32_t)bumpG; bumpG += (tu + cls[s] + 1) & ~(int64_t)1; spL = baseL; }
         else { uoff2[s] = (int32_t)baseL; spL = baseL + tu; peakL = std::max(peakL, spL); }
         peakG = bumpG;

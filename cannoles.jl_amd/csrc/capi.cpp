@@ -288,7 +288,7 @@ int setup_v2(cnl_handle* h) {
       h->resident_waves = (int)std::min<long long>(resident, 1 << 20);
     }
   }
-  // Rounds 4 - 5, for the record: staged handles on plans with out-of-line front classes (order 17 .. 64) gave
+  // Rounds 4 - 5, for the record (profiles/HISTORY.md 4b item 8, 4c): staged handles on plans with out-of-line front classes (order 17 .. 64) gave
   // history-dependent wrong decisions and memory faults.  Three causes, all found with garbage left in LDS / scratch / registers in
   // front of every launch (CNL_DBG_SCRATCHFILL, CNL_DBG_LDSFILL) and tools/fuzz_parity.py: the update-matrix slots of the global scratch
   // were padded for 16-lane rows whatever the class of the front (analysis.cpp); the class-64 elimination publishes its pivot row two

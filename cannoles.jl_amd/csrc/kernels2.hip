@@ -282,7 +282,7 @@ struct Ctx2 {
 // block per pivot position (elim_dpp.inc), entered by wave-uniform branches.
 // (Round-2 experiments on this kernel that were measured and NOT kept — a row-per-lane backward sweep through the DPP broadcast,
 // a backward sweep fed by global_load_lds_dwordx4 with headers through the scalar cache, a four-operation division chain — are
-// recorded in DESIGN.md section 4; their code lives in the git history, not here.)
+// recorded in profiles/HISTORY.md section 4; their code lives in the git history, not here.)
 #define CNL_DPP_DIV fast_div
 #ifndef CNL_PIV_BITMASK
 #define CNL_PIV_BITMASK 1
@@ -749,7 +749,7 @@ __device__ int cnl_trace_n;
 // in the instantiations that CALL slow_front right behind a wait it placed the register spills that belong in front of the call
 // into the tail of that region, i.e. on a path the regular case never takes: the reloads behind the call then returned whatever
 // earlier kernels had left in scratch memory (pointers among them).  Garbage-filled scratch made it deterministic, zeroed scratch
-// hid it; ending the wavefront in the give-up branch (a tracing build) made it disappear.  
+// hid it; ending the wavefront in the give-up branch (a tracing build) made it disappear.  (profiles/HISTORY.md 4c.)
 __device__ __forceinline__ void spin_until(const int* p, int target, int limit, int* status_total, int* status_call, [[maybe_unused]] int site = 0) {
   int ok = 0;
   for (int it = 0; it < limit; it++) {
@@ -833,7 +833,7 @@ __global__ void __launch_bounds__(256, CNL_WAVES_PER_SIMD) newton2_kernel_t(cons
   // A wave-uniform test BY CONSTRUCTION (readfirstlane): the pointer is the same in all lanes, but the compiler cannot know (it derives
   // from the wavefront's index), and a lane-divergent `if (dep_wait)` in front of a call made it place the register spills of the call
   // in front of the EXEC restore of the join block — reached with EXEC = 0 whenever there was nothing to wait for, so the spills stored
-  // nothing (tools/check_spill_exec.py finds the pattern in the ISA)
+  // nothing (tools/check_spill_exec.py finds the pattern in the ISA; profiles/HISTORY.md 4c)
 #define DEP_WAITING (__builtin_amdgcn_readfirstlane(dep_wait != nullptr ? 1 : 0) != 0)
   int t_nchild_l = 0, t_parent_l = -1, tix_l = 0;   // fused ladder launch (phase 2): the task's links, kept for every rung
   [[maybe_unused]] int* lad = nullptr;              // ... and the control block of its group of problems

@@ -1354,7 +1354,7 @@ def test_randomised_parity_is_independent_of_what_earlier_kernels_left(built, fi
     of its own, once as it is and six times with every launch preceded by kernels that leave a byte pattern in the LDS, the scratch
     memory and the vector registers of the device (CNL_DBG_SCRATCHFILL / CNL_DBG_LDSFILL).  Round 4: the staged instantiations with
     out-of-line front classes took decisions that depended on the scratch contents of earlier kernels — invisible to a test-suite
-    whose processes start with zeroed scratch.  Round 5: the cause is found (register spills stored with EXEC = 0) and
+    whose processes start with zeroed scratch.  Round 5: the cause is found (register spills stored with EXEC = 0, profiles/HISTORY.md 4c) and
     every plan runs staged with the in-kernel ladder again; 1 260 cases, 1 140 of them with garbage fills: the range 9 200 .. 9 499
     holds the cases that faulted deterministically before the fix (9 236, 9 472), the three wide runs (600 cases) draw random settings
     of every remaining execution option (the band kernels', row f1's and the dense route's included)."""

@@ -1,4 +1,4 @@
-"""The code-generation hazard behind the staged-execution fault of rounds 4 - 5: register spills placed in front of the
+"""The code-generation hazard behind the staged-execution fault of rounds 4 - 5 (profiles/HISTORY.md 4c): register spills placed in front of the
 EXEC restore of a join block (reached with EXEC = 0 when the divergent region in front is skipped: the spills store nothing, the
 reloads behind the call return what earlier kernels left in scratch memory).  tools/check_spill_exec.py looks for the pattern in
 the ISA hipcc emits for gfx950 (cross-compiled: no GPU needed); the kernels that contain calls are checked in every CPU run."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Looks for the code-generation hazard that caused the staged-execution fault of rounds 4 - 5: register SPILL
+"""Looks for the code-generation hazard that caused the staged-execution fault of rounds 4 - 5 (profiles/HISTORY.md section 4c): register SPILL
 stores placed in a join block in front of the instruction that restores EXEC.  When the divergent region in front is skipped by
 `s_cbranch_execz`, the join block is entered with EXEC = 0 and the stores store nothing; the reloads behind the call they belong to
 then return whatever is in scratch memory.
