@@ -647,7 +647,7 @@ int run(cnl_handle* h, cnl::LaunchArgs& a, double* d_vals, const double* d_rhs, 
   } else {
     const int B = (int)h->batch;
     const int s_mat = (int)(C.ncs + C.nvar), s_all = (int)C.cstride;
-    double* crhs = h->d_cbuf + s_mat;
+    double* crhs = h->d_cbuf ? h->d_cbuf + s_mat : nullptr;   // (band handles own no condensed buffer)
     hipError_t e = hipSuccess;
     const bool direct = h->use_v2 && h->plan->P.rec_direct;  // the register-front kernel condenses on the fly
     const bool count_d = direct && h->dp2.count_d;  // the kernel counts the condensed pivots itself
@@ -1270,8 +1270,8 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     if ((rc = upload(h, C.r_orig, &dc.r_orig))) return bail(rc);
     dc.N = (int32_t)N; dc.nnz = (int32_t)nnz; dc.nvar = (int32_t)nvar; dc.N2 = (int32_t)C.N2; dc.ncs = (int32_t)C.ncs;
     dc.ncond = (int32_t)C.r_orig.size(); dc.cstride = C.cstride;
-    if ((rc = dalloc(h, &h->d_cbuf, (size_t)batch * (size_t)C.cstride))) return bail(rc);
-    if ((rc = dalloc(h, &h->d_d2, (size_t)batch * (size_t)C.N2))) return bail(rc);
+    // (d_cbuf / d_d2 — the condensed buffer and the reduced solution of the stand-alone condensation passes — are allocated below,
+    //  once it is known whether the band kernels serve the handle: they never touch them)
     if ((rc = dalloc(h, &h->d_xpos, (size_t)batch))) return bail(rc);
     if ((rc = dalloc(h, &h->d_xzer, (size_t)batch))) return bail(rc);
   }
@@ -1307,6 +1307,14 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
       if (hipMemset(h->d_Lband, 0, (((size_t)batch + 32) * (size_t)bd.lsize + 64) * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
       h->band = true;
     }
+  }
+  // Storage only the register-front / general kernels and the stand-alone condensation passes use.  A band handle runs all three
+  // calls of the plugin surface on the band kernels (round 6), so it owns the band factor records alone: 0.48 MB per problem of
+  // cfg3's size instead of 0.48 + 1.16 (factor panels) + 0.64 (condensed buffer, reduced solution) — 16 384 problems: 29 GB less,
+  // and twice the batch fits the 288 GB of a device beside the caller's arrays.
+  if (plan->C.active && !h->band) {
+    if ((rc = dalloc(h, &h->d_cbuf, (size_t)batch * (size_t)plan->C.cstride))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_d2, (size_t)batch * (size_t)plan->C.N2))) return bail(rc);
   }
   if (plan->split_mode && h->staged) {
     // x groups of four problems on the chain (two wavefronts each), the rest on the single stream: 2 x + y = 2048 slots
@@ -1368,7 +1376,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
   }
   {
     // factor storage, zero-filled and padded: the row prefetch of the backward pass reads (never uses) a little past a panel
-    const size_t ldoubles = (size_t)batch * (size_t)dp.lsize + 4096;
+    const size_t ldoubles = (h->band ? 0 : (size_t)batch * (size_t)dp.lsize) + 4096;   // (band handles: see above)
     if ((rc = dalloc(h, &h->d_L, ldoubles))) return bail(rc);
     if (hipMemset(h->d_L, 0, ldoubles * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
   }
