@@ -1990,7 +1990,7 @@ def _band_opts(hipldl, **kw):
 
 
 @pytest.mark.parametrize("n,p,B,nl,hw", [(200, 4, 5, 16, 2), (96, 2, 3, 16, 2), (1000, 10, 37, 8, 2), (1000, 10, 37, 32, 2), (1000, 10, 70, 16, 2), (360, 6, 19, 16, 1),
-                                         (400, 0, 9, 16, 2), (10000, 50, 33, 16, 2)])
+                                         (400, 0, 9, 16, 2), (10000, 50, 33, 16, 2), (24, 2, 7, 16, 2), (40, 2, 7, 16, 2)])
 def test_band_kernels_against_the_oracle(built, n, p, B, nl, hw):
     """one lane per (problem, half of the chain): decisions identical to the oracle's on the product's order and on the canonical one,
     d within the forward / backward bar; batches that are no multiple of the workgroup's problems, one part (n < 80) and two"""
