@@ -365,6 +365,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   bool done = !valid, success = false, ovr = false;
 
   static_assert(NI <= 4, "at most four problem groups per mover lane");
+  constexpr bool BAND_ISSUE_ALWAYS = false;
   double stg[NPC][NI];   // operand pieces in flight
   int4 rstg0;            // step blocks in flight (one 16-byte word per lane: 256 ints)
   int pcs[NPC];          // piece descriptors of the epoch being loaded
@@ -378,8 +379,8 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 #define BAND_ISSUE1(K, I) if constexpr (I < NI) stg[K][I] = *reinterpret_cast<const double*>(pb + ((movp[I] * strd + tl) << 3));
 #define BAND_COMMIT1(K, I) if constexpr (I < NI) *reinterpret_cast<double*>(wblk + ldsb[I] + (BAND_IN_OFF + 8 * K) * 8) = stg[K][I];
 #define BAND_ISSUE(K)                                                                                                         \
-  if (pcs[K] >= 0) {   /* (wave-uniform: an unused piece costs the memory pipeline what a used one does) */                   \
-    const int pc = pcs[K];                                                                                                    \
+  if (BAND_ISSUE_ALWAYS || pcs[K] >= 0) {   /* (wave-uniform: an unused piece costs the memory pipeline what a used one does) */ \
+    const int pc = pcs[K] >= 0 ? pcs[K] : 0;   /* (ALWAYS: an unused piece loads element 0 of vals — a static number of loads per epoch) */ \
     const int arr = pc >> 28;                                                                                                 \
     const int el_ = (pc & ((1 << 28) - 1)) + (arr == 2 ? loff8 : 0);                                                          \
     /* lane offset (doubles) = problem * strd + tl, tl = t + (t >> 3) * gap with t = m + element of the lane: the caller's arrays    \
@@ -727,6 +728,450 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   }
 }
 
+#if defined(BAND_MW) && !defined(CNL_EXPERIMENT)
+#error "BAND_MW needs -DCNL_EXPERIMENT=1"
+#endif
+#ifdef BAND_MW
+// ======================================================================================================================================
+// EXPERIMENT (round 6; not in the product build: -DCNL_EXPERIMENT=1 -DBAND_MW, tuning key band_movers=1): the same program with LOADER
+// wavefronts.  A workgroup of EIGHT wavefronts serves two groups of NL problems; per (group, part) one wavefront computes AND streams
+// its own factor records / solution components out (as in band_newton_kernel), and one wavefront only LOADS: it keeps two sets of staging
+// registers — the loads of epoch e + 2 are issued while epoch e computes — and commits a set to LDS between two workgroup barriers.  Only
+// a wavefront without stores can wait for the OLDER set alone: on gfx950 loads and stores share one counter (vmcnt) and return out of
+// order with respect to each other (profiles/r06_band_movers.jsonl: the first two look-ahead experiments waited with vmcnt(0) for loads
+// issued a few steps earlier).  Roles: waves 0,1 compute / 2,3 load for group 0, waves 4,5 load / 6,7 compute for group 1 — wavefronts w
+// and w + 4 share a SIMD (tools/simd_map.hip), so every SIMD holds one of each.
+#define MW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+constexpr int MW_LANE_D = BAND_LANE_DOUBLES;   // the standard lane block
+
+template <int NL>
+__global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P, const LaunchArgs Ain) {
+  constexpr int NI = NL / 8;
+  constexpr int LANE_D = MW_LANE_D;
+  constexpr bool LINT = true;   // factor records interleaved over the group's problems (the address arithmetic is the mover's, off the chain)
+  extern __shared__ double lds[];
+  const int mode = Ain.mode, batch = Ain.batch;
+  double* const gvals = as_global(Ain.vals);
+  const double* const grhs = as_global(Ain.rhs);
+  double* const gd = as_global(Ain.d);
+  double* const gL = as_global(Ain.L);
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int grp = wv >> 2, part = wv & 1;
+  const bool computes = ((wv >> 1) & 1) == grp;
+  const int lq = lane >> 3, le = lane & 7;
+  const int prob0 = (blockIdx.x * 2 + grp) * NL;
+  const bool has_rhs = mode != MODE_FACTOR && grhs != nullptr;
+  char* wblk = reinterpret_cast<char*>(lds + (size_t)(grp * 2 + part) * NL * LANE_D);
+  char* recb = reinterpret_cast<char*>(lds + (size_t)4 * NL * LANE_D) + (size_t)(grp * 2 + part) * BAND_REC_MAX * 4;
+  double* ctrl = reinterpret_cast<double*>(reinterpret_cast<char*>(lds + (size_t)4 * NL * LANE_D) + (size_t)4 * BAND_REC_MAX * 4) + (size_t)grp * (2 * NL + 8);
+  cptr epochs = as_const(P.epochs[part]);
+  const int nepochs = P.nepochs[part];
+  const int nepmax = P.nepochs[0] > P.nepochs[1] ? P.nepochs[0] : P.nepochs[1];
+  const int nnz = P.nnz, N = P.N;
+  const bool live = prob0 < batch;   // (the last workgroup's second group may be empty: it only joins the barriers)
+  const double tol = Ain.params[0];
+
+  if (!computes) {
+    // ================================================ mover ================================================
+    const int* fops_g = as_global(P.fops[part]);
+    const int* bops_g = as_global(P.bops[part]);
+    const long long lsize = P.lsize;
+    const double* vbase = gvals + (long long)prob0 * nnz;
+    const double* rbase = has_rhs ? grhs + (long long)prob0 * N : gvals;
+    double* lbase_g = gL + (long long)prob0 * lsize;
+    const int loff8 = (int)P.loff[part];
+    unsigned movp[NI], ldsb[NI];
+    bool movok[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      int pl = i * 8 + lq;
+      movok[i] = prob0 + pl < batch;
+      if (!movok[i]) pl = live ? batch - 1 - prob0 : 0;
+      movp[i] = (unsigned)pl;
+      ldsb[i] = ((unsigned)(i * 8 + lq) * (unsigned)LANE_D + (unsigned)le) << 3;
+    }
+    // two staging sets: the loads of epoch e + 2 are issued while epoch e computes (the mover has the registers for it: one epoch of
+    // lead — the compute time of eight steps — is less than the latency of this access pattern under load)
+    double stgA[NPC][NI], stgB[NPC][NI];
+    int4 rstgA, rstgB;
+    int pcs[NPC];
+    // every piece slot is loaded whether the epoch uses it or not: the number of loads in flight behind a staging set is then a
+    // compile-time constant, which is what lets the compiler wait for the OLDER set with s_waitcnt vmcnt(31) instead of vmcnt(0)
+    constexpr bool BAND_ISSUE_ALWAYS = true;
+    // (the step blocks' load FIRST: the compiler copies its four registers away at the next issue, which waits for that load — as the
+    //  youngest of its set that wait was s_waitcnt vmcnt(0), i.e. for every load in flight)
+#define MW_ISSUE_ALL(EP, OFS, OPS, OPOFF)                                                                                     \
+    {                                                                                                                         \
+      BAND_ISSUE_DESC(EP, OFS)                                                                                                \
+      BAND_ISSUE_REC(OPS, OPOFF)                                                                                              \
+      BAND_ISSUE(0) BAND_ISSUE(1) BAND_ISSUE(2) BAND_ISSUE(3) BAND_ISSUE(4) BAND_ISSUE(5) BAND_ISSUE(6) BAND_ISSUE(7)         \
+      BAND_ISSUE(8) BAND_ISSUE(9) BAND_ISSUE(10) BAND_ISSUE(11) BAND_ISSUE(12) BAND_ISSUE(13) BAND_ISSUE(14)                  \
+    }
+#define MW_FWD_EPOCH(E_)                                                                                                      \
+      {                                                                                                                       \
+        const int e = (E_);                                                                                                   \
+        if (live && e < nepochs) BAND_COMMIT_ALL()                                                                            \
+        MW_BARRIER();   /* X: the epoch's operands are in LDS */                                                              \
+        if (live && e + 2 < nepochs) MW_ISSUE_ALL(epochs + (e + 2) * BAND_EW, BE_FP, fops_g, epochs[(e + 2) * BAND_EW + BE_FOFF]) \
+        MW_BARRIER();   /* Y: the compute wavefront is through the epoch */                                                   \
+      }
+    while (true) {
+      // ---- forward ----
+      if (live) {
+#define stg stgA
+#define rstg0 rstgA
+        MW_ISSUE_ALL(epochs, BE_FP, fops_g, 0)
+#undef stg
+#undef rstg0
+#define stg stgB
+#define rstg0 rstgB
+        if (nepochs > 1) MW_ISSUE_ALL(epochs + BAND_EW, BE_FP, fops_g, epochs[BAND_EW + BE_FOFF])
+#undef stg
+#undef rstg0
+      }
+      for (int e2 = 0; e2 < nepmax; e2 += 2) {
+#define stg stgA
+#define rstg0 rstgA
+        MW_FWD_EPOCH(e2)
+#undef stg
+#undef rstg0
+#define stg stgB
+#define rstg0 rstgB
+        if (e2 + 1 < nepmax) MW_FWD_EPOCH(e2 + 1)
+#undef stg
+#undef rstg0
+      }
+      MW_BARRIER();   // J1
+      MW_BARRIER();   // J2: the decision is in the control block
+      const bool alldone = ctrl[2 * NL] != 0.0;
+      MW_BARRIER();   // J3
+      if (alldone) break;
+    }
+    if (mode == MODE_FACTOR) return;
+    // ---- backward ----
+    MW_BARRIER();   // K1
+    MW_BARRIER();   // K2: which problems store
+    // trip t handles epoch e = nepmax - 1 - t; staging set = parity of t
+#define MW_BWD_EPOCH(T_)                                                                                                      \
+    {                                                                                                                         \
+      const int e = nepmax - 1 - (T_);                                                                                        \
+      if (live && e < nepochs) BAND_COMMIT_ALL()                                                                              \
+      MW_BARRIER();   /* X */                                                                                                 \
+      if (live && e >= 2 && e - 2 < nepochs) MW_ISSUE_ALL(epochs + (e - 2) * BAND_EW, BE_BP, bops_g, epochs[(e - 2) * BAND_EW + BE_BOFF]) \
+      MW_BARRIER();   /* Y */                                                                                                 \
+    }
+    if (live) {
+#define stg stgA
+#define rstg0 rstgA
+      if (nepmax - 1 < nepochs) MW_ISSUE_ALL(epochs + (nepmax - 1) * BAND_EW, BE_BP, bops_g, epochs[(nepmax - 1) * BAND_EW + BE_BOFF])
+#undef stg
+#undef rstg0
+#define stg stgB
+#define rstg0 rstgB
+      if (nepmax - 2 >= 0 && nepmax - 2 < nepochs) MW_ISSUE_ALL(epochs + (nepmax - 2) * BAND_EW, BE_BP, bops_g, epochs[(nepmax - 2) * BAND_EW + BE_BOFF])
+#undef stg
+#undef rstg0
+    }
+    for (int t2 = 0; t2 < nepmax; t2 += 2) {
+#define stg stgA
+#define rstg0 rstgA
+      MW_BWD_EPOCH(t2)
+#undef stg
+#undef rstg0
+#define stg stgB
+#define rstg0 rstgB
+      if (t2 + 1 < nepmax) MW_BWD_EPOCH(t2 + 1)
+#undef stg
+#undef rstg0
+    }
+    return;
+  }
+
+  // ================================================ compute ================================================
+  cptr borders = as_const(P.borders[part]);
+  const bool clane = lane < NL;
+  const int cprob = prob0 + (clane ? lane : 0);
+  const bool valid = clane && cprob < batch;
+  const int cpl = valid ? cprob - prob0 : (live ? batch - 1 - prob0 : 0);
+  char* myb = wblk + (size_t)(clane ? lane : 0) * LANE_D * 8;
+  const long long pv = live ? (long long)(prob0 + cpl) * nnz : 0, pr = live ? (long long)(prob0 + cpl) * N : 0;
+  // the wavefront streams its own factor records / solution components out (all 64 lanes: lane (lq, le) = element le of problems lq, lq + 8)
+  const long long lsize = P.lsize;
+  double* lbase_g = gL + (long long)prob0 * lsize;
+  const int loff8 = (int)P.loff[part];
+  double* dbase = gd ? gd + (long long)prob0 * N : nullptr;
+  unsigned movp[NI], ldsb[NI];
+  bool movok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    int pl = i * 8 + lq;
+    movok[i] = prob0 + pl < batch;
+    if (!movok[i]) pl = live ? batch - 1 - prob0 : 0;
+    movp[i] = (unsigned)pl;
+    ldsb[i] = ((unsigned)(i * 8 + lq) * (unsigned)LANE_D + (unsigned)le) << 3;
+  }
+  for (int t = lane; t < NL; t += 64) *reinterpret_cast<double*>(wblk + ((size_t)t * LANE_D + BAND_ZERO_OFF) * 8) = 0.0;
+  const double kdec = Ain.params[2], kinc = Ain.params[3], klarge = Ain.params[4], rho0 = Ain.params[5], rhomax = Ain.params[6], rhomin = Ain.params[7];
+  double rho = 0.0, wrote = 0.0;
+  double rho_old = (mode == MODE_NEWTON && valid) ? as_global(Ain.rho_old)[cprob] : 0.0;
+  int nfact = 0;
+  bool done = !valid, success = false, ovr = false;
+  Win W;
+  int npos = 0, nzer = 0;
+  double lj[6], zj[4];
+  for (int q = 0; q < 6; q++) lj[q] = 0.0;
+  for (int q = 0; q < 4; q++) zj[q] = 0.0;
+  while (true) {
+#pragma unroll
+    for (int q = 0; q < NS * (NS + 1) / 2; q++) W.S[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NS; q++) { W.X[q] = 0.0; W.c[q] = 0.0; }
+    W.S55 = 0.0; W.c5 = 0.0;
+    npos = 0; nzer = 0;
+    for (int e = 0; e < nepmax; e++) {
+      MW_BARRIER();   // X
+      if (live && e < nepochs) {
+        cptr E = epochs + e * BAND_EW;
+        const int nst = E[BE_NSTEP];
+        int o = 0;
+        Rec stC, stN;
+        RowRec rwC, rwN;
+        load_rec(stC, recb, 0);
+        load_row(rwC, recb, BAND_SW);
+#define BAND_FSTEP_MW(PHV)                                                                                                  \
+        if (PHV < nst) {                                                                                                    \
+          const int fl = __builtin_amdgcn_readfirstlane(stC.v[BS_FLAGS]);                                                   \
+          const int onext = o + BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                      \
+          if (PHV + 1 < nst) { load_rec(stN, recb, onext); load_row(rwN, recb, onext + BAND_SW); }                          \
+          if (clane) {                                                                                                      \
+            FOps op_;                                                                                                       \
+            fload(op_, stC, rwC, fl, myb);                                                                                  \
+            fstep<PHV>(W, op_, stC, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer);    \
+          }                                                                                                                 \
+          o = onext; stC = stN; rwC = rwN;                                                                                  \
+        }
+        BAND_FSTEP_MW(0) BAND_FSTEP_MW(1) BAND_FSTEP_MW(2) BAND_FSTEP_MW(3)
+        BAND_LFLUSH(E[BE_LBASE], E[BE_LCNT])
+        BAND_FSTEP_MW(4) BAND_FSTEP_MW(5) BAND_FSTEP_MW(6) BAND_FSTEP_MW(7)
+        if (nst == BAND_EPOCH) {
+#pragma unroll
+          for (int a = 0; a < NS; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++)
+              if (b < 4) W.S[sidx(a, b)] = 0.0;
+#pragma unroll
+          for (int a = 0; a < 4; a++) { W.X[a] = 0.0; W.c[a] = 0.0; }
+        }
+        BAND_LFLUSH(E[BE_LBASE2], E[BE_LCNT2])
+      }
+      MW_BARRIER();   // Y
+    }
+    // ---- junction + inertia rule + rho ladder: as in band_newton_kernel (two parts) ----
+    int tpos = npos, tzer = nzer;
+    if (clane) {
+      double* ex = reinterpret_cast<double*>(myb + EXCH_OFF * 8);
+#pragma unroll
+      for (int q = 0; q < NS * (NS + 1) / 2; q++) ex[q] = W.S[q];
+#pragma unroll
+      for (int q = 0; q < NS; q++) ex[36 + q] = W.c[q];
+      ex[44] = (double)npos; ex[45] = (double)nzer;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the factor records are in L2 before the loader wavefront reads them back
+    MW_BARRIER();   // J1
+    if (part == 0 && clane) {
+      const double* exL = reinterpret_cast<const double*>(myb + EXCH_OFF * 8);
+      const double* exR = reinterpret_cast<const double*>(myb + (size_t)NL * LANE_D * 8 + EXCH_OFF * 8);
+      const int tL = P.m0 % NS, tR = (P.n - 1 - P.m0) % NS;
+      double SJ[10], cJ[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int aL = (tL + i) % NS, aR = (tR - i + NS) % NS;
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+          const int bL = (tL + j) % NS, bR = (tR - j + NS) % NS;
+          const int iL = aL >= bL ? aL * (aL + 1) / 2 + bL : bL * (bL + 1) / 2 + aL;
+          const int iR = aR >= bR ? aR * (aR + 1) / 2 + bR : bR * (bR + 1) / 2 + aR;
+          SJ[i * (i + 1) / 2 + j] = exL[iL] + exR[iR];
+        }
+        cJ[i] = exL[36 + aL] + exR[36 + aR];
+      }
+      tpos += (int)exR[44]; tzer += (int)exR[45];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const double d = SJ[sidx(i, i)];
+        tpos += d > tol;
+        tzer += fabs(d) <= tol;
+        const double r = rrcp(d);
+        zj[i] = rdiv(cJ[i], d, r);
+        double w[4];
+#pragma unroll
+        for (int a = i + 1; a < 4; a++) { w[a] = SJ[sidx(a, i)]; lj[sidx(a - 1, i)] = rdiv(w[a], d, r); }
+#pragma unroll
+        for (int a = i + 1; a < 4; a++) {
+#pragma unroll
+          for (int b = i + 1; b <= a; b++) SJ[sidx(a, b)] = fma(w[a], -lj[sidx(b - 1, i)], SJ[sidx(a, b)]);
+          cJ[a] = fma(w[a], -zj[i], cJ[a]);
+        }
+      }
+    }
+    bool alldone = true;
+    if (part == 0) {
+      const bool ok = tpos == P.nvar && tzer == 0;
+      if (mode == MODE_FACTOR) {
+        if (valid) {
+          as_global(Ain.success)[cprob] = ok ? 1 : 0;
+          if (Ain.npos) as_global(Ain.npos)[cprob] = tpos;
+          if (Ain.nzero) as_global(Ain.nzero)[cprob] = tzer;
+        }
+        done = true;
+      } else if (mode == MODE_SOLVE) {
+        success = ok;
+        done = true;
+      } else if (!done) {
+        nfact++;
+        if (ok) { done = true; success = true; }
+        else if (nfact == 1) {
+          rho = rho_old == 0.0 ? rho0 : fmax(rhomin, kdec * rho_old);
+          ovr = true; wrote = rho;
+        } else if (rho <= rhomax) {
+          rho = rho_old == 0.0 ? klarge * rho : kinc * rho;
+          if (rho <= rhomax) wrote = rho; else done = true;
+        } else done = true;
+      }
+      alldone = __all(done || !clane);
+      if (clane) { ctrl[lane] = rho; ctrl[NL + lane] = (ovr ? 1.0 : 0.0) + (success ? 2.0 : 0.0); }
+      if (lane == 0) ctrl[2 * NL] = alldone ? 1.0 : 0.0;
+    }
+    MW_BARRIER();   // J2
+    if (part == 1) {
+      if (clane) { rho = ctrl[lane]; const int f = (int)ctrl[NL + lane]; ovr = f & 1; success = f & 2; }
+      alldone = ctrl[2 * NL] != 0.0;
+    }
+    MW_BARRIER();   // J3
+    if (alldone) break;
+  }
+  if (mode == MODE_FACTOR) return;
+  // ---- backward ----
+  {
+    double xs[NS + 1];
+#pragma unroll
+    for (int q = 0; q < NS + 1; q++) xs[q] = 0.0;
+    if (part == 0 && clane) {
+      double xj[4];
+      xj[3] = zj[3];
+      xj[2] = fma(-lj[sidx(2, 2)], xj[3], zj[2]);
+      xj[1] = fma(-lj[sidx(2, 1)], xj[3], fma(-lj[sidx(1, 1)], xj[2], zj[1]));
+      xj[0] = fma(-lj[sidx(2, 0)], xj[3], fma(-lj[sidx(1, 0)], xj[2], fma(-lj[sidx(0, 0)], xj[1], zj[0])));
+      double* ex = reinterpret_cast<double*>(myb + EXCH_OFF * 8);
+      double* exR = reinterpret_cast<double*>(myb + (size_t)NL * LANE_D * 8 + EXCH_OFF * 8);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        ex[i] = xj[i]; exR[i] = xj[i];
+        if (valid && success) gd[(long long)cprob * N + P.m0 + i] = -xj[i];
+      }
+    }
+    MW_BARRIER();   // K1
+    if (clane) {
+      const double* ex = reinterpret_cast<const double*>(myb + EXCH_OFF * 8);
+      const int t0 = part == 0 ? P.m0 % NS : (P.n - 1 - P.m0) % NS;
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const int i = part == 0 ? (s - t0 + NS) % NS : (t0 - s + NS) % NS;
+        xs[s] = i < 4 ? ex[i] : 0.0;
+      }
+    }
+    if (part == 0 && clane) ctrl[NL + lane] = (valid && success) ? 2.0 : 0.0;
+    MW_BARRIER();   // K2
+    const bool okme = valid && ctrl[NL + lane % NL] != 0.0 && clane;
+    bool movst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) movst[i] = movok[i] && ctrl[NL + i * 8 + lq] != 0.0;
+    const long long pd = live ? (long long)(prob0 + cpl) * N : 0;
+    for (int e = nepmax - 1; e >= 0; e--) {
+      MW_BARRIER();   // X
+      if (live && e < nepochs) {
+        cptr E = epochs + e * BAND_EW;
+        const int nst = E[BE_NSTEP];
+        int o = 0;
+        Rec stC, stN;
+        RowRec rwC, rwN;
+        load_rec(stC, recb, 0);
+        load_row(rwC, recb, BAND_SW);
+#define BAND_BSTEP_MW(PHV)                                                                                                  \
+        if (PHV < nst) {                                                                                                    \
+          const int fl = __builtin_amdgcn_readfirstlane(stC.v[BS_FLAGS]);                                                   \
+          const int onext = o + BAND_SW + BAND_RW * ((fl >> 8) & 255);                                                      \
+          if (PHV > 0) { load_rec(stN, recb, onext); load_row(rwN, recb, onext + BAND_SW); }                                \
+          if (clane) {                                                                                                      \
+            BOps op_;                                                                                                       \
+            bload(op_, stC, rwC, fl, myb);                                                                                  \
+            bstep<PHV>(xs, op_, stC, rwC, fl, recb, o, myb, borders, gd, pd, okme);                                         \
+          }                                                                                                                 \
+          o = onext; stC = stN; rwC = rwN;                                                                                  \
+        }
+        BAND_BSTEP_MW(7) BAND_BSTEP_MW(6) BAND_BSTEP_MW(5) BAND_BSTEP_MW(4) BAND_BSTEP_MW(3) BAND_BSTEP_MW(2) BAND_BSTEP_MW(1) BAND_BSTEP_MW(0)
+        {   // solution components of the epoch
+          const int xlo = E[BE_DXLO], xc = E[BE_DXCNT], rlo = E[BE_DRLO], rc = E[BE_DRCNT];
+          char* dxo = reinterpret_cast<char*>(dbase) + ((long long)xlo << 3);
+          char* dro = reinterpret_cast<char*>(dbase) + ((long long)rlo << 3);
+          double dx_[NI], dr_[BAND_DR_MAX / 8][NI];
+#pragma unroll
+          for (int i = 0; i < NI; i++) dx_[i] = *reinterpret_cast<const double*>(wblk + ldsb[i] + BAND_DX_OFF * 8);
+#pragma unroll
+          for (int cpc = 0; cpc < BAND_DR_MAX / 8; cpc++)
+#pragma unroll
+            for (int i = 0; i < NI; i++) dr_[cpc][i] = *reinterpret_cast<const double*>(wblk + ldsb[i] + (BAND_DR_OFF + 8 * cpc) * 8);
+#pragma unroll
+          for (int i = 0; i < NI; i++)
+            if (movst[i] && le < xc) *reinterpret_cast<double*>(dxo + ((movp[i] * (unsigned)N + (unsigned)le) << 3)) = dx_[i];
+#pragma unroll
+          for (int cpc = 0; cpc < BAND_DR_MAX / 8; cpc++)
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+              if (movst[i] && cpc * 8 + le < rc) *reinterpret_cast<double*>(dro + (((movp[i] * (unsigned)N + (unsigned)le) << 3) + 64 * cpc)) = dr_[cpc][i];
+        }
+      }
+      MW_BARRIER();   // Y
+    }
+  }
+  // ---- outputs of newton_system! ----
+  if (part == 0 && mode == MODE_NEWTON) {
+    if (nfact > 1 && rho <= rhomax) rho_old = rho;
+    if (valid) {
+      as_global(Ain.rho)[cprob] = rho;
+      as_global(Ain.rho_old)[cprob] = rho_old;
+      as_global(Ain.nfact)[cprob] = nfact;
+      as_global(Ain.success)[cprob] = success ? 1 : 0;
+    }
+    for (int q = 0; q < NL; q++) {
+      const int nf = __builtin_amdgcn_readlane(nfact, q);
+      const int vq = __builtin_amdgcn_readlane((int)valid, q);
+      if (nf > 1 && vq) {
+        const double wq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wrote), q), __builtin_amdgcn_readlane(__double2loint(wrote), q));
+        double* vt = gvals + (long long)(prob0 + q) * nnz + (nnz - P.nvar);
+        for (int i = lane; i < P.nvar; i += 64) vt[i] = wq;
+      }
+    }
+  }
+}
+
+size_t band_mw_lds_bytes(int nl) { return ((size_t)4 * nl * MW_LANE_D + 2 * (2 * nl + 8)) * sizeof(double) + (size_t)4 * BAND_REC_MAX * 4; }
+
+hipError_t launch_band_mw(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream) {
+  if (P.nparts != 2 || nl != 16) return hipErrorInvalidConfiguration;
+  const size_t ldsb = band_mw_lds_bytes(nl);
+  const int grid = (a.batch + 2 * nl - 1) / (2 * nl);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_newton_mw_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr_cap((int)ldsb));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(band_newton_mw_kernel<16>, dim3(grid), dim3(512), ldsb, stream, P, a);
+  return hipGetLastError();
+}
+
+#else
+size_t band_mw_lds_bytes(int) { return (size_t)-1; }   // (not compiled in: see the experiment above)
+hipError_t launch_band_mw(const BandDev&, int, const LaunchArgs&, hipStream_t) { return hipErrorNotSupported; }
+#endif
 size_t band_lds_bytes(int nparts, int nl) { return ((size_t)nparts * nl * LANE_D + 2 * nl + 8) * sizeof(double) + (size_t)nparts * BAND_REC_MAX * 4; }
 
 hipError_t launch_band(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream) {

@@ -164,6 +164,9 @@ struct BandDev {
 // band factor storage [batch][P.lsize]
 hipError_t launch_band(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream);
 size_t band_lds_bytes(int nparts, int nl);
+// EXPERIMENT builds (-DCNL_EXPERIMENT=1 -DBAND_MW): the same program with loader wavefronts (band.hip, band_newton_mw_kernel)
+hipError_t launch_band_mw(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream);
+size_t band_mw_lds_bytes(int nl);
 
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);

@@ -321,7 +321,7 @@ class HIPLDLStruct:
         self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4]),
                        "kernel": {2: "v2", 3: "dense", 4: "v2-staged"}.get(int(cfg[5]) & 15, "v1"), "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7]),
                        "lean": bool(int(cfg[5]) & 16), "tail": bool(int(cfg[5]) & 32), "band": bool(int(cfg[5]) & 64), "f1_tiles": bool(int(cfg[5]) & 128),
-                       "band_nl": (int(cfg[5]) >> 8) & 255, "band_parts": (int(cfg[5]) >> 16) & 255}
+                       "band_nl": (int(cfg[5]) >> 8) & 255, "band_parts": (int(cfg[5]) >> 16) & 255, "band_movers": bool((int(cfg[5]) >> 24) & 1)}
 
     def plan_array(self, name):
         return _plan_array(lib().cnl_get_plan(self._h), name)
