@@ -710,7 +710,7 @@ int build_plan(Plan& P, int64_t N64, int64_t nnz, const int64_t* rows1, const in
       }
     };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t nthr = std::min<size_t>({jobs.size(), (size_t)hw, (size_t)16});
+    const size_t nthr = opt.threads > 0 ? std::min<size_t>(jobs.size(), (size_t)opt.threads) : std::min<size_t>({jobs.size(), (size_t)hw, (size_t)16});
     if (nthr <= 1 || N < 2000) work();   // (small systems: a thread start costs more than their candidates)
     else {
       std::vector<std::thread> th;

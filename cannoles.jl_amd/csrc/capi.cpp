@@ -970,7 +970,7 @@ static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64
   opt.latency = latency; opt.par = std::max(1, par); opt.slots = slots;
   opt.order_mode = o.order_mode; opt.nd_leaf = o.nd_leaf; opt.relax = o.relax; opt.task_cap = o.task_cap;
   opt.early = o.multipliers_early; opt.register_front = o.register_front; opt.ubig = o.ubig; opt.wait_thr = o.wait_thr;
-  opt.verbose = verbose ? 1 : 0; opt.force_order = o.force_order;
+  opt.verbose = verbose ? 1 : 0; opt.force_order = o.force_order; opt.threads = o.analysis_threads;
   const auto t_start = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {   // (verbose log: seconds since the analysis started)
     if (verbose) fprintf(stderr, "[cnl] analysis %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());

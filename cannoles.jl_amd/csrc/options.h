@@ -54,6 +54,7 @@ namespace cnl {
   X(band_kernel, 1)          /* band-structured throughput handles run on the band kernels (band.h); 2: chain in one part   */ \
   X(band_problems_per_group, 0) /* band kernels: problems per workgroup (8, 16, 32); 0 = by batch                           */ \
   X(band_movers, 0)          /* EXPERIMENT builds only (-DCNL_EXPERIMENT=1 -DBAND_MW): band kernel with loader wavefronts            */ \
+  X(analysis_threads, 0)     /* host threads of the symbolic analysis (candidate orders); 0 = by the hardware, at most 16      */ \
   X(f1_tiles, 1)             /* row f1 streams column tiles through LDS where the pattern allows                            */
 
 struct Tuning {

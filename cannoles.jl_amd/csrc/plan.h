@@ -54,6 +54,7 @@ struct Options {
   int ubig = 17;           // update matrices of order above this live in the global scratch
   int wait_thr = 2;        // update matrices that wait for more than this many fronts go to the global scratch
   int verbose = 0;
+  int threads = 0;         // host threads for the candidate orders (0: one per candidate, at most 16 / the hardware's); the plan does not depend on it
   std::string force_order; // pick an ordering candidate by name (experiments)
   // elimination positions (of the chosen order) at which a supernode must be cut in two: the caller found a front whose condensed
   // residual rows do not fit the row form's sixteen lanes (Plan::rows_overflow) and asks for the same plan with that front split

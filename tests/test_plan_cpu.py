@@ -260,3 +260,18 @@ def test_staged_plans_reproduce_the_oracle(shape):
         kept = ~np.isnan(d)
         assert kept.sum() == (s.N if plan.array("brec")[7] & 256 else s.N - s.nequ)
         assert np.abs(d[kept] - d0[kept]).max() <= 1e-10 * np.abs(d0).max()
+
+
+def test_analysis_does_not_depend_on_its_host_threads(built):
+    """round 6: the candidate orders of the symbolic analysis are built and evaluated on host threads; the results land in a fixed order,
+    so the plan (order, supernodes, record streams, tasks) is the same on one thread and on many — for a latency plan, a mid-size plan and
+    a throughput plan"""
+    s = syn.band_structure(1200, 12)
+    rows, cols = s.kkt_pattern()
+    for batch in (1, 200, 20000):
+        a = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=batch, options=hipldl.Options(analysis_threads=1))
+        b = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=batch, options=hipldl.Options(analysis_threads=7))
+        c = hipldl.Plan(s.N, rows, cols, s.nvar, s.nequ, s.ncon, batch=batch)
+        assert a.info == b.info == c.info
+        for name in ("perm", "rec", "brec", "tasks"):
+            assert np.array_equal(a.array(name), b.array(name)) and np.array_equal(a.array(name), c.array(name)), (batch, name)
