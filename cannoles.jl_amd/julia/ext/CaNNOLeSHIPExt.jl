@@ -19,8 +19,14 @@ mutable struct HIPLDLStruct{Ti <: Integer} <: LinearSolverStruct
   factor::CaNNOLeSHIP.HIPFactor  # solve_ldl! dispatches on the type of this field
 end
 
+# Below this order of the KKT system the reference's own CPU backend is kept: one `newton_system!` through the device costs a fixed
+# ~0.1 ms of launches and ~0.1 ms of transfers whatever the size (INTEGRATION.md §6), and the one-time symbolic analysis 0.1 ... 0.3 s at
+# N = 2e4; LDLFactorizations needs microseconds for the reference's small test problems.  A `Ref` so that a caller can move it.
+const MIN_ORDER = Ref(2000)
+
 # the hook the if-chain of /root/reference/src/CaNNOLeS.jl:322-332 calls for `linsolve = :hipldl` (INTEGRATION.md §3)
 function linear_solver_struct(::Val{:hipldl}, N, rows::Vector{Ti}, cols::Vector{Ti}, vals::Vector{Float64}, nvar, nequ, ncon) where {Ti}
+  N < MIN_ORDER[] && return CaNNOLeS.LDLFactStruct(N, rows, cols, vals)   # small systems stay on the CPU backend (src/solver_types.jl:61-65)
   r64 = Ti === Int64 ? rows : Vector{Int64}(rows)
   c64 = Ti === Int64 ? cols : Vector{Int64}(cols)
   return HIPLDLStruct{Ti}(rows, cols, vals, CaNNOLeSHIP.HIPFactor(N, r64, c64, nvar, nequ, ncon))
