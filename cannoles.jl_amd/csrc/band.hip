@@ -733,21 +733,30 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 #endif
 #ifdef BAND_MW
 // ======================================================================================================================================
-// EXPERIMENT (round 6; not in the product build: -DCNL_EXPERIMENT=1 -DBAND_MW, tuning key band_movers=1): the same program with LOADER
+// EXPERIMENT (round 6; not in the product build: -DCNL_EXPERIMENT=1 -DBAND_MW, tuning key band_movers=1..3): the same program with LOADER
 // wavefronts.  A workgroup of EIGHT wavefronts serves two groups of NL problems; per (group, part) one wavefront computes AND streams
-// its own factor records / solution components out (as in band_newton_kernel), and one wavefront only LOADS: it keeps two sets of staging
-// registers — the loads of epoch e + 2 are issued while epoch e computes — and commits a set to LDS between two workgroup barriers.  Only
-// a wavefront without stores can wait for the OLDER set alone: on gfx950 loads and stores share one counter (vmcnt) and return out of
-// order with respect to each other (profiles/r06_band_movers.jsonl: the first two look-ahead experiments waited with vmcnt(0) for loads
-// issued a few steps earlier).  Roles: waves 0,1 compute / 2,3 load for group 0, waves 4,5 load / 6,7 compute for group 1 — wavefronts w
-// and w + 4 share a SIMD (tools/simd_map.hip), so every SIMD holds one of each.
+// its own factor records / solution components out (as in band_newton_kernel), and one wavefront only LOADS into staging registers and
+// commits them to LDS around the workgroup barriers of an epoch.  Only a wavefront without stores can wait for a set of loads alone: on
+// gfx950 loads and stores share one counter (vmcnt) and return out of order with respect to each other (profiles/r06_band_movers.jsonl:
+// the first two look-ahead experiments waited with vmcnt(0) for loads issued a few steps earlier).  Roles: waves 0,1 compute / 2,3 load
+// for group 0, waves 4,5 load / 6,7 compute for group 1 — wavefronts w and w + 4 share a SIMD (tools/simd_map.hip), so every SIMD holds
+// one of each.  Measured (same file): +6 ... 10 % at 8 192 problems, nothing at 16 384 — the look-ahead question is closed.
 #define MW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-constexpr int MW_LANE_D = BAND_LANE_DOUBLES;   // the standard lane block
+// v5: every (problem, part) owns TWO standard lane blocks (pieces | half ring | zero cell): the loader commits the operands of epoch
+// e + 1 into block (e + 1) % 2 WHILE epoch e computes out of block e % 2 — the compute wavefronts never wait for a commit.  One staging
+// set in registers: the loads of epoch e + 2 are issued behind the commit of e + 1 (a single generation in flight: the waits at the
+// next commit are counted, nothing younger to wait for).  The step blocks have ONE buffer, written between the two barriers of an epoch
+// boundary.  307 doubles per lane (odd): 4 x 16 lanes of a workgroup = 157 KB of the 160 KB of a CU.
+// v6 (DB = false): ONE block per lane and the staging registers as the second buffer — the loads of epoch e + 1 are issued behind
+// barrier X of epoch e and committed behind its barrier Y; 32 problems per group (4 x 32 lanes = the LDS of a CU, as band_newton_kernel<32>
+// at 16 384 problems).
+constexpr int MW_BLK = BAND_LANE_DOUBLES * 8;   // byte offset of the second block
+constexpr int mw_lane_d(bool db) { return db ? 2 * BAND_LANE_DOUBLES + 1 : BAND_LANE_DOUBLES; }
 
-template <int NL>
+template <int NL, bool DB>
 __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P, const LaunchArgs Ain) {
   constexpr int NI = NL / 8;
-  constexpr int LANE_D = MW_LANE_D;
+  constexpr int LANE_D = mw_lane_d(DB);
   constexpr bool LINT = true;   // factor records interleaved over the group's problems (the address arithmetic is the mover's, off the chain)
   extern __shared__ double lds[];
   const int mode = Ain.mode, batch = Ain.batch;
@@ -773,7 +782,7 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
   const double tol = Ain.params[0];
 
   if (!computes) {
-    // ================================================ mover ================================================
+    // ================================================ loader ================================================
     const int* fops_g = as_global(P.fops[part]);
     const int* bops_g = as_global(P.bops[part]);
     const long long lsize = P.lsize;
@@ -781,7 +790,7 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
     const double* rbase = has_rhs ? grhs + (long long)prob0 * N : gvals;
     double* lbase_g = gL + (long long)prob0 * lsize;
     const int loff8 = (int)P.loff[part];
-    unsigned movp[NI], ldsb[NI];
+    unsigned movp[NI], ldsb0[NI];
     bool movok[NI];
 #pragma unroll
     for (int i = 0; i < NI; i++) {
@@ -789,18 +798,22 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
       movok[i] = prob0 + pl < batch;
       if (!movok[i]) pl = live ? batch - 1 - prob0 : 0;
       movp[i] = (unsigned)pl;
-      ldsb[i] = ((unsigned)(i * 8 + lq) * (unsigned)LANE_D + (unsigned)le) << 3;
+      ldsb0[i] = ((unsigned)(i * 8 + lq) * (unsigned)LANE_D + (unsigned)le) << 3;
     }
-    // two staging sets: the loads of epoch e + 2 are issued while epoch e computes (the mover has the registers for it: one epoch of
-    // lead — the compute time of eight steps — is less than the latency of this access pattern under load)
-    double stgA[NPC][NI], stgB[NPC][NI];
-    int4 rstgA, rstgB;
+    double stg[NPC][NI];   // ONE staging set
+    int4 rstg0, rkeep;     // step blocks: in flight / waiting for their epoch boundary
     int pcs[NPC];
-    // every piece slot is loaded whether the epoch uses it or not: the number of loads in flight behind a staging set is then a
-    // compile-time constant, which is what lets the compiler wait for the OLDER set with s_waitcnt vmcnt(31) instead of vmcnt(0)
-    constexpr bool BAND_ISSUE_ALWAYS = true;
-    // (the step blocks' load FIRST: the compiler copies its four registers away at the next issue, which waits for that load — as the
-    //  youngest of its set that wait was s_waitcnt vmcnt(0), i.e. for every load in flight)
+    constexpr bool BAND_ISSUE_ALWAYS = true;   // (a static number of loads per generation: counted waits)
+    // pieces of the staged epoch into block PAR of every lane; the step blocks are kept for the epoch boundary
+#define MW_COMMIT_PIECES(PAR)                                                                                                 \
+    {                                                                                                                         \
+      unsigned ldsb[NI];                                                                                                      \
+      _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) ldsb[i_] = ldsb0[i_] + (unsigned)(DB ? (PAR) * MW_BLK : 0);                     \
+      BAND_COMMIT(0) BAND_COMMIT(1) BAND_COMMIT(2) BAND_COMMIT(3) BAND_COMMIT(4) BAND_COMMIT(5) BAND_COMMIT(6) BAND_COMMIT(7) \
+      BAND_COMMIT(8) BAND_COMMIT(9) BAND_COMMIT(10) BAND_COMMIT(11) BAND_COMMIT(12) BAND_COMMIT(13) BAND_COMMIT(14)           \
+      rkeep = rstg0;                                                                                                          \
+    }
+#define MW_COMMIT_REC() { reinterpret_cast<int4*>(recb)[lane] = rkeep; }
 #define MW_ISSUE_ALL(EP, OFS, OPS, OPOFF)                                                                                     \
     {                                                                                                                         \
       BAND_ISSUE_DESC(EP, OFS)                                                                                                \
@@ -808,39 +821,29 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
       BAND_ISSUE(0) BAND_ISSUE(1) BAND_ISSUE(2) BAND_ISSUE(3) BAND_ISSUE(4) BAND_ISSUE(5) BAND_ISSUE(6) BAND_ISSUE(7)         \
       BAND_ISSUE(8) BAND_ISSUE(9) BAND_ISSUE(10) BAND_ISSUE(11) BAND_ISSUE(12) BAND_ISSUE(13) BAND_ISSUE(14)                  \
     }
-#define MW_FWD_EPOCH(E_)                                                                                                      \
-      {                                                                                                                       \
-        const int e = (E_);                                                                                                   \
-        if (live && e < nepochs) BAND_COMMIT_ALL()                                                                            \
-        MW_BARRIER();   /* X: the epoch's operands are in LDS */                                                              \
-        if (live && e + 2 < nepochs) MW_ISSUE_ALL(epochs + (e + 2) * BAND_EW, BE_FP, fops_g, epochs[(e + 2) * BAND_EW + BE_FOFF]) \
-        MW_BARRIER();   /* Y: the compute wavefront is through the epoch */                                                   \
-      }
     while (true) {
-      // ---- forward ----
-      if (live) {
-#define stg stgA
-#define rstg0 rstgA
+      // ---- forward: epoch e computes out of block e % 2 ----
+      if (live && nepochs > 0) {
         MW_ISSUE_ALL(epochs, BE_FP, fops_g, 0)
-#undef stg
-#undef rstg0
-#define stg stgB
-#define rstg0 rstgB
-        if (nepochs > 1) MW_ISSUE_ALL(epochs + BAND_EW, BE_FP, fops_g, epochs[BAND_EW + BE_FOFF])
-#undef stg
-#undef rstg0
+        MW_COMMIT_PIECES(0)
+        MW_COMMIT_REC()
+        if (DB && nepochs > 1) MW_ISSUE_ALL(epochs + BAND_EW, BE_FP, fops_g, epochs[BAND_EW + BE_FOFF])
       }
-      for (int e2 = 0; e2 < nepmax; e2 += 2) {
-#define stg stgA
-#define rstg0 rstgA
-        MW_FWD_EPOCH(e2)
-#undef stg
-#undef rstg0
-#define stg stgB
-#define rstg0 rstgB
-        if (e2 + 1 < nepmax) MW_FWD_EPOCH(e2 + 1)
-#undef stg
-#undef rstg0
+      for (int e = 0; e < nepmax; e++) {
+        MW_BARRIER();   // X: pieces and step blocks of epoch e are in LDS
+        if (live) {
+          if constexpr (DB) {
+            if (e + 1 < nepochs) MW_COMMIT_PIECES((e + 1) & 1)   // (its block is free: the compute wavefront is past epoch e - 1)
+            if (e + 2 < nepochs) MW_ISSUE_ALL(epochs + (e + 2) * BAND_EW, BE_FP, fops_g, epochs[(e + 2) * BAND_EW + BE_FOFF])
+          } else {
+            if (e + 1 < nepochs) MW_ISSUE_ALL(epochs + (e + 1) * BAND_EW, BE_FP, fops_g, epochs[(e + 1) * BAND_EW + BE_FOFF])
+          }
+        }
+        MW_BARRIER();   // Y: the compute wavefront is through epoch e
+        if (live && e + 1 < nepochs) {
+          if constexpr (!DB) MW_COMMIT_PIECES(0)
+          MW_COMMIT_REC()
+        }
       }
       MW_BARRIER();   // J1
       MW_BARRIER();   // J2: the decision is in the control block
@@ -849,41 +852,35 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
       if (alldone) break;
     }
     if (mode == MODE_FACTOR) return;
-    // ---- backward ----
+    // ---- backward: trip t handles epoch e = nepmax - 1 - t out of block t % 2 ----
     MW_BARRIER();   // K1
-    MW_BARRIER();   // K2: which problems store
-    // trip t handles epoch e = nepmax - 1 - t; staging set = parity of t
-#define MW_BWD_EPOCH(T_)                                                                                                      \
-    {                                                                                                                         \
-      const int e = nepmax - 1 - (T_);                                                                                        \
-      if (live && e < nepochs) BAND_COMMIT_ALL()                                                                              \
-      MW_BARRIER();   /* X */                                                                                                 \
-      if (live && e >= 2 && e - 2 < nepochs) MW_ISSUE_ALL(epochs + (e - 2) * BAND_EW, BE_BP, bops_g, epochs[(e - 2) * BAND_EW + BE_BOFF]) \
-      MW_BARRIER();   /* Y */                                                                                                 \
-    }
-    if (live) {
-#define stg stgA
-#define rstg0 rstgA
-      if (nepmax - 1 < nepochs) MW_ISSUE_ALL(epochs + (nepmax - 1) * BAND_EW, BE_BP, bops_g, epochs[(nepmax - 1) * BAND_EW + BE_BOFF])
-#undef stg
-#undef rstg0
-#define stg stgB
-#define rstg0 rstgB
-      if (nepmax - 2 >= 0 && nepmax - 2 < nepochs) MW_ISSUE_ALL(epochs + (nepmax - 2) * BAND_EW, BE_BP, bops_g, epochs[(nepmax - 2) * BAND_EW + BE_BOFF])
-#undef stg
-#undef rstg0
-    }
-    for (int t2 = 0; t2 < nepmax; t2 += 2) {
-#define stg stgA
-#define rstg0 rstgA
-      MW_BWD_EPOCH(t2)
-#undef stg
-#undef rstg0
-#define stg stgB
-#define rstg0 rstgB
-      if (t2 + 1 < nepmax) MW_BWD_EPOCH(t2 + 1)
-#undef stg
-#undef rstg0
+    MW_BARRIER();   // K2 (behind it the junction exchange in block 0 is read)
+    {
+      // the first trip with an epoch of this part, and the one behind it
+      const int t0 = nepmax - nepochs;   // trips 0 .. t0 - 1 have no epoch here
+      if (live && nepochs > 0) {
+        MW_ISSUE_ALL(epochs + (nepochs - 1) * BAND_EW, BE_BP, bops_g, epochs[(nepochs - 1) * BAND_EW + BE_BOFF])
+        MW_COMMIT_PIECES(t0 & 1)
+        MW_COMMIT_REC()
+        if (DB && nepochs > 1) MW_ISSUE_ALL(epochs + (nepochs - 2) * BAND_EW, BE_BP, bops_g, epochs[(nepochs - 2) * BAND_EW + BE_BOFF])
+      }
+      for (int t = 0; t < nepmax; t++) {
+        const int e = nepmax - 1 - t;   // epoch of this trip (>= nepochs: none)
+        MW_BARRIER();   // X
+        if (live && e < nepochs) {
+          if constexpr (DB) {
+            if (e - 1 >= 0) MW_COMMIT_PIECES((t + 1) & 1)
+            if (e - 2 >= 0) MW_ISSUE_ALL(epochs + (e - 2) * BAND_EW, BE_BP, bops_g, epochs[(e - 2) * BAND_EW + BE_BOFF])
+          } else {
+            if (e - 1 >= 0) MW_ISSUE_ALL(epochs + (e - 1) * BAND_EW, BE_BP, bops_g, epochs[(e - 1) * BAND_EW + BE_BOFF])
+          }
+        }
+        MW_BARRIER();   // Y
+        if (live && e < nepochs && e - 1 >= 0) {
+          if constexpr (!DB) MW_COMMIT_PIECES(0)
+          MW_COMMIT_REC()
+        }
+      }
     }
     return;
   }
@@ -911,7 +908,12 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
     movp[i] = (unsigned)pl;
     ldsb[i] = ((unsigned)(i * 8 + lq) * (unsigned)LANE_D + (unsigned)le) << 3;
   }
-  for (int t = lane; t < NL; t += 64) *reinterpret_cast<double*>(wblk + ((size_t)t * LANE_D + BAND_ZERO_OFF) * 8) = 0.0;
+  for (int t = lane; t < NL; t += 64) {   // the zero cells
+    *reinterpret_cast<double*>(wblk + ((size_t)t * LANE_D + BAND_ZERO_OFF) * 8) = 0.0;
+    if constexpr (DB) *reinterpret_cast<double*>(wblk + ((size_t)t * LANE_D + BAND_ZERO_OFF) * 8 + MW_BLK) = 0.0;
+  }
+  char* const wblk0 = wblk;
+  char* const myb0 = myb;
   const double kdec = Ain.params[2], kinc = Ain.params[3], klarge = Ain.params[4], rho0 = Ain.params[5], rhomax = Ain.params[6], rhomin = Ain.params[7];
   double rho = 0.0, wrote = 0.0;
   double rho_old = (mode == MODE_NEWTON && valid) ? as_global(Ain.rho_old)[cprob] : 0.0;
@@ -934,6 +936,8 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
       if (live && e < nepochs) {
         cptr E = epochs + e * BAND_EW;
         const int nst = E[BE_NSTEP];
+        char* const wblk = wblk0 + (DB ? (e & 1) * MW_BLK : 0);   // the block of the epoch: operands, out ring, zero cell
+        char* const myb = myb0 + (DB ? (e & 1) * MW_BLK : 0);
         int o = 0;
         Rec stC, stN;
         RowRec rwC, rwN;
@@ -1093,6 +1097,8 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
       if (live && e < nepochs) {
         cptr E = epochs + e * BAND_EW;
         const int nst = E[BE_NSTEP];
+        char* const wblk = wblk0 + (DB ? ((nepmax - 1 - e) & 1) * MW_BLK : 0);   // the block of the trip
+        char* const myb = myb0 + (DB ? ((nepmax - 1 - e) & 1) * MW_BLK : 0);
         int o = 0;
         Rec stC, stN;
         RowRec rwC, rwN;
@@ -1156,19 +1162,32 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
   }
 }
 
-size_t band_mw_lds_bytes(int nl) { return ((size_t)4 * nl * MW_LANE_D + 2 * (2 * nl + 8)) * sizeof(double) + (size_t)4 * BAND_REC_MAX * 4; }
+// variants (tuning key band_movers): 1 = 16 problems per group, two blocks per lane (v5); 2 = 32 per group, one block (v6); 3 = 16, one block
+static int mw_nl(int variant) { return variant == 2 ? 32 : 16; }
+int band_mw_group(int variant) { return variant >= 1 && variant <= 3 ? mw_nl(variant) : 0; }
+size_t band_mw_lds_bytes(int variant) {
+  const int nl = mw_nl(variant);
+  return ((size_t)4 * nl * mw_lane_d(variant == 1) + 2 * (2 * nl + 8)) * sizeof(double) + (size_t)4 * BAND_REC_MAX * 4;
+}
 
-hipError_t launch_band_mw(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream) {
-  if (P.nparts != 2 || nl != 16) return hipErrorInvalidConfiguration;
-  const size_t ldsb = band_mw_lds_bytes(nl);
+hipError_t launch_band_mw(const BandDev& P, int variant, const LaunchArgs& a, hipStream_t stream) {
+  if (P.nparts != 2 || variant < 1 || variant > 3) return hipErrorInvalidConfiguration;
+  const size_t ldsb = band_mw_lds_bytes(variant);
+  const int nl = mw_nl(variant);
   const int grid = (a.batch + 2 * nl - 1) / (2 * nl);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_newton_mw_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr_cap((int)ldsb));
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(band_newton_mw_kernel<16>, dim3(grid), dim3(512), ldsb, stream, P, a);
-  return hipGetLastError();
+  auto go = [&](auto kern) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr_cap((int)ldsb));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ldsb, stream, P, a);
+    return hipGetLastError();
+  };
+  if (variant == 1) return go(band_newton_mw_kernel<16, true>);
+  if (variant == 2) return go(band_newton_mw_kernel<32, false>);
+  return go(band_newton_mw_kernel<16, false>);
 }
 
 #else
+int band_mw_group(int) { return 0; }
 size_t band_mw_lds_bytes(int) { return (size_t)-1; }   // (not compiled in: see the experiment above)
 hipError_t launch_band_mw(const BandDev&, int, const LaunchArgs&, hipStream_t) { return hipErrorNotSupported; }
 #endif

@@ -126,7 +126,7 @@ struct cnl_handle {
   bool band = false;
   cnl::BandDev bd{};
   int band_nl = 16;            // problems per workgroup
-  bool band_mw = false;        // EXPERIMENT builds: the kernel with loader wavefronts serves the handle (band.hip, band_newton_mw_kernel)
+  int band_mw = 0;             // EXPERIMENT builds: the kernel with loader wavefronts serves the handle (band.hip, band_newton_mw_kernel)
   double* d_Lband = nullptr;   // [batch][bd.lsize] factor records of the band kernels
 };
 
@@ -371,7 +371,7 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
     // is gone
     cnl::LaunchArgs b = a;
     b.L = h->d_Lband;
-    e = h->band_mw ? cnl::launch_band_mw(h->bd, h->band_nl, b, stream) : cnl::launch_band(h->bd, h->band_nl, b, stream);
+    e = h->band_mw ? cnl::launch_band_mw(h->bd, h->band_mw, b, stream) : cnl::launch_band(h->bd, h->band_nl, b, stream);
     g_launches[0]++;
   } else if (h->use_v2 && (a.mode != cnl::MODE_SOLVE || h->v2_solve)) {
     a.scratch = h->d_gs;
@@ -1293,10 +1293,12 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     // 32 per workgroup (the LDS of a CU holds two such workgroups: 16384 problems resident) — tools/time_band.py
     h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : (batch > 8192 ? 32 : 16);
     if (h->band_nl != 8 && h->band_nl != 16 && h->band_nl != 32) return bail(fail(CNL_ERR_ARG, "band_problems_per_group must be 8, 16 or 32"));
-    if (plan->opt.band_movers > 0 && cnl::band_mw_lds_bytes(16) == (size_t)-1)
-      return bail(fail(CNL_ERR_ARG, "tuning key band_movers needs a library built with -DCNL_EXPERIMENT=1 -DBAND_MW (csrc/band.hip)"));
-    h->band_mw = plan->opt.band_movers > 0 && bd.nparts == 2 && cnl::band_mw_lds_bytes(16) <= std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024);
-    if (h->band_mw) h->band_nl = 16;
+    if (plan->opt.band_movers > 0 && cnl::band_mw_group(plan->opt.band_movers) == 0)
+      return bail(fail(CNL_ERR_ARG, "tuning key band_movers (1 .. 3) needs a library built with -DCNL_EXPERIMENT=1 -DBAND_MW (csrc/band.hip)"));
+    if (plan->opt.band_movers > 0 && bd.nparts == 2 && cnl::band_mw_lds_bytes(plan->opt.band_movers) <= std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024)) {
+      h->band_mw = plan->opt.band_movers;
+      h->band_nl = cnl::band_mw_group(h->band_mw);
+    }
     // 32-bit byte offsets inside a workgroup's problems
     const uint64_t span = 8ull * (uint64_t)h->band_nl * (uint64_t)std::max<int64_t>({(int64_t)nnz, N, bd.lsize});
     if (span < (1ull << 32) && cnl::band_lds_bytes(bd.nparts, h->band_nl) <= std::min<size_t>(cnl::max_lds_bytes(), 160 * 1024)) {

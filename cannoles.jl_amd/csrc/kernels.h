@@ -165,8 +165,9 @@ struct BandDev {
 hipError_t launch_band(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream);
 size_t band_lds_bytes(int nparts, int nl);
 // EXPERIMENT builds (-DCNL_EXPERIMENT=1 -DBAND_MW): the same program with loader wavefronts (band.hip, band_newton_mw_kernel)
-hipError_t launch_band_mw(const BandDev& P, int nl, const LaunchArgs& a, hipStream_t stream);
-size_t band_mw_lds_bytes(int nl);
+hipError_t launch_band_mw(const BandDev& P, int variant, const LaunchArgs& a, hipStream_t stream);
+size_t band_mw_lds_bytes(int variant);
+int band_mw_group(int variant);   // problems per group of the variant (0: no such variant)
 
 // returns hipSuccess or the launch error
 hipError_t launch_newton(const DevPlan& P, const KernelConfig& cfg, const LaunchArgs& a, hipStream_t stream);

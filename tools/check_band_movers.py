@@ -15,11 +15,12 @@ import test_gpu_parity as T  # noqa: E402
 
 def main():
     hipldl, syn, O = T._mods()
+    mv = int(os.environ.get("MW_VARIANT", "1"))   # tuning key band_movers: 1 .. 3 (csrc/band.hip)
     for (n, p, B, hw) in [(200, 4, 5, 2), (1000, 10, 37, 2), (1000, 10, 70, 2), (360, 6, 19, 1), (400, 0, 33, 2), (10000, 50, 33, 2)]:
         s = syn.band_structure(n, p, hw=hw)
         vals, rhs = syn.batch_values(s, B, cfg=4)
-        info, cfg = T.run_case(s, vals, rhs, options=T._band_opts(hipldl, band_movers=1))
-        assert cfg["band"] and cfg["band_movers"] and cfg["band_nl"] == 16
+        info, cfg = T.run_case(s, vals, rhs, options=T._band_opts(hipldl, band_movers=mv))
+        assert cfg["band"] and cfg["band_movers"] and cfg["band_nl"] == (32 if mv == 2 else 16)
         print("ok", n, p, B, hw, flush=True)
     s = syn.band_structure(600, 6)
     B = 45
@@ -30,12 +31,12 @@ def main():
     ro = np.zeros(B)
     ro[5] = 0.3
     ro[2] = 1e-3
-    T.run_case(s, vals, rhs, rho_old=ro, options=T._band_opts(hipldl, band_movers=1))
+    T.run_case(s, vals, rhs, rho_old=ro, options=T._band_opts(hipldl, band_movers=mv))
     rows, cols = s.kkt_pattern()
     p = hipldl.default_params()
     out = {}
-    for mw in (0, 1):
-        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=T._band_opts(hipldl, band_movers=mw, band_problems_per_group=16))
+    for mw in (0, mv):
+        L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=T._band_opts(hipldl, band_movers=mw, band_problems_per_group=32 if mv == 2 else 16))
         assert L.config["band"] and L.config["band_movers"] == bool(mw)
         okf, npos, nzer = hipldl.try_to_factorize(L, vals, s.nvar, s.nequ, s.ncon, p[0], return_inertia=True)
         v = vals.copy()
@@ -45,7 +46,7 @@ def main():
         hipldl.solve_ldl_(rhs, L.factor, d2)
         out[mw] = [np.array(x, copy=True) for x in (okf, npos, nzer, d, ok, rho, ro_out, nf, v, d2)]
         L.close()
-    for a, b in zip(out[0], out[1]):
+    for a, b in zip(out[0], out[mv]):
         assert np.array_equal(a, b)
     print("bit-equal to band_newton_kernel: ok")
 

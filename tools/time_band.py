@@ -18,7 +18,8 @@ rows, cols = s.kkt_pattern()
 par = hipldl.default_params()
 dev = torch.device("cuda", 0)
 variants = {"front": dict(band_kernel=0), "band8": dict(band_kernel=1, band_problems_per_group=8), "band16": dict(band_kernel=1, band_problems_per_group=16),
-            "band32": dict(band_kernel=1, band_problems_per_group=32), "bandmw": dict(band_kernel=1, band_movers=1)}
+            "band32": dict(band_kernel=1, band_problems_per_group=32), "bandmw": dict(band_kernel=1, band_movers=1), "bandmw2": dict(band_kernel=1, band_movers=2),
+            "bandmw3": dict(band_kernel=1, band_movers=3)}
 if os.environ.get("BAND_VARIANTS"):
     variants = {k: v for k, v in variants.items() if k in os.environ["BAND_VARIANTS"].split(",")}
 for B in [int(a) for a in sys.argv[1:]] or [8192]:
