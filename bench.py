@@ -110,10 +110,17 @@ class DeviceProblem:
         self.params = hipldl.default_params()
         self.L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, device=device_index, options=options)
         self.stream = stream
+        # cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED: the kernel's `vals` is the interleaved array (what row f2 writes on such a
+        # handle); the problem-major copy stays for the other blocks
+        self.vin = self.vals
+        if self.L.config.get("batch_layout"):
+            self.vin = torch.empty(hipldl.layout_len(self.L, 0), dtype=torch.float64, device=dev)
+            hipldl.interleave_dev(self.L, 0, self.vals.data_ptr(), self.vin.data_ptr(), 0)
+            torch.cuda.synchronize()
 
     def step(self):
         self.rho_old.zero_()
-        self.hipldl.newton_system_dev(self.L, self.vals.data_ptr(), self.rhs.data_ptr(), self.d.data_ptr(), self.rho_old.data_ptr(),
+        self.hipldl.newton_system_dev(self.L, self.vin.data_ptr(), self.rhs.data_ptr(), self.d.data_ptr(), self.rho_old.data_ptr(),
                                       self.rho.data_ptr(), self.nfact.data_ptr(), self.succ.data_ptr(), self.params, self.stream.cuda_stream)
 
     def timed(self, steps, warmup):
@@ -214,6 +221,10 @@ def main():
     ap.add_argument("--ncon", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="problems timed on the CPU oracle (-1 auto, 0 off)")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch, PCIe-inclusive, cfg2 and f1 blocks")
+    ap.add_argument("--layout", choices=("interleaved", "problem-major"), default="interleaved",
+                    help="layout of the device-resident `vals` of the headline handle: interleaved = cnl_options.batch_layout 1 (what row f2 writes on "
+                         "such a handle; falls back to problem-major where the band kernels do not serve the handle), problem-major = the reference's "
+                         "vector per problem; the line carries both")
     ap.add_argument("--opt", default="", help="cnl_options fields for the headline handle, key=value[,key=value] (measurement tools; default: the library's own choices)")
     ap.add_argument("--multi", action="store_true", help="ONE process drives --gpus devices through cnl_multi_newton_system_dev / cnl_multi_synchronize "
                                                          "(the second front end of DESIGN section 6) instead of one process per GPU")
@@ -261,6 +272,12 @@ def main():
             rhs[b0:b0 + nb].copy_(torch.from_numpy(rh))
             if b0 == 0:
                 host_chunk["vals"], host_chunk["rhs"] = vh, rh
+        if args.layout == "interleaved":
+            try:
+                return DeviceProblem(torch, hipldl, s, rows, cols, vals, rhs, nloc, local_rank, stream,
+                                     options=parse_options(hipldl, (args.opt + "," if args.opt else "") + "batch_layout=1"))
+            except hipldl.CnlError:   # (the band kernels do not serve this shape / batch: the reference's layout)
+                pass
         return DeviceProblem(torch, hipldl, s, rows, cols, vals, rhs, nloc, local_rank, stream, options=parse_options(hipldl, args.opt))
 
     # the per-rank driver shared with the CPU (gloo) test: shard, warm-up, barrier + synchronize on both sides of exactly
@@ -303,7 +320,7 @@ def main():
         d_two = torch.zeros_like(prob.d)
         with torch.cuda.stream(stream):
             for _ in range(3):
-                hipldl._check(hipldl.lib().cnl_factorize_dev(LDLT._h, prob.vals.data_ptr(), 2.220446049250313e-16, prob.succ.data_ptr(), stream.cuda_stream))
+                hipldl._check(hipldl.lib().cnl_factorize_dev(LDLT._h, prob.vin.data_ptr(), 2.220446049250313e-16, prob.succ.data_ptr(), stream.cuda_stream))
                 torch.cuda.synchronize()
                 fms.append(LDLT.last_kernel_ms())
                 hipldl._check(hipldl.lib().cnl_solve_dev(LDLT._h, prob.rhs.data_ptr(), d_two.data_ptr(), stream.cuda_stream))
@@ -350,6 +367,8 @@ def main():
         "config": {"workload": f"cfg3 band constrained NLS n={args.n} nequ={args.n} ncon={args.ncon}, "
                                + (f"{total} independent problems split over {world} GPU(s)" if args.strong else f"{B} independent problems per GPU")
                                + ", one newton_system! per problem per step",
+                   "vals_layout": ("interleaved over groups of 32 problems (cnl_options.batch_layout = 1: what cnl_prepare_newton_system_dev writes on "
+                                   "such a handle; rhs, d problem-major)" if LDLT.config.get("batch_layout") else "problem-major (the reference's vector per problem)"),
                    "batch_per_gpu": B, "total_problems": counts[0], "sharding": f"independent problems, {world} contiguous shard(s), no collective",
                    "ordering": info["order"], "nnzL_stored": info["nnzL"], "nnzL_exact": info["nnzL_exact"], "fronts": info["nsuper"],
                    "kernel": LDLT.config, "all_success": ok, "backward_error": berr},
@@ -439,7 +458,7 @@ def compact_line(out):
         "cfg4_B256_ms": g("cfg4", "B256", "ms_per_call"), "cfg4_B256_frac": g("cfg4", "B256", "frac"), "cfg4_B32_ms": g("cfg4", "B32", "ms_per_call"),
         "cfg4_B4096_frac": g("cfg4", "B4096", "frac"), "cfg5_B256_ms": g("cfg5", "B256", "ms_per_call"), "cfg5_B256_frac": g("cfg5", "B256", "frac"),
         "f1_residual_vectors_ms": g("aux_f1", "residual_vectors", "ms"), "f1_residual_vectors_frac": g("aux_f1", "residual_vectors", "frac"),
-        "f1_trial_point_frac": g("aux_f1", "trial_point", "frac"), "f2_prepare_frac": g("aux_f1", "f2_prepare", "frac"),
+        "f1_trial_point_frac": g("aux_f1", "trial_point", "frac"), "f2_prepare_frac": g("aux_f1", "f2_prepare", "frac"), "f2_prepare_interleaved_frac": g("aux_f1", "f2_prepare", "interleaved", "frac"),
         "f3_ms_per_step": g("aux_f3", "ms_per_step"), "two_call_over_newton": _dig(out.get("roofline"), ("two_call_sequence", "total_over_newton_system")),
         "pcie_inclusive_ksys_s": _k(g("pcie_inclusive", "systems_per_s")),
         "single_system_host_ms": g("call_pattern_single_system", "newton_system_ms"), "single_system_analysis_s": g("call_pattern_single_system", "analysis_s"), "multi_front_end_ratio": g("multi_front_end", "ratio_to_single_handle"),
@@ -450,6 +469,9 @@ def compact_line(out):
     # the default batch moved from 8192 (rounds 1-4) to 16384 in round 5 — say which batch `value` is measured on, and
     # carry the 8192-problem figure as a top-level key whenever this run measured it
     c["value_batch_per_gpu"] = cfg["batch_per_gpu"]
+    c["value_vals_layout"] = "interleaved" if cfg["kernel"].get("batch_layout") else "problem-major"
+    if g("problem_major_layout", "systems_per_s") is not None:
+        c["value_problem_major_layout"] = g("problem_major_layout", "systems_per_s")   # rounds 1-5 quoted `value` on this layout
     b8 = g("small_batch", "B8192", "systems_per_s")
     if b8 is not None:
         c["value_at_batch_8192"] = b8
@@ -471,6 +493,19 @@ def _k(v):
 def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_h, prob, B, dev, local_rank, stream, args):
     """Reported beside `value`, never part of it: small batches, the host-pointer (PCIe-inclusive) entry,
     BASELINE config 2 on the dense backend, and the vectors either side of the system (row f1)."""
+    # ---- the headline batch on the reference's problem-major `vals` (what rounds 1-5 quoted) when `value` is on the interleaved layout
+    twin = None
+    if prob.L.config.get("batch_layout"):
+        twin = DeviceProblem(torch, hipldl, s, rows, cols, vals, rhs, B, local_rank, stream, options=parse_options(hipldl, args.opt))
+        ms = twin.timed(min(10, max(2, args.steps)), 2)
+        same = bool(torch.equal(twin.d, prob.d)) if twin.L.config.get("band_nl") == prob.L.config.get("band_nl") else None
+        r = out["roofline"]
+        out["problem_major_layout"] = {"systems_per_s": B / (ms * 1e-3), "ms_per_step": ms, "kernel": twin.L.config,
+                                       "frac": r["bytes_per_system"] * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                       "frac_on_kernel_bytes": (r["kernel_bytes_per_system"] * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if r.get("kernel_bytes_per_system") else None,
+                                       "d_bit_equal_to_interleaved": same, "all_success": bool((twin.succ == 1).all().item()),
+                                       "speedup_of_interleaved": (ms / out["roofline"]["step_ms"]) if out["roofline"]["step_ms"] else None}
+        out["value_problem_major_layout"] = B / (ms * 1e-3)
     # ---- small batches of the same pattern: handles planned for latency (staged execution of the elimination tree)
     sb = {}
     # 4608: the chain's 4096 + a remainder of 512 on a handle of its own (cnl_options.split_tail); then two large parts (the
@@ -529,7 +564,7 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
         out["cfg2_dense"] = {"error": str(e)}
     # ---- SURVEY 8 row f1 (vectors either side of the system, device-resident), on the headline shapes; algorithmic bytes =
     # J_F and J_c values + r, lambda, F, c read + rhs written (resp. x, r, lambda, d read + xt, rt, lambdat, dlambda written)
-    LDLT = prob.L
+    LDLT = (twin or prob).L   # (rows f1 / f4 read problem-major vals)
     sh = stream.cuda_stream
     rv = torch.randn((B, s.nequ), dtype=torch.float64, device=dev)
     lam = torch.randn((B, max(s.ncon, 1)), dtype=torch.float64, device=dev)
@@ -571,6 +606,15 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
         f2 = {"ms": ms_p, "batch": Bp, "bytes_per_system": by_p, "GBps": by_p * Bp / (ms_p * 1e-3) / 1e9, "frac": by_p * Bp / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         if Lp is not LDLT:
             Lp.close()
+        if prob.L.config.get("batch_layout"):   # the same pass writing `vals` interleaved (what the headline kernel reads)
+            Li = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=Bp, options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, batch_layout=1))
+            v3 = torch.zeros(hipldl.layout_len(Li, 0), dtype=torch.float64, device=dev)
+            ms_i = timed(lambda: hipldl.prepare_newton_system_dev(Li, nhF, nhc, njF, njc, a_hF.data_ptr(), a_hc.data_ptr() if s.ncon else 0, a_Jx.data_ptr(),
+                                                                  a_Jc.data_ptr() if s.ncon else 0, a_de.data_ptr() if s.ncon else 0, v3.data_ptr(), sh))
+            hipldl.deinterleave_dev(Li, 0, v3.data_ptr(), v2.data_ptr(), sh)   # (v2 holds the problem-major pass's output: compare through a copy)
+            f2["interleaved"] = {"ms": ms_i, "GBps": by_p * Bp / (ms_i * 1e-3) / 1e9, "frac": by_p * Bp / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            Li.close()
+            del v3
         del a_hF, a_hc, a_Jx, a_Jc, v2
     except Exception as e:   # the extras never take the headline down
         f2 = {"error": str(e)}
@@ -582,6 +626,9 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
                      "trial_point": {"ms": ms_tp, "bytes_per_system": by_tp, "GBps": by_tp * B / (ms_tp * 1e-3) / 1e9,
                                      "frac": by_tp * B / (ms_tp * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                      "f2_prepare": f2}
+    if twin is not None:
+        twin.close()
+        del twin
     # ---- BASELINE config 4 (n = nequ = 1000, ncon = 10; the config the 1/2/4/8 scaling is defined on) and config 5 (its
     # pattern with the rho ladder climbed to nfact = 6), each on its own algorithmic bytes
     try:
@@ -593,9 +640,10 @@ def extra_blocks(out, torch, hipldl, syn, s, rows, cols, vals, rhs, vals_h, rhs_
     try:
         dtm, npm, okm, shm = multi_front_end(torch, hipldl, s, rows, cols, [local_rank], B, min(10, max(2, args.steps)), 2)
         rate = npm * min(10, max(2, args.steps)) / dtm
+        single = out.get("value_problem_major_layout") or out["value"]   # (the multi front end takes the reference's problem-major arrays)
         out["multi_front_end"] = {"entry": "cnl_multi_newton_system_dev + cnl_multi_synchronize, one process, devices [0]", "systems_per_s": rate,
-                                  "ms_per_step": dtm / min(10, max(2, args.steps)) * 1e3, "ratio_to_single_handle": rate / out["value"],
-                                  "within_3_percent": abs(rate / out["value"] - 1.0) <= 0.03, "all_success": okm, "shards": shm,
+                                  "ms_per_step": dtm / min(10, max(2, args.steps)) * 1e3, "ratio_to_single_handle": rate / single,
+                                  "within_3_percent": abs(rate / single - 1.0) <= 0.03, "all_success": okm, "shards": shm,
                                   "timer": "wall clock (enqueue loop + final synchronize)"}
     except Exception as e:
         out["multi_front_end"] = {"error": str(e)}

@@ -47,6 +47,16 @@ constexpr int BAND_ZERO_OFF = BAND_LOUT_OFF + BAND_LOUT_MAX;         // holds 0.
 constexpr int BAND_LANE_DOUBLES = BAND_ZERO_OFF + 1;                 // 153: odd, so that 32 lanes reading one offset hit 32 bank pairs
 static_assert(BAND_DR_OFF + BAND_DR_MAX <= BAND_ZERO_OFF && BAND_LANE_DOUBLES % 2 == 1, "lane block layout");
 
+// cnl_options.batch_layout = 1 (include/cannoles_hip.h): `vals` interleaved over groups of BAND_IL_GROUP problems in blocks of eight
+// doubles — element e of problem p at ((p / 32 * band_il_blocks(nnz) + e / 8) * 32 + p % 32) * 8 + e % 8.  One spare block per problem:
+// an operand piece is eight doubles from ANY element, the last one may reach into the block behind the array's last.
+constexpr int BAND_IL_GROUP = 32;
+constexpr long long band_il_blocks(long long len) { return (len + 7) / 8 + 1; }
+constexpr long long band_il_len(long long batch, long long len) { return (batch + BAND_IL_GROUP - 1) / BAND_IL_GROUP * band_il_blocks(len) * (BAND_IL_GROUP * 8); }
+constexpr long long band_il_index(long long p, long long e, long long len) {
+  return ((p / BAND_IL_GROUP * band_il_blocks(len) + e / 8) * BAND_IL_GROUP + p % BAND_IL_GROUP) * 8 + e % 8;
+}
+
 // step block (BAND_SW ints); LDS offsets are BYTES inside the lane block
 enum {
   BS_FLAGS = 0,        // BF_* | rows << 8

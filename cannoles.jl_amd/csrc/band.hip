@@ -117,12 +117,16 @@ __device__ __forceinline__ void fload(FOps& P, const Rec& st, const RowRec& row0
   }
 }
 
+// offset of element e of a problem from the problem's first element: e for the ABI's problem-major arrays (stride 0); for arrays
+// interleaved over the NL problems of a workgroup in blocks of eight doubles (stride = NL * 8) block e / 8 is NL * 8 doubles further
+__device__ __forceinline__ long long band_il_offset(int e, int stride) { return stride ? (long long)(e >> 3) * stride + (e & 7) : (long long)e; }
+
 // one forward step of phase PH = step number % 8: enter slot PH, pivot slot PH - 4; fl = flags word (wave-uniform), o = int
 // offset of the step block in the record buffer.  The operands were read (fload) while the previous step computed.
 template <int PH>
 __device__ __forceinline__ void fstep(Win& W, const FOps& OP, const Rec& st, const int fl, const char* recb, const int o, char* myb,
                                       const double* __restrict__ gvals, const double* __restrict__ grhs, cptr borders, long long pv, long long pr,
-                                      bool has_rhs, double rho, bool ovr, double tol, int& npos, int& nzer) {
+                                      bool has_rhs, double rho, bool ovr, double tol, int& npos, int& nzer, const int vstride = 0, const int rstride = 0) {
   constexpr int es = PH, ps = lslot(PH, 0);
   const int nrows = (fl >> 8) & 255;
   const double (&eo)[15] = OP.eo;
@@ -170,8 +174,9 @@ __device__ __forceinline__ void fstep(Win& W, const FOps& OP, const Rec& st, con
   // ---- border pivot ----
   if (fl & BF_PIVOT_B) {
     cptr bt = borders + BAND_BW * __builtin_amdgcn_readfirstlane(st.v[BS_BORDER]);
-    W.S55 += gvals[pv + bt[BB_DSRC]];
-    W.c5 += has_rhs ? grhs[pr + bt[BB_RHS]] : 0.0;
+    // (vstride / rstride != 0: the array is interleaved over the workgroup's problems in blocks of eight doubles, see band_il_offset)
+    W.S55 += gvals[pv + band_il_offset(bt[BB_DSRC], vstride)];
+    W.c5 += has_rhs ? grhs[pr + band_il_offset(bt[BB_RHS], rstride)] : 0.0;
     const double d = W.S55;
     npos += d > tol;
     nzer += fabs(d) <= tol;
@@ -324,8 +329,15 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   const int nnz = P.nnz, N = P.N;
   const long long lsize = P.lsize;
   // mover: wave-uniform base pointers + 32-bit per-lane byte offsets (NL problems span < 4 GB)
-  const double* vbase = gvals + (long long)prob0 * nnz;
-  const double* rbase = has_rhs ? grhs + (long long)prob0 * N : gvals;
+  // cnl_options.batch_layout = 1 (32 problems per workgroup only): `vals` is given INTERLEAVED over the 32 problems of a workgroup in
+  // blocks of eight doubles, the layout of the factor records below — element e of problem p of group g at
+  // ((g * band_il_blocks(nnz) + e / 8) * 32 + p) * 8 + e % 8 — so that the eight 64-byte runs of a mover load are 512 contiguous bytes
+  // and every 128-byte line that is fetched is used whole (16 384 problems: 12.5 -> 11.0 ms with vals and rhs interleaved, bit-equal).
+  // Bit 1 of the layout word: the same for `rhs`.  d is problem-major always.
+  const bool vil = NL == 32 && (Ain.layout & 1), ril = NL == 32 && (Ain.layout & 2);
+  const int vstride = vil ? NL * 8 : 0, rstride = ril ? NL * 8 : 0;
+  const double* vbase = gvals + (vil ? (long long)blockIdx.x * band_il_blocks(nnz) * (NL * 8) : (long long)prob0 * nnz);
+  const double* rbase = !has_rhs ? gvals : grhs + (ril ? (long long)blockIdx.x * band_il_blocks(N) * (NL * 8) : (long long)prob0 * N);
   // The factor records are private to the launch (written by the forward sweep, read by the backward sweep of the SAME workgroup), so
   // their layout is the kernel's choice: INTERLEAVED over the NL problems of the workgroup in blocks of eight doubles — element e of
   // problem p of the workgroup lives at ((e >> 3) * NL + p) * 8 + (e & 7) of the workgroup's region — so that the eight 64-byte runs one
@@ -354,7 +366,8 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   const bool valid = clane && cprob < batch;
   const int cpl = valid ? cprob - prob0 : batch - 1 - prob0;   // problem whose data this lane's block holds
   char* myb = wblk + (size_t)(clane ? lane : 0) * LANE_D * 8;
-  const long long pv = (long long)(prob0 + cpl) * nnz, pr = (long long)(prob0 + cpl) * N;
+  const long long pv = vil ? (long long)blockIdx.x * band_il_blocks(nnz) * (NL * 8) + cpl * 8 : (long long)(prob0 + cpl) * nnz;
+  const long long pr = ril ? (long long)blockIdx.x * band_il_blocks(N) * (NL * 8) + cpl * 8 : (long long)(prob0 + cpl) * N;
   for (int t = lane; t < NL; t += 64) *reinterpret_cast<double*>(wblk + ((size_t)t * LANE_D + BAND_ZERO_OFF) * 8) = 0.0;   // every block's zero cell
 
   const double tol = Ain.params[0], kdec = Ain.params[2], kinc = Ain.params[3], klarge = Ain.params[4], rho0 = Ain.params[5], rhomax = Ain.params[6],
@@ -385,12 +398,13 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     const int el_ = (pc & ((1 << 28) - 1)) + (arr == 2 ? loff8 : 0);                                                          \
     /* lane offset (doubles) = problem * strd + tl, tl = t + (t >> 3) * gap with t = m + element of the lane: the caller's arrays    \
        are problem-major (m = 0, t < 8: gap = 0), the factor is interleaved in blocks of eight (see lbase_g) */                \
-    const int m_ = (LINT && arr == 2) ? (el_ & 7) : 0;                                                                        \
-    const unsigned gap_ = (LINT && arr == 2) ? (unsigned)(NL * 8 - 8) : 0u;                                                   \
+    const bool il_ = arr == 0 ? vil : arr == 1 ? ril : LINT;   /* (wave-uniform) */                                           \
+    const int m_ = il_ ? (el_ & 7) : 0;                                                                                       \
+    const unsigned gap_ = il_ ? (unsigned)(NL * 8 - 8) : 0u;                                                                  \
     const char* pb = (arr == 0 ? reinterpret_cast<const char*>(vbase) : arr == 1 ? reinterpret_cast<const char*>(rbase)       \
                                                                                  : reinterpret_cast<const char*>(lbase_g)) +   \
-                     (((LINT && arr == 2) ? (long long)(el_ >> 3) * (NL * 8) : (long long)el_) << 3);                         \
-    const unsigned strd = arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : LINT ? 8u : (unsigned)lsize;                    \
+                     ((il_ ? (long long)(el_ >> 3) * (NL * 8) : (long long)el_) << 3);                                        \
+    const unsigned strd = il_ ? 8u : arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : (unsigned)lsize;                     \
     const unsigned t_ = (unsigned)m_ + (unsigned)le;                                                                          \
     const unsigned tl = t_ + (t_ >> 3) * gap_;                                                                                \
     BAND_ISSUE1(K, 0) BAND_ISSUE1(K, 1) BAND_ISSUE1(K, 2) BAND_ISSUE1(K, 3)                                                   \
@@ -459,7 +473,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
         if (clane && !(BAND_DBG & 2)) {                                                                                     \
           FOps op_;                                                                                                         \
           fload(op_, stC, rwC, fl, myb);                                                                                    \
-          fstep<PHV>(W, op_, stC, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer);      \
+          fstep<PHV>(W, op_, stC, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer, vstride, rstride); \
         }                                                                                                                   \
         o = onext; stC = stN; rwC = rwN;                                                                                    \
       }
@@ -721,8 +735,13 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       const int vq = __builtin_amdgcn_readlane((int)valid, q);
       if (nf > 1 && vq) {
         const double wq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wrote), q), __builtin_amdgcn_readlane(__double2loint(wrote), q));
-        double* vt = gvals + (long long)(prob0 + q) * nnz + (nnz - P.nvar);
-        for (int i = lane; i < P.nvar; i += 64) vt[i] = wq;
+        if (vil) {
+          double* vg = gvals + (long long)blockIdx.x * band_il_blocks(nnz) * (NL * 8) + q * 8;
+          for (int i = lane; i < P.nvar; i += 64) vg[band_il_offset(nnz - P.nvar + i, vstride)] = wq;
+        } else {
+          double* vt = gvals + (long long)(prob0 + q) * nnz + (nnz - P.nvar);
+          for (int i = lane; i < P.nvar; i += 64) vt[i] = wq;
+        }
       }
     }
   }
@@ -779,6 +798,8 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
   const int nepmax = P.nepochs[0] > P.nepochs[1] ? P.nepochs[0] : P.nepochs[1];
   const int nnz = P.nnz, N = P.N;
   const bool live = prob0 < batch;   // (the last workgroup's second group may be empty: it only joins the barriers)
+  const bool vil = NL == 32 && (Ain.layout & 1), ril = NL == 32 && (Ain.layout & 2);   // interleaved vals / rhs (band_newton_kernel)
+  const int vstride = vil ? NL * 8 : 0, rstride = ril ? NL * 8 : 0;
   const double tol = Ain.params[0];
 
   if (!computes) {
@@ -786,8 +807,8 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
     const int* fops_g = as_global(P.fops[part]);
     const int* bops_g = as_global(P.bops[part]);
     const long long lsize = P.lsize;
-    const double* vbase = gvals + (long long)prob0 * nnz;
-    const double* rbase = has_rhs ? grhs + (long long)prob0 * N : gvals;
+    const double* vbase = gvals + (vil ? (long long)(prob0 / NL) * band_il_blocks(nnz) * (NL * 8) : (long long)prob0 * nnz);
+    const double* rbase = !has_rhs ? gvals : grhs + (ril ? (long long)(prob0 / NL) * band_il_blocks(N) * (NL * 8) : (long long)prob0 * N);
     double* lbase_g = gL + (long long)prob0 * lsize;
     const int loff8 = (int)P.loff[part];
     unsigned movp[NI], ldsb0[NI];
@@ -892,7 +913,8 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
   const bool valid = clane && cprob < batch;
   const int cpl = valid ? cprob - prob0 : (live ? batch - 1 - prob0 : 0);
   char* myb = wblk + (size_t)(clane ? lane : 0) * LANE_D * 8;
-  const long long pv = live ? (long long)(prob0 + cpl) * nnz : 0, pr = live ? (long long)(prob0 + cpl) * N : 0;
+  const long long pv = !live ? 0 : vil ? (long long)(prob0 / NL) * band_il_blocks(nnz) * (NL * 8) + cpl * 8 : (long long)(prob0 + cpl) * nnz;
+  const long long pr = !live ? 0 : ril ? (long long)(prob0 / NL) * band_il_blocks(N) * (NL * 8) + cpl * 8 : (long long)(prob0 + cpl) * N;
   // the wavefront streams its own factor records / solution components out (all 64 lanes: lane (lq, le) = element le of problems lq, lq + 8)
   const long long lsize = P.lsize;
   double* lbase_g = gL + (long long)prob0 * lsize;
@@ -951,7 +973,7 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
           if (clane) {                                                                                                      \
             FOps op_;                                                                                                       \
             fload(op_, stC, rwC, fl, myb);                                                                                  \
-            fstep<PHV>(W, op_, stC, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer);    \
+            fstep<PHV>(W, op_, stC, fl, recb, o, myb, gvals, grhs, borders, pv, pr, has_rhs, rho, ovr, tol, npos, nzer, vstride, rstride); \
           }                                                                                                                 \
           o = onext; stC = stN; rwC = rwN;                                                                                  \
         }
@@ -1155,8 +1177,13 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
       const int vq = __builtin_amdgcn_readlane((int)valid, q);
       if (nf > 1 && vq) {
         const double wq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wrote), q), __builtin_amdgcn_readlane(__double2loint(wrote), q));
-        double* vt = gvals + (long long)(prob0 + q) * nnz + (nnz - P.nvar);
-        for (int i = lane; i < P.nvar; i += 64) vt[i] = wq;
+        if (vil) {
+          double* vg = gvals + (long long)(prob0 / NL) * band_il_blocks(nnz) * (NL * 8) + q * 8;
+          for (int i = lane; i < P.nvar; i += 64) vg[band_il_offset(nnz - P.nvar + i, vstride)] = wq;
+        } else {
+          double* vt = gvals + (long long)(prob0 + q) * nnz + (nnz - P.nvar);
+          for (int i = lane; i < P.nvar; i += 64) vt[i] = wq;
+        }
       }
     }
   }

@@ -126,6 +126,7 @@ struct cnl_handle {
   bool band = false;
   cnl::BandDev bd{};
   int band_nl = 16;            // problems per workgroup
+  int layout = 0;              // band handles: bit 0 = vals (cnl_options.batch_layout), bit 1 = rhs interleaved over groups of 32 problems (band.h)
   int band_mw = 0;             // EXPERIMENT builds: the kernel with loader wavefronts serves the handle (band.hip, band_newton_mw_kernel)
   double* d_Lband = nullptr;   // [batch][bd.lsize] factor records of the band kernels
 };
@@ -371,8 +372,11 @@ int launch(cnl_handle* h, cnl::LaunchArgs& a, hipStream_t stream) {
     // is gone
     cnl::LaunchArgs b = a;
     b.L = h->d_Lband;
+    b.layout = h->layout;
     e = h->band_mw ? cnl::launch_band_mw(h->bd, h->band_mw, b, stream) : cnl::launch_band(h->bd, h->band_nl, b, stream);
     g_launches[0]++;
+  } else if (h->layout) {
+    return fail(CNL_ERR_STATE, "this call is not served by the band kernels: a handle with batch_layout = CNL_LAYOUT_INTERLEAVED has no other");
   } else if (h->use_v2 && (a.mode != cnl::MODE_SOLVE || h->v2_solve)) {
     a.scratch = h->d_gs;
     e = cnl::launch_newton2(h->dp2, h->wpb2, h->lds2, a, stream);
@@ -869,7 +873,7 @@ void cnl_options_init(cnl_options* o) {
   o->staged_max_batch = t.staged_max_batch;
   o->verbose = t.verbose; o->band_kernel = t.band_kernel; o->dense_backend = t.dense_backend; o->staged = t.staged; o->dataflow = t.dataflow;
   o->device_ladder = t.device_ladder; o->host_ladder = t.host_ladder; o->split_tail = t.split_tail; o->multi_share_plan = t.multi_share_plan;
-  o->f1_tiles = t.f1_tiles;
+  o->batch_layout = t.batch_layout;
 }
 
 static int plan_create_impl(cnl_plan** plan, int64_t N, int64_t nnz, const int64_t* rows1, const int64_t* cols1, int64_t nvar,
@@ -887,7 +891,7 @@ static int resolve_options(const cnl_options* in, cnl::Tuning& out) {
   if (in->struct_size != (int32_t)sizeof(cnl_options)) return fail(CNL_ERR_ARG, "cnl_options.struct_size does not match this library (use cnl_options_init)");
   out.plan_kind = in->plan_kind; out.staged_max_batch = in->staged_max_batch; out.verbose = in->verbose; out.band_kernel = in->band_kernel;
   out.dense_backend = in->dense_backend; out.staged = in->staged; out.dataflow = in->dataflow; out.device_ladder = in->device_ladder;
-  out.host_ladder = in->host_ladder; out.split_tail = in->split_tail; out.multi_share_plan = in->multi_share_plan; out.f1_tiles = in->f1_tiles;
+  out.host_ladder = in->host_ladder; out.split_tail = in->split_tail; out.multi_share_plan = in->multi_share_plan; out.batch_layout = in->batch_layout;
   std::memcpy(out.force_order, in->force_order, sizeof(out.force_order));
   out.force_order[sizeof(out.force_order) - 1] = 0;
   char tun[sizeof(in->tuning) + 1];
@@ -1291,7 +1295,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     bd.nparts = Bp.nparts; bd.m0 = Bp.m0; bd.n = Bp.n; bd.N = Bp.N; bd.nnz = Bp.nnz; bd.nvar = (int32_t)nvar; bd.lsize = Bp.lsize;
     // 16 problems per workgroup (two workgroups = four wavefronts per CU: one per SIMD) up to the 8192 problems that fills; above,
     // 32 per workgroup (the LDS of a CU holds two such workgroups: 16384 problems resident) — tools/time_band.py
-    h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : (batch > 8192 ? 32 : 16);
+    h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : (batch > 8192 || plan->opt.batch_layout ? 32 : 16);
     if (h->band_nl != 8 && h->band_nl != 16 && h->band_nl != 32) return bail(fail(CNL_ERR_ARG, "band_problems_per_group must be 8, 16 or 32"));
     if (plan->opt.band_movers > 0 && cnl::band_mw_group(plan->opt.band_movers) == 0)
       return bail(fail(CNL_ERR_ARG, "tuning key band_movers (1 .. 3) needs a library built with -DCNL_EXPERIMENT=1 -DBAND_MW (csrc/band.hip)"));
@@ -1307,6 +1311,14 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
       if (hipMemset(h->d_Lband, 0, (((size_t)batch + 32) * (size_t)bd.lsize + 64) * sizeof(double)) != hipSuccess) return bail(fail(CNL_ERR_HIP, "hipMemset failed"));
       h->band = true;
     }
+  }
+  if (plan->opt.batch_layout != CNL_LAYOUT_PROBLEM_MAJOR) {
+    // the interleaved layout is the band kernels' (groups of 32 problems = one workgroup of the 32-problem instantiation)
+    if (plan->opt.batch_layout != CNL_LAYOUT_INTERLEAVED) return bail(fail(CNL_ERR_ARG, "cnl_options.batch_layout: unknown layout"));
+    if (!h->band || h->band_nl != cnl::BAND_IL_GROUP)   // (band_mw: experiment builds, the 32-problem variant)
+      return bail(fail(CNL_ERR_ARG, "batch_layout = CNL_LAYOUT_INTERLEAVED needs a handle the band kernels serve with 32 problems per workgroup "
+                                    "(band-structured pattern, throughput plan, cnl_options.band_kernel != 0; csrc/band.h)"));
+    h->layout = 1 | (plan->opt.band_rhs_interleaved ? 2 : 0);
   }
   // Storage only the register-front / general kernels and the stand-alone condensation passes use.  A band handle runs all three
   // calls of the plugin surface on the band kernels (round 6), so it owns the band factor records alone: 0.48 MB per problem of
@@ -1350,7 +1362,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     // bidirectional chain, ...): it gets a handle of its own, enqueued behind the full loads (run_split).
     // (band kernels: 512 workgroups of 32 problems are resident at once)
     const int64_t cap = h->band ? 16384 : 4 * (int64_t)h->resident_waves, r = batch % cap;
-    if (batch > cap && r > 0 && r <= cap - cap / 16) {
+    if (batch > cap && r > 0 && r <= cap - cap / 16 && !h->layout) {   // (an interleaved batch is one array of whole groups)
       cnl_handle* t = nullptr;
       if (create_tuned(&t, N, nnz, rows1, cols1, nvar, nequ, ncon, r, device, plan->opt) == CNL_OK) {
         if (t->staged && t->use_v2 && !t->dense && !t->gdense) { h->tail = t; h->split_staged = batch - r; }
@@ -1534,7 +1546,7 @@ int cnl_prepare_newton_system_dev(cnl_handle* h, int64_t nnzhF, int64_t nnzhc, i
   if (J.ncon == 0 && (nnzhc != 0 || nnzjc != 0)) return fail(CNL_ERR_DIM, "constraint segments must be empty when ncon == 0");
   HIPCHK(hipSetDevice(h->device));
   hipError_t e = cnl::launch_prepare((int)nnzhF, (int)nnzhc, (int)nnzjF, (int)nnzjc, J.nvar, J.nequ, J.ncon, d_hF, d_hc, d_Jx, d_Jcx,
-                                     d_delta, d_vals, (int)h->batch, (hipStream_t)stream);
+                                     d_delta, d_vals, (int)h->batch, h->layout & 1, (hipStream_t)stream);
   if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("prepare_newton_system: ") + hipGetErrorString(e));
   return CNL_OK;
 }
@@ -1544,6 +1556,7 @@ int cnl_cgls_multipliers_dev(cnl_handle* h, const double* d_vals, const double* 
   if (!h || !d_vals || !d_r) return fail(CNL_ERR_ARG, "null argument");
   if (h->djt.ncon == 0) return CNL_OK;  // nothing to estimate
   if (!d_lambda) return fail(CNL_ERR_ARG, "null lambda");
+  if (h->layout & 1) return fail(CNL_ERR_STATE, "cnl_cgls_multipliers_dev reads problem-major vals (handle with batch_layout = CNL_LAYOUT_INTERLEAVED)");
   if (h->djt.ncon > 1024) return fail(CNL_ERR_DIM, "cnl_cgls_multipliers_dev supports at most 1024 constraints");
   HIPCHK(hipSetDevice(h->device));
   if (!h->d_cgls_ws) {
@@ -1561,6 +1574,7 @@ int cnl_residual_vectors_dev(cnl_handle* h, const double* d_vals, const double* 
                              const double* d_cx, double* d_rhs, double* d_norms, void* stream) {
   if (!h || !d_vals || !d_r || !d_Fx || !d_rhs || !d_norms) return fail(CNL_ERR_ARG, "null argument");
   if (h->djt.ncon > 0 && (!d_lambda || !d_cx)) return fail(CNL_ERR_ARG, "lambda / c are required when ncon > 0");
+  if (h->layout & 1) return fail(CNL_ERR_STATE, "cnl_residual_vectors_dev reads problem-major vals (handle with batch_layout = CNL_LAYOUT_INTERLEAVED)");
   HIPCHK(hipSetDevice(h->device));
   hipError_t e = cnl::launch_residual_vectors(h->djt, d_vals, d_r, d_lambda, d_Fx, d_cx, d_rhs, d_norms, (int)h->batch, (hipStream_t)stream);
   if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("residual_vectors: ") + hipGetErrorString(e));
@@ -1577,6 +1591,33 @@ int cnl_trial_point_dev(cnl_handle* h, const double* d_x, const double* d_r, con
   if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("trial_point: ") + hipGetErrorString(e));
   return CNL_OK;
 }
+
+// ---- cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED: lengths and conversions (csrc/band.h: band_il_index) ----
+static int layout_rowlen(const cnl_handle* h, int which, int64_t* len) {
+  if (which == 0) *len = h->djt.nnz;
+  else if (which == 1) *len = (int64_t)h->djt.nvar + h->djt.nequ + h->djt.ncon;
+  else return fail(CNL_ERR_ARG, "which: 0 = vals, 1 = an N-vector per problem (rhs)");
+  return CNL_OK;
+}
+int cnl_layout_len(const cnl_handle* h, int which, int64_t* doubles) {
+  if (!h || !doubles) return fail(CNL_ERR_ARG, "null argument");
+  int64_t len = 0;
+  if (int rc = layout_rowlen(h, which, &len)) return rc;
+  *doubles = cnl::band_il_len(h->batch, len);
+  return CNL_OK;
+}
+static int convert_layout(cnl_handle* h, int which, const double* src, double* dst, int to_interleaved, void* stream) {
+  if (!h || !src || !dst) return fail(CNL_ERR_ARG, "null argument");
+  if (src == dst) return fail(CNL_ERR_ARG, "the conversion is not in place");
+  int64_t len = 0;
+  if (int rc = layout_rowlen(h, which, &len)) return rc;
+  HIPCHK(hipSetDevice(h->device));
+  hipError_t e = cnl::launch_interleave(src, dst, (int)h->batch, len, to_interleaved, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("interleave: ") + hipGetErrorString(e));
+  return CNL_OK;
+}
+int cnl_interleave_dev(cnl_handle* h, int which, const double* d_src, double* d_dst, void* stream) { return convert_layout(h, which, d_src, d_dst, 1, stream); }
+int cnl_deinterleave_dev(cnl_handle* h, int which, const double* d_src, double* d_dst, void* stream) { return convert_layout(h, which, d_src, d_dst, 0, stream); }
 
 int cnl_set_timing(cnl_handle* h, int enable) {
   if (!h) return fail(CNL_ERR_ARG, "null handle");
@@ -1604,7 +1645,7 @@ int cnl_get_config(const cnl_handle* h, int64_t cfg[8]) {
   cfg[5] = (h->dense || h->gdense) ? 3 : (h->use_v2 ? (h->staged ? 4 : 2) : 1);
   if (h->lean && !h->dense && !h->gdense) cfg[5] |= 16;  // newton_system / factorize run the kernels' LEAN instantiation
   if (h->tail) cfg[5] |= 32;                             // the remainder of the batch runs on a handle of its own (split_tail)
-  if (h->band) cfg[5] |= 64 | ((int64_t)h->band_nl << 8) | ((int64_t)h->bd.nparts << 16) | (h->band_mw ? (int64_t)1 << 24 : 0);   // newton_system runs on the band kernels (csrc/band.h): problems per workgroup, parts
+  if (h->band) cfg[5] |= 64 | ((int64_t)h->band_nl << 8) | ((int64_t)h->bd.nparts << 16) | (h->band_mw ? (int64_t)1 << 24 : 0) | ((int64_t)h->layout << 25);   // newton_system runs on the band kernels (csrc/band.h): problems per workgroup, parts
   if (h->djt.rv_ntiles > 0) cfg[5] |= 128;               // row f1 runs on column tiles (kernels.h: DevJt::rv_*)
   cfg[6] = h->wpb2;
   cfg[7] = (int64_t)h->lds2;
@@ -1658,6 +1699,7 @@ int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, do
 // ---- host-pointer entry points (what the Julia glue ccalls) ------------------------
 int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* success, int64_t* npos, int64_t* nzero) {
   if (!h || !vals || !success) return fail(CNL_ERR_ARG, "null argument");
+  if (h->layout) return fail(CNL_ERR_STATE, "host-pointer calls take the reference's problem-major arrays: this handle was created with batch_layout = CNL_LAYOUT_INTERLEAVED (device-pointer entry points only)");
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_staging(h);
   if (rc) return rc;
@@ -1695,6 +1737,7 @@ int cnl_factorize(cnl_handle* h, const double* vals, double eig_tol, int32_t* su
 
 int cnl_solve(cnl_handle* h, const double* rhs, double* d) {
   if (!h || !rhs || !d) return fail(CNL_ERR_ARG, "null argument");
+  if (h->layout) return fail(CNL_ERR_STATE, "host-pointer calls take the reference's problem-major arrays: this handle was created with batch_layout = CNL_LAYOUT_INTERLEAVED (device-pointer entry points only)");
   if (!h->factorized) return fail(CNL_ERR_STATE, "cnl_solve before cnl_factorize");
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_staging(h);
@@ -1930,6 +1973,7 @@ static int host_ladder_run(cnl_handle* h, const double params[9], const double* 
 int cnl_newton_system(cnl_handle* h, double* vals, const double* rhs, double* d, const double* rho_old, const double params[9],
                       double* rho, double* rho_old_out, int32_t* nfact, int32_t* success) {
   if (!h || !vals || !rhs || !d || !params || !rho || !rho_old_out || !nfact || !success) return fail(CNL_ERR_ARG, "null argument");
+  if (h->layout) return fail(CNL_ERR_STATE, "host-pointer calls take the reference's problem-major arrays: this handle was created with batch_layout = CNL_LAYOUT_INTERLEAVED (device-pointer entry points only)");
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_staging(h);
   if (rc) return rc;

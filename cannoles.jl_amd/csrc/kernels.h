@@ -91,6 +91,7 @@ struct LaunchArgs {
   int batch;
   double* vals;          // [batch][nnz]   (NEWTON: rho tail written back; FACTOR: read only)
   const double* rhs;     // [batch][N]     (NEWTON, SOLVE)
+  int layout;            // band kernels, 32 problems per workgroup: bit 0 = vals, bit 1 = rhs interleaved over the workgroup's problems (band.h: band_il_index)
   double* d;             // [batch][N]     (NEWTON, SOLVE)
   double* L;             // [batch][lsize] factor storage
   double* scratch;       // [batch][work_doubles] when !lds_work
@@ -182,7 +183,9 @@ hipError_t launch_condense_tiled(const DevCond& C, const double* vals, const dou
 hipError_t launch_cond_inertia(const DevCond& C, const double* vals, int* extra_pos, int* extra_zer, double eig_tol, int batch,
                                hipStream_t stream);
 hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon, const double* hF, const double* hc,
-                          const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, hipStream_t stream);
+                          const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, int interleaved, hipStream_t stream);
+// problem-major <-> interleaved over groups of 32 problems (band.h: band_il_index); rows of `len` doubles
+hipError_t launch_interleave(const double* src, double* dst, int batch, long long len, int to_interleaved, hipStream_t stream);
 hipError_t launch_cgls(const DevJt& J, const double* vals, const double* r, double* lambda, double* Jxtr, double* ws, int32_t* iters,
                        double atol, double rtol, int itmax, int ones_if_zero, int batch, hipStream_t stream);
 hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const double* r, const double* lambda, const double* Fx,

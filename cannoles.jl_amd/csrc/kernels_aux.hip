@@ -5,6 +5,7 @@
 // They stream over independent (problem, entry) pairs at full occupancy; no dependency chains.
 #include <hip/hip_runtime.h>
 
+#include "band.h"
 #include "condense.h"
 #include "kernels.h"
 
@@ -693,6 +694,98 @@ __global__ void __launch_bounds__(256) prepare_kernel(int nnzhF, int nnzhc, int 
   }
 }
 
+// ---- cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED (band.h: band_il_index) ----------------------------------------------------
+// A workgroup moves a tile of 32 problems x 128 elements through LDS: on the problem-major side a problem's 128 elements are 1 KB
+// contiguous, on the interleaved side the tile is 16 blocks x (32 problems x 8 doubles) = 32 KB contiguous.
+constexpr int IL_TILE = 128, IL_PITCH = IL_TILE + 8;   // (pitch: the 4 x 8 lanes of a half-wavefront hit 32 different bank pairs)
+__device__ __forceinline__ long long il_tile_dst(long long g, long long nb, int chunk, int idx, int& p, int& kk) {
+  const int bl = idx >> 8, j = idx & 7;
+  p = (idx >> 3) & 31;
+  kk = bl * 8 + j;
+  return ((g * nb + (long long)chunk * (IL_TILE / 8) + bl) * BAND_IL_GROUP + p) * 8 + j;
+}
+__global__ void __launch_bounds__(256) interleave_kernel(const double* __restrict__ src, double* __restrict__ dst, int batch, long long len,
+                                                         int to_interleaved) {
+  __shared__ double tile[BAND_IL_GROUP * IL_PITCH];
+  const long long g = blockIdx.y, nb = band_il_blocks(len);
+  const int chunk = blockIdx.x, t = threadIdx.x;
+  if (to_interleaved) {
+    double x[BAND_IL_GROUP / 2];   // (every load before the first LDS store)
+    const int kk = t & (IL_TILE - 1);
+    const long long k = (long long)chunk * IL_TILE + kk;
+#pragma unroll
+    for (int it = 0; it < BAND_IL_GROUP / 2; it++) {
+      const long long prob = g * BAND_IL_GROUP + 2 * it + (t >> 7);
+      x[it] = (prob < batch && k < len) ? __builtin_nontemporal_load(src + prob * len + k) : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < BAND_IL_GROUP / 2; it++) tile[(2 * it + (t >> 7)) * IL_PITCH + kk] = x[it];
+    __syncthreads();
+    for (int i = 0; i < BAND_IL_GROUP * IL_TILE / 256; i++) {
+      int p, kk;
+      const long long o = il_tile_dst(g, nb, chunk, i * 256 + t, p, kk);
+      if ((long long)chunk * (IL_TILE / 8) + kk / 8 < nb) __builtin_nontemporal_store(tile[p * IL_PITCH + kk], dst + o);   // (pads and the spare block: zeros)
+    }
+  } else {
+    for (int i = 0; i < BAND_IL_GROUP * IL_TILE / 256; i++) {
+      int p, kk;
+      const long long o = il_tile_dst(g, nb, chunk, i * 256 + t, p, kk);
+      tile[p * IL_PITCH + kk] = ((long long)chunk * (IL_TILE / 8) + kk / 8 < nb) ? __builtin_nontemporal_load(src + o) : 0.0;
+    }
+    __syncthreads();
+    for (int it = 0; it < BAND_IL_GROUP / 2; it++) {
+      const int pi = 2 * it + (t >> 7), kk = t & (IL_TILE - 1);
+      const long long prob = g * BAND_IL_GROUP + pi, k = (long long)chunk * IL_TILE + kk;
+      if (prob < batch && k < len) __builtin_nontemporal_store(tile[pi * IL_PITCH + kk], dst + prob * len + k);
+    }
+  }
+}
+
+hipError_t launch_interleave(const double* src, double* dst, int batch, long long len, int to_interleaved, hipStream_t stream) {
+  const long long groups = (batch + BAND_IL_GROUP - 1) / BAND_IL_GROUP, chunks = (band_il_blocks(len) * 8 + IL_TILE - 1) / IL_TILE;
+  if (batch <= 0 || len <= 0 || groups > 65535 || chunks > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+  hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)chunks, (unsigned)groups), dim3(256), 0, stream, src, dst, batch, len, to_interleaved);
+  return hipGetLastError();
+}
+
+// prepare_newton_system! writing `vals` interleaved (the values and the "left alone" rules of prepare_kernel above, the tiles of
+// interleave_kernel): the model's arrays are read 1 KB per problem, `vals` is written 32 KB contiguous per workgroup
+__global__ void __launch_bounds__(256) prepare_il_kernel(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon,
+                                                         const double* __restrict__ hF, const double* __restrict__ hc,
+                                                         const double* __restrict__ Jx, const double* __restrict__ Jcx,
+                                                         const double* __restrict__ delta, double* __restrict__ vals, int batch) {
+  __shared__ double tile[BAND_IL_GROUP * IL_PITCH];
+  const int o1 = nnzhF, o2 = o1 + nnzhc, o3 = o2 + nnzjF, o4 = o3 + nnzjc, o5 = o4 + nequ, o6 = o5 + ncon, nnz = o6 + nvar;
+  const long long g = blockIdx.y, nb = band_il_blocks(nnz);
+  const int chunk = blockIdx.x, t = threadIdx.x;
+  // every load is issued before the first LDS store (one predicated load per element: source pointer, validity and sign are selected,
+  // not branched on — loads inside the branches of prepare_kernel's chain were waited for one by one: 0.51 of the HBM rate against 0.65)
+  double x[BAND_IL_GROUP / 2];
+  const int kk0 = t & (IL_TILE - 1), k0 = chunk * IL_TILE + kk0;
+  const int seg = k0 < o1 ? 0 : k0 < o2 ? 1 : k0 < o3 ? 2 : k0 < o4 ? 3 : k0 < o5 ? 4 : k0 < o6 ? 5 : 6;
+  const double* sbase = seg == 0 ? hF : seg == 1 ? hc : seg == 2 ? Jx : seg == 3 ? Jcx : delta;
+  const long long sstr = seg == 0 ? nnzhF : seg == 1 ? nnzhc : seg == 2 ? nnzjF : seg == 3 ? nnzjc : 1;
+  const int soff = seg == 0 ? k0 : seg == 1 ? k0 - o1 : seg == 2 ? k0 - o2 : seg == 3 ? k0 - o3 : 0;
+  const bool rd = k0 < nnz && (seg == 0 ? hF != nullptr : seg == 1 || seg == 3 ? ncon > 0 : seg == 2 || seg == 5);
+  const bool neg = seg == 1 || seg == 5;
+#pragma unroll
+  for (int it = 0; it < BAND_IL_GROUP / 2; it++) {
+    const long long b = g * BAND_IL_GROUP + 2 * it + (t >> 7);
+    x[it] = (rd && b < batch) ? __builtin_nontemporal_load(sbase + b * sstr + soff) : 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < BAND_IL_GROUP / 2; it++) tile[(2 * it + (t >> 7)) * IL_PITCH + kk0] = neg ? -x[it] : x[it];
+  __syncthreads();
+  for (int i = 0; i < BAND_IL_GROUP * IL_TILE / 256; i++) {
+    int p, kk;
+    const long long o = il_tile_dst(g, nb, chunk, i * 256 + t, p, kk);
+    const int k = chunk * IL_TILE + kk;
+    // the slots prepare_newton_system! leaves alone: H_F without a Hessian, the constraint segments without constraints, -I; and the pads
+    const bool wr = k < o1 ? hF != nullptr : k < o2 ? ncon > 0 : k < o3 ? true : k < o4 ? ncon > 0 : k < o5 ? false : k < nnz;
+    if (wr && g * BAND_IL_GROUP + p < batch) __builtin_nontemporal_store(tile[p * IL_PITCH + kk], vals + o);
+  }
+}
+
 // Row f4 of the scope table: least-squares multiplier estimate  min || Jc' lambda - Jx' r ||  by CGLS, as the reference
 // obtains it from Krylov.jl (`krylov_solve!(cgls_workspace, Jcx', Jxtr)`, /root/reference/src/CaNNOLeS.jl:507-518 and
 // :880-882; Krylov.jl is an un-vendored dependency, Project.toml compat "0.10": its cgls is the textbook recurrence
@@ -797,8 +890,15 @@ hipError_t launch_cgls(const DevJt& J, const double* vals, const double* r, doub
 static inline bool linear_grid_ok(long long nch, long long batch) { return nch > 0 && batch > 0 && nch * batch <= 0x7fffffffLL; }
 
 hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, int nequ, int ncon, const double* hF, const double* hc,
-                          const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, hipStream_t stream) {
+                          const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, int interleaved, hipStream_t stream) {
   const int nnz = nnzhF + nnzhc + nnzjF + nnzjc + nequ + ncon + nvar;
+  if (interleaved) {
+    const long long groups = (batch + BAND_IL_GROUP - 1) / BAND_IL_GROUP, chunks = (nnz + IL_TILE - 1) / IL_TILE;
+    if (batch <= 0 || nnz <= 0 || groups > 65535) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(prepare_il_kernel, dim3((unsigned)chunks, (unsigned)groups), dim3(256), 0, stream, nnzhF, nnzhc, nnzjF, nnzjc, nvar, nequ,
+                       ncon, hF, hc, Jx, Jcx, delta, vals, batch);
+    return hipGetLastError();
+  }
   const long long nch = (nnz + 256 * PREP_UNROLL - 1) / (256 * PREP_UNROLL);   // (0 when nnz == 0: the kernel divides by it)
   if (!linear_grid_ok(nch, batch)) return hipErrorInvalidConfiguration;
   hipLaunchKernelGGL(prepare_kernel, dim3((unsigned)(nch * batch)), dim3(256), 0, stream, nnzhF, nnzhc, nnzjF, nnzjc, nvar, nequ, ncon,

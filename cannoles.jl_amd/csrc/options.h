@@ -55,7 +55,9 @@ namespace cnl {
   X(band_problems_per_group, 0) /* band kernels: problems per workgroup (8, 16, 32); 0 = by batch                           */ \
   X(band_movers, 0)          /* EXPERIMENT builds only (-DCNL_EXPERIMENT=1 -DBAND_MW): band kernel with loader wavefronts            */ \
   X(analysis_threads, 0)     /* host threads of the symbolic analysis (candidate orders); 0 = by the hardware, at most 16      */ \
-  X(f1_tiles, 1)             /* row f1 streams column tiles through LDS where the pattern allows                            */
+  X(f1_tiles, 1)             /* row f1 streams column tiles through LDS where the pattern allows; 0: gather kernel          */ \
+  X(batch_layout, 0)         /* CNL_LAYOUT_*: layout of `vals` at the device-pointer entry points (band handles)            */ \
+  X(band_rhs_interleaved, 0) /* measurement: the band kernels also take `rhs` interleaved (batch_layout = 1 handles)        */
 
 struct Tuning {
 #define X(name, dflt) int32_t name = dflt;

@@ -41,17 +41,35 @@ ABI_SYMBOLS = [
     "cnl_multi_create", "cnl_multi_destroy", "cnl_multi_shards", "cnl_multi_factorize", "cnl_multi_solve", "cnl_multi_newton_system",
     "cnl_outer_begin_dev", "cnl_outer_newton_done_dev", "cnl_outer_extrapolated_dev", "cnl_outer_trial_done_dev", "cnl_outer_end_dev",
     "cnl_outer_ls_begin_dev", "cnl_outer_ls_test_dev", "cnl_outer_ls_step_dev", "cnl_outer_ls_take_dev",
+    "cnl_layout_len", "cnl_interleave_dev", "cnl_deinterleave_dev",
 ]
 
 
 PLAN_AUTO, PLAN_THROUGHPUT, PLAN_LATENCY = 0, 1, 2
+LAYOUT_PROBLEM_MAJOR, LAYOUT_INTERLEAVED = 0, 1   # cnl_options.batch_layout (include/cannoles_hip.h)
+IL_GROUP = 32
+
+
+def il_blocks(length):
+    """blocks of eight doubles per problem of an interleaved array (one spare block; csrc/band.h: band_il_blocks)"""
+    return (int(length) + 7) // 8 + 1
+
+
+def il_len(batch, length):
+    return (int(batch) + IL_GROUP - 1) // IL_GROUP * il_blocks(length) * IL_GROUP * 8
+
+
+def il_index(p, e, length):
+    """position of element e of problem p in an array interleaved over groups of 32 problems in blocks of eight doubles
+    (CNL_LAYOUT_INTERLEAVED, csrc/band.h: band_il_index); p, e may be numpy arrays"""
+    return ((p // IL_GROUP * il_blocks(length) + e // 8) * IL_GROUP + p % IL_GROUP) * 8 + e % 8
 
 
 class cnl_options(C.Structure):
     """struct cnl_options of include/cannoles_hip.h (field order and types must match)"""
     _fields_ = [("struct_size", C.c_int32), ("plan_kind", C.c_int32), ("staged_max_batch", C.c_int64)] + [
         (k, C.c_int32) for k in ("verbose", "band_kernel", "dense_backend", "staged", "dataflow", "device_ladder", "host_ladder", "split_tail",
-                                 "multi_share_plan", "f1_tiles")] + [("force_order", C.c_char * 32), ("tuning", C.c_char * 192)]
+                                 "multi_share_plan", "batch_layout")] + [("force_order", C.c_char * 32), ("tuning", C.c_char * 192)]
 
 
 _PUBLIC_OPTIONS = {f[0] for f in cnl_options._fields_} - {"struct_size", "tuning"}
@@ -201,6 +219,9 @@ def lib():
         L.cnl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cnl_get_config.argtypes = [vp, _i64p]
         L.cnl_launch_counts.argtypes = [_i64p]
+        L.cnl_layout_len.argtypes = [vp, C.c_int, C.POINTER(i64)]
+        L.cnl_interleave_dev.argtypes = [vp, C.c_int, vp, vp, vp]
+        L.cnl_deinterleave_dev.argtypes = [vp, C.c_int, vp, vp, vp]
         for fn in ("cnl_outer_begin_dev", "cnl_outer_extrapolated_dev", "cnl_outer_trial_done_dev", "cnl_outer_end_dev", "cnl_outer_ls_begin_dev",
                    "cnl_outer_ls_step_dev", "cnl_outer_ls_take_dev"):
             getattr(L, fn).argtypes = [vp, vp]
@@ -321,7 +342,8 @@ class HIPLDLStruct:
         self.config = {"tpp": int(cfg[0]), "ppb": int(cfg[1]), "lds_bytes": int(cfg[2]), "lds_work": int(cfg[3]), "grid": int(cfg[4]),
                        "kernel": {2: "v2", 3: "dense", 4: "v2-staged"}.get(int(cfg[5]) & 15, "v1"), "wpb": int(cfg[6]), "lds2_bytes": int(cfg[7]),
                        "lean": bool(int(cfg[5]) & 16), "tail": bool(int(cfg[5]) & 32), "band": bool(int(cfg[5]) & 64), "f1_tiles": bool(int(cfg[5]) & 128),
-                       "band_nl": (int(cfg[5]) >> 8) & 255, "band_parts": (int(cfg[5]) >> 16) & 255, "band_movers": bool((int(cfg[5]) >> 24) & 1)}
+                       "band_nl": (int(cfg[5]) >> 8) & 255, "band_parts": (int(cfg[5]) >> 16) & 255, "band_movers": bool((int(cfg[5]) >> 24) & 1),
+                       "batch_layout": (int(cfg[5]) >> 25) & 1, "rhs_interleaved": bool((int(cfg[5]) >> 26) & 1)}
 
     def plan_array(self, name):
         return _plan_array(lib().cnl_get_plan(self._h), name)
@@ -446,6 +468,23 @@ def trial_point_dev(LDLT, x_ptr, r_ptr, lambda_ptr, d_ptr, max_dlambda, xt_ptr, 
     (src/CaNNOLeS.jl:654,661-668), batched and device-resident (cnl_trial_point_dev)."""
     _check(lib().cnl_trial_point_dev(LDLT._h, x_ptr, r_ptr, lambda_ptr, d_ptr, float(max_dlambda), xt_ptr, rt_ptr, lambdat_ptr,
                                      dlambda_ptr, stream))
+
+
+def layout_len(LDLT, which):
+    """doubles of the interleaved array of the handle's batch; which = 0: vals, 1: an N-vector per problem (cnl_layout_len)"""
+    n = C.c_int64(0)
+    _check(lib().cnl_layout_len(LDLT._h, int(which), C.byref(n)))
+    return int(n.value)
+
+
+def interleave_dev(LDLT, which, src_ptr, dst_ptr, stream=0):
+    """problem-major -> CNL_LAYOUT_INTERLEAVED on the device, out of place (cnl_interleave_dev)"""
+    _check(lib().cnl_interleave_dev(LDLT._h, int(which), src_ptr, dst_ptr, stream))
+
+
+def deinterleave_dev(LDLT, which, src_ptr, dst_ptr, stream=0):
+    """CNL_LAYOUT_INTERLEAVED -> problem-major on the device, out of place (cnl_deinterleave_dev)"""
+    _check(lib().cnl_deinterleave_dev(LDLT._h, int(which), src_ptr, dst_ptr, stream))
 
 
 def prepare_newton_system_dev(LDLT, nnzhF, nnzhc, nnzjF, nnzjc, hF_ptr, hc_ptr, Jx_ptr, Jcx_ptr, delta_ptr, vals_ptr, stream=0):

@@ -73,6 +73,14 @@ void cnl_default_params(double params[9]);
 #define CNL_PLAN_AUTO 0        /* by batch size: latency plan up to staged_max_batch problems, throughput plan above           */
 #define CNL_PLAN_THROUGHPUT 1  /* least total work, one sequential record stream per four problems                             */
 #define CNL_PLAN_LATENCY 2     /* bushy elimination tree cut into tasks (staged execution)                                      */
+#define CNL_LAYOUT_PROBLEM_MAJOR 0   /* vals[b * nnz + k]: problem after problem, the reference's vector per problem               */
+#define CNL_LAYOUT_INTERLEAVED 1     /* groups of 32 problems interleaved in blocks of eight doubles:
+                                        vals[((b / 32 * (nnz_blocks) + k / 8) * 32 + b % 32) * 8 + k % 8], nnz_blocks = (nnz + 7) / 8 + 1;
+                                        cnl_layout_len gives the array's length, cnl_interleave_dev / cnl_deinterleave_dev convert,
+                                        cnl_prepare_newton_system_dev (row f2) writes it directly.  For device-resident callers of
+                                        band-structured batches: every load of the band kernels then moves 512 contiguous bytes
+                                        (16 384 problems of the headline pattern: 12.5 -> 11.0 ms).  rhs and d are problem-major in
+                                        both layouts.  cnl_create fails (CNL_ERR_ARG) when the band kernels do not serve the handle. */
 typedef struct cnl_options {
   int32_t struct_size;         /* sizeof(cnl_options), set by cnl_options_init (ABI evolution)                                  */
   int32_t plan_kind;           /* CNL_PLAN_*                                                                                    */
@@ -96,8 +104,8 @@ typedef struct cnl_options {
   int32_t split_tail;          /* 1: the remainder of a batch above a machine-filling one runs on a handle of its own, with the plan
                                   cnl_create picks for a batch of that size, behind the rest on the caller's stream             */
   int32_t multi_share_plan;    /* 1: cnl_multi_create analyses the pattern once for all shards of equal plan kind               */
-  int32_t f1_tiles;            /* 1: row f1 (cnl_residual_vectors_dev) streams column tiles through LDS where the pattern allows;
-                                  0: gather kernel                                                                               */
+  int32_t batch_layout;        /* layout of the `vals` arrays of the DEVICE-pointer entry points (CNL_LAYOUT_*; host-pointer calls take
+                                  the reference's arrays, one problem after the other, always).  CNL_LAYOUT_INTERLEAVED: see below  */
   char force_order[32];        /* name of an ordering candidate to force ("" = none)                                            */
   char tuning[192];            /* "key=value[,key=value...]": any switch of csrc/options.h (measurement / test use)             */
 } cnl_options;
@@ -204,6 +212,15 @@ int cnl_residual_vectors_dev(cnl_handle* h, const double* d_vals, const double* 
 int cnl_prepare_newton_system_dev(cnl_handle* h, int64_t nnzhF, int64_t nnzhc, int64_t nnzjF, int64_t nnzjc, const double* d_hF,
                                   const double* d_hc, const double* d_Jx, const double* d_Jcx, const double* d_delta, double* d_vals,
                                   void* stream);
+/* On a handle created with cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED, cnl_prepare_newton_system_dev WRITES d_vals interleaved
+ * (the model's arrays stay problem-major), and cnl_factorize_dev / cnl_newton_system_dev read — the rho slots: write — d_vals in that
+ * layout; d_rhs and d_d are problem-major.  cnl_residual_vectors_dev and cnl_cgls_multipliers_dev read problem-major vals only
+ * (CNL_ERR_STATE on such a handle), the host-pointer entry points likewise.
+ *   cnl_layout_len: doubles of the interleaved array for the handle's batch, which = 0: vals, 1: an N-vector per problem;
+ *   cnl_interleave_dev / cnl_deinterleave_dev: problem-major -> interleaved / back (out of place; pads are written as zeros).     */
+int cnl_layout_len(const cnl_handle* h, int which, int64_t* doubles);
+int cnl_interleave_dev(cnl_handle* h, int which, const double* d_src, double* d_dst, void* stream);
+int cnl_deinterleave_dev(cnl_handle* h, int which, const double* d_src, double* d_dst, void* stream);
 
 /* cnl_cgls_multipliers_dev: least-squares multiplier estimate  min || Jc' lambda - Jx' r ||  (SURVEY 8 row f4), what the
  * reference obtains with `mul!(Jxtr, Jx', r); krylov_solve!(cgls_workspace, Jcx', Jxtr)` at src/CaNNOLeS.jl:507-518 and

@@ -2177,3 +2177,186 @@ def test_band_remainder_handle(built, B):
         assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
         assert np.abs(d2[b] - 2.0 * d0).max() <= FWD_TOL * 2.0 * np.abs(d0).max()
     L.close()
+
+
+# ---- cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED (round 6: `vals` interleaved over groups of 32 problems, include/cannoles_hip.h) ----
+def _il_handles(hipldl, s, B, **kw):
+    rows, cols = s.kkt_pattern()
+    mk = lambda **o: hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=_band_opts(hipldl, **o, **kw))
+    LA, LB = mk(band_problems_per_group=32), mk(batch_layout=hipldl.LAYOUT_INTERLEAVED)
+    assert LA.config["band"] and LA.config["band_nl"] == 32 and LA.config["batch_layout"] == 0
+    assert LB.config["band"] and LB.config["band_nl"] == 32 and LB.config["batch_layout"] == 1
+    return LA, LB
+
+
+@pytest.mark.parametrize("n,p,B,hw", [(200, 4, 5, 2), (1000, 10, 37, 2), (360, 6, 70, 1), (400, 0, 33, 2), (10000, 50, 64, 2), (240, 4, 8192 + 40, 2)])
+def test_interleaved_vals_layout(built, n, p, B, hw):
+    """The band kernels on `vals` interleaved over groups of 32 problems (CNL_LAYOUT_INTERLEAVED) against the oracle, and bit-equal in
+    every output — d, flags, rho, rho_old, nfact, the rho slots written back into vals, try_to_factorize -> solve_ldl! — to the same
+    kernels on the reference's problem-major arrays; batches that are no multiple of 32, ladder climbers, a hopeless problem, rho_old > 0."""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(n, p, hw=hw)
+    if B > 1000:
+        v8, r8 = syn.batch_values(s, 8, cfg=3)
+        rng = np.random.default_rng(5)
+        vals = np.tile(v8, (B // 8 + 1, 1))[:B] * (1.0 + 1e-3 * rng.standard_normal((B, 1)))
+        rhs = np.tile(r8, (B // 8 + 1, 1))[:B] + 1e-3 * np.arange(B)[:, None]
+        off = s.offsets()
+        vals[:, off[4]:off[5]] = -1.0
+    else:
+        vals, rhs = syn.batch_values(s, B, cfg=4)
+    climbers = [b for b in (1, 4, 17, 36, 69, 8200) if b < B]
+    for b in climbers:
+        vals[b], rhs[b] = syn.band_values(s, 5000 + b, stress="ladder")
+    hopeless = 3 if B > 3 else None
+    if hopeless is not None:
+        vals[hopeless, s.offsets()[0]] = -1e300
+    ro_h = np.zeros(B)
+    ro_h[0] = 1e-3
+    if B > 4:
+        ro_h[4] = 0.3
+    LA, LB = _il_handles(hipldl, s, B)
+    dev = torch.device("cuda", 0)
+    p_ = hipldl.default_params()
+    tr = torch.from_numpy(rhs).to(dev)
+    out = {}
+    for name, L in (("pm", LA), ("il", LB)):
+        tv = torch.from_numpy(vals).to(dev)
+        if name == "il":
+            assert hipldl.layout_len(L, 0) == hipldl.il_len(B, s.nnzNS) and hipldl.layout_len(L, 1) == hipldl.il_len(B, s.N)
+            tvi = torch.full((hipldl.layout_len(L, 0),), 9.0, dtype=torch.float64, device=dev)
+            hipldl.interleave_dev(L, 0, tv.data_ptr(), tvi.data_ptr(), 0)
+            tin = tvi
+        else:
+            tin = tv
+        su = torch.zeros(B, dtype=torch.int32, device=dev)
+        td2 = torch.full((B, s.N), 7.0, dtype=torch.float64, device=dev)
+        hipldl._check(hipldl.lib().cnl_factorize_dev(L._h, tin.data_ptr(), float(p_[0]), su.data_ptr(), 0))
+        hipldl._check(hipldl.lib().cnl_solve_dev(L._h, tr.data_ptr(), td2.data_ptr(), 0))
+        td = torch.full((B, s.N), 3.0, dtype=torch.float64, device=dev)
+        ro, rho = torch.from_numpy(ro_h).to(dev), torch.zeros(B, dtype=torch.float64, device=dev)
+        nf, ok = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+        hipldl.newton_system_dev(L, tin.data_ptr(), tr.data_ptr(), td.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), ok.data_ptr(), p_, 0)
+        if name == "il":
+            hipldl.deinterleave_dev(L, 0, tvi.data_ptr(), tv.data_ptr(), 0)
+        torch.cuda.synchronize()
+        out[name] = [x.cpu().numpy() for x in (su, td2, td, ro, rho, nf, ok, tv)]
+        L.close()
+    for a, b in zip(out["pm"], out["il"]):
+        assert np.array_equal(a, b)
+    su, d_two, d, ro_o, rho, nf, ok, v_after = out["il"]
+    if hopeless is not None:
+        assert ok[hopeless] == 0 and np.all(d[hopeless] == 3.0)
+    assert all(nf[b] > 1 for b in climbers)
+    # ... and against the oracle (decisions, the rho slots, d) on a sample that holds every special problem
+    rows, cols = s.kkt_pattern()
+    orc = O.Oracle(s.N, rows, cols, O.canonical_perm(s.nvar, s.nequ, s.ncon))
+    sample = sorted(set([0, B - 1, B // 2] + climbers + ([hopeless] if hopeless is not None else []) + [b for b in (4, 31, 32, 63) if b < B]))
+    for b in sample:
+        v0 = vals[b].copy()
+        d0, ok0, rho0, ro0, nf0 = O.newton_system(orc, s.nvar, s.nequ, s.ncon, rhs[b], v0, float(ro_h[b]), O.default_params())
+        assert bool(ok[b]) == bool(ok0) and nf[b] == nf0 and rho[b] == rho0 and ro_o[b] == ro0
+        assert np.array_equal(v_after[b, -s.nvar:], v0[-s.nvar:])
+        if ok0:
+            assert np.abs(d[b] - d0).max() <= FWD_TOL * np.abs(d0).max()
+
+
+@pytest.mark.parametrize("B", [1, 33, 96])
+def test_interleave_conversions_and_index(built, B):
+    """cnl_interleave_dev / cnl_deinterleave_dev against the index function of the header (hipldl.il_index): every element where the
+    formula puts it, pads zero, round trip exact; vals (which = 0) and N-vectors (which = 1)"""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(150, 3)
+    rows, cols = s.kkt_pattern()
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=_band_opts(hipldl, batch_layout=1))
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(B)
+    for which, length in ((0, s.nnzNS), (1, s.N)):
+        a = rng.standard_normal((B, length))
+        ta = torch.from_numpy(a).to(dev)
+        n = hipldl.layout_len(L, which)
+        ti = torch.full((n,), np.nan, dtype=torch.float64, device=dev)
+        hipldl.interleave_dev(L, which, ta.data_ptr(), ti.data_ptr(), 0)
+        tb = torch.zeros_like(ta)
+        hipldl.deinterleave_dev(L, which, ti.data_ptr(), tb.data_ptr(), 0)
+        torch.cuda.synchronize()
+        got = ti.cpu().numpy()
+        want = np.zeros(n)
+        pp, ee = np.meshgrid(np.arange(B), np.arange(length), indexing="ij")
+        want[hipldl.il_index(pp, ee, length)] = a
+        assert np.array_equal(got, want)
+        assert np.array_equal(tb.cpu().numpy(), a)
+    with pytest.raises(hipldl.CnlError):
+        hipldl.layout_len(L, 2)
+    L.close()
+
+
+@pytest.mark.parametrize("gn", [False, True])
+def test_prepare_newton_system_dev_interleaved(built, gn):
+    """row f2 writing `vals` interleaved: bit-equal to the problem-major prepare (which the oracle checks above) after cnl_deinterleave_dev,
+    including what prepare_newton_system! leaves alone (the -I segment, H_F of the Gauss-Newton variants) and the pads"""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(400, 4)
+    B = 37
+    LA, LB = _il_handles(hipldl, s, B)
+    rng = np.random.default_rng(3)
+    nhF, nhc, njF, njc = len(s.hF[0]), len(s.hc[0]), s.nnzjF, s.nnzjc
+    hF, hc = rng.standard_normal((B, nhF)), rng.standard_normal((B, nhc))
+    hc[:, 0] = 0.0  # -> -0.0
+    Jx, Jcx, delta = rng.standard_normal((B, njF)), rng.standard_normal((B, njc)), rng.uniform(0.01, 1.0, B)
+    vals0 = rng.standard_normal((B, s.nnzNS))
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    thF, thc, tJx, tJc, tde = t(hF), t(hc), t(Jx), t(Jcx), t(delta)
+    tva = t(vals0)
+    hipldl.prepare_newton_system_dev(LA, nhF, nhc, njF, njc, 0 if gn else thF.data_ptr(), thc.data_ptr(), tJx.data_ptr(), tJc.data_ptr(),
+                                     tde.data_ptr(), tva.data_ptr(), 0)
+    tvi = torch.full((hipldl.layout_len(LB, 0),), 5.0, dtype=torch.float64, device=dev)
+    hipldl.interleave_dev(LB, 0, t(vals0).data_ptr(), tvi.data_ptr(), 0)
+    before = tvi.clone()
+    hipldl.prepare_newton_system_dev(LB, nhF, nhc, njF, njc, 0 if gn else thF.data_ptr(), thc.data_ptr(), tJx.data_ptr(), tJc.data_ptr(),
+                                     tde.data_ptr(), tvi.data_ptr(), 0)
+    tvb = torch.zeros_like(tva)
+    hipldl.deinterleave_dev(LB, 0, tvi.data_ptr(), tvb.data_ptr(), 0)
+    torch.cuda.synchronize()
+    a, b = tva.cpu().numpy(), tvb.cpu().numpy()
+    assert np.array_equal(a, b) and np.array_equal(np.signbit(a), np.signbit(b))
+    # nothing outside the problems' elements was touched (pads, the spare blocks, the rows of the last group beyond the batch)
+    mask = np.ones(tvi.numel(), bool)
+    pp, ee = np.meshgrid(np.arange(B), np.arange(s.nnzNS), indexing="ij")
+    mask[hipldl.il_index(pp, ee, s.nnzNS)] = False
+    assert np.array_equal(tvi.cpu().numpy()[mask], before.cpu().numpy()[mask])
+    LA.close()
+    LB.close()
+
+
+def test_interleaved_layout_is_refused_where_it_is_not_served(built):
+    """CNL_LAYOUT_INTERLEAVED is the band kernels': cnl_create refuses other handles; on such a handle the host-pointer entry points and the
+    rows that read problem-major vals (f1, f4) fail loudly instead of misreading the array"""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.random_structure(30, 40, 3, 0.2, 1)
+    rows, cols = s.kkt_pattern()
+    with pytest.raises(hipldl.CnlError):
+        hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=64, options=hipldl.Options(batch_layout=1))
+    s = syn.band_structure(200, 4)
+    rows, cols = s.kkt_pattern()
+    with pytest.raises(hipldl.CnlError):
+        hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=64, options=_band_opts(hipldl, batch_layout=1, band_problems_per_group=16))
+    with pytest.raises(hipldl.CnlError):
+        hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=64, options=_band_opts(hipldl, batch_layout=2))
+    B = 6
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=_band_opts(hipldl, batch_layout=1))
+    vals, rhs = syn.batch_values(s, B, cfg=4)
+    with pytest.raises(hipldl.CnlError):
+        hipldl.newton_system_(np.zeros((B, s.N)), s.nvar, s.nequ, s.ncon, rhs, vals.copy(), L, np.zeros(B), hipldl.default_params())
+    with pytest.raises(hipldl.CnlError):
+        hipldl.try_to_factorize(L, vals, s.nvar, s.nequ, s.ncon, 1e-10)
+    dev = torch.device("cuda", 0)
+    z = torch.zeros(B * max(s.nnzNS, s.N), dtype=torch.float64, device=dev)
+    with pytest.raises(hipldl.CnlError):
+        hipldl._check(hipldl.lib().cnl_residual_vectors_dev(L._h, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0))
+    L.close()

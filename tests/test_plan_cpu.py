@@ -275,3 +275,19 @@ def test_analysis_does_not_depend_on_its_host_threads(built):
         assert a.info == b.info == c.info
         for name in ("perm", "rec", "brec", "tasks"):
             assert np.array_equal(a.array(name), b.array(name)) and np.array_equal(a.array(name), c.array(name)), (batch, name)
+
+
+def test_interleaved_layout_index_function():
+    """CNL_LAYOUT_INTERLEAVED (include/cannoles_hip.h): the host mirror of the index function is a bijection of (problem, element) into
+    the array cnl_layout_len sizes, keeps the eight doubles of a block together and the 32 problems of a group 64 bytes apart"""
+    from cannoles_jl_amd import hipldl
+    for B, n in ((1, 5), (33, 64), (70, 1001)):
+        pp, ee = np.meshgrid(np.arange(B), np.arange(n), indexing="ij")
+        idx = hipldl.il_index(pp, ee, n)
+        assert idx.min() == 0 and idx.max() < hipldl.il_len(B, n) and np.unique(idx).size == B * n
+        assert hipldl.il_len(B, n) == (B + 31) // 32 * ((n + 7) // 8 + 1) * 256
+        assert np.all(idx[:, 1:8] - idx[:, 0:7] == 1)
+        if B > 1:
+            assert np.all(idx[1:min(B, 32), 0] - idx[0:min(B, 32) - 1, 0] == 8)
+        if n > 8:
+            assert idx[0, 8] - idx[0, 0] == 256

@@ -19,7 +19,10 @@ par = hipldl.default_params()
 dev = torch.device("cuda", 0)
 variants = {"front": dict(band_kernel=0), "band8": dict(band_kernel=1, band_problems_per_group=8), "band16": dict(band_kernel=1, band_problems_per_group=16),
             "band32": dict(band_kernel=1, band_problems_per_group=32), "bandmw": dict(band_kernel=1, band_movers=1), "bandmw2": dict(band_kernel=1, band_movers=2),
-            "bandmw3": dict(band_kernel=1, band_movers=3)}
+            "bandmw3": dict(band_kernel=1, band_movers=3),
+            # cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED: vals interleaved over groups of 32 problems; il2: rhs as well (tuning key)
+            "band32il": dict(band_kernel=1, batch_layout=1), "band32il2": dict(band_kernel=1, batch_layout=1, band_rhs_interleaved=1),
+            "bandmw2il": dict(band_kernel=1, band_movers=2, batch_layout=1), "bandmw2il2": dict(band_kernel=1, band_movers=2, batch_layout=1, band_rhs_interleaved=1)}
 if os.environ.get("BAND_VARIANTS"):
     variants = {k: v for k, v in variants.items() if k in os.environ["BAND_VARIANTS"].split(",")}
 for B in [int(a) for a in sys.argv[1:]] or [8192]:
@@ -39,8 +42,17 @@ for B in [int(a) for a in sys.argv[1:]] or [8192]:
         L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, **opt))
         d.zero_()
 
+        vin, rin = vals, rhs
+        if L.config.get("batch_layout"):
+            vin = torch.empty(hipldl.layout_len(L, 0), dtype=torch.float64, device=dev)
+            hipldl.interleave_dev(L, 0, vals.data_ptr(), vin.data_ptr(), 0)
+            if L.config.get("rhs_interleaved"):
+                rin = torch.empty(hipldl.layout_len(L, 1), dtype=torch.float64, device=dev)
+                hipldl.interleave_dev(L, 1, rhs.data_ptr(), rin.data_ptr(), 0)
+            torch.cuda.synchronize()
+
         def step():
-            hipldl.newton_system_dev(L, vals.data_ptr(), rhs.data_ptr(), d.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), su.data_ptr(), par, st.cuda_stream)
+            hipldl.newton_system_dev(L, vin.data_ptr(), rin.data_ptr(), d.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), su.data_ptr(), par, st.cuda_stream)
         with torch.cuda.stream(st):
             for _ in range(3):
                 step()
