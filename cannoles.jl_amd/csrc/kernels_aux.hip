@@ -674,18 +674,18 @@ __global__ void __launch_bounds__(256) prepare_kernel(int nnzhF, int nnzhc, int 
   double* v = vals + b * nnz;
   double x[PREP_UNROLL];
   bool st[PREP_UNROLL];
+  // one predicated load per slot — source, validity and sign are SELECTED (round 6: loads inside the branches of an if-chain were
+  // waited for one by one)
 #pragma unroll
   for (int j = 0; j < PREP_UNROLL; j++) {
     const int k = chunk * (256 * PREP_UNROLL) + j * 256 + threadIdx.x;
-    x[j] = 0.0; st[j] = false;
-    if (k >= nnz) continue;
-    if (k < o1) { if (hF) { x[j] = __builtin_nontemporal_load(hF + b * nnzhF + k); st[j] = true; } }
-    else if (k < o2) { if (ncon > 0) { x[j] = -__builtin_nontemporal_load(hc + b * nnzhc + (k - o1)); st[j] = true; } }
-    else if (k < o3) { x[j] = __builtin_nontemporal_load(Jx + b * nnzjF + (k - o2)); st[j] = true; }
-    else if (k < o4) { if (ncon > 0) { x[j] = __builtin_nontemporal_load(Jcx + b * nnzjc + (k - o3)); st[j] = true; } }
-    else if (k < o5) {}
-    else if (k < o6) { x[j] = -delta[b]; st[j] = true; }   // (under the branch: delta may be null when ncon == 0)
-    else { x[j] = 0.0; st[j] = true; }
+    const int seg = k < o1 ? 0 : k < o2 ? 1 : k < o3 ? 2 : k < o4 ? 3 : k < o5 ? 4 : k < o6 ? 5 : 6;
+    const double* sp = seg == 0 ? hF + b * nnzhF + k : seg == 1 ? hc + b * nnzhc + (k - o1) : seg == 2 ? Jx + b * nnzjF + (k - o2)
+                     : seg == 3 ? Jcx + b * nnzjc + (k - o3) : delta + b;
+    const bool rd = k < nnz && (seg == 0 ? hF != nullptr : seg == 1 || seg == 3 ? ncon > 0 : seg == 2 || seg == 5);
+    const double y = rd ? __builtin_nontemporal_load(sp) : 0.0;
+    x[j] = (seg == 1 || seg == 5) ? -y : y;
+    st[j] = rd || (seg == 6 && k < nnz);   // (rho I <- 0; -I and the segments without a source are left alone)
   }
 #pragma unroll
   for (int j = 0; j < PREP_UNROLL; j++) {
