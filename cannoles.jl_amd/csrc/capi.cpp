@@ -126,6 +126,8 @@ struct cnl_handle {
   bool band = false;
   cnl::BandDev bd{};
   int band_nl = 16;            // problems per workgroup
+  bool jac_segments = false;   // the J_F and the J_c entries are one run of slots each: [jf_lo, jf_lo + jf_n), [jc_lo, jc_lo + jc_n)
+  int64_t jf_lo = 0, jf_n = 0, jc_lo = 0, jc_n = 0;
   int layout = 0;              // band handles: bit 0 = vals (cnl_options.batch_layout), bit 1 = rhs interleaved over groups of 32 problems (band.h)
   int band_mw = 0;             // EXPERIMENT builds: the kernel with loader wavefronts serves the handle (band.hip, band_newton_mw_kernel)
   double* d_Lband = nullptr;   // [batch][bd.lsize] factor records of the band kernels
@@ -1415,6 +1417,18 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     }
     cnl::DevJt& J = h->djt;
     if ((rc = upload(h, ptrF, &J.ptrF))) return bail(rc);
+    // the J_F / J_c entries as segments of `vals` (the reference's 7-segment layout, src/CaNNOLeS.jl:256-315): rows f1 / f4 can
+    // read them from the model's arrays instead (cnl_residual_vectors_jac_dev) when each kind occupies one run of slots
+    {
+      auto run = [](const std::vector<int32_t>& sl, int64_t& lo) {
+        if (sl.empty()) { lo = 0; return true; }
+        const auto mm = std::minmax_element(sl.begin(), sl.end());
+        lo = *mm.first;
+        return (int64_t)*mm.second - *mm.first + 1 == (int64_t)sl.size();
+      };
+      h->jac_segments = run(slotF, h->jf_lo) && run(slotC, h->jc_lo);
+      h->jf_n = (int64_t)slotF.size(); h->jc_n = (int64_t)slotC.size();
+    }
     if ((rc = upload(h, slotF, &J.slotF))) return bail(rc);
     if ((rc = upload(h, idxF, &J.idxF))) return bail(rc);
     if ((rc = upload(h, ptrC, &J.ptrC))) return bail(rc);
@@ -1551,12 +1565,10 @@ int cnl_prepare_newton_system_dev(cnl_handle* h, int64_t nnzhF, int64_t nnzhc, i
   return CNL_OK;
 }
 
-int cnl_cgls_multipliers_dev(cnl_handle* h, const double* d_vals, const double* d_r, double* d_lambda, double* d_Jxtr, double atol,
-                             double rtol, int64_t itmax, int ones_if_zero, int32_t* d_iters, void* stream) {
-  if (!h || !d_vals || !d_r) return fail(CNL_ERR_ARG, "null argument");
+static int cgls_impl(cnl_handle* h, const cnl::JacSrc& S, const double* d_r, double* d_lambda, double* d_Jxtr, double atol,
+                     double rtol, int64_t itmax, int ones_if_zero, int32_t* d_iters, void* stream) {
   if (h->djt.ncon == 0) return CNL_OK;  // nothing to estimate
   if (!d_lambda) return fail(CNL_ERR_ARG, "null lambda");
-  if (h->layout & 1) return fail(CNL_ERR_STATE, "cnl_cgls_multipliers_dev reads problem-major vals (handle with batch_layout = CNL_LAYOUT_INTERLEAVED)");
   if (h->djt.ncon > 1024) return fail(CNL_ERR_DIM, "cnl_cgls_multipliers_dev supports at most 1024 constraints");
   HIPCHK(hipSetDevice(h->device));
   if (!h->d_cgls_ws) {
@@ -1564,21 +1576,63 @@ int cnl_cgls_multipliers_dev(cnl_handle* h, const double* d_vals, const double* 
     if (rc) return rc;
   }
   if (itmax <= 0) itmax = (int64_t)h->djt.nvar + h->djt.ncon;  // Krylov.jl's default: m + n
-  hipError_t e = cnl::launch_cgls(h->djt, d_vals, d_r, d_lambda, d_Jxtr, h->d_cgls_ws, d_iters, atol, rtol, (int)itmax, ones_if_zero,
+  hipError_t e = cnl::launch_cgls(h->djt, S, d_r, d_lambda, d_Jxtr, h->d_cgls_ws, d_iters, atol, rtol, (int)itmax, ones_if_zero,
                                   (int)h->batch, (hipStream_t)stream);
   if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("cgls: ") + hipGetErrorString(e));
   return CNL_OK;
 }
 
-int cnl_residual_vectors_dev(cnl_handle* h, const double* d_vals, const double* d_r, const double* d_lambda, const double* d_Fx,
-                             const double* d_cx, double* d_rhs, double* d_norms, void* stream) {
-  if (!h || !d_vals || !d_r || !d_Fx || !d_rhs || !d_norms) return fail(CNL_ERR_ARG, "null argument");
+int cnl_cgls_multipliers_dev(cnl_handle* h, const double* d_vals, const double* d_r, double* d_lambda, double* d_Jxtr, double atol,
+                             double rtol, int64_t itmax, int ones_if_zero, int32_t* d_iters, void* stream) {
+  if (!h || !d_vals || !d_r) return fail(CNL_ERR_ARG, "null argument");
+  if (h->layout & 1) return fail(CNL_ERR_STATE, "cnl_cgls_multipliers_dev reads problem-major vals: on a handle with batch_layout = CNL_LAYOUT_INTERLEAVED use cnl_cgls_multipliers_jac_dev");
+  return cgls_impl(h, cnl::JacSrc{d_vals, h->djt.nnz, d_vals, h->djt.nnz, 0, 0}, d_r, d_lambda, d_Jxtr, atol, rtol, itmax, ones_if_zero, d_iters, stream);
+}
+
+// the Jacobian values from the model's arrays (problem-major [batch][nnz(J_F)], [batch][nnz(J_c)]: what cnl_prepare_newton_system_dev takes)
+static int jac_source(cnl_handle* h, int64_t nnzjF, int64_t nnzjc, const double* d_Jx, const double* d_Jcx, cnl::JacSrc* S) {
+  if (!h->jac_segments) return fail(CNL_ERR_STATE, "the J_F / J_c entries of this pattern are not one run of slots each (7-segment layout of src/CaNNOLeS.jl:256-315)");
+  if (nnzjF != h->jf_n || nnzjc != h->jc_n) return fail(CNL_ERR_DIM, "nnzjF / nnzjc do not match the pattern's Jacobian entries");
+  if (h->jf_n == 0) return fail(CNL_ERR_STATE, "the pattern has no J_F entries");
+  if (!d_Jx || (h->jc_n > 0 && !d_Jcx)) return fail(CNL_ERR_ARG, "null Jacobian values");
+  // (no J_c entries: the J_c source aliases the J_F one, nothing is read through it but the gather kernel's loads of absent entries)
+  if (h->jc_n > 0) *S = cnl::JacSrc{d_Jx - h->jf_lo, h->jf_n, d_Jcx - h->jc_lo, h->jc_n, (int)h->jf_lo, (int)h->jc_lo};
+  else *S = cnl::JacSrc{d_Jx - h->jf_lo, h->jf_n, d_Jx - h->jf_lo, h->jf_n, (int)h->jf_lo, (int)h->jf_lo};
+  return CNL_OK;
+}
+
+int cnl_cgls_multipliers_jac_dev(cnl_handle* h, int64_t nnzjF, int64_t nnzjc, const double* d_Jx, const double* d_Jcx, const double* d_r,
+                                 double* d_lambda, double* d_Jxtr, double atol, double rtol, int64_t itmax, int ones_if_zero, int32_t* d_iters,
+                                 void* stream) {
+  if (!h || !d_r) return fail(CNL_ERR_ARG, "null argument");
+  cnl::JacSrc S{};
+  if (int rc = jac_source(h, nnzjF, nnzjc, d_Jx, d_Jcx, &S)) return rc;
+  return cgls_impl(h, S, d_r, d_lambda, d_Jxtr, atol, rtol, itmax, ones_if_zero, d_iters, stream);
+}
+
+static int residual_vectors_impl(cnl_handle* h, const cnl::JacSrc& S, const double* d_r, const double* d_lambda, const double* d_Fx,
+                                 const double* d_cx, double* d_rhs, double* d_norms, void* stream) {
+  if (!d_r || !d_Fx || !d_rhs || !d_norms) return fail(CNL_ERR_ARG, "null argument");
   if (h->djt.ncon > 0 && (!d_lambda || !d_cx)) return fail(CNL_ERR_ARG, "lambda / c are required when ncon > 0");
-  if (h->layout & 1) return fail(CNL_ERR_STATE, "cnl_residual_vectors_dev reads problem-major vals (handle with batch_layout = CNL_LAYOUT_INTERLEAVED)");
   HIPCHK(hipSetDevice(h->device));
-  hipError_t e = cnl::launch_residual_vectors(h->djt, d_vals, d_r, d_lambda, d_Fx, d_cx, d_rhs, d_norms, (int)h->batch, (hipStream_t)stream);
+  hipError_t e = cnl::launch_residual_vectors(h->djt, S, d_r, d_lambda, d_Fx, d_cx, d_rhs, d_norms, (int)h->batch, (hipStream_t)stream);
   if (e != hipSuccess) return fail(CNL_ERR_HIP, std::string("residual_vectors: ") + hipGetErrorString(e));
   return CNL_OK;
+}
+
+int cnl_residual_vectors_dev(cnl_handle* h, const double* d_vals, const double* d_r, const double* d_lambda, const double* d_Fx,
+                             const double* d_cx, double* d_rhs, double* d_norms, void* stream) {
+  if (!h || !d_vals) return fail(CNL_ERR_ARG, "null argument");
+  if (h->layout & 1) return fail(CNL_ERR_STATE, "cnl_residual_vectors_dev reads problem-major vals: on a handle with batch_layout = CNL_LAYOUT_INTERLEAVED use cnl_residual_vectors_jac_dev");
+  return residual_vectors_impl(h, cnl::JacSrc{d_vals, h->djt.nnz, d_vals, h->djt.nnz, 0, 0}, d_r, d_lambda, d_Fx, d_cx, d_rhs, d_norms, stream);
+}
+
+int cnl_residual_vectors_jac_dev(cnl_handle* h, int64_t nnzjF, int64_t nnzjc, const double* d_Jx, const double* d_Jcx, const double* d_r,
+                                 const double* d_lambda, const double* d_Fx, const double* d_cx, double* d_rhs, double* d_norms, void* stream) {
+  if (!h) return fail(CNL_ERR_ARG, "null argument");
+  cnl::JacSrc S{};
+  if (int rc = jac_source(h, nnzjF, nnzjc, d_Jx, d_Jcx, &S)) return rc;
+  return residual_vectors_impl(h, S, d_r, d_lambda, d_Fx, d_cx, d_rhs, d_norms, stream);
 }
 
 int cnl_trial_point_dev(cnl_handle* h, const double* d_x, const double* d_r, const double* d_lambda, const double* d_d,

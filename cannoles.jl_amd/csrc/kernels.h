@@ -78,6 +78,14 @@ struct DevJt {
   const uint32_t* rv_table;   // [rv_ntiles][RVT_KF + RVT_KC + 1][RVT_COLS]: window offsets of a column's first entries, counts
   int32_t rv_ntiles, rv_lds_doubles, rv_primal_tiles;
 };
+// where rows f1 / f4 read the Jacobian values: value of slot k (a position in `vals`) of problem b = vF[b * sF + k] for the J_F
+// entries, vC[b * sC + k] for the J_c entries.  From `vals` itself: {vals, nnz, vals, nnz}; from the model's arrays Jx / Jcx (what
+// prepare_newton_system! copies into those segments, src/CaNNOLeS.jl:968-974): {Jx - first J_F slot, nnz(J_F), Jcx - first J_c slot, nnz(J_c)}
+struct JacSrc {
+  const double* vF; long long sF;
+  const double* vC; long long sC;
+  int safeF, safeC;   // a slot of each kind that exists in every problem (the gather kernel's loads of absent entries; vC is never null)
+};
 constexpr int RVT_COLS = 256;   // columns per tile: one per thread of a 256-thread workgroup (two per thread: 190 registers)
 constexpr int RVT_KF = 6, RVT_KC = 2;   // entries of a column held in the table (the rest of a longer column: index lists)
 constexpr int RVT_MAXF = 2046, RVT_MAXR = 510, RVT_MAXC = 510, RVT_MAXL = 510;   // window limits (doubles): 4 + 1 + 1 + 1 chunks of 16 bytes per thread
@@ -186,9 +194,9 @@ hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, 
                           const double* Jx, const double* Jcx, const double* delta, double* vals, int batch, int interleaved, hipStream_t stream);
 // problem-major <-> interleaved over groups of 32 problems (band.h: band_il_index); rows of `len` doubles
 hipError_t launch_interleave(const double* src, double* dst, int batch, long long len, int to_interleaved, hipStream_t stream);
-hipError_t launch_cgls(const DevJt& J, const double* vals, const double* r, double* lambda, double* Jxtr, double* ws, int32_t* iters,
+hipError_t launch_cgls(const DevJt& J, const JacSrc& S, const double* r, double* lambda, double* Jxtr, double* ws, int32_t* iters,
                        double atol, double rtol, int itmax, int ones_if_zero, int batch, hipStream_t stream);
-hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const double* r, const double* lambda, const double* Fx,
+hipError_t launch_residual_vectors(const DevJt& J, const JacSrc& S, const double* r, const double* lambda, const double* Fx,
                                    const double* cx, double* rhs, double* norms, int batch, hipStream_t stream);
 hipError_t launch_trial_point(const DevJt& J, const double* x, const double* r, const double* lambda, const double* d,
                               double max_dlambda, double* xt, double* rt, double* lambdat, double* dlambda, int batch,

@@ -312,7 +312,7 @@ constexpr int RPT = 4;
 // the kernel spent its time on (2.4 ms at 8192 systems of cfg3's size, 0.34 of the HBM rate; a workgroup walking several groups of
 // problems, or the slots staged through LDS, changed nothing).  The sum itself stays sequential in COO order.
 constexpr int RV_KF = 6, RV_KC = 2;
-__global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, const double* __restrict__ vals,
+__global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, const JacSrc S,
                                                                const double* __restrict__ r, const double* __restrict__ lambda,
                                                                const double* __restrict__ Fx, const double* __restrict__ cx,
                                                                double* __restrict__ rhs, double* __restrict__ norms, int batch) {
@@ -320,6 +320,7 @@ __global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, 
   DevJt J = Jin;
   J.ptrF = as_global(Jin.ptrF); J.slotF = as_global(Jin.slotF); J.idxF = as_global(Jin.idxF);
   J.ptrC = as_global(Jin.ptrC); J.slotC = as_global(Jin.slotC); J.idxC = as_global(Jin.idxC);
+  const double* __restrict__ vF = S.vF; const double* __restrict__ vC = S.vC;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int b0 = blockIdx.y * RPT;
   long long bq[RPT];
@@ -336,16 +337,16 @@ __global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, 
       for (int q = 0; q < RPT; q++) s1[q] = s2[q] = 0.0;
       const int kf0 = J.ptrF[i], kf1 = J.ptrF[i + 1], kc0 = J.ptrC[i], kc1 = J.ptrC[i + 1];
       {
-        // the first RV_KF entries: indices, then all operands, in flight together (entries past the end read slot / index 0 and
-        // are not added)
+        // the first RV_KF entries: indices, then all operands, in flight together (entries past the end read a slot that exists —
+        // JacSrc::safeF / safeC — and index 0, and are not added)
         int sl[RV_KF], ix[RV_KF];
 #pragma unroll
-        for (int u = 0; u < RV_KF; u++) { const bool on = kf0 + u < kf1; sl[u] = on ? J.slotF[kf0 + u] : 0; ix[u] = on ? J.idxF[kf0 + u] : 0; }
+        for (int u = 0; u < RV_KF; u++) { const bool on = kf0 + u < kf1; sl[u] = on ? J.slotF[kf0 + u] : S.safeF; ix[u] = on ? J.idxF[kf0 + u] : 0; }
         double jv[RV_KF][RPT], xv[RV_KF][RPT];
 #pragma unroll
         for (int u = 0; u < RV_KF; u++)
 #pragma unroll
-          for (int q = 0; q < RPT; q++) { jv[u][q] = vals[bq[q] * J.nnz + sl[u]]; xv[u][q] = r[bq[q] * J.nequ + ix[u]]; }
+          for (int q = 0; q < RPT; q++) { jv[u][q] = vF[bq[q] * S.sF + sl[u]]; xv[u][q] = r[bq[q] * J.nequ + ix[u]]; }
 #pragma unroll
         for (int u = 0; u < RV_KF; u++)
           if (kf0 + u < kf1) {
@@ -356,17 +357,17 @@ __global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, 
       for (int k = kf0 + RV_KF; k < kf1; k++) {
         const int sl = J.slotF[k], ix = J.idxF[k];
 #pragma unroll
-        for (int q = 0; q < RPT; q++) { const double t_ = vals[bq[q] * J.nnz + sl] * r[bq[q] * J.nequ + ix]; s1[q] = s1[q] + t_; }
+        for (int q = 0; q < RPT; q++) { const double t_ = vF[bq[q] * S.sF + sl] * r[bq[q] * J.nequ + ix]; s1[q] = s1[q] + t_; }
       }
       {
         int sl[RV_KC], ix[RV_KC];
 #pragma unroll
-        for (int u = 0; u < RV_KC; u++) { const bool on = kc0 + u < kc1; sl[u] = on ? J.slotC[kc0 + u] : 0; ix[u] = on ? J.idxC[kc0 + u] : 0; }
+        for (int u = 0; u < RV_KC; u++) { const bool on = kc0 + u < kc1; sl[u] = on ? J.slotC[kc0 + u] : S.safeC; ix[u] = on ? J.idxC[kc0 + u] : 0; }
         double jv[RV_KC][RPT], xv[RV_KC][RPT];
 #pragma unroll
         for (int u = 0; u < RV_KC; u++)
 #pragma unroll
-          for (int q = 0; q < RPT; q++) { jv[u][q] = vals[bq[q] * J.nnz + sl[u]]; xv[u][q] = kc0 + u < kc1 ? lambda[bq[q] * J.ncon + ix[u]] : 0.0; }
+          for (int q = 0; q < RPT; q++) { jv[u][q] = vC[bq[q] * S.sC + sl[u]]; xv[u][q] = kc0 + u < kc1 ? lambda[bq[q] * J.ncon + ix[u]] : 0.0; }
 #pragma unroll
         for (int u = 0; u < RV_KC; u++)
           if (kc0 + u < kc1) {
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(256) residual_vectors_kernel(const DevJt Jin, 
       for (int k = kc0 + RV_KC; k < kc1; k++) {
         const int sl = J.slotC[k], ix = J.idxC[k];
 #pragma unroll
-        for (int q = 0; q < RPT; q++) { const double t_ = vals[bq[q] * J.nnz + sl] * lambda[bq[q] * J.ncon + ix]; s2[q] = s2[q] + t_; }
+        for (int q = 0; q < RPT; q++) { const double t_ = vC[bq[q] * S.sC + sl] * lambda[bq[q] * J.ncon + ix]; s2[q] = s2[q] + t_; }
       }
 #pragma unroll
       for (int q = 0; q < RPT; q++) out[q] = s1[q] - s2[q];
@@ -454,7 +455,7 @@ __device__ __forceinline__ int rvt_par(const double* g) { return (int)((reinterp
 __device__ __forceinline__ int rvt_even(int w) { return (w + 3) & ~1; }
 constexpr int RVT_NFX = (RVT_MAXR + 255) / 256;   // primal rows of a tile per thread
 
-__global__ void __launch_bounds__(256) residual_vectors_tiled_kernel(const DevJt Jin, const double* __restrict__ vals,
+__global__ void __launch_bounds__(256) residual_vectors_tiled_kernel(const DevJt Jin, const JacSrc S,
                                                                      const double* __restrict__ r, const double* __restrict__ lambda,
                                                                      const double* __restrict__ Fx, const double* __restrict__ cx,
                                                                      double* __restrict__ rhs, double* __restrict__ norms, int batch, int pb) {
@@ -509,10 +510,10 @@ __global__ void __launch_bounds__(256) residual_vectors_tiled_kernel(const DevJt
 #define RVT_ISSUE(B_)                                                                              \
   {                                                                                                \
     const long long b_ = (B_);                                                                     \
-    rvt_issue<4, NT>(vals + b_ * J.nnz + fslo, wF, t, pF);                                                \
+    rvt_issue<4, NT>(S.vF + b_ * S.sF + fslo, wF, t, pF);                                             \
     rvt_issue<1, NT>(r + b_ * J.nequ + rlo, wR, t, pR);                                                  \
     if (wC) {                                                                                      \
-      rvt_issue<1, NT>(vals + b_ * J.nnz + cslo, wC, t, pC);                                             \
+      rvt_issue<1, NT>(S.vC + b_ * S.sC + cslo, wC, t, pC);                                           \
       rvt_issue<1, NT>(lambda + b_ * J.ncon + llo, wL, t, pL);                                           \
     }                                                                                              \
     _Pragma("unroll") for (int k = 0; k < RVT_NFX; k++) {                                          \
@@ -522,8 +523,8 @@ __global__ void __launch_bounds__(256) residual_vectors_tiled_kernel(const DevJt
   }
   RVT_ISSUE(b_begin)
   for (int b = b_begin; b < b_end; b++) {
-    const int parF = rvt_par(vals + (long long)b * J.nnz + fslo), parR = rvt_par(r + (long long)b * J.nequ + rlo);
-    const int parC = wC ? rvt_par(vals + (long long)b * J.nnz + cslo) : 0, parL = wC ? rvt_par(lambda + (long long)b * J.ncon + llo) : 0;
+    const int parF = rvt_par(S.vF + (long long)b * S.sF + fslo), parR = rvt_par(r + (long long)b * J.nequ + rlo);
+    const int parC = wC ? rvt_par(S.vC + (long long)b * S.sC + cslo) : 0, parL = wC ? rvt_par(lambda + (long long)b * J.ncon + llo) : 0;
     rvt_commit(lds + oF, wF, parF, t, pF);
     rvt_commit(lds + oR, wR, parR, t, pR);
     if (wC) { rvt_commit(lds + oC, wC, parC, t, pC); rvt_commit(lds + oL, wL, parL, t, pL); }
@@ -551,7 +552,7 @@ __global__ void __launch_bounds__(256) residual_vectors_tiled_kernel(const DevJt
         if (u < nF) { const double t_ = jv[u] * xv[u]; s1 = s1 + t_; }
       if (nF > RVT_KF) {
         const int q0 = J.ptrF[col];
-        for (int k = RVT_KF; k < nF; k++) { const double t_ = vals[(long long)b * J.nnz + J.slotF[q0 + k]] * r[(long long)b * J.nequ + J.idxF[q0 + k]]; s1 = s1 + t_; }
+        for (int k = RVT_KF; k < nF; k++) { const double t_ = S.vF[(long long)b * S.sF + J.slotF[q0 + k]] * r[(long long)b * J.nequ + J.idxF[q0 + k]]; s1 = s1 + t_; }
       }
       if (wC) {
 #pragma unroll
@@ -559,7 +560,7 @@ __global__ void __launch_bounds__(256) residual_vectors_tiled_kernel(const DevJt
           if (u < nC) { const double t_ = cv[u] * lv[u]; s2 = s2 + t_; }
         if (nC > RVT_KC) {
           const int q0 = J.ptrC[col];
-          for (int k = RVT_KC; k < nC; k++) { const double t_ = vals[(long long)b * J.nnz + J.slotC[q0 + k]] * lambda[(long long)b * J.ncon + J.idxC[q0 + k]]; s2 = s2 + t_; }
+          for (int k = RVT_KC; k < nC; k++) { const double t_ = S.vC[(long long)b * S.sC + J.slotC[q0 + k]] * lambda[(long long)b * J.ncon + J.idxC[q0 + k]]; s2 = s2 + t_; }
         }
       }
       if (col < J.nvar) {
@@ -801,7 +802,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
 }
-__global__ void __launch_bounds__(256) cgls_kernel(const DevJt Jin, const double* __restrict__ vals, const double* __restrict__ r,
+__global__ void __launch_bounds__(256) cgls_kernel(const DevJt Jin, const JacSrc S, const double* __restrict__ r,
                                                    double* __restrict__ lambda, double* __restrict__ Jxtr, double* __restrict__ ws,
                                                    int* __restrict__ iters, double atol, double rtol, int itmax, int ones_if_zero) {
   DevJt J = Jin;
@@ -812,7 +813,8 @@ __global__ void __launch_bounds__(256) cgls_kernel(const DevJt Jin, const double
   __shared__ double red[4];
   const long long b = blockIdx.x;
   const int t = threadIdx.x, n = J.nvar, p = J.ncon;
-  const double* v = vals + b * J.nnz;
+  const double* __restrict__ vF = S.vF + b * S.sF;
+  const double* __restrict__ vC = S.vC + b * S.sC;
   const double* rb = r + b * J.nequ;
   double* res = ws + b * 2 * n;  // residual of the least-squares problem
   double* q = res + n;
@@ -821,7 +823,7 @@ __global__ void __launch_bounds__(256) cgls_kernel(const DevJt Jin, const double
 #pragma clang fp contract(off)  // separately rounded multiply and add, as the reference's scalar loop
     for (int j = t; j < n; j += 256) {
       double s1 = 0.0;
-      for (int k = J.ptrF[j]; k < J.ptrF[j + 1]; k++) { const double t_ = v[J.slotF[k]] * rb[J.idxF[k]]; s1 = s1 + t_; }
+      for (int k = J.ptrF[j]; k < J.ptrF[j + 1]; k++) { const double t_ = vF[J.slotF[k]] * rb[J.idxF[k]]; s1 = s1 + t_; }
       res[j] = s1;
       if (Jxtr) Jxtr[b * n + j] = s1;
     }
@@ -832,7 +834,7 @@ __global__ void __launch_bounds__(256) cgls_kernel(const DevJt Jin, const double
   auto at_res = [&]() {
     for (int k = t >> 6; k < p; k += 4) {
       double acc = 0.0;
-      for (int e = J.rptrC[k] + (t & 63); e < J.rptrC[k + 1]; e += 64) acc += v[J.rslotC[e]] * res[J.rcolC[e]];
+      for (int e = J.rptrC[k] + (t & 63); e < J.rptrC[k + 1]; e += 64) acc += vC[J.rslotC[e]] * res[J.rcolC[e]];
       for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if ((t & 63) == 0) sv[k] = acc;
     }
@@ -851,7 +853,7 @@ __global__ void __launch_bounds__(256) cgls_kernel(const DevJt Jin, const double
     part = 0.0;
     for (int j = t; j < n; j += 256) {
       double s2 = 0.0;
-      for (int k = J.ptrC[j]; k < J.ptrC[j + 1]; k++) s2 += v[J.slotC[k]] * pv[J.idxC[k]];
+      for (int k = J.ptrC[j]; k < J.ptrC[j + 1]; k++) s2 += vC[J.slotC[k]] * pv[J.idxC[k]];
       q[j] = s2;
       part += s2 * s2;
     }
@@ -879,10 +881,10 @@ __global__ void __launch_bounds__(256) cgls_kernel(const DevJt Jin, const double
   if (t == 0 && iters) iters[b] = it;
 }
 
-hipError_t launch_cgls(const DevJt& J, const double* vals, const double* r, double* lambda, double* Jxtr, double* ws, int32_t* iters,
+hipError_t launch_cgls(const DevJt& J, const JacSrc& S, const double* r, double* lambda, double* Jxtr, double* ws, int32_t* iters,
                        double atol, double rtol, int itmax, int ones_if_zero, int batch, hipStream_t stream) {
   if (J.ncon > CGLS_PMAX) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(cgls_kernel, dim3(batch), dim3(256), 0, stream, J, vals, r, lambda, Jxtr, ws, iters, atol, rtol, itmax, ones_if_zero);
+  hipLaunchKernelGGL(cgls_kernel, dim3(batch), dim3(256), 0, stream, J, S, r, lambda, Jxtr, ws, iters, atol, rtol, itmax, ones_if_zero);
   return hipGetLastError();
 }
 
@@ -906,7 +908,7 @@ hipError_t launch_prepare(int nnzhF, int nnzhc, int nnzjF, int nnzjc, int nvar, 
   return hipGetLastError();
 }
 
-hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const double* r, const double* lambda, const double* Fx,
+hipError_t launch_residual_vectors(const DevJt& J, const JacSrc& S, const double* r, const double* lambda, const double* Fx,
                                    const double* cx, double* rhs, double* norms, int batch, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(norms, 0, sizeof(double) * 2 * (size_t)batch, stream);
   if (e != hipSuccess) return e;
@@ -914,11 +916,11 @@ hipError_t launch_residual_vectors(const DevJt& J, const double* vals, const dou
   // ahead (measured at 8192 systems of cfg3's pattern: 1 -> 1.40 ms, 2 -> 1.30, 4 -> 1.27, 16 -> 1.32)
   const int pb = J.rv_ntiles > 0 ? (batch >= 512 ? 4 : batch >= 64 ? 2 : 1) : RPT;
   // the second grid dimension holds at most 65535 groups of problems: larger batches go in slices of that many groups, every
-  // per-problem pointer advanced to the slice's first problem (row strides: nnz, nequ, ncon, N, 2)
+  // per-problem pointer advanced to the slice's first problem (row strides: the Jacobian sources', nequ, ncon, N, 2)
   const long long slice = 65535LL * pb;
   for (long long b0 = 0; b0 < batch; b0 += slice) {
     const int nb = (int)std::min<long long>(slice, batch - b0);
-    const double* v_ = vals + b0 * J.nnz;
+    const JacSrc v_{S.vF + b0 * S.sF, S.sF, S.vC + b0 * S.sC, S.sC, S.safeF, S.safeC};
     const double* r_ = r + b0 * J.nequ;
     const double* l_ = lambda ? lambda + b0 * J.ncon : nullptr;
     const double* f_ = Fx + b0 * J.nequ;

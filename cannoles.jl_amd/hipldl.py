@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "cnl_multi_create", "cnl_multi_destroy", "cnl_multi_shards", "cnl_multi_factorize", "cnl_multi_solve", "cnl_multi_newton_system",
     "cnl_outer_begin_dev", "cnl_outer_newton_done_dev", "cnl_outer_extrapolated_dev", "cnl_outer_trial_done_dev", "cnl_outer_end_dev",
     "cnl_outer_ls_begin_dev", "cnl_outer_ls_test_dev", "cnl_outer_ls_step_dev", "cnl_outer_ls_take_dev",
-    "cnl_layout_len", "cnl_interleave_dev", "cnl_deinterleave_dev",
+    "cnl_layout_len", "cnl_interleave_dev", "cnl_deinterleave_dev", "cnl_residual_vectors_jac_dev", "cnl_cgls_multipliers_jac_dev",
 ]
 
 
@@ -220,6 +220,8 @@ def lib():
         L.cnl_get_config.argtypes = [vp, _i64p]
         L.cnl_launch_counts.argtypes = [_i64p]
         L.cnl_layout_len.argtypes = [vp, C.c_int, C.POINTER(i64)]
+        L.cnl_residual_vectors_jac_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cnl_cgls_multipliers_jac_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, dbl, dbl, i64, C.c_int, vp, vp]
         L.cnl_interleave_dev.argtypes = [vp, C.c_int, vp, vp, vp]
         L.cnl_deinterleave_dev.argtypes = [vp, C.c_int, vp, vp, vp]
         for fn in ("cnl_outer_begin_dev", "cnl_outer_extrapolated_dev", "cnl_outer_trial_done_dev", "cnl_outer_end_dev", "cnl_outer_ls_begin_dev",
@@ -463,6 +465,13 @@ def residual_vectors_dev(LDLT, vals_ptr, r_ptr, lambda_ptr, Fx_ptr, cx_ptr, rhs_
     _check(lib().cnl_residual_vectors_dev(LDLT._h, vals_ptr, r_ptr, lambda_ptr, Fx_ptr, cx_ptr, rhs_ptr, norms_ptr, stream))
 
 
+def residual_vectors_jac_dev(LDLT, nnzjF, nnzjc, Jx_ptr, Jcx_ptr, r_ptr, lambda_ptr, Fx_ptr, cx_ptr, rhs_ptr, norms_ptr, stream=0):
+    """residual_vectors_dev with the Jacobian values read from the model's arrays Jx [batch][nnzjF], Jcx [batch][nnzjc] instead of
+    from the J segments of vals (cnl_residual_vectors_jac_dev): no prepare pass in front, any batch_layout"""
+    _check(lib().cnl_residual_vectors_jac_dev(LDLT._h, int(nnzjF), int(nnzjc), Jx_ptr, Jcx_ptr, r_ptr, lambda_ptr, Fx_ptr, cx_ptr, rhs_ptr,
+                                              norms_ptr, stream))
+
+
 def trial_point_dev(LDLT, x_ptr, r_ptr, lambda_ptr, d_ptr, max_dlambda, xt_ptr, rt_ptr, lambdat_ptr, dlambda_ptr, stream=0):
     """xt = x + dx, rt = r + dr, dlambda = -d[n+m+1:N] capped at max_dlambda in the 2-norm, lambdat = lambda + dlambda
     (src/CaNNOLeS.jl:654,661-668), batched and device-resident (cnl_trial_point_dev)."""
@@ -503,6 +512,16 @@ def cgls_multipliers_dev(LDLT, vals_ptr, r_ptr, lambda_ptr, Jxtr_ptr=0, atol=Non
     rtol = np.sqrt(eps) if rtol is None else rtol
     _check(lib().cnl_cgls_multipliers_dev(LDLT._h, vals_ptr, r_ptr, lambda_ptr, Jxtr_ptr, float(atol), float(rtol), int(itmax),
                                           1 if ones_if_zero else 0, iters_ptr, stream))
+
+
+def cgls_multipliers_jac_dev(LDLT, nnzjF, nnzjc, Jx_ptr, Jcx_ptr, r_ptr, lambda_ptr, Jxtr_ptr=0, atol=None, rtol=None, itmax=0,
+                             ones_if_zero=True, iters_ptr=0, stream=0):
+    """cgls_multipliers_dev with the Jacobian values read from the model's arrays (cnl_cgls_multipliers_jac_dev)"""
+    eps = float(np.finfo(np.float64).eps)
+    atol = np.sqrt(eps) if atol is None else atol
+    rtol = np.sqrt(eps) if rtol is None else rtol
+    _check(lib().cnl_cgls_multipliers_jac_dev(LDLT._h, int(nnzjF), int(nnzjc), Jx_ptr, Jcx_ptr, r_ptr, lambda_ptr, Jxtr_ptr, float(atol),
+                                              float(rtol), int(itmax), 1 if ones_if_zero else 0, iters_ptr, stream))
 
 
 class MultiHIPLDLStruct:

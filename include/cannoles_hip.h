@@ -203,6 +203,17 @@ int cnl_newton_system_dev(cnl_handle* h, double* d_vals, const double* d_rhs, do
 int cnl_residual_vectors_dev(cnl_handle* h, const double* d_vals, const double* d_r, const double* d_lambda, const double* d_Fx,
                              const double* d_cx, double* d_rhs, double* d_norms, void* stream);
 
+/* The same two rows with the Jacobian values read from the MODEL's arrays Jx [batch][nnzjF], Jcx [batch][nnzjc] — what
+ * prepare_newton_system! copies into the J_F / J_c segments of vals, and what the reference's own products use (`mul!(Jxtr, Jx', r)`,
+ * src/CaNNOLeS.jl:507: the Jx operator is built on Jx_vals) — instead of from `vals`: no prepare pass is needed in front of them, and they
+ * serve handles of either batch_layout.  Results bit-identical to the `vals` variants (same kernels, another base pointer).  The pattern's
+ * J_F and J_c entries must be one run of COO slots each (the reference's 7-segment layout; CNL_ERR_STATE otherwise).               */
+int cnl_residual_vectors_jac_dev(cnl_handle* h, int64_t nnzjF, int64_t nnzjc, const double* d_Jx, const double* d_Jcx, const double* d_r,
+                                 const double* d_lambda, const double* d_Fx, const double* d_cx, double* d_rhs, double* d_norms, void* stream);
+int cnl_cgls_multipliers_jac_dev(cnl_handle* h, int64_t nnzjF, int64_t nnzjc, const double* d_Jx, const double* d_Jcx, const double* d_r,
+                                 double* d_lambda, double* d_Jxtr, double atol, double rtol, int64_t itmax, int ones_if_zero,
+                                 int32_t* d_iters, void* stream);
+
 /* cnl_prepare_newton_system_dev: prepare_newton_system!(meth, vals, nls, x, lambda, r, Jx_vals, Jcx_vals, delta, Fx) —
  * src/CaNNOLeS.jl:947-981 — for a batch whose model values already live on the device: the value
  * arrays are copied into the segments of `vals` ([H_F | H_c | J_F | J_c | -I | -delta I | rho I], sizes nnzhF, nnzhc,
@@ -215,7 +226,7 @@ int cnl_prepare_newton_system_dev(cnl_handle* h, int64_t nnzhF, int64_t nnzhc, i
 /* On a handle created with cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED, cnl_prepare_newton_system_dev WRITES d_vals interleaved
  * (the model's arrays stay problem-major), and cnl_factorize_dev / cnl_newton_system_dev read — the rho slots: write — d_vals in that
  * layout; d_rhs and d_d are problem-major.  cnl_residual_vectors_dev and cnl_cgls_multipliers_dev read problem-major vals only
- * (CNL_ERR_STATE on such a handle), the host-pointer entry points likewise.
+ * (CNL_ERR_STATE on such a handle: use their `_jac` twins above), the host-pointer entry points likewise.
  *   cnl_layout_len: doubles of the interleaved array for the handle's batch, which = 0: vals, 1: an N-vector per problem;
  *   cnl_interleave_dev / cnl_deinterleave_dev: problem-major -> interleaved / back (out of place; pads are written as zeros).     */
 int cnl_layout_len(const cnl_handle* h, int which, int64_t* doubles);

@@ -296,6 +296,18 @@ def test_f1_residual_vectors_bit_exact(built, kind, tiles):
         rhs0, (nd0, np0) = O.residual_vectors(rows, cols, vals[b], s.nvar, s.nequ, s.ncon, r[b], lam[b], Fx[b], cx[b])
         assert np.array_equal(rhs[b], rhs0, equal_nan=True)
         assert np.array_equal(nrm[b], np.array([nd0, np0]), equal_nan=True)
+    # the same row reading the Jacobian values from the model's arrays (cnl_residual_vectors_jac_dev): bit-equal
+    off = s.offsets()
+    tJ, tJc = t(vals[:, off[2]:off[3]]), t(vals[:, off[3]:off[4]])
+    trhs2 = torch.zeros((B, s.N), dtype=torch.float64, device=dev)
+    tn2 = torch.full((B, 2), -1.0, dtype=torch.float64, device=dev)
+    hipldl.residual_vectors_jac_dev(LDLT, s.nnzjF, s.nnzjc, tJ.data_ptr(), tJc.data_ptr() if s.ncon else 0, tr.data_ptr(), tl.data_ptr() if s.ncon else 0,
+                                    tF.data_ptr(), tc.data_ptr() if s.ncon else 0, trhs2.data_ptr(), tn2.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(trhs2.cpu().numpy(), rhs, equal_nan=True) and np.array_equal(tn2.cpu().numpy(), nrm, equal_nan=True)
+    with pytest.raises(hipldl.CnlError):
+        hipldl.residual_vectors_jac_dev(LDLT, s.nnzjF + 1, s.nnzjc, tJ.data_ptr(), tJc.data_ptr() if s.ncon else 0, tr.data_ptr(), tl.data_ptr() if s.ncon else 0,
+                                        tF.data_ptr(), tc.data_ptr() if s.ncon else 0, trhs2.data_ptr(), tn2.data_ptr(), 0)
     LDLT.close()
 
 
@@ -578,6 +590,13 @@ def test_f4_cgls_multipliers(built):
         assert its[b] == it0
         np.testing.assert_allclose(lam[b], lam0, rtol=1e-10, atol=1e-12)
     assert np.array_equal(lam[3], np.ones(s.ncon))
+    # the same row reading the Jacobian values from the model's arrays (cnl_cgls_multipliers_jac_dev): bit-equal
+    off = s.offsets()
+    tJ, tJc = tv[:, off[2]:off[3]].contiguous(), tv[:, off[3]:off[4]].contiguous()
+    tl2, tj2, ti2 = torch.zeros_like(tl), torch.zeros_like(tj), torch.zeros_like(ti)
+    hipldl.cgls_multipliers_jac_dev(LDLT, s.nnzjF, s.nnzjc, tJ.data_ptr(), tJc.data_ptr(), tr.data_ptr(), tl2.data_ptr(), tj2.data_ptr(), iters_ptr=ti2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(tl2, tl) and torch.equal(tj2, tj) and torch.equal(ti2, ti)
     LDLT.close()
 
 
@@ -2359,4 +2378,7 @@ def test_interleaved_layout_is_refused_where_it_is_not_served(built):
     z = torch.zeros(B * max(s.nnzNS, s.N), dtype=torch.float64, device=dev)
     with pytest.raises(hipldl.CnlError):
         hipldl._check(hipldl.lib().cnl_residual_vectors_dev(L._h, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0))
+    # ... while the twins that read the model's arrays serve it
+    hipldl.residual_vectors_jac_dev(L, s.nnzjF, s.nnzjc, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0)
+    torch.cuda.synchronize()
     L.close()
