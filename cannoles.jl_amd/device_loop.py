@@ -157,7 +157,7 @@ PROFILE = False   # tools/time_device_loop.py --profile: wall time per section o
 
 
 def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=None, rtol=None, Fatol=None, Frtol=None, delta_dec=0.1,
-                       device_index=0):
+                       device_index=0, layout="auto"):
     """All B problems of `fam` in lockstep on the device.  Returns a dict of numpy arrays: solution [B, n], multipliers,
     status (list of strings), iter, nfact, nlinsolve, nbk, objective, and `steps` (global steps = batched Newton rounds).
 
@@ -182,35 +182,52 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
     P = max(p, 1)
     rows, cols, (nnzhF, nnzhc, nnzjF, nnzjc) = kkt_pattern_of(fam)
     nnz = len(rows)
-    L = hipldl.HIPLDLStruct(N, rows, cols, None, n, m, p, batch=B, device=device_index)
+    # `vals` interleaved over groups of 32 problems where the band kernels serve the batch (cnl_options.batch_layout, round 6): row f2
+    # writes that layout, newton_system reads it; rows f1 / f4 read the Jacobian values from the model's arrays, whatever the layout
+    L = None
+    if layout in ("auto", "interleaved"):
+        try:
+            L = hipldl.HIPLDLStruct(N, rows, cols, None, n, m, p, batch=B, device=device_index, options=hipldl.Options(batch_layout=hipldl.LAYOUT_INTERLEAVED))
+        except hipldl.CnlError:
+            if layout == "interleaved":
+                raise
+    if L is None:
+        L = hipldl.HIPLDLStruct(N, rows, cols, None, n, m, p, batch=B, device=device_index)
     lib = hipldl.lib()
     f64 = dict(dtype=t.float64, device=dev)
     Z = lambda *sh: t.zeros(sh, **f64)
     ZI = lambda dt, *sh: t.zeros(sh, dtype=dt, device=dev)
     o_I = nnzhF + nnzhc + nnzjF + nnzjc
 
+    st = t.cuda.current_stream(dev).cuda_stream
+    ptr = lambda a: a.data_ptr()
+
     def new_vals():
         v = t.ones((B, nnz), **f64)
         v[:, o_I:o_I + m] = -1.0     # the -I block is set once (src/CaNNOLeS.jl:306); prepare never writes it
+        if L.config.get("batch_layout"):
+            vi = t.empty(hipldl.layout_len(L, 0), **f64)
+            hipldl.interleave_dev(L, 0, ptr(v), ptr(vi), st)
+            return vi
         return v
 
-    vals_cur, vals_t = new_vals(), new_vals()
+    vals_cur = new_vals()   # (ONE vals array: only newton_system reads it; the trial point's products read Jt)
     hc0 = Z(B, max(nnzhc, 1))
-    st = t.cuda.current_stream(dev).cuda_stream
-    ptr = lambda a: a.data_ptr()
 
     def prepare(vals, hF, Jv_, Jcv_, delta_):
         hipldl.prepare_newton_system_dev(L, nnzhF, nnzhc, nnzjF, nnzjc, ptr(hF) if hF is not None else 0, ptr(hc0) if p else 0, ptr(Jv_),
                                          ptr(Jcv_) if p else 0, ptr(delta_) if p else 0, ptr(vals), st)
 
-    def resid_vectors(vals, r_, lam_, F_, c_, rhs_out, nrm_out):
-        """[dual; primal] = [Jx'r - Jc'lam; F - r; c] and the two infinity norms, from the J segments of `vals` (in place)"""
-        hipldl.residual_vectors_dev(L, ptr(vals), ptr(r_), ptr(lam_) if p else 0, ptr(F_), ptr(c_) if p else 0, ptr(rhs_out), ptr(nrm_out), st)
+    def resid_vectors(Jv_, Jcv_, r_, lam_, F_, c_, rhs_out, nrm_out):
+        """[dual; primal] = [Jx'r - Jc'lam; F - r; c] and the two infinity norms; the Jacobian values come from the model's arrays
+        (cnl_residual_vectors_jac_dev: no prepare pass in front — round 6; rounds 2-5 copied them into `vals` first)"""
+        hipldl.residual_vectors_jac_dev(L, nnzjF, nnzjc, ptr(Jv_), ptr(Jcv_) if p else 0, ptr(r_), ptr(lam_) if p else 0, ptr(F_), ptr(c_) if p else 0,
+                                        ptr(rhs_out), ptr(nrm_out), st)
 
-    def multipliers(vals, r_, ones_if_zero):
+    def multipliers(Jv_, Jcv_, r_, ones_if_zero):
         lam_ = Z(B, P)
         if p:
-            hipldl.cgls_multipliers_dev(L, ptr(vals), ptr(r_), ptr(lam_), 0, None, None, 0, ones_if_zero, 0, st)
+            hipldl.cgls_multipliers_jac_dev(L, nnzjF, nnzjc, ptr(Jv_), ptr(Jcv_), ptr(r_), ptr(lam_), 0, None, None, 0, ones_if_zero, 0, st)
         return lam_
 
     W = lambda mask, a, b: t.where(mask if a.dim() == 1 else mask[:, None], a, b)
@@ -229,10 +246,9 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
     cx = fam.cons(x).contiguous()
     r = Fx.clone()
     delta = t.ones(B, **f64)
-    prepare(vals_cur, None, Jv, Jcv, delta)
-    lam = multipliers(vals_cur, r, True)
+    lam = multipliers(Jv, Jcv, r, True)
     rhs_cur, nrm0 = Z(B, N), Z(B, 2)
-    resid_vectors(vals_cur, r, lam, Fx, cx, rhs_cur, nrm0)
+    resid_vectors(Jv, Jcv, r, lam, Fx, cx, rhs_cur, nrm0)
     normdual, normprimal = nrm0[:, 0].clone(), nrm0[:, 1].clone()
     epsF = (Fatol + Frtol * 2 * t.sqrt(fx)).contiguous()
     epstol = (atol + rtol * normdual).contiguous()
@@ -243,10 +259,9 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
     def small_res_check(mask):
         """src/CaNNOLeS.jl:873-897 for the problems of `mask`: r = F, least-squares multipliers, dual, primal = [0; c] (in place)"""
         r2 = W(mask, Fx, r)
-        prepare(vals_cur, None, Jv, Jcv, delta)
-        lam2 = multipliers(vals_cur, r2, False)
+        lam2 = multipliers(Jv, Jcv, r2, False)
         lam.copy_(W(mask, lam2, lam))
-        resid_vectors(vals_cur, r2, lam, r2, cx, rv_rhs, rv_nrm)   # F - r = 0 for the masked problems
+        resid_vectors(Jv, Jcv, r2, lam, r2, cx, rv_rhs, rv_nrm)   # F - r = 0 for the masked problems
         rhs_cur.copy_(W(mask, rv_rhs, rhs_cur))
         normdual.copy_(W(mask, rv_nrm[:, 0], normdual))
         normprimal.copy_(W(mask, ninf(cx[:, :p]) if p else Z(B), normprimal))
@@ -339,8 +354,7 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
         tk = tick("extrapolation", tk)
         # ---- Armijo line search on the merit function, :1054-1112
         if any_ls:
-            prepare(vals_cur, None, Jv, Jcv, delta)
-            resid_vectors(vals_cur, Fx, lam_ls, Fx, cx, rv_rhs, rv_nrm)      # dual part: Jx'Fx - Jc'(lam - c/delta), lam_ls by cnl_outer_newton_done_dev
+            resid_vectors(Jv, Jcv, Fx, lam_ls, Fx, cx, rv_rhs, rv_nrm)      # dual part: Jx'Fx - Jc'(lam - c/delta), lam_ls by cnl_outer_newton_done_dev
             chk_(lib.cnl_outer_ls_begin_dev(Sref, st))
             Fl.copy_(fam.residual(xl))
             cl.copy_(fam.cons(xl))
@@ -356,15 +370,13 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
         ct.copy_(fam.cons(xt))
         # ---- optimality measures at the trial point, :722-732; acceptance and the state update, :733-800
         Jt.copy_(fam.jac_vals(xt))
-        prepare(vals_t, None, Jt, Jcv, delta)
-        resid_vectors(vals_t, rt, lamt, Ft, ct, rhs_t, nrm_t)
+        resid_vectors(Jt, Jcv, rt, lamt, Ft, ct, rhs_t, nrm_t)
         tk = tick("trial_eval", tk)
         chk_(lib.cnl_outer_trial_done_dev(Sref, st))
         any_rej, any_chk = read_flags()[4:6]
         tk = tick("trial_done", tk)
         if any_rej:   # dual at (x, r, lam) again; primal keeps the trial's value, as in the reference (:742-747)
-            prepare(vals_cur, None, Jv, Jcv, delta)
-            resid_vectors(vals_cur, r, lam, Fx, cx, rv_rhs, rv_nrm)
+            resid_vectors(Jv, Jcv, r, lam, Fx, cx, rv_rhs, rv_nrm)
             rhs_cur[:, :n] = t.where(masks["rej"][:, None], rv_rhs[:, :n], rhs_cur[:, :n])
         if any_chk:
             small_res_check(masks["chk"])
@@ -375,7 +387,7 @@ def solve_batch_device(fam, params=None, max_steps=400, max_inner=10000, atol=No
     names = {UNKNOWN: "unknown", FIRST: "first_order", SMALL: "small_residual", EXC: "exception", TIRED: "max_eval", STALL: "stalled"}
     out = {"solution": x.cpu().numpy(), "multipliers": lam[:, :p].cpu().numpy(), "status": [names[int(v)] for v in status.cpu().numpy()],
            "iter": it.cpu().numpy(), "nfact": nfact.cpu().numpy(), "nlinsolve": nlin.cpu().numpy(), "nbk": nbk.cpu().numpy(),
-           "objective": fx.cpu().numpy(), "steps": steps, "kernel": L.config["kernel"],
+           "objective": fx.cpu().numpy(), "steps": steps, "kernel": L.config["kernel"], "vals_layout": "interleaved" if L.config.get("batch_layout") else "problem-major",
            "loop_seconds": loop_seconds}   # the global steps alone (the symbolic analysis of the pattern and the start-up evaluations are not in it)
     if prof is not None:
         out["profile_ms_per_step"] = {k: 1e3 * v / max(steps, 1) for k, v in prof.items()}
