@@ -24,7 +24,14 @@
 #ifndef BAND_DBG
 #define BAND_DBG 0
 #endif
-#if (BAND_DBG || defined(BAND_STAMPS)) && !defined(CNL_EXPERIMENT)
+// probe: every operand piece / factor flush moved down to a multiple of eight doubles (WRONG results; what perfectly aligned streams
+// would be worth — build with -DBAND_DBG=1 so that garbage triggers no ladder)
+#ifdef BAND_PROBE_ALIGNED
+constexpr int BAND_ALIGN_MASK = ~7;
+#else
+constexpr int BAND_ALIGN_MASK = ~0;
+#endif
+#if (BAND_DBG || defined(BAND_STAMPS) || defined(BAND_PROBE_ALIGNED)) && !defined(CNL_EXPERIMENT)
 #error "BAND_DBG needs -DCNL_EXPERIMENT=1"
 #endif
 
@@ -395,7 +402,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   if (BAND_ISSUE_ALWAYS || pcs[K] >= 0) {   /* (wave-uniform: an unused piece costs the memory pipeline what a used one does) */ \
     const int pc = pcs[K] >= 0 ? pcs[K] : 0;   /* (ALWAYS: an unused piece loads element 0 of vals — a static number of loads per epoch) */ \
     const int arr = pc >> 28;                                                                                                 \
-    const int el_ = (pc & ((1 << 28) - 1)) + (arr == 2 ? loff8 : 0);                                                          \
+    const int el_ = ((pc & ((1 << 28) - 1)) + (arr == 2 ? loff8 : 0)) & BAND_ALIGN_MASK;   /* (probe builds: -DBAND_PROBE_ALIGNED) */ \
     /* lane offset (doubles) = problem * strd + tl, tl = t + (t >> 3) * gap with t = m + element of the lane: the caller's arrays    \
        are problem-major (m = 0, t < 8: gap = 0), the factor is interleaved in blocks of eight (see lbase_g) */                \
     const bool il_ = arr == 0 ? vil : arr == 1 ? ril : LINT;   /* (wave-uniform) */                                           \
@@ -483,7 +490,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
 #define BAND_LFLUSH(LB, LC)                                                                                                 \
       if (mode != MODE_FACTOR) {                                                                                            \
         const int lc_ = (LC);                                                                                               \
-        const int lb_ = (LB) + loff8;                                                                                       \
+        const int lb_ = ((LB) + loff8) & BAND_ALIGN_MASK;                                                                   \
         char* lout = reinterpret_cast<char*>(lbase_g) + ((LINT ? (long long)(lb_ >> 3) * (NL * 8) : (long long)lb_) << 3);  \
         const unsigned t_ = (LINT ? (unsigned)(lb_ & 7) : 0u) + (unsigned)le;                                               \
         const unsigned tl = t_ + (LINT ? (t_ >> 3) * (unsigned)(NL * 8 - 8) : 0u);                                          \

@@ -186,6 +186,28 @@ for case in range(ncases):
                         bad.append(f"d[{b}] rel {np.abs(d[b] - d0[b]).max() / np.abs(d0[b]).max():.2e} backward error {be:.1e} (oracle {be0:.1e})")
             elif not (d[b] == 7.0).all():
                 bad.append(f"d[{b}] touched")
+        # band handles: the same batch through the DEVICE-pointer entry with `vals` interleaved (cnl_options.batch_layout = 1) must give
+        # the host-pointer results bit for bit (the same kernels on another address function; 32 problems per workgroup)
+        if L.config.get("band") and B > 1:
+            import torch
+            dv = torch.device("cuda", 0)
+            Li = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B,
+                                     options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, batch_layout=1, band_kernel=ropt.get("band_kernel", 1)))
+            tv, trh = torch.from_numpy(vals).to(dv), torch.from_numpy(rhs).to(dv)
+            tvi = torch.empty(hipldl.layout_len(Li, 0), dtype=torch.float64, device=dv)
+            hipldl.interleave_dev(Li, 0, tv.data_ptr(), tvi.data_ptr(), 0)
+            tdi = torch.full((B, s.N), 7.0, dtype=torch.float64, device=dv)
+            tro, trho = torch.from_numpy(ro_in.copy()).to(dv), torch.zeros(B, dtype=torch.float64, device=dv)
+            tnf, tok = torch.zeros(B, dtype=torch.int32, device=dv), torch.zeros(B, dtype=torch.int32, device=dv)
+            hipldl.newton_system_dev(Li, tvi.data_ptr(), trh.data_ptr(), tdi.data_ptr(), tro.data_ptr(), trho.data_ptr(), tnf.data_ptr(), tok.data_ptr(), p, 0)
+            hipldl.deinterleave_dev(Li, 0, tvi.data_ptr(), tv.data_ptr(), 0)
+            torch.cuda.synchronize()
+            same = (np.array_equal(tdi.cpu().numpy(), d) and np.array_equal(tok.cpu().numpy().astype(bool), ok.astype(bool)) and np.array_equal(tnf.cpu().numpy(), nf)
+                    and np.array_equal(trho.cpu().numpy(), rho) and np.array_equal(tro.cpu().numpy(), ro) and np.array_equal(tv.cpu().numpy(), v.reshape(B, -1)))
+            if not same:
+                bad.append("interleaved layout differs from the problem-major call")
+            kinds["+interleaved twin"] = kinds.get("+interleaved twin", 0) + 1
+            Li.close()
         # the two-call sequence with the rho the ladder left
         okf = np.atleast_1d(hipldl.try_to_factorize(L, v, s.nvar, s.nequ, s.ncon, p[0]))
         if not np.array_equal(okf.astype(bool)[keep], np.atleast_1d(ok0).astype(bool)[keep]):
