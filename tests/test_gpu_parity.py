@@ -2382,3 +2382,45 @@ def test_interleaved_layout_is_refused_where_it_is_not_served(built):
     hipldl.residual_vectors_jac_dev(L, s.nnzjF, s.nnzjc, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0)
     torch.cuda.synchronize()
     L.close()
+
+
+def test_multi_device_shards_with_interleaved_vals(built):
+    """cnl_multi_*_dev with cnl_options.batch_layout = 1: every shard's `vals` is an interleaved array of ITS problems (groups of 32 start
+    at the shard's first problem); decisions and d as the single problem-major handle gives them, the rho slots written back in place"""
+    import torch
+    hipldl, syn, O = _mods()
+    s = syn.band_structure(300, 4)
+    rows, cols = s.kkt_pattern()
+    B = 75
+    vals, rhs = syn.batch_values(s, B, cfg=4)
+    vl, rl = syn.batch_values(s, B, cfg=5, stress="ladder")
+    for b in (6, 40, 74):
+        vals[b], rhs[b] = vl[b], rl[b]
+    p = hipldl.default_params()
+    M = hipldl.MultiHIPLDLStruct(s.N, rows, cols, s.nvar, s.nequ, s.ncon, B, [0, 0], options=_band_opts(hipldl, batch_layout=1))
+    dev = torch.device("cuda", 0)
+    sh = []
+    for a, c, _ in M.shards:
+        vi = np.zeros(hipldl.il_len(c, s.nnzNS))
+        pp, ee = np.meshgrid(np.arange(c), np.arange(s.nnzNS), indexing="ij")
+        idx = hipldl.il_index(pp, ee, s.nnzNS)
+        vi[idx] = vals[a:a + c]
+        sh.append(dict(vals=torch.from_numpy(vi).to(dev), rhs=torch.from_numpy(rhs[a:a + c].copy()).to(dev), idx=idx,
+                       d=torch.zeros((c, s.N), dtype=torch.float64, device=dev), ro=torch.zeros(c, dtype=torch.float64, device=dev),
+                       rho=torch.zeros(c, dtype=torch.float64, device=dev), nf=torch.zeros(c, dtype=torch.int32, device=dev),
+                       su=torch.zeros(c, dtype=torch.int32, device=dev)))
+    ptr = lambda k: [x[k].data_ptr() for x in sh]
+    M.newton_system_dev(ptr("vals"), ptr("rhs"), ptr("d"), ptr("ro"), ptr("rho"), ptr("nf"), ptr("su"), p)
+    M.synchronize()
+    L = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=_band_opts(hipldl, band_problems_per_group=32))
+    v1 = vals.copy()
+    d1, ok1, rho1, ro1, nf1 = hipldl.newton_system_(np.zeros((B, s.N)), s.nvar, s.nequ, s.ncon, rhs, v1, L, np.zeros(B), p)
+    L.close()
+    assert np.array_equal(np.concatenate([x["su"].cpu().numpy() for x in sh]).astype(bool), ok1) and nf1[6] > 1 and nf1[74] > 1
+    assert np.array_equal(np.concatenate([x["nf"].cpu().numpy() for x in sh]), nf1)
+    assert np.array_equal(np.concatenate([x["rho"].cpu().numpy() for x in sh]), rho1)
+    assert np.array_equal(np.concatenate([x["d"].cpu().numpy() for x in sh]), d1.reshape(B, -1))
+    assert np.array_equal(np.concatenate([x["vals"].cpu().numpy()[x["idx"]] for x in sh]), v1)
+    with pytest.raises(hipldl.CnlError):   # the host-pointer front end takes the reference's arrays only
+        M.newton_system_(np.zeros((B, s.N)), rhs, vals.copy(), np.zeros(B), p)
+    M.close()

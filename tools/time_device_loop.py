@@ -9,7 +9,7 @@ from cannoles_jl_amd import device_loop as DL, synthetic as syn, outer_loop, hip
 
 def main():
     out = []
-    for (n, p, B) in [(300, 4, 256), (300, 4, 2048), (300, 4, 8192), (2000, 10, 1024)]:
+    for (n, p, B) in [(300, 4, 256), (300, 4, 2048), (300, 4, 8192), (2000, 10, 1024), (1000, 10, 16384)]:
         s = syn.band_structure(n, p)
         fam = DL.BandQuadFamily(s, B, seed=7, torch=torch, device="cuda:0", curvature=1.5, start=1.0, noise=0.5)
         prm = hipldl.default_params()
@@ -23,7 +23,7 @@ def main():
         dt = time.perf_counter() - t0
         rec = {"n": n, "p": p, "B": B, "seconds": dt, "problems_per_s": B / dt, "steps": got["steps"], "ms_per_step": 1e3 * got["loop_seconds"] / got["steps"], "setup_seconds": dt - got["loop_seconds"],
                "newton_systems": int(got["nlinsolve"].sum()), "factorisations": int(got["nfact"].sum()),
-               "first_order": sum(st == "first_order" for st in got["status"]), "kernel": got["kernel"]}
+               "first_order": sum(st == "first_order" for st in got["status"]), "kernel": got["kernel"], "vals_layout": got.get("vals_layout")}
         if os.path.isdir("oracle"):
             from tests.test_oracle_pinning import oracle_newton, oracle_solver
             t0 = time.perf_counter()
