@@ -336,15 +336,20 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   const int nnz = P.nnz, N = P.N;
   const long long lsize = P.lsize;
   // mover: wave-uniform base pointers + 32-bit per-lane byte offsets (NL problems span < 4 GB)
-  // cnl_options.batch_layout = 1 (32 problems per workgroup only): `vals` is given INTERLEAVED over the 32 problems of a workgroup in
-  // blocks of eight doubles, the layout of the factor records below — element e of problem p of group g at
+  // cnl_options.batch_layout = 1: `vals` is given INTERLEAVED over groups of 32 problems in blocks of eight doubles, the layout of the
+  // factor records below — element e of problem p of group g at
   // ((g * band_il_blocks(nnz) + e / 8) * 32 + p) * 8 + e % 8 — so that the eight 64-byte runs of a mover load are 512 contiguous bytes
   // and every 128-byte line that is fetched is used whole (16 384 problems: 12.5 -> 11.0 ms with vals and rhs interleaved, bit-equal).
   // Bit 1 of the layout word: the same for `rhs`.  d is problem-major always.
-  const bool vil = NL == 32 && (Ain.layout & 1), ril = NL == 32 && (Ain.layout & 2);
-  const int vstride = vil ? NL * 8 : 0, rstride = ril ? NL * 8 : 0;
-  const double* vbase = gvals + (vil ? (long long)blockIdx.x * band_il_blocks(nnz) * (NL * 8) : (long long)prob0 * nnz);
-  const double* rbase = !has_rhs ? gvals : grhs + (ril ? (long long)blockIdx.x * band_il_blocks(N) * (NL * 8) : (long long)prob0 * N);
+  // (the groups of the LAYOUT are 32 problems whatever the workgroup holds: a workgroup of 16 problems works on half a group)
+  constexpr int G8 = BAND_IL_GROUP * 8;
+  static_assert(BAND_IL_GROUP % NL == 0, "a workgroup's problems lie in one group of the interleaved layout");
+  const bool vil = (Ain.layout & 1) != 0, ril = (Ain.layout & 2) != 0;
+  const int vstride = vil ? G8 : 0, rstride = ril ? G8 : 0;
+  const long long ilg = prob0 / BAND_IL_GROUP;        // group of the workgroup's problems
+  const int ilp = (prob0 % BAND_IL_GROUP) * 8;        // ... and the offset of its first problem inside a block row
+  const double* vbase = gvals + (vil ? ilg * band_il_blocks(nnz) * G8 + ilp : (long long)prob0 * nnz);
+  const double* rbase = !has_rhs ? gvals : grhs + (ril ? ilg * band_il_blocks(N) * G8 + ilp : (long long)prob0 * N);
   // The factor records are private to the launch (written by the forward sweep, read by the backward sweep of the SAME workgroup), so
   // their layout is the kernel's choice: INTERLEAVED over the NL problems of the workgroup in blocks of eight doubles — element e of
   // problem p of the workgroup lives at ((e >> 3) * NL + p) * 8 + (e & 7) of the workgroup's region — so that the eight 64-byte runs one
@@ -373,8 +378,8 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   const bool valid = clane && cprob < batch;
   const int cpl = valid ? cprob - prob0 : batch - 1 - prob0;   // problem whose data this lane's block holds
   char* myb = wblk + (size_t)(clane ? lane : 0) * LANE_D * 8;
-  const long long pv = vil ? (long long)blockIdx.x * band_il_blocks(nnz) * (NL * 8) + cpl * 8 : (long long)(prob0 + cpl) * nnz;
-  const long long pr = ril ? (long long)blockIdx.x * band_il_blocks(N) * (NL * 8) + cpl * 8 : (long long)(prob0 + cpl) * N;
+  const long long pv = vil ? ilg * band_il_blocks(nnz) * G8 + ilp + cpl * 8 : (long long)(prob0 + cpl) * nnz;
+  const long long pr = ril ? ilg * band_il_blocks(N) * G8 + ilp + cpl * 8 : (long long)(prob0 + cpl) * N;
   for (int t = lane; t < NL; t += 64) *reinterpret_cast<double*>(wblk + ((size_t)t * LANE_D + BAND_ZERO_OFF) * 8) = 0.0;   // every block's zero cell
 
   const double tol = Ain.params[0], kdec = Ain.params[2], kinc = Ain.params[3], klarge = Ain.params[4], rho0 = Ain.params[5], rhomax = Ain.params[6],
@@ -406,11 +411,12 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
     /* lane offset (doubles) = problem * strd + tl, tl = t + (t >> 3) * gap with t = m + element of the lane: the caller's arrays    \
        are problem-major (m = 0, t < 8: gap = 0), the factor is interleaved in blocks of eight (see lbase_g) */                \
     const bool il_ = arr == 0 ? vil : arr == 1 ? ril : LINT;   /* (wave-uniform) */                                           \
+    const int ilw_ = arr == 2 ? NL * 8 : BAND_IL_GROUP * 8;    /* doubles per block row: the factor's own layout / the ABI's */  \
     const int m_ = il_ ? (el_ & 7) : 0;                                                                                       \
-    const unsigned gap_ = il_ ? (unsigned)(NL * 8 - 8) : 0u;                                                                  \
+    const unsigned gap_ = il_ ? (unsigned)(ilw_ - 8) : 0u;                                                                    \
     const char* pb = (arr == 0 ? reinterpret_cast<const char*>(vbase) : arr == 1 ? reinterpret_cast<const char*>(rbase)       \
                                                                                  : reinterpret_cast<const char*>(lbase_g)) +   \
-                     ((il_ ? (long long)(el_ >> 3) * (NL * 8) : (long long)el_) << 3);                                        \
+                     ((il_ ? (long long)(el_ >> 3) * ilw_ : (long long)el_) << 3);                                            \
     const unsigned strd = il_ ? 8u : arr == 0 ? (unsigned)nnz : arr == 1 ? (unsigned)N : (unsigned)lsize;                     \
     const unsigned t_ = (unsigned)m_ + (unsigned)le;                                                                          \
     const unsigned tl = t_ + (t_ >> 3) * gap_;                                                                                \
@@ -743,7 +749,7 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
       if (nf > 1 && vq) {
         const double wq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wrote), q), __builtin_amdgcn_readlane(__double2loint(wrote), q));
         if (vil) {
-          double* vg = gvals + (long long)blockIdx.x * band_il_blocks(nnz) * (NL * 8) + q * 8;
+          double* vg = gvals + ilg * band_il_blocks(nnz) * G8 + ilp + q * 8;
           for (int i = lane; i < P.nvar; i += 64) vg[band_il_offset(nnz - P.nvar + i, vstride)] = wq;
         } else {
           double* vt = gvals + (long long)(prob0 + q) * nnz + (nnz - P.nvar);
@@ -805,8 +811,11 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
   const int nepmax = P.nepochs[0] > P.nepochs[1] ? P.nepochs[0] : P.nepochs[1];
   const int nnz = P.nnz, N = P.N;
   const bool live = prob0 < batch;   // (the last workgroup's second group may be empty: it only joins the barriers)
-  const bool vil = NL == 32 && (Ain.layout & 1), ril = NL == 32 && (Ain.layout & 2);   // interleaved vals / rhs (band_newton_kernel)
-  const int vstride = vil ? NL * 8 : 0, rstride = ril ? NL * 8 : 0;
+  constexpr int G8 = BAND_IL_GROUP * 8;
+  const bool vil = (Ain.layout & 1) != 0, ril = (Ain.layout & 2) != 0;   // interleaved vals / rhs (band_newton_kernel)
+  const int vstride = vil ? G8 : 0, rstride = ril ? G8 : 0;
+  const long long ilg = prob0 / BAND_IL_GROUP;
+  const int ilp = (prob0 % BAND_IL_GROUP) * 8;
   const double tol = Ain.params[0];
 
   if (!computes) {
@@ -814,8 +823,8 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
     const int* fops_g = as_global(P.fops[part]);
     const int* bops_g = as_global(P.bops[part]);
     const long long lsize = P.lsize;
-    const double* vbase = gvals + (vil ? (long long)(prob0 / NL) * band_il_blocks(nnz) * (NL * 8) : (long long)prob0 * nnz);
-    const double* rbase = !has_rhs ? gvals : grhs + (ril ? (long long)(prob0 / NL) * band_il_blocks(N) * (NL * 8) : (long long)prob0 * N);
+    const double* vbase = gvals + (vil ? ilg * band_il_blocks(nnz) * G8 + ilp : (long long)prob0 * nnz);
+    const double* rbase = !has_rhs ? gvals : grhs + (ril ? ilg * band_il_blocks(N) * G8 + ilp : (long long)prob0 * N);
     double* lbase_g = gL + (long long)prob0 * lsize;
     const int loff8 = (int)P.loff[part];
     unsigned movp[NI], ldsb0[NI];
@@ -920,8 +929,8 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
   const bool valid = clane && cprob < batch;
   const int cpl = valid ? cprob - prob0 : (live ? batch - 1 - prob0 : 0);
   char* myb = wblk + (size_t)(clane ? lane : 0) * LANE_D * 8;
-  const long long pv = !live ? 0 : vil ? (long long)(prob0 / NL) * band_il_blocks(nnz) * (NL * 8) + cpl * 8 : (long long)(prob0 + cpl) * nnz;
-  const long long pr = !live ? 0 : ril ? (long long)(prob0 / NL) * band_il_blocks(N) * (NL * 8) + cpl * 8 : (long long)(prob0 + cpl) * N;
+  const long long pv = !live ? 0 : vil ? ilg * band_il_blocks(nnz) * G8 + ilp + cpl * 8 : (long long)(prob0 + cpl) * nnz;
+  const long long pr = !live ? 0 : ril ? ilg * band_il_blocks(N) * G8 + ilp + cpl * 8 : (long long)(prob0 + cpl) * N;
   // the wavefront streams its own factor records / solution components out (all 64 lanes: lane (lq, le) = element le of problems lq, lq + 8)
   const long long lsize = P.lsize;
   double* lbase_g = gL + (long long)prob0 * lsize;
@@ -1185,7 +1194,7 @@ __global__ void __launch_bounds__(512, 2) band_newton_mw_kernel(const BandDev P,
       if (nf > 1 && vq) {
         const double wq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wrote), q), __builtin_amdgcn_readlane(__double2loint(wrote), q));
         if (vil) {
-          double* vg = gvals + (long long)(prob0 / NL) * band_il_blocks(nnz) * (NL * 8) + q * 8;
+          double* vg = gvals + ilg * band_il_blocks(nnz) * G8 + ilp + q * 8;
           for (int i = lane; i < P.nvar; i += 64) vg[band_il_offset(nnz - P.nvar + i, vstride)] = wq;
         } else {
           double* vt = gvals + (long long)(prob0 + q) * nnz + (nnz - P.nvar);

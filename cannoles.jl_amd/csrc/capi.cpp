@@ -1297,7 +1297,7 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
     bd.nparts = Bp.nparts; bd.m0 = Bp.m0; bd.n = Bp.n; bd.N = Bp.N; bd.nnz = Bp.nnz; bd.nvar = (int32_t)nvar; bd.lsize = Bp.lsize;
     // 16 problems per workgroup (two workgroups = four wavefronts per CU: one per SIMD) up to the 8192 problems that fills; above,
     // 32 per workgroup (the LDS of a CU holds two such workgroups: 16384 problems resident) — tools/time_band.py
-    h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : (batch > 8192 || plan->opt.batch_layout ? 32 : 16);
+    h->band_nl = plan->opt.band_problems_per_group > 0 ? plan->opt.band_problems_per_group : (batch > 8192 ? 32 : 16);
     if (h->band_nl != 8 && h->band_nl != 16 && h->band_nl != 32) return bail(fail(CNL_ERR_ARG, "band_problems_per_group must be 8, 16 or 32"));
     if (plan->opt.band_movers > 0 && cnl::band_mw_group(plan->opt.band_movers) == 0)
       return bail(fail(CNL_ERR_ARG, "tuning key band_movers (1 .. 3) needs a library built with -DCNL_EXPERIMENT=1 -DBAND_MW (csrc/band.hip)"));
@@ -1317,8 +1317,8 @@ static int create_from_plan(cnl_handle** hout, cnl_plan* plan, const int64_t* ro
   if (plan->opt.batch_layout != CNL_LAYOUT_PROBLEM_MAJOR) {
     // the interleaved layout is the band kernels' (groups of 32 problems = one workgroup of the 32-problem instantiation)
     if (plan->opt.batch_layout != CNL_LAYOUT_INTERLEAVED) return bail(fail(CNL_ERR_ARG, "cnl_options.batch_layout: unknown layout"));
-    if (!h->band || h->band_nl != cnl::BAND_IL_GROUP)   // (band_mw: experiment builds, the 32-problem variant)
-      return bail(fail(CNL_ERR_ARG, "batch_layout = CNL_LAYOUT_INTERLEAVED needs a handle the band kernels serve with 32 problems per workgroup "
+    if (!h->band)
+      return bail(fail(CNL_ERR_ARG, "batch_layout = CNL_LAYOUT_INTERLEAVED needs a handle the band kernels serve "
                                     "(band-structured pattern, throughput plan, cnl_options.band_kernel != 0; csrc/band.h)"));
     h->layout = 1 | (plan->opt.band_rhs_interleaved ? 2 : 0);
   }

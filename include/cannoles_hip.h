@@ -79,8 +79,9 @@ void cnl_default_params(double params[9]);
                                         cnl_layout_len gives the array's length, cnl_interleave_dev / cnl_deinterleave_dev convert,
                                         cnl_prepare_newton_system_dev (row f2) writes it directly.  For device-resident callers of
                                         band-structured batches: every load of the band kernels then moves 512 contiguous bytes
-                                        (16 384 problems of the headline pattern: 12.5 -> 11.0 ms).  rhs and d are problem-major in
-                                        both layouts.  cnl_create fails (CNL_ERR_ARG) when the band kernels do not serve the handle. */
+                                        (16 384 problems of the headline pattern: 12.5 -> 11.0 ms; nothing to gain below 8 193
+                                        problems).  rhs and d are problem-major in both layouts.  cnl_create fails (CNL_ERR_ARG) when
+                                        the band kernels do not serve the handle.                                                   */
 typedef struct cnl_options {
   int32_t struct_size;         /* sizeof(cnl_options), set by cnl_options_init (ABI evolution)                                  */
   int32_t plan_kind;           /* CNL_PLAN_*                                                                                    */

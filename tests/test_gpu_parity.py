@@ -2199,17 +2199,19 @@ def test_band_remainder_handle(built, B):
 
 
 # ---- cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED (round 6: `vals` interleaved over groups of 32 problems, include/cannoles_hip.h) ----
-def _il_handles(hipldl, s, B, **kw):
+def _il_handles(hipldl, s, B, nl=0, **kw):
     rows, cols = s.kkt_pattern()
     mk = lambda **o: hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=_band_opts(hipldl, **o, **kw))
-    LA, LB = mk(band_problems_per_group=32), mk(batch_layout=hipldl.LAYOUT_INTERLEAVED)
+    LA, LB = mk(band_problems_per_group=32), mk(batch_layout=hipldl.LAYOUT_INTERLEAVED, band_problems_per_group=nl)
     assert LA.config["band"] and LA.config["band_nl"] == 32 and LA.config["batch_layout"] == 0
-    assert LB.config["band"] and LB.config["band_nl"] == 32 and LB.config["batch_layout"] == 1
+    # (the layout's groups are 32 problems whatever the workgroups hold: 16 per workgroup up to 8192 problems, 32 above)
+    assert LB.config["band"] and LB.config["band_nl"] == (nl or (32 if B > 8192 else 16)) and LB.config["batch_layout"] == 1
     return LA, LB
 
 
-@pytest.mark.parametrize("n,p,B,hw", [(200, 4, 5, 2), (1000, 10, 37, 2), (360, 6, 70, 1), (400, 0, 33, 2), (10000, 50, 64, 2), (240, 4, 8192 + 40, 2)])
-def test_interleaved_vals_layout(built, n, p, B, hw):
+@pytest.mark.parametrize("n,p,B,hw,nl", [(200, 4, 5, 2, 0), (1000, 10, 37, 2, 0), (360, 6, 70, 1, 8), (400, 0, 33, 2, 32), (10000, 50, 64, 2, 0), (240, 4, 8192 + 40, 2, 0),
+                                          (600, 6, 77, 2, 16)])
+def test_interleaved_vals_layout(built, n, p, B, hw, nl):
     """The band kernels on `vals` interleaved over groups of 32 problems (CNL_LAYOUT_INTERLEAVED) against the oracle, and bit-equal in
     every output — d, flags, rho, rho_old, nfact, the rho slots written back into vals, try_to_factorize -> solve_ldl! — to the same
     kernels on the reference's problem-major arrays; batches that are no multiple of 32, ladder climbers, a hopeless problem, rho_old > 0."""
@@ -2235,7 +2237,7 @@ def test_interleaved_vals_layout(built, n, p, B, hw):
     ro_h[0] = 1e-3
     if B > 4:
         ro_h[4] = 0.3
-    LA, LB = _il_handles(hipldl, s, B)
+    LA, LB = _il_handles(hipldl, s, B, nl)
     dev = torch.device("cuda", 0)
     p_ = hipldl.default_params()
     tr = torch.from_numpy(rhs).to(dev)
@@ -2364,7 +2366,7 @@ def test_interleaved_layout_is_refused_where_it_is_not_served(built):
     s = syn.band_structure(200, 4)
     rows, cols = s.kkt_pattern()
     with pytest.raises(hipldl.CnlError):
-        hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=64, options=_band_opts(hipldl, batch_layout=1, band_problems_per_group=16))
+        hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=64, options=_band_opts(hipldl, batch_layout=1, band_kernel=0))
     with pytest.raises(hipldl.CnlError):
         hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=64, options=_band_opts(hipldl, batch_layout=2))
     B = 6

@@ -21,7 +21,7 @@ variants = {"front": dict(band_kernel=0), "band8": dict(band_kernel=1, band_prob
             "band32": dict(band_kernel=1, band_problems_per_group=32), "bandmw": dict(band_kernel=1, band_movers=1), "bandmw2": dict(band_kernel=1, band_movers=2),
             "bandmw3": dict(band_kernel=1, band_movers=3),
             # cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED: vals interleaved over groups of 32 problems; il2: rhs as well (tuning key)
-            "band32il": dict(band_kernel=1, batch_layout=1), "band32il2": dict(band_kernel=1, batch_layout=1, band_rhs_interleaved=1),
+            "band32il": dict(band_kernel=1, batch_layout=1, band_problems_per_group=32), "band16il": dict(band_kernel=1, batch_layout=1, band_problems_per_group=16), "band32il2": dict(band_kernel=1, batch_layout=1, band_rhs_interleaved=1),
             "bandmw2il": dict(band_kernel=1, band_movers=2, batch_layout=1), "bandmw2il2": dict(band_kernel=1, band_movers=2, batch_layout=1, band_rhs_interleaved=1)}
 if os.environ.get("BAND_VARIANTS"):
     variants = {k: v for k, v in variants.items() if k in os.environ["BAND_VARIANTS"].split(",")}
