@@ -752,8 +752,25 @@ def test_headline_pattern_large_batch_sample_vs_oracle(built, B, kernel, order, 
     rho = torch.ones(B, dtype=torch.float64, device=dev)
     nf = torch.zeros(B, dtype=torch.int32, device=dev)
     ok = torch.zeros(B, dtype=torch.int32, device=dev)
+    vals_in = vals.clone() if band_nl == 32 else None
     hipldl.newton_system_dev(L, vals.data_ptr(), rhs.data_ptr(), d.data_ptr(), ro.data_ptr(), rho.data_ptr(), nf.data_ptr(), ok.data_ptr(), p, 0)
     torch.cuda.synchronize()
+    if band_nl == 32:
+        # what bench.py times since round 6: the same instantiation on `vals` interleaved over groups of 32 problems (cnl_options.batch_layout
+        # = 1) — every output bit-equal to the problem-major call that is checked against the oracle below
+        Li = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(batch_layout=hipldl.LAYOUT_INTERLEAVED))
+        assert Li.config["band"] and Li.config["band_nl"] == 32 and Li.config["batch_layout"] == 1
+        vi = torch.empty(hipldl.layout_len(Li, 0), dtype=torch.float64, device=dev)
+        hipldl.interleave_dev(Li, 0, vals_in.data_ptr(), vi.data_ptr(), 0)
+        d_i, ro_i, rho_i = torch.zeros_like(d), torch.zeros_like(ro), torch.ones_like(rho)
+        nf_i, ok_i = torch.zeros_like(nf), torch.zeros_like(ok)
+        hipldl.newton_system_dev(Li, vi.data_ptr(), rhs.data_ptr(), d_i.data_ptr(), ro_i.data_ptr(), rho_i.data_ptr(), nf_i.data_ptr(), ok_i.data_ptr(), p, 0)
+        hipldl.deinterleave_dev(Li, 0, vi.data_ptr(), vals_in.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert torch.equal(d_i, d) and torch.equal(ro_i, ro) and torch.equal(rho_i, rho) and torch.equal(nf_i, nf) and torch.equal(ok_i, ok)
+        assert torch.equal(vals_in, vals)
+        Li.close()
+        del vi, d_i, vals_in
     nfh, rhoh = nf.cpu().numpy(), rho.cpu().numpy()
     assert bool((ok == 1).all())
     if not climbers:
