@@ -26,12 +26,16 @@
 #endif
 // probe: every operand piece / factor flush moved down to a multiple of eight doubles (WRONG results; what perfectly aligned streams
 // would be worth — build with -DBAND_DBG=1 so that garbage triggers no ladder)
+// probe: only every other operand load instruction is issued (WRONG results: what half the vector-memory LOAD instructions would be worth)
+#ifndef BAND_PROBE_HALF_LOADS
+#define BAND_PROBE_HALF_LOADS 0
+#endif
 #ifdef BAND_PROBE_ALIGNED
 constexpr int BAND_ALIGN_MASK = ~7;
 #else
 constexpr int BAND_ALIGN_MASK = ~0;
 #endif
-#if (BAND_DBG || defined(BAND_STAMPS) || defined(BAND_PROBE_ALIGNED)) && !defined(CNL_EXPERIMENT)
+#if (BAND_DBG || defined(BAND_STAMPS) || defined(BAND_PROBE_ALIGNED) || BAND_PROBE_HALF_LOADS) && !defined(CNL_EXPERIMENT)
 #error "BAND_DBG needs -DCNL_EXPERIMENT=1"
 #endif
 
@@ -401,7 +405,16 @@ __global__ void __launch_bounds__(128, (NL <= 8 ? 2 : 1)) band_newton_kernel(con
   // piece's array are selected with scalar instructions, the lane's offset is problem * stride + element.  (Three guarded loads
   // made the compiler form all three 64-bit addresses of every piece up front — 96 NI VGPRs; selecting among per-array offset
   // arrays made it index them in scratch memory; lambdas instead of macros put every captured variable into scratch.)
-#define BAND_ISSUE1(K, I) if constexpr (I < NI) stg[K][I] = *reinterpret_cast<const double*>(pb + ((movp[I] * strd + tl) << 3));
+#if BAND_PROBE_HALF_LOADS == 2   /* one 16-byte load per lane instead of two 8-byte ones: the same lines, half the instructions (interleaved vals only) */
+#define BAND_ISSUE1(K, I)                                                                                                     \
+  if constexpr (I < NI && (I & 1) == 0) {                                                                                     \
+    const double2 v2_ = *reinterpret_cast<const double2*>(pb + ((movp[I] * strd + tl + (unsigned)lane) << 3));                \
+    stg[K][I] = v2_.x;                                                                                                        \
+    if constexpr (I + 1 < NI) stg[K][I + 1] = v2_.y;                                                                          \
+  }
+#else
+#define BAND_ISSUE1(K, I) if constexpr (I < NI && (!BAND_PROBE_HALF_LOADS || (I & 1) == 0)) stg[K][I] = *reinterpret_cast<const double*>(pb + ((movp[I] * strd + tl) << 3));
+#endif
 #define BAND_COMMIT1(K, I) if constexpr (I < NI) *reinterpret_cast<double*>(wblk + ldsb[I] + (BAND_IN_OFF + 8 * K) * 8) = stg[K][I];
 #define BAND_ISSUE(K)                                                                                                         \
   if (BAND_ISSUE_ALWAYS || pcs[K] >= 0) {   /* (wave-uniform: an unused piece costs the memory pipeline what a used one does) */ \
