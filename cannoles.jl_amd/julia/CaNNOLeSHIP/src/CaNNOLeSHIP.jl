@@ -129,4 +129,35 @@ cgls_multipliers_dev!(f::HIPFactor, vals, r, λ; Jxtr = C_NULL, atol = √eps(Fl
     (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Int64, Cint, Ptr{Int32}, Ptr{Cvoid}),
     f.handle, vals, r, λ, Jxtr, atol, rtol, itmax, ones_if_zero ? 1 : 0, iters, stream))
 
+"the same as `residual_vectors_dev!` with the Jacobian values read from the model's arrays Jx [batch][nnzjF], Jcx [batch][nnzjc] (no prepare pass in front; any `vals` layout)"
+residual_vectors_jac_dev!(f::HIPFactor, nnzjF, nnzjc, Jx, Jcx, r, λ, Fx, cx, rhs, norms; stream = C_NULL) =
+  check(ccall((:cnl_residual_vectors_jac_dev, libcnl), Cint,
+    (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+    f.handle, nnzjF, nnzjc, Jx, Jcx, r, λ, Fx, cx, rhs, norms, stream))
+
+"the same as `cgls_multipliers_dev!` with the Jacobian values read from the model's arrays"
+cgls_multipliers_jac_dev!(f::HIPFactor, nnzjF, nnzjc, Jx, Jcx, r, λ; Jxtr = C_NULL, atol = √eps(Float64), rtol = √eps(Float64), itmax = 0,
+                          ones_if_zero = true, iters = C_NULL, stream = C_NULL) =
+  check(ccall((:cnl_cgls_multipliers_jac_dev, libcnl), Cint,
+    (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Int64, Cint, Ptr{Int32}, Ptr{Cvoid}),
+    f.handle, nnzjF, nnzjc, Jx, Jcx, r, λ, Jxtr, atol, rtol, itmax, ones_if_zero ? 1 : 0, iters, stream))
+
+# ---- `vals` interleaved over groups of 32 problems (cnl_options.batch_layout = CNL_LAYOUT_INTERLEAVED, include/cannoles_hip.h): batched
+# handles created through `cnl_create_ex` with that option take / write this layout at the device-pointer entry points --------------
+
+"doubles of the interleaved array of the handle's batch; which = 0: vals, 1: an N-vector per problem"
+function layout_len(f::HIPFactor, which::Integer)
+  n = Ref{Int64}(0)
+  check(ccall((:cnl_layout_len, libcnl), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}), f.handle, which, n))
+  return n[]
+end
+
+"problem-major -> interleaved on the device, out of place"
+interleave_dev!(f::HIPFactor, which::Integer, src, dst; stream = C_NULL) =
+  check(ccall((:cnl_interleave_dev, libcnl), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), f.handle, which, src, dst, stream))
+
+"interleaved -> problem-major on the device, out of place"
+deinterleave_dev!(f::HIPFactor, which::Integer, src, dst; stream = C_NULL) =
+  check(ccall((:cnl_deinterleave_dev, libcnl), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), f.handle, which, src, dst, stream))
+
 end # module
