@@ -63,6 +63,27 @@ for case in range(ncases):
             rhs0, (nd0, np0) = O.residual_vectors(rows, cols, vals[b], s.nvar, s.nequ, s.ncon, r[b], lam[b], Fx[b], cx[b])
             if not (np.array_equal(rhs[b], rhs0, equal_nan=True) and np.array_equal(nrm[b], np.array([nd0, np0]), equal_nan=True)):
                 bad.append(f"residual_vectors[{b}]")
+        # ---- f1 with the Jacobian values read from the model's arrays (cnl_residual_vectors_jac_dev): bit-equal to the vals variant
+        off_ = s.offsets()
+        tJ_, tJc_ = t(vals[:, off_[2]:off_[3]]), t(vals[:, off_[3]:off_[4]])
+        trhs_j = torch.zeros_like(trhs)
+        tn_j = torch.full((B, 2), -1.0, dtype=torch.float64, device=dev)
+        hipldl.residual_vectors_jac_dev(L, s.nnzjF, s.nnzjc, tJ_.data_ptr(), tJc_.data_ptr() if s.nnzjc else 0, tr.data_ptr(), tl.data_ptr() if s.ncon else 0,
+                                        tF.data_ptr(), tc.data_ptr() if s.ncon else 0, trhs_j.data_ptr(), tn_j.data_ptr(), 0)
+        torch.cuda.synchronize()
+        if not (np.array_equal(trhs_j.cpu().numpy(), rhs, equal_nan=True) and np.array_equal(tn_j.cpu().numpy(), nrm, equal_nan=True)):
+            bad.append("residual_vectors from the model's arrays")
+        # ---- layout conversions (any handle): round trip and the index function of the header
+        ti_ = torch.full((hipldl.layout_len(L, 0),), np.nan, dtype=torch.float64, device=dev)
+        hipldl.interleave_dev(L, 0, tv.data_ptr(), ti_.data_ptr(), 0)
+        tb_ = torch.zeros_like(tv)
+        hipldl.deinterleave_dev(L, 0, ti_.data_ptr(), tb_.data_ptr(), 0)
+        torch.cuda.synchronize()
+        pp_, ee_ = np.meshgrid(np.arange(B), np.arange(s.nnzNS), indexing="ij")
+        want_ = np.zeros(ti_.numel())
+        want_[hipldl.il_index(pp_, ee_, s.nnzNS)] = vals
+        if not (np.array_equal(ti_.cpu().numpy(), want_) and np.array_equal(tb_.cpu().numpy(), vals)):
+            bad.append("interleave / deinterleave")
         # ---- f2: prepare_newton_system
         nhF, nhc, njF, njc = len(s.hF[0]), len(s.hc[0]), s.nnzjF, s.nnzjc
         gn = nhF == 0 or bool(rng.integers(4) == 0)
@@ -85,6 +106,26 @@ for case in range(ncases):
             O.prepare(ref, s.nvar, s.nequ, s.ncon, nhF, nhc, njF, njc, None if gn else hF[b], hc[b], Jx[b], Jcx[b], delta[b])
             if not (np.array_equal(got[b], ref) and np.array_equal(np.signbit(got[b]), np.signbit(ref))):
                 bad.append(f"prepare[{b}]")
+        # ---- f2 writing `vals` interleaved (band handles with cnl_options.batch_layout = 1): bit-equal to the pass above after cnl_deinterleave_dev
+        if s.name == "band" and B > 1:
+            try:
+                Li = hipldl.HIPLDLStruct(s.N, rows, cols, None, s.nvar, s.nequ, s.ncon, batch=B, options=hipldl.Options(plan_kind=hipldl.PLAN_THROUGHPUT, batch_layout=1))
+            except hipldl.CnlError:
+                Li = None   # (outside the band kernels' envelope: half-widths 3, 4)
+            if Li is not None:
+                tvi = torch.full((hipldl.layout_len(Li, 0),), 3.0, dtype=torch.float64, device=dev)
+                hipldl.interleave_dev(Li, 0, t(vals0).data_ptr(), tvi.data_ptr(), 0)
+                hipldl.prepare_newton_system_dev(Li, 0 if (gn and nhF == 0) else nhF, nhc, njF, njc, 0 if gn else thF.data_ptr(), thc.data_ptr() if nhc else 0,
+                                                 tJx.data_ptr(), tJc.data_ptr() if njc else 0, tde.data_ptr(), tvi.data_ptr(), 0)
+                tvb = torch.zeros_like(tv0)
+                hipldl.deinterleave_dev(Li, 0, tvi.data_ptr(), tvb.data_ptr(), 0)
+                torch.cuda.synchronize()
+                gb = tvb.cpu().numpy()
+                if not (np.array_equal(gb, got) and np.array_equal(np.signbit(gb), np.signbit(got))):
+                    bad.append("prepare (interleaved)")
+                ilcases = globals().get("ilcases", 0) + 1
+                globals()["ilcases"] = ilcases
+                Li.close()
         # ---- f1: trial point
         x = rng.standard_normal((B, s.nvar)); d = rng.standard_normal((B, s.N))
         if s.ncon:
@@ -111,6 +152,11 @@ for case in range(ncases):
             hipldl.cgls_multipliers_dev(L, tv.data_ptr(), tr2.data_ptr(), tl2.data_ptr(), tj.data_ptr(), iters_ptr=ti.data_ptr())
             torch.cuda.synchronize()
             lam2, jxtr, its = tl2.cpu().numpy(), tj.cpu().numpy(), ti.cpu().numpy()
+            tl3, tj3, ti3 = torch.zeros_like(tl2), torch.zeros_like(tj), torch.zeros_like(ti)
+            hipldl.cgls_multipliers_jac_dev(L, s.nnzjF, s.nnzjc, tJ_.data_ptr(), tJc_.data_ptr(), tr2.data_ptr(), tl3.data_ptr(), tj3.data_ptr(), iters_ptr=ti3.data_ptr())
+            torch.cuda.synchronize()
+            if not (torch.equal(tl3, tl2) and torch.equal(tj3, tj) and torch.equal(ti3, ti)):
+                bad.append("cgls from the model's arrays")
             for b in list(range(min(B, 4))) + [B - 1]:
                 lam0, jx0, it0 = O.cgls_multipliers(rows, cols, vals[b], s.nvar, s.nequ, s.ncon, r2[b])
                 if not np.array_equal(jxtr[b], jx0):
@@ -125,5 +171,5 @@ for case in range(ncases):
     if bad:
         fails += 1
         print("FAIL", tag, bad[:5], flush=True)
-print(f"{ncases} cases ({tiled} with row f1 on column tiles), {fails} failures", flush=True)
+print(f"{ncases} cases ({tiled} with row f1 on column tiles, {globals().get('ilcases', 0)} with row f2 writing the interleaved layout), {fails} failures", flush=True)
 sys.exit(1 if fails else 0)
